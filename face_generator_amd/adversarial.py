@@ -1,0 +1,228 @@
+"""ADVERSARIAL: the GAN training loop of adversarial.lua re-hosted on the device plan.
+
+`train(dataset, maxAccuracyD, accsInterval)` keeps adversarial.lua:30's signature and loop structure (stride B/2,
+thisBatchSize, skip < 4, D_iterations x D-step then G_iterations x G-step, confusion print, EPOCH += 1); the closure
+bodies fevalD / fevalG_on_D (adversarial.lua:83-231) run as `Trainer.step_D` / `Trainer.step_G`: G->D hand-off,
+BCE, backward, penalty + clamp + Adam all stay in HBM (the reference round-trips through host memory at every
+nn.Copy).  Deliberate deviation C6: the G-step does not compute D's weight gradients (the reference
+computes then discards them; GRAD_PARAMETERS_D is zeroed at :92 before its next use).
+
+Multi-GPU: one process per GPU; the flat gradient vector of the net being updated is all-reduced (sum) with
+torch.distributed (backend "nccl" == RCCL over xGMI) and scaled by 1/world inside the fused Adam pass; the clamp
+is applied after the reduce (adversarial.lua:121-123 is non-linear).
+"""
+import time
+
+import torch
+
+from . import interruptable_optimizers as IO
+from .nn import BCECriterion
+from .state import S
+
+
+class Trainer:
+    def __init__(self, ctx, model_G, model_D, opt, dist=None):
+        self.ctx = ctx
+        self.G, self.D = model_G, model_D
+        self.dnG, self.dnD = model_G._inner().device_net, model_D._inner().device_net
+        self.opt = dict(D_L1=0.0, D_L2=1e-4, G_L1=0.0, G_L2=0.0, D_clamp=1.0, G_clamp=5.0, D_optmethod="adam",
+                        G_optmethod="adam")
+        self.opt.update(opt)
+        self.crit = BCECriterion()
+        self.optstate = dict(adam=dict(D={}, G={}), sgd=dict(D={}, G={}), adagrad=dict(D={}, G={}))
+        self.dist = dist          # torch.distributed module (initialised) or None
+        self.world = dist.get_world_size() if dist is not None else 1
+        self._targets = {}
+        self._inputs = {}
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _targets_for(self, B, kind):
+        key = (B, kind)
+        if key not in self._targets:
+            t = self.ctx.zeros(B)
+            if kind == "D":
+                t[:B // 2] = 1.0      # Y_NOT_GENERATOR = 1 for the real half (adversarial.lua:247), fakes 0 (:255)
+            else:
+                t[:] = 1.0            # targets:fill(Y_NOT_GENERATOR) (adversarial.lua:277)
+            self._targets[key] = t
+        return self._targets[key]
+
+    def _inputs_for(self, B):
+        if B not in self._inputs:
+            dn = self.dnD
+            self._inputs[B] = self.ctx.empty(B, dn.in_h, dn.in_w, dn.in_c)
+        return self._inputs[B]
+
+    def _allreduce(self, grads):
+        if self.world > 1:
+            self.dist.all_reduce(grads, op=self.dist.ReduceOp.SUM)
+
+    def _update(self, which, params, grads, f):
+        o = self.opt
+        l1, l2, clamp = o[which + "_L1"], o[which + "_L2"], o[which + "_clamp"]
+        if l1 == 0 and l2 == 0:
+            l1_mul = 0.0
+        else:
+            # adversarial.lua:109 (D: sign*D_L1) vs :223 (G: sign*G_L2 -- quirk C4, preserved)
+            l1_mul = l1 if which == "D" else l2
+        fused = dict(gscale=1.0 / self.world, l1_mul=l1_mul, l2=l2 if (l1 != 0 or l2 != 0) else 0.0, clamp=clamp)
+        method = o[which + "_optmethod"]
+        fn = dict(adam=IO.interruptableAdam, sgd=IO.interruptableSgd, adagrad=IO.interruptableAdagrad)[method]
+        fn(lambda x: (f, grads), params, self.optstate[method][which], fused=fused)
+
+    def penalty_f(self, which, params):
+        """f += L1*|p|_1 + L2*|p|_2^2/2 (adversarial.lua:105-106): only evaluated on request (host sync)."""
+        o = self.opt
+        l1, l2 = o[which + "_L1"], o[which + "_L2"]
+        if l1 == 0 and l2 == 0:
+            return 0.0
+        out, scr = self.ctx.empty(2), self.ctx.empty(1024)
+        self.ctx.check(self.ctx.lib.fg_norms(self.ctx.h, params.data_ptr(), params.numel(), out.data_ptr(),
+                                             scr.data_ptr()))
+        n1, n2 = out.tolist()
+        return l1 * n1 + l2 * n2 / 2
+
+    # -- the two closures ----------------------------------------------------------------------
+    def step_D(self, real_nhwc, noise_half, masks=None, keep_grad=False, gate=None):
+        """adversarial.lua:240-268 + fevalD (:83-179).  real_nhwc: device [B/2,H,W,C]; noise_half: [B/2,noiseDim].
+        gate(accuracy)->bool reproduces the maxAccuracyD interrupt (host sync only when a gate is given)."""
+        half = real_nhwc.shape[0]
+        B = 2 * half
+        fake = self.dnG.forward(noise_half, train=True)          # C5: G in TRAIN mode, BN batch stats over B/2
+        inputs = self._inputs_for(B)
+        inputs[:half].copy_(real_nhwc)
+        inputs[half:].copy_(fake)
+        targets = self._targets_for(B, "D")
+        out = self.dnD.forward(inputs, masks=masks, train=True)
+        loss, dprob, conf = self.crit.forward_backward_device(self.ctx, out.reshape(-1), targets)
+        self.dnD.backward(dprob.view(B, 1), param_grads=True, input_grad=False)
+        res = dict(loss=loss, outputs=out, confusion=conf)
+        pD, gD = self.dnD.params, self.dnD.grads
+        if keep_grad:   # parity/debug: the penalised + clamped gradient fevalD returns, and f with the penalty
+            g = gD.clone() / 1.0
+            o = self.opt
+            if o["D_L1"] != 0 or o["D_L2"] != 0:
+                g += torch.sign(pD) * o["D_L1"] + pD * o["D_L2"]
+            if o["D_clamp"] != 0:
+                g.clamp_(-o["D_clamp"], o["D_clamp"])
+            res["grad"] = g
+            res["f"] = loss.item() + self.penalty_f("D", pD)
+        do_train = True
+        if gate is not None:
+            c = conf.tolist()
+            acc = (c[0] + c[3]) / max(1, sum(c))     # [pred0,t0] + [pred1,t1]
+            do_train = gate(acc)
+        if do_train:
+            self._allreduce(gD)
+            self._update("D", pD, gD, loss)
+            self.dnD.params_changed()
+        res["trained"] = do_train
+        return res
+
+    def step_G(self, noise, masks=None, keep_grad=False):
+        """adversarial.lua:275-288 + fevalG_on_D (:187-231)."""
+        B = noise.shape[0]
+        samples = self.dnG.forward(noise, train=True)
+        targets = self._targets_for(B, "G")
+        out = self.dnD.forward(samples, masks=masks, train=True)
+        loss, dprob, _ = self.crit.forward_backward_device(self.ctx, out.reshape(-1), targets, want_confusion=False)
+        df_do = self.dnD.backward(dprob.view(B, 1), param_grads=False, input_grad=True)   # MODEL_D.modules[1].gradInput
+        self.dnG.backward(df_do, param_grads=True, input_grad=False)
+        res = dict(loss=loss, outputs=out, samples=samples)
+        pG, gG = self.dnG.params, self.dnG.grads
+        if keep_grad:
+            g = gG.clone()
+            o = self.opt
+            if o["G_L1"] != 0 or o["G_L2"] != 0:
+                g += torch.sign(pG) * o["G_L2"] + pG * o["G_L2"]
+            if o["G_clamp"] != 0:
+                g.clamp_(-o["G_clamp"], o["G_clamp"])
+            res["grad"] = g
+            res["f"] = loss.item() + self.penalty_f("G", pG)
+        self._allreduce(gG)
+        self._update("G", pG, gG, loss)
+        self.dnG.params_changed()
+        return res
+
+    def iteration(self, real_nhwc, seed_noise=None, D_iterations=1, G_iterations=1):
+        """One loop body of adversarial.lua:54-288 on device-resident inputs (used by bench.py)."""
+        B = 2 * real_nhwc.shape[0]
+        nd = self.dnG.in_c
+        for _ in range(D_iterations):
+            nz = S.next_noise(self.ctx, B // 2, nd)
+            self.step_D(real_nhwc, nz)
+        for _ in range(G_iterations):
+            nz = S.next_noise(self.ctx, B, nd)
+            self.step_G(nz)
+
+
+def mean(t):
+    """adversarial.mean (adversarial.lua:15-27)."""
+    v = [x for x in t if isinstance(x, (int, float))]
+    return sum(v) / len(v)
+
+
+accs = []
+
+
+def train(dataset, maxAccuracyD=1.01, accsInterval=20):
+    """adversarial.train(dataset, maxAccuracyD, accsInterval) -- adversarial.lua:30-335.  Reads the same globals
+    (OPT, MODEL_G, MODEL_D, IMG_DIMENSIONS, EPOCH, CONFUSION ...) from face_generator_amd.state.S."""
+    global accs
+    OPT = S.OPT
+    S.EPOCH = S.EPOCH or 1
+    N_epoch = OPT["N_epoch"]
+    if N_epoch <= 0:
+        N_epoch = dataset.size()
+    dataBatchSize = OPT["batchSize"] // 2
+    t0 = time.time()
+    tr = S.trainer()
+    ctx = tr.ctx
+    countTrainedD = countNotTrainedD = 0
+    conf_total = torch.zeros(4, dtype=torch.int64)
+    pending = []
+    print("<trainer> Epoch #%d [batchSize = %d]" % (S.EPOCH, OPT["batchSize"]))
+
+    def gate(acc):
+        accs.append(acc)
+        if len(accs) > accsInterval:
+            accs.pop(0)
+        return mean(accs) < maxAccuracyD
+    use_gate = maxAccuracyD <= 1.0
+
+    for t in range(1, N_epoch + 1, dataBatchSize):
+        thisBatchSize = min(OPT["batchSize"], N_epoch - t + 1)
+        if thisBatchSize < 4:
+            print("[INFO] skipping batch at t=%d, because its size is less than 4" % t)
+            break
+        thisBatchSize -= thisBatchSize % 2
+        half = thisBatchSize // 2
+        for _ in range(OPT.get("D_iterations", 1)):
+            idx = [S.rng.randrange(dataset.size()) for _ in range(half)]            # math.random picks (:245)
+            real = torch.stack([torch.as_tensor(dataset[i], dtype=torch.float32) for i in idx])
+            real_d = ctx.to_device_nhwc(real)
+            nz = S.next_noise(ctx, half, OPT["noiseDim"])
+            r = tr.step_D(real_d, nz, gate=gate if use_gate else None)
+            pending.append(r["confusion"])
+            if r["trained"]:
+                countTrainedD += 1
+            else:
+                countNotTrainedD += 1
+        for _ in range(OPT.get("G_iterations", 1)):
+            nz = S.next_noise(ctx, thisBatchSize, OPT["noiseDim"])
+            tr.step_G(nz)
+    for c in pending:                      # deferred: one host read at the end of the epoch
+        conf_total += c.cpu().to(torch.int64)
+    dt = time.time() - t0
+    print("<trainer> time required for this epoch = %d s" % dt)
+    print("<trainer> time to learn 1 sample = %f ms" % (1000 * dt / N_epoch))
+    print("<trainer> trained D %d of %d times." % (countTrainedD, countTrainedD + countNotTrainedD))
+    c = conf_total.tolist()
+    tV = (c[0] + c[3]) / max(1, sum(c))
+    print("Confusion of normal D: [pred][target] = %s  totalValid = %.4f" % (c, tV))
+    S.CONFUSION = c
+    if S.EPOCH % OPT.get("saveFreq", 30) == 0:
+        from . import nn_utils
+        nn_utils.save_checkpoint()
+    S.EPOCH += 1
+    return tV

@@ -1,0 +1,331 @@
+// C-ABI entry points of libfacegen_hip.so (declared in include/facegen_hip.h): context, memory,
+// optimizer / criterion / RNG and the module-level (nn.Module protocol) operator entries.
+#include "fg_internal.h"
+#include "conv_ops.h"
+#include "../../include/facegen_hip.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+static char g_err[512] = "";
+
+int fg_set_err(fg_ctx* c, int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c ? c->err : g_err, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define NEED(ctx, cond, msg) \
+    do { if (!(cond)) return fg_set_err((ctx), FG_ERR_INVALID, "%s: %s", __func__, msg); } while (0)
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+const char* fg_version(void) { return "facegen_hip 0.1 (gfx950)"; }
+
+int fg_ctx_create(int device, fg_ctx** out) {
+    if (!out) return fg_set_err(nullptr, FG_ERR_INVALID, "fg_ctx_create: null out");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fg_set_err(nullptr, FG_ERR_HIP, "fg_ctx_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fg_set_err(nullptr, FG_ERR_INVALID, "fg_ctx_create: device %d of %d", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fg_set_err(nullptr, FG_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fg_set_err(nullptr, FG_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fg_set_err(nullptr, FG_ERR_UNSUPPORTED, "fg_ctx_create: built for gfx950, device is %s", prop.gcnArchName);
+    fg_ctx* c = new fg_ctx();
+    c->device = device; c->stream = nullptr; c->err[0] = 0; c->sm_count = prop.multiProcessorCount;
+    *out = c;
+    return FG_OK;
+}
+int fg_ctx_destroy(fg_ctx* ctx) { delete ctx; return FG_OK; }
+int fg_ctx_set_stream(fg_ctx* ctx, void* s) { NEED(ctx, ctx, "null ctx"); ctx->stream = (hipStream_t)s; return FG_OK; }
+const char* fg_last_error(const fg_ctx* ctx) { return ctx ? ctx->err : g_err; }
+int fg_stream_sync(fg_ctx* ctx) { NEED(ctx, ctx, "null ctx"); FG_HIP(ctx, hipStreamSynchronize(ctx->stream)); return FG_OK; }
+int fg_malloc(fg_ctx* ctx, size_t bytes, void** out) {
+    NEED(ctx, ctx && out, "null argument");
+    if (hipMalloc(out, bytes) != hipSuccess) return fg_set_err(ctx, FG_ERR_NOMEM, "fg_malloc(%zu)", bytes);
+    return FG_OK;
+}
+int fg_free(fg_ctx* ctx, void* p) { NEED(ctx, ctx, "null ctx"); FG_HIP(ctx, hipFree(p)); return FG_OK; }
+int fg_h2d(fg_ctx* ctx, void* d, const void* s, size_t n) {
+    NEED(ctx, ctx && d && s, "null argument");
+    FG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, ctx->stream));
+    return FG_OK;
+}
+int fg_d2h(fg_ctx* ctx, void* d, const void* s, size_t n) {
+    NEED(ctx, ctx && d && s, "null argument");
+    FG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, ctx->stream));
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FG_OK;
+}
+int fg_d2d(fg_ctx* ctx, void* d, const void* s, size_t n) {
+    NEED(ctx, ctx && d && s, "null argument");
+    FG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, ctx->stream));
+    return FG_OK;
+}
+int fg_fill(fg_ctx* ctx, float* p, float v, long long n) { NEED(ctx, ctx && p && n >= 0, "bad argument"); return fg_launch_fill(ctx, p, v, n); }
+int fg_axpby(fg_ctx* ctx, float a, const float* x, float b, float* y, long long n) {
+    NEED(ctx, ctx && x && y && n >= 0, "bad argument");
+    return fg_launch_axpby(ctx, a, x, b, y, n);
+}
+int fg_nchw_to_nhwc(fg_ctx* ctx, const float* s, float* d, int n, int c, int h, int w) {
+    NEED(ctx, ctx && s && d && n >= 0 && c > 0 && h > 0 && w > 0, "bad argument");
+    return fg_launch_nchw_to_nhwc(ctx, s, d, n, c, h, w);
+}
+int fg_nhwc_to_nchw(fg_ctx* ctx, const float* s, float* d, int n, int c, int h, int w) {
+    NEED(ctx, ctx && s && d && n >= 0 && c > 0 && h > 0 && w > 0, "bad argument");
+    return fg_launch_nhwc_to_nchw(ctx, s, d, n, c, h, w);
+}
+int fg_rng_uniform(fg_ctx* ctx, uint64_t seed, uint64_t off, float* o, long long n, float lo, float hi) {
+    NEED(ctx, ctx && o && n >= 0, "bad argument");
+    return fg_launch_rng_uniform(ctx, seed, off, o, n, lo, hi);
+}
+int fg_rng_bernoulli(fg_ctx* ctx, uint64_t seed, uint64_t off, float* o, long long n, float keep) {
+    NEED(ctx, ctx && o && n >= 0 && keep >= 0.f && keep <= 1.f, "bad argument");
+    return fg_launch_rng_bernoulli(ctx, seed, off, o, n, keep);
+}
+int fg_rng_normal(fg_ctx* ctx, uint64_t seed, uint64_t off, float* o, long long n, float mean, float std) {
+    NEED(ctx, ctx && o && n >= 0, "bad argument");
+    return fg_launch_rng_normal(ctx, seed, off, o, n, mean, std);
+}
+
+int fg_bce_forward_backward(fg_ctx* ctx, const float* prob, const float* target, int n, float* loss, float* grad, int* conf) {
+    NEED(ctx, ctx && prob && target && n > 0, "bad argument");
+    return fg_launch_bce(ctx, prob, target, loss, grad, conf, n);
+}
+
+int fg_adam_fused(fg_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float gscale, float l1_mul,
+                  float l2, float clamp, float lr, float beta1, float beta2, float eps, int t, float* g_out) {
+    NEED(ctx, ctx && p && g && m && v && n >= 0 && t >= 1, "bad argument");
+    AdamArgs a; a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.gscale = gscale; a.l1 = 0.f; a.l1_mul = l1_mul; a.l2 = l2;
+    a.clamp = clamp; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.t = t; a.gout = g_out;
+    return fg_launch_adam(ctx, a);
+}
+int fg_sgd_fused(fg_ctx* ctx, float* p, const float* g, float* mom, long long n, float gscale, float l1_mul, float l2,
+                 float clamp, float lr, float momentum, float dampening, float wd, int nesterov, int first) {
+    NEED(ctx, ctx && p && g && n >= 0 && (momentum == 0.f || mom), "bad argument");
+    return fg_launch_sgd(ctx, p, g, mom, n, gscale, l1_mul, l2, clamp, lr, momentum, dampening, wd, nesterov, first);
+}
+int fg_adagrad_fused(fg_ctx* ctx, float* p, const float* g, float* var, long long n, float gscale, float l1_mul, float l2,
+                     float clamp, float clr) {
+    NEED(ctx, ctx && p && g && var && n >= 0, "bad argument");
+    return fg_launch_adagrad(ctx, p, g, var, n, gscale, l1_mul, l2, clamp, clr);
+}
+int fg_norms(fg_ctx* ctx, const float* p, long long n, float* out2, float* scratch) {
+    NEED(ctx, ctx && p && out2 && scratch && n >= 0, "bad argument");
+    return fg_launch_norms(ctx, p, n, out2, scratch);
+}
+
+// ---------------------------------------------------------------- module-level conv / linear
+static bool thin_in(int cin, int cout) { return cin <= 4 && cout % 64 == 0; }
+static bool thin_out(int cin, int cout) { return cout <= 4 && cin % 64 == 0; }
+static ConvGeom mk_geom(int b, int h, int w, int cin, int cout, int k, int pad, int up) {
+    ConvGeom g; memset(&g, 0, sizeof(g));
+    g.B = b; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout; g.k = k; g.pad = pad; g.fold = up;
+    return g;
+}
+static inline long long a64(long long v) { return (v + 63) / 64 * 64; }
+
+size_t fg_conv2d_workspace_bytes(int batch, int h, int w, int cin, int cout, int k, int up) {
+    if (thin_in(cin, cout) || thin_out(cin, cout)) {
+        const long long na = (long long)k * k * (cin <= 4 ? cin : cout), cw = cin <= 4 ? cout : cin;
+        return (size_t)(a64((long long)cin * cout * k * k) + 257 * na * cw + 258LL * (cout > 64 ? cout : 64) + 256) * 4;
+    }
+    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, (k - 1) / 2, up);
+    long long pf = fg_geom_pack_floats(g, 0), pb = fg_geom_pack_floats(g, 1);
+    return (size_t)(a64(pf > pb ? pf : pb) + fg_conv_scratch_floats(g) + 64) * sizeof(float);
+}
+static int conv_check(fg_ctx* ctx, int cin, int cout, int k, int pad, int up) {
+    if (k % 2 != 1 || pad != (k - 1) / 2) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: only odd-k 'same' stride-1");
+    if (thin_in(cin, cout) || thin_out(cin, cout)) {
+        if (up) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: upsample fold on a thin conv");
+        return FG_OK;
+    }
+    if (cin % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: nInputPlane %% 4 != 0");
+    if (k * k * (up ? 4 : 1) > FG_MAX_GROUPS && up) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: fold groups");
+    return FG_OK;
+}
+
+int fg_conv2d_forward(fg_ctx* ctx, const float* x, const float* wt, const float* bias, float* y, int batch, int h,
+                      int w, int cin, int cout, int k, int pad, int up, void* wsv, size_t ws_bytes) {
+    NEED(ctx, ctx && x && wt && y && wsv, "null argument");
+    int rc = conv_check(ctx, cin, cout, k, pad, up);
+    if (rc) return rc;
+    if (ws_bytes < fg_conv2d_workspace_bytes(batch, h, w, cin, cout, k, up)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv2d: workspace");
+    float* ws = (float*)wsv;
+    if (thin_in(cin, cout)) {
+        if ((rc = fg_launch_thin_pack(ctx, wt, ws, cout, cin, k, 0))) return rc;
+        return fg_launch_thin_in_conv(ctx, x, ws, bias, y, batch, h, w, cin, cout, k, 0);
+    }
+    if (thin_out(cin, cout)) {
+        if ((rc = fg_launch_thin_pack(ctx, wt, ws, cout, cin, k, 1))) return rc;
+        return fg_launch_thin_out_conv(ctx, x, ws, bias, y, batch, h, w, cin, cout, k, 0, 0);
+    }
+    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, pad, up);
+    const long long pf = a64(fg_geom_pack_floats(g, 0));
+    if ((rc = fg_conv_pack(ctx, g, wt, ws, nullptr))) return rc;
+    return fg_conv_forward_run(ctx, g, x, ws, bias, y, ws + pf, (long long)(ws_bytes / 4) - pf);
+}
+int fg_conv2d_backward_data(fg_ctx* ctx, const float* gy, const float* wt, float* gx, int batch, int h, int w, int cin,
+                            int cout, int k, int pad, int up, void* wsv, size_t ws_bytes) {
+    NEED(ctx, ctx && gy && wt && gx && wsv, "null argument");
+    int rc = conv_check(ctx, cin, cout, k, pad, up);
+    if (rc) return rc;
+    if (ws_bytes < fg_conv2d_workspace_bytes(batch, h, w, cin, cout, k, up)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv2d: workspace");
+    float* ws = (float*)wsv;
+    if (thin_in(cin, cout)) {  // dX (thin) from dY (wide)
+        if ((rc = fg_launch_thin_pack(ctx, wt, ws, cout, cin, k, 0))) return rc;
+        return fg_launch_thin_out_conv(ctx, gy, ws, nullptr, gx, batch, h, w, cout, cin, k, 1, 0);
+    }
+    if (thin_out(cin, cout)) {
+        if ((rc = fg_launch_thin_pack(ctx, wt, ws, cout, cin, k, 1))) return rc;
+        return fg_launch_thin_in_conv(ctx, gy, ws, nullptr, gx, batch, h, w, cout, cin, k, 1);
+    }
+    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, pad, up);
+    const long long pb = a64(fg_geom_pack_floats(g, 1));
+    if ((rc = fg_conv_pack(ctx, g, wt, nullptr, ws))) return rc;
+    return fg_conv_dgrad_run(ctx, g, gy, ws, gx, ws + pb, (long long)(ws_bytes / 4) - pb);
+}
+int fg_conv2d_backward_weight(fg_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, float beta, int batch,
+                              int h, int w, int cin, int cout, int k, int pad, int up, void* wsv, size_t ws_bytes) {
+    NEED(ctx, ctx && x && gy && gw && wsv, "null argument");
+    int rc = conv_check(ctx, cin, cout, k, pad, up);
+    if (rc) return rc;
+    if (ws_bytes < fg_conv2d_workspace_bytes(batch, h, w, cin, cout, k, up)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv2d: workspace");
+    float* ws = (float*)wsv;
+    if (thin_in(cin, cout) || thin_out(cin, cout)) {
+        const bool tin = thin_in(cin, cout);
+        const int cs = tin ? cin : cout, cw = tin ? cout : cin;
+        float* gwt = ws + (long long)256 * k * k * cs * cw;
+        rc = tin ? fg_launch_thin_wgrad(ctx, x, gy, gwt, batch, h, w, cs, cw, k, +1, ws)
+                 : fg_launch_thin_wgrad(ctx, gy, x, gwt, batch, h, w, cs, cw, k, -1, ws);
+        if (rc) return rc;
+        if ((rc = fg_launch_thin_unpack_grad(ctx, gwt, gw, cout, cin, k, tin ? 0 : 1, beta))) return rc;
+        if (gb) return fg_launch_colsum(ctx, gy, (long long)batch * h * w, cout, beta, gb, ws);
+        return FG_OK;
+    }
+    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, pad, up);
+    return fg_conv_wgrad_run(ctx, g, x, gy, gw, gb, beta, ws, (long long)(ws_bytes / 4));
+}
+
+size_t fg_linear_workspace_bytes(int batch, int in_f, int out_f) {
+    ConvGeom g = mk_geom(batch, 1, 1, in_f, out_f, 1, 0, 0);
+    long long pf = fg_geom_pack_floats(g, 0), pb = fg_geom_pack_floats(g, 1);
+    return (size_t)(a64(pf > pb ? pf : pb) + fg_conv_scratch_floats(g) + 64) * sizeof(float);
+}
+int fg_linear_forward(fg_ctx* ctx, const float* x, const float* wt, const float* bias, float* y, int batch, int in_f,
+                      int out_f, void* wsv, size_t ws_bytes) {
+    NEED(ctx, ctx && x && wt && y && wsv, "null argument");
+    if (in_f % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "linear: in_features %% 4 != 0");
+    if (ws_bytes < fg_linear_workspace_bytes(batch, in_f, out_f)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "linear: workspace");
+    if (out_f == 1) return fg_launch_gemv_forward(ctx, x, wt, bias, y, batch, in_f, 0);
+    ConvGeom g = mk_geom(batch, 1, 1, in_f, out_f, 1, 0, 0);
+    float* ws = (float*)wsv;
+    const long long pf = a64(fg_geom_pack_floats(g, 0));
+    int rc = fg_conv_pack(ctx, g, wt, ws, nullptr);
+    if (rc) return rc;
+    return fg_conv_forward_run(ctx, g, x, ws, bias, y, ws + pf, (long long)(ws_bytes / 4) - pf);
+}
+int fg_linear_backward_data(fg_ctx* ctx, const float* gy, const float* wt, float* gx, int batch, int in_f, int out_f,
+                            void* wsv, size_t ws_bytes) {
+    NEED(ctx, ctx && gy && wt && gx && wsv, "null argument");
+    if (out_f % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "linear dgrad: out_features %% 4 != 0");
+    if (ws_bytes < fg_linear_workspace_bytes(batch, in_f, out_f)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "linear: workspace");
+    ConvGeom g = mk_geom(batch, 1, 1, in_f, out_f, 1, 0, 0);
+    float* ws = (float*)wsv;
+    const long long pb = a64(fg_geom_pack_floats(g, 1));
+    int rc = fg_conv_pack(ctx, g, wt, nullptr, ws);
+    if (rc) return rc;
+    return fg_conv_dgrad_run(ctx, g, gy, ws, gx, ws + pb, (long long)(ws_bytes / 4) - pb);
+}
+int fg_linear_backward_weight(fg_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, float beta, int batch,
+                              int in_f, int out_f, void* wsv, size_t ws_bytes) {
+    NEED(ctx, ctx && x && gy && gw && wsv, "null argument");
+    if (in_f % 4 || out_f % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "linear wgrad: features %% 4 != 0");
+    if (ws_bytes < fg_linear_workspace_bytes(batch, in_f, out_f)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "linear: workspace");
+    ConvGeom g = mk_geom(batch, 1, 1, in_f, out_f, 1, 0, 0);
+    return fg_conv_wgrad_run(ctx, g, x, gy, gw, gb, beta, (float*)wsv, (long long)(ws_bytes / 4));
+}
+
+// ---------------------------------------------------------------- module-level pointwise
+long long fg_bn_scratch_floats(int c) { return (long long)3 * CR_ROWBLOCKS_MAX * c + 2 * c + 64; }
+int fg_batchnorm_forward(fg_ctx* ctx, const float* x, float* y, long long rows, int c, const float* gamma,
+                         const float* beta, const float* slope, float* save_mean, float* save_invstd, float* rmean,
+                         float* rvar, float eps, float momentum, int train, float* scratch) {
+    NEED(ctx, ctx && x && y && gamma && beta && save_mean && save_invstd && scratch && rows > 0, "bad argument");
+    NEED(ctx, train || (rmean && rvar), "evaluate mode needs running stats");
+    BnArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y; a.M = rows; a.C = c; a.gamma = gamma; a.beta = beta; a.slope = slope; a.mean = save_mean;
+    a.invstd = save_invstd; a.running_mean = rmean; a.running_var = rvar; a.eps = eps; a.momentum = momentum;
+    a.train = train; a.scratch = scratch;
+    return fg_launch_bn_forward(ctx, a);
+}
+int fg_batchnorm_backward(fg_ctx* ctx, const float* x, const float* gy, float* gx, long long rows, int c,
+                          const float* gamma, const float* beta, const float* slope, const float* save_mean,
+                          const float* save_invstd, float* ggamma, float* gbeta, float* gslope, float acc, float* scratch) {
+    NEED(ctx, ctx && x && gy && gamma && beta && save_mean && save_invstd && scratch && rows > 0, "bad argument");
+    BnBwdArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.gy = gy; a.gx = gx; a.M = rows; a.C = c; a.gamma = gamma; a.beta = beta; a.slope = slope;
+    a.mean = save_mean; a.invstd = save_invstd; a.ggamma = ggamma; a.gbeta = gbeta; a.gslope = gslope; a.gbeta_acc = acc;
+    a.scratch = scratch;
+    return fg_launch_bn_backward(ctx, a);
+}
+int fg_prelu_forward(fg_ctx* ctx, const float* x, const float* slope, const float* mask, float mscale, float* y, long long n) {
+    NEED(ctx, ctx && x && slope && y && n >= 0, "bad argument");
+    return fg_launch_prelu_forward(ctx, x, slope, mask, mscale, y, n);
+}
+int fg_prelu_backward(fg_ctx* ctx, const float* x, const float* gy, const float* slope, const float* mask, float mscale,
+                      float* gx, float* gslope, float acc, long long n, float* scratch) {
+    NEED(ctx, ctx && x && gy && slope && scratch && n >= 0, "bad argument");
+    return fg_launch_prelu_backward(ctx, x, gy, slope, mask, mscale, gx, gslope, acc, n, scratch);
+}
+int fg_actpool_forward(fg_ctx* ctx, const float* x, const float* slope, const float* mask, float mscale, float* y,
+                       int batch, int h, int w, int c) {
+    NEED(ctx, ctx && x && y, "null argument");
+    return fg_launch_actpool_forward(ctx, x, slope, mask, mscale, y, batch, h, w, c);
+}
+int fg_actpool_backward(fg_ctx* ctx, const float* x, const float* gy, const float* slope, const float* mask, float mscale,
+                        float* gx, float* gslope, float acc, int batch, int h, int w, int c, float* scratch) {
+    NEED(ctx, ctx && x && gy && scratch, "null argument");
+    return fg_launch_actpool_backward(ctx, x, gy, slope, mask, mscale, gx, gslope, acc, batch, h, w, c, scratch);
+}
+int fg_spatial_dropout_apply(fg_ctx* ctx, const float* x, const float* mask, float mscale, float* y, int batch, int hw, int c) {
+    NEED(ctx, ctx && x && y, "null argument");
+    return fg_launch_scale_mask_nc(ctx, x, mask, mscale, y, batch, hw, c);
+}
+int fg_avgpool2x2_forward(fg_ctx* ctx, const float* x, float* y, int b, int h, int w, int c) {
+    NEED(ctx, ctx && x && y && h % 2 == 0 && w % 2 == 0, "bad argument");
+    return fg_launch_avgpool_forward(ctx, x, y, b, h, w, c);
+}
+int fg_avgpool2x2_backward(fg_ctx* ctx, const float* gy, float* gx, int b, int h, int w, int c) {
+    NEED(ctx, ctx && gy && gx && h % 2 == 0 && w % 2 == 0, "bad argument");
+    return fg_launch_avgpool_backward(ctx, gy, gx, b, h, w, c);
+}
+int fg_upsample_nearest2x_forward(fg_ctx* ctx, const float* x, float* y, int b, int h, int w, int c) {
+    NEED(ctx, ctx && x && y, "null argument");
+    return fg_launch_upsample_forward(ctx, x, y, b, h, w, c);
+}
+int fg_upsample_nearest2x_backward(fg_ctx* ctx, const float* gy, float* gx, int b, int h, int w, int c) {
+    NEED(ctx, ctx && gy && gx, "null argument");
+    return fg_launch_upsample_backward(ctx, gy, gx, b, h, w, c);
+}
+int fg_sigmoid_forward(fg_ctx* ctx, const float* x, float* y, long long n) { NEED(ctx, ctx && x && y, "null argument"); return fg_launch_sigmoid_forward(ctx, x, y, n); }
+int fg_sigmoid_backward(fg_ctx* ctx, const float* y, const float* gy, float* gx, long long n) {
+    NEED(ctx, ctx && y && gy && gx, "null argument");
+    return fg_launch_sigmoid_backward(ctx, y, gy, gx, n);
+}
+int fg_leakyrelu_forward(fg_ctx* ctx, const float* x, float s, float* y, long long n) { NEED(ctx, ctx && x && y, "null argument"); return fg_launch_leakyrelu_forward(ctx, x, s, y, n); }
+int fg_leakyrelu_backward(fg_ctx* ctx, const float* x, const float* gy, float s, float* gx, long long n) {
+    NEED(ctx, ctx && x && gy && gx, "null argument");
+    return fg_launch_leakyrelu_backward(ctx, x, gy, s, gx, n);
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -1,0 +1,27 @@
+// Reference-geometry description of one conv / Linear layer and the host drivers around the MFMA kernels.
+#pragma once
+#include "fg_internal.h"
+
+#define CR_ROWBLOCKS_MAX 256
+
+struct ConvGeom {
+    int B;          // batch
+    int H, W;       // input spatial size (source resolution: BEFORE the folded nearest-x2 upsample). Linear: 1,1
+    int Cin, Cout;  // reference nInputPlane / nOutputPlane (Linear: in / out features)
+    int k, pad;     // odd k, "same" pad = (k-1)/2. Linear: 1, 0
+    int fold;       // 1: an nn.SpatialUpSamplingNearest(2) in front of the conv is folded into its taps
+    // Linear next to an nn.View: NCHW-flatten <-> NHWC-memory feature permutation (0 = none)
+    int o_c, o_hw, i_c, i_hw;
+};
+
+void fg_geom_weightmap(const ConvGeom& g, WeightMap* wm);
+void fg_geom_pack_dims(const ConvGeom& g, int* rows_f, int* cols_f, int* rows_b, int* cols_b);
+long long fg_geom_pack_floats(const ConvGeom& g, int bwd);
+long long fg_conv_scratch_floats(const ConvGeom& g);
+int fg_conv_pack(fg_ctx* ctx, const ConvGeom& g, const float* W, float* wp_fwd, float* wp_bwd);
+int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* wp_fwd, const float* bias,
+                        float* y, float* scratch, long long scratch_floats);
+int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const float* wp_bwd, float* gx, float* scratch,
+                      long long scratch_floats);
+int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* gy, float* gradW, float* gradb,
+                      float beta, float* scratch, long long scratch_floats);

@@ -1,0 +1,236 @@
+// Host-side drivers that turn a convolution / Linear layer (reference geometry) into launches of the
+// igemm / wgrad kernels: group-offset tables, nearest-x2 tap folding, tile and split heuristics.
+#include "fg_internal.h"
+#include "conv_ops.h"
+#include <string.h>
+
+static inline int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+void fg_geom_weightmap(const ConvGeom& g, WeightMap* wm) {
+    memset(wm, 0, sizeof(*wm));
+    wm->O = g.Cout; wm->I = g.Cin; wm->k = g.k; wm->pad = g.pad;
+    wm->o_c = g.o_c; wm->o_hw = g.o_hw; wm->i_c = g.i_c; wm->i_hw = g.i_hw;
+    if (g.fold) {
+        wm->kind = 1;
+        fg_fold_window(g.k, g.pad, &wm->T, &wm->rmin);
+        wm->G = wm->T * wm->T;
+        wm->P = 4;
+    } else {
+        wm->kind = 0;
+        wm->T = g.k; wm->rmin = -g.pad;
+        wm->G = g.k * g.k;
+        wm->P = 1;
+    }
+}
+
+static inline int pad_rows(int n) { return n < 128 ? fg_round_up(n, 64) : fg_round_up(n, 128); }
+
+void fg_geom_pack_dims(const ConvGeom& g, int* rows_f, int* cols_f, int* rows_b, int* cols_b) {
+    *rows_f = pad_rows(g.Cout); *cols_f = fg_round_up(g.Cin, 32);
+    *rows_b = pad_rows(g.Cin);  *cols_b = fg_round_up(g.Cout, 32);
+}
+long long fg_geom_pack_floats(const ConvGeom& g, int bwd) {
+    WeightMap wm; fg_geom_weightmap(g, &wm);
+    int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
+    return (long long)wm.P * wm.G * (bwd ? (long long)rb * cb : (long long)rf * cf);
+}
+
+int fg_conv_pack(fg_ctx* ctx, const ConvGeom& g, const float* W, float* wp_fwd, float* wp_bwd) {
+    WeightMap wm; fg_geom_weightmap(g, &wm);
+    int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
+    int rc;
+    if (wp_fwd && (rc = fg_launch_pack_weights(ctx, wm, 0, W, wp_fwd, rf, cf))) return rc;
+    if (wp_bwd && (rc = fg_launch_pack_weights(ctx, wm, 1, W, wp_bwd, rb, cb))) return rc;
+    return FG_OK;
+}
+
+// ---- tile / split heuristics: fill >= 2 blocks per CU (256 CUs) where the problem allows ----
+static void choose_igemm(long long M, int Npad, int G, int P, int* tile, int* splits) {
+    const long long target = 512;
+    long long b0 = (Npad % 128 == 0) ? (long long)fg_cdiv(M, 128) * (Npad / 128) * P : 0;
+    long long b1 = (long long)fg_cdiv(M, 128) * (Npad / 64) * P;
+    long long b2 = (long long)fg_cdiv(M, 64) * (Npad / 64) * P;
+    *splits = 1;
+    if (b0 >= target) { *tile = 0; return; }
+    if (b1 >= target) { *tile = 1; return; }
+    *tile = 2;
+    if (b2 < 384 && G > 1) {
+        int s = fg_cdiv(target, b2 > 0 ? b2 : 1);
+        if (s > G) s = G;
+        if (s > 12) s = 12;
+        // make every split non-empty
+        int gper = (G + s - 1) / s;
+        s = (G + gper - 1) / gper;
+        *splits = s;
+    }
+}
+static void choose_wgrad(long long M, int Cout, int Cin, int G, int P, int* tile, int* S, int* mper, int* Npad, int* Cpad) {
+    int bt = (Cout >= 128 && Cin >= 128) ? 128 : 64;
+    *tile = bt == 128 ? 0 : 2;
+    *Npad = fg_round_up(Cout, bt);
+    *Cpad = fg_round_up(Cin, bt);
+    long long base = (long long)(*Npad / bt) * (*Cpad / bt) * G * P;
+    long long s = (768 + base - 1) / base;
+    long long maxs = (M + 63) / 64;  // at least 2 K-steps per split
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    int mp = fg_round_up((int)((M + s - 1) / s), 32);
+    *mper = mp;
+    *S = (int)((M + mp - 1) / mp);
+}
+
+long long fg_conv_scratch_floats(const ConvGeom& g) {
+    WeightMap wm; fg_geom_weightmap(g, &wm);
+    const long long M = (long long)g.B * g.H * g.W;  // source-resolution M-space
+    long long need = 0;
+    int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
+    int tile, splits;
+    choose_igemm(M, rf, wm.G, wm.P, &tile, &splits);
+    const long long outM = g.fold ? M * 4 : M;
+    if (splits > 1) need = (long long)splits * outM * g.Cout;
+    choose_igemm(M, rb, wm.G * wm.P, 1, &tile, &splits);
+    if (splits > 1) { long long n2 = (long long)splits * M * g.Cin; if (n2 > need) need = n2; }
+    int wt, S, mper, Np, Cp;
+    choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
+    long long n3 = (long long)wm.P * wm.G * S * Np * Cp;
+    if (n3 > need) need = n3;
+    long long n4 = (long long)(CR_ROWBLOCKS_MAX + 2) * g.Cout;
+    if (n4 > need) need = n4;
+    return need + 64;
+}
+
+static void fill_mspace(IgemmArgs& a, int B, int H, int W) {
+    a.Nb = B; a.Hm = H; a.Wm = W; a.M = B * H * W;
+    a.lgH = ilog2_exact(H); a.lgW = ilog2_exact(W);
+    if (a.lgH < 0 || a.lgW < 0) a.lgH = a.lgW = -1;
+}
+
+int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* wp_fwd, const float* bias,
+                        float* y, float* scratch, long long scratch_floats) {
+    if (g.B == 0) return FG_OK;
+    WeightMap wm; fg_geom_weightmap(g, &wm);
+    int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
+    IgemmArgs a; memset(&a, 0, sizeof(a));
+    fill_mspace(a, g.B, g.H, g.W);
+    a.A = x; a.Bp = wp_fwd; a.bias = bias; a.Out = y;
+    a.Ha = g.H; a.Wa = g.W; a.Ca = g.Cin; a.Kpad = cf; a.asy = a.asx = 1;
+    a.N = g.Cout; a.G = wm.G; a.Npad = rf;
+    if (g.fold) {
+        a.Ho = 2 * g.H; a.Wo = 2 * g.W; a.osy = a.osx = 2;
+        for (int p = 0; p < 4; ++p) {
+            a.ooy[p] = (signed char)(p >> 1); a.oox[p] = (signed char)(p & 1);
+            for (int t = 0; t < wm.G; ++t) {
+                a.aoy[p][t] = (signed char)(t / wm.T + wm.rmin);
+                a.aox[p][t] = (signed char)(t % wm.T + wm.rmin);
+            }
+        }
+    } else {
+        a.Ho = g.H; a.Wo = g.W; a.osy = a.osx = 1;
+        for (int t = 0; t < wm.G; ++t) {
+            a.aoy[0][t] = (signed char)(t / g.k - g.pad);
+            a.aox[0][t] = (signed char)(t % g.k - g.pad);
+        }
+    }
+    int tile, splits;
+    choose_igemm(a.M, rf, wm.G, wm.P, &tile, &splits);
+    const long long out_count = (long long)a.M * (g.fold ? 4 : 1) * g.Cout;
+    a.splits = splits;
+    if (splits > 1) {
+        if ((long long)splits * out_count > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv fwd: scratch");
+        a.Out = scratch; a.split_stride = out_count;
+    }
+    int rc = fg_launch_igemm(ctx, a, wm.P, tile);
+    if (rc) return rc;
+    if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, bias, g.Cout, y, out_count);
+    return FG_OK;
+}
+
+int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const float* wp_bwd, float* gx, float* scratch,
+                      long long scratch_floats) {
+    if (g.B == 0) return FG_OK;
+    WeightMap wm; fg_geom_weightmap(g, &wm);
+    int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
+    IgemmArgs a; memset(&a, 0, sizeof(a));
+    fill_mspace(a, g.B, g.H, g.W);
+    a.A = gy; a.Bp = wp_bwd; a.bias = nullptr; a.Out = gx;
+    a.Ca = g.Cout; a.Kpad = cb;
+    a.Ho = g.H; a.Wo = g.W; a.osy = a.osx = 1; a.N = g.Cin; a.Npad = rb;
+    a.G = wm.G * wm.P;
+    if (a.G > FG_MAX_GROUPS) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv dgrad: %d groups", a.G);
+    if (g.fold) {
+        a.Ha = 2 * g.H; a.Wa = 2 * g.W; a.asy = a.asx = 2;
+        for (int p = 0; p < 4; ++p)
+            for (int t = 0; t < wm.G; ++t) {
+                const int ry = t / wm.T + wm.rmin, rx = t % wm.T + wm.rmin;
+                a.aoy[0][p * wm.G + t] = (signed char)((p >> 1) - 2 * ry);
+                a.aox[0][p * wm.G + t] = (signed char)((p & 1) - 2 * rx);
+            }
+    } else {
+        a.Ha = g.H; a.Wa = g.W; a.asy = a.asx = 1;
+        for (int t = 0; t < wm.G; ++t) {
+            a.aoy[0][t] = (signed char)(g.pad - t / g.k);
+            a.aox[0][t] = (signed char)(g.pad - t % g.k);
+        }
+    }
+    int tile, splits;
+    choose_igemm(a.M, rb, a.G, 1, &tile, &splits);
+    const long long out_count = (long long)a.M * g.Cin;
+    a.splits = splits;
+    if (splits > 1) {
+        if ((long long)splits * out_count > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv dgrad: scratch");
+        a.Out = scratch; a.split_stride = out_count;
+    }
+    int rc = fg_launch_igemm(ctx, a, 1, tile);
+    if (rc) return rc;
+    if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, nullptr, g.Cin, gx, out_count);
+    return FG_OK;
+}
+
+int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* gy, float* gradW, float* gradb,
+                      float beta, float* scratch, long long scratch_floats) {
+    if (g.B == 0) return FG_OK;
+    WeightMap wm; fg_geom_weightmap(g, &wm);
+    WgradArgs a; memset(&a, 0, sizeof(a));
+    a.dY = gy; a.X = x; a.Part = scratch;
+    a.Nb = g.B; a.Hm = g.H; a.Wm = g.W; a.M = g.B * g.H * g.W;
+    a.lgH = ilog2_exact(g.H); a.lgW = ilog2_exact(g.W);
+    if (a.lgH < 0 || a.lgW < 0) a.lgH = a.lgW = -1;
+    a.Nd = g.Cout; a.Cx = g.Cin; a.Hx = g.H; a.Wx = g.W; a.xsy = a.xsx = 1;
+    a.G = wm.G;
+    if (g.fold) {
+        a.Hd = 2 * g.H; a.Wd = 2 * g.W; a.dsy = a.dsx = 2;
+        for (int p = 0; p < 4; ++p) {
+            a.doy[p] = (signed char)(p >> 1); a.dox[p] = (signed char)(p & 1);
+            for (int t = 0; t < wm.G; ++t) {
+                a.xoy[p][t] = (signed char)(t / wm.T + wm.rmin);
+                a.xox[p][t] = (signed char)(t % wm.T + wm.rmin);
+            }
+        }
+    } else {
+        a.Hd = g.H; a.Wd = g.W; a.dsy = a.dsx = 1;
+        for (int t = 0; t < wm.G; ++t) {
+            a.xoy[0][t] = (signed char)(t / g.k - g.pad);
+            a.xox[0][t] = (signed char)(t % g.k - g.pad);
+        }
+    }
+    int tile;
+    choose_wgrad(a.M, g.Cout, g.Cin, wm.G, wm.P, &tile, &a.S, &a.m_per_split, &a.Npad, &a.Cpad);
+    const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;
+    if (need > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad: scratch %lld > %lld", need, scratch_floats);
+    int rc = fg_launch_wgrad(ctx, a, wm.P, tile);
+    if (rc) return rc;
+    if ((rc = fg_launch_wgrad_finish(ctx, wm, scratch, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
+    if (gradb) {
+        // bias grad = column sums of gy over all output pixels
+        const long long rows = (long long)a.M * (g.fold ? 4 : 1);
+        if ((long long)CR_ROWBLOCKS_MAX * g.Cout > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "bias grad: scratch");
+        if ((rc = fg_launch_colsum(ctx, gy, rows, g.Cout, beta, gradb, scratch))) return rc;
+    }
+    return FG_OK;
+}

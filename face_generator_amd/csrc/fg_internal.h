@@ -1,0 +1,197 @@
+// Internal declarations shared by the HIP translation units of libfacegen_hip.so.
+// gfx950 (MI355X / CDNA4) only.  All device tensors are fp32, activations NHWC.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/facegen_hip.h"
+
+#define FG_MAX_GROUPS 64   // (parity,tap) groups per launch table (7x7 plain = 49, folded dgrad = 36)
+
+struct fg_ctx {
+    int device;
+    hipStream_t stream;
+    char err[512];
+    int sm_count;
+};
+
+
+int fg_set_err(fg_ctx* c, int code, const char* fmt, ...);
+#define FG_HIP(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return fg_set_err((ctx), FG_ERR_HIP, "%s: %s (%s:%d)", #call,              \
+                              hipGetErrorString(e_), __FILE__, __LINE__);              \
+    } while (0)
+#define FG_CHECK_LAUNCH(ctx) FG_HIP(ctx, hipGetLastError())
+
+static inline int fg_round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int fg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------
+// Implicit-GEMM (gather-A) contraction:  Out[m][n] = bias[n] + sum_{g,c} A[pix(m,g)][c] * Bp[g][n][c]
+//   m runs over an "M-space" of pixels (Nb x Hm x Wm); group g = one (parity,tap) with an
+//   integer pixel offset into the A image; out-of-range A pixels read as zero.
+//   Covers conv forward, conv data-grad, nearest-x2-folded conv forward / data-grad and
+//   Linear forward / data-grad (Hm = Wm = 1, G = 1).
+// ---------------------------------------------------------------------------------
+struct IgemmArgs {
+    const float* A;      // NHWC [Nb][Ha][Wa][Ca]
+    const float* Bp;     // packed [P][G][Npad][Kpad]  (row = output channel, contiguous k)
+    const float* bias;   // [N] or nullptr
+    float* Out;          // NHWC [Nb][Ho][Wo][N]  (or [splits][...] partials)
+    int Nb, Hm, Wm, M;   // M = Nb*Hm*Wm
+    int lgH, lgW;        // log2(Hm), log2(Wm) if both are powers of two, else -1
+    int Ha, Wa, Ca, Kpad;
+    int asy, asx;        // A coord = y*asy + aoy[p][g]
+    int Ho, Wo, N;
+    int osy, osx;        // out coord = y*osy + ooy[p]
+    int G, Npad;
+    int splits;          // split-K over groups (gridDim.y); partials at Out + s*split_stride
+    long long split_stride;
+    signed char aoy[4][FG_MAX_GROUPS], aox[4][FG_MAX_GROUPS];
+    signed char ooy[4], oox[4];
+};
+// tile: 0 = 128x128, 1 = 128x64, 2 = 64x64.  P = gridDim.z parities.
+int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a, int P, int tile);
+// sums split partials (+bias) : out[i] = bias[i % N] + sum_s part[s*stride + i]
+int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long stride, const float* bias,
+                         int N, float* out, long long count);
+
+// ---------------------------------------------------------------------------------
+// Weight-gradient contraction: Part[pg][s][n][c] = sum_{m in split s} dY[pixd(m,p)][n] * X[pixx(m,pg)][c]
+// ---------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* dY;     // NHWC [Nb][Hd][Wd][Nd]
+    const float* X;      // NHWC [Nb][Hx][Wx][Cx]
+    float* Part;         // [P*G][S][Npad][Cpad]
+    int Nb, Hm, Wm, M, lgH, lgW;
+    int Hd, Wd, Nd, dsy, dsx;
+    int Hx, Wx, Cx, xsy, xsx;
+    int G, S, Npad, Cpad;
+    int m_per_split;     // multiple of 32
+    signed char doy[4], dox[4];
+    signed char xoy[4][FG_MAX_GROUPS], xox[4][FG_MAX_GROUPS];
+};
+int fg_launch_wgrad(fg_ctx* ctx, const WgradArgs& a, int P, int tile);  // tile: 0 = 128x128, 2 = 64x64
+
+// Reference-layout <-> packed-layout description of one weight tensor.
+struct WeightMap {
+    int kind;            // 0 = plain conv / linear (k=1), 1 = nearest-x2 folded conv
+    int O, I, k, pad;    // reference W[O][I][k][k]
+    int T, rmin;         // folded: window T x T, r = t + rmin
+    int G;               // groups per parity (k*k plain, T*T folded)
+    int P;               // parities (1 plain, 4 folded)
+    // feature permutations for Linear next to a View (NCHW flatten <-> NHWC memory):
+    int o_c, o_hw;       // if o_hw > 1: ref row o = c*o_hw + hw  <->  packed row = hw*o_c + c
+    int i_c, i_hw;       // same for columns
+};
+// mode 0: forward pack  Bp[p][g][O_pad][I_pad]; mode 1: data-grad pack Bp[g'][I_pad][O_pad]
+int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const float* W, float* Bp, int rows_pad,
+                           int cols_pad);
+// gradW_ref = beta*gradW_ref + sum over splits / parities of Part ([P*G][S][Npad][Cpad], n = O, c = I)
+int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,
+                           float* gradW);
+void fg_fold_window(int k, int pad, int* T, int* rmin);
+static inline int fg_fold_r(int parity, int d, int pad) {  // floor((parity + d - pad)/2)
+    int v = parity + d - pad;
+    return (v >= 0) ? v / 2 : -((-v + 1) / 2);
+}
+
+// ---------------------------------------------------------------------------------
+// pointwise / reduction kernels (pointwise.hip)
+// ---------------------------------------------------------------------------------
+int fg_launch_nchw_to_nhwc(fg_ctx*, const float* src, float* dst, int N, int C, int H, int W);
+int fg_launch_nhwc_to_nchw(fg_ctx*, const float* src, float* dst, int N, int C, int H, int W);
+int fg_launch_fill(fg_ctx*, float* p, float v, long long n);
+// column sums of [M][N] -> out[N] = beta*out + sum (two-stage, deterministic). scratch >= 256*N floats
+int fg_launch_colsum(fg_ctx*, const float* x, long long M, int N, float beta, float* out, float* scratch);
+
+// BatchNorm (+ optional PReLU) over NHWC [M][C]
+struct BnArgs {
+    const float* x; float* y; long long M; int C;
+    const float* gamma; const float* beta; const float* slope;  // slope nullptr -> no PReLU
+    float* mean; float* invstd;        // [C] saved stats (train)
+    float* running_mean; float* running_var; float eps, momentum; int train;
+    float* scratch;                    // >= (2*nblk*C + 4*C) floats, nblk <= 1024
+};
+int fg_launch_bn_forward(fg_ctx*, const BnArgs& a);
+struct BnBwdArgs {
+    const float* x; const float* gy; float* gx; long long M; int C;
+    const float* gamma; const float* beta; const float* slope; const float* mean; const float* invstd;
+    float* ggamma; float* gbeta; float* gslope; float gbeta_acc;  // grads = acc*old + new
+    float* scratch;
+};
+int fg_launch_bn_backward(fg_ctx*, const BnBwdArgs& a);
+
+// PReLU [+ dropout mask (scaled)] elementwise over n elements; mask index = i (same shape) or nullptr
+int fg_launch_prelu_forward(fg_ctx*, const float* x, const float* slope, const float* mask, float mscale, float* y,
+                            long long n);
+int fg_launch_prelu_backward(fg_ctx*, const float* x, const float* gy, const float* slope, const float* mask,
+                             float mscale, float* gx, float* gslope, float acc, long long n, float* scratch);
+// fused PReLU -> SpatialDropout(mask[B][C], unscaled in train / (1-p) in eval) -> AvgPool2x2 on NHWC [B][H][W][C]
+int fg_launch_actpool_forward(fg_ctx*, const float* x, const float* slope, const float* mask, float mscale, float* y,
+                              int B, int H, int W, int C);
+int fg_launch_actpool_backward(fg_ctx*, const float* x, const float* gy, const float* slope, const float* mask,
+                               float mscale, float* gx, float* gslope, float acc, int B, int H, int W, int C,
+                               float* scratch);
+// standalone pieces (module-level API)
+int fg_launch_scale_mask_nc(fg_ctx*, const float* x, const float* mask, float mscale, float* y, int B, int HW, int C);
+int fg_launch_avgpool_forward(fg_ctx*, const float* x, float* y, int B, int H, int W, int C);
+int fg_launch_avgpool_backward(fg_ctx*, const float* gy, float* gx, int B, int H, int W, int C);
+int fg_launch_upsample_forward(fg_ctx*, const float* x, float* y, int B, int H, int W, int C);
+int fg_launch_upsample_backward(fg_ctx*, const float* gy, float* gx, int B, int H, int W, int C);
+int fg_launch_sigmoid_forward(fg_ctx*, const float* x, float* y, long long n);
+int fg_launch_sigmoid_backward(fg_ctx*, const float* y, const float* gy, float* gx, long long n);
+int fg_launch_leakyrelu_forward(fg_ctx*, const float* x, float s, float* y, long long n);
+int fg_launch_leakyrelu_backward(fg_ctx*, const float* x, const float* gy, float s, float* gx, long long n);
+int fg_launch_axpby(fg_ctx*, float a, const float* x, float b, float* y, long long n);  // y = a*x + b*y
+
+// thin convolutions (3 <-> wide channels), NHWC, stride 1, "same" pad, odd k <= 7
+// thin-in : out[pix][c<Cw] = bias[c] + sum_{tap, s<Cs} in[pix+off(tap)][s] * Wp[tap][s][c]
+int fg_launch_thin_in_conv(fg_ctx*, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
+                           int W, int Cs, int Cw, int k, int flip);
+// thin-out: out[pix][s<Cs] = act(bias[s] + sum_{tap, c<Cw} in[pix+off(tap)][c] * Wp[tap][s][c])
+int fg_launch_thin_out_conv(fg_ctx*, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
+                            int W, int Cw, int Cs, int k, int flip, int sigmoid);
+// thin wgrad: gw[tap][s][c] (partials reduced) = sum_pix thin[pix + sgn*off(tap)][s] * wide[pix][c]
+int fg_launch_thin_wgrad(fg_ctx*, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
+                         int Cw, int k, int shift_thin, float* scratch);
+// repack between reference [O][I][k][k] and thin layouts
+// mode 0: Wp[tap][s=I][c=O] (thin-in fwd, I small)      mode 1: Wp[tap][s=O][c=I] (thin-out fwd, O small)
+int fg_launch_thin_pack(fg_ctx*, const float* W, float* Wp, int O, int I, int k, int mode);
+// gradW_ref[O][I][k][k] = beta*gradW + gw[tap][s][c]  (mode as above: s = I (0) or s = O (1))
+int fg_launch_thin_unpack_grad(fg_ctx*, const float* gw, float* gradW, int O, int I, int k, int mode, float beta);
+
+// Linear(K -> 1) head: y[b] = act(x[b].w + b0)
+int fg_launch_gemv_forward(fg_ctx*, const float* x, const float* w, const float* b, float* y, int B, int K,
+                           int sigmoid);
+// gy is grad wrt y (post-sigmoid if sigmoid) ; writes gx [B][K] (optional), gradw[K], gradb[1] (acc*old + new)
+int fg_launch_gemv_backward(fg_ctx*, const float* x, const float* w, const float* y, const float* gy, float* gx,
+                            float* gw, float* gb, float acc, int B, int K, int sigmoid);
+
+// BCECriterion forward+backward fused: loss (device scalar), grad[B], confusion[4] = [pred][target] counts
+int fg_launch_bce(fg_ctx*, const float* prob, const float* target, float* loss, float* grad, int* confusion, int B);
+
+// fused penalty + clamp + Torch7-Adam over a flat vector
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; long long n;
+    float gscale;            // gradient pre-scale (1/world after an all-reduce sum)
+    float l1, l1_mul, l2;    // g += l1_mul*sign(p) + l2*p   (l1_mul: quirk C4 lets G use G_L2 here)
+    float clamp;             // 0 = off
+    float lr, beta1, beta2, eps; int t;  // t already incremented
+    float* gout;             // optional: write the penalised+clamped gradient back (feval's return value)
+};
+int fg_launch_adam(fg_ctx*, const AdamArgs& a);
+int fg_launch_sgd(fg_ctx*, float* p, const float* g, float* mom, long long n, float gscale, float l1mul, float l2,
+                  float clamp, float lr, float momentum, float dampening, float wd, int nesterov, int first);
+int fg_launch_adagrad(fg_ctx*, float* p, const float* g, float* var, long long n, float gscale, float l1mul, float l2,
+                      float clamp, float clr);
+// out[0] = sum|p|, out[1] = sum p^2 (fp64 accumulate in the final stage)
+int fg_launch_norms(fg_ctx*, const float* p, long long n, float* out2, float* scratch);
+
+// Philox4x32-10 counter RNG
+int fg_launch_rng_uniform(fg_ctx*, uint64_t seed, uint64_t offset, float* out, long long n, float lo, float hi);
+int fg_launch_rng_bernoulli(fg_ctx*, uint64_t seed, uint64_t offset, float* out, long long n, float keep_prob);
+int fg_launch_rng_normal(fg_ctx*, uint64_t seed, uint64_t offset, float* out, long long n, float mean, float std);

@@ -1,0 +1,455 @@
+// fp32-MFMA implicit-GEMM kernels for gfx950 (MI355X):
+//   igemm_kernel  : gather-A contraction  (conv fwd / dgrad, nearest-x2-folded conv fwd / dgrad, Linear fwd / dgrad)
+//   wgrad_kernel  : pixel-reduction contraction (conv / Linear weight gradients), split over pixels
+//   pack / finish : reference [O][I][kH][kW] <-> packed tile layouts (incl. the nearest-x2 tap folding)
+//
+// Replaces, for the hot path, what the reference dispatches to THNN SpatialConvolutionMM / cuDNN v3 /
+// cuBLAS sgemm (models.lua:59-73, 385-412).  Exact fp32: v_mfma_f32_32x32x2_f32 is
+// bit-for-bit a k-ordered fmaf chain.
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile BMxBN, BK = 32, register-staged double-buffered LDS,
+// rows padded to 36 floats so the ds_read_b128 fragment reads are conflict-free (16 distinct 16-B slots
+// per 16-lane group).  Lane l of an MFMA holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; one ds_read_b128 per
+// 32-row fragment feeds 4 MFMAs (k = kk+j for lanes<32, kk+4+j for lanes>=32 -- same permutation on A and B).
+#include "fg_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void fg_decode_m(int m, int lgH, int lgW, int Hm, int Wm, int& n, int& y, int& x) {
+    if (lgW >= 0) {
+        x = m & (Wm - 1);
+        y = (m >> lgW) & (Hm - 1);
+        n = m >> (lgW + lgH);
+    } else {
+        x = m % Wm;
+        int t = m / Wm;
+        y = t % Hm;
+        n = t / Hm;
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
+    constexpr int LDK = 36;
+    constexpr int RA = BM / 32, RB = BN / 32;  // float4 loads per thread per K-step
+    constexpr int MI = BM / 64, NI = BN / 64;  // 32x32 MFMA tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDK;
+    int* rowoff = (int*)(smem + 2 * (BM + BN) * LDK);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int ntn = a.Npad / BN;
+    const int tile_m = blockIdx.x / ntn, tile_n = blockIdx.x - tile_m * ntn;
+    const int p = blockIdx.z, split = blockIdx.y;
+    const int gper = (a.G + a.splits - 1) / a.splits;
+    const int g0 = split * gper;
+    const int g1 = min(a.G, g0 + gper);
+
+    if (tid < BM) {
+        int m = tile_m * BM + tid, off = -1;
+        if (m < a.M) {
+            int n, y, x;
+            fg_decode_m(m, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
+            off = ((n * a.Ho + y * a.osy + a.ooy[p]) * a.Wo + x * a.osx + a.oox[p]) * a.N;
+        }
+        rowoff[tid] = off;
+    }
+
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;
+    int ry[RA], rx[RA], rn[RA];
+    bool rv[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        int m = tile_m * BM + lrow + 32 * i;
+        rv[i] = m < a.M;
+        int n, y, x;
+        fg_decode_m(rv[i] ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
+        rn[i] = n * a.Ha * a.Wa;
+        ry[i] = y * a.asy;
+        rx[i] = x * a.asx;
+    }
+    const int kc = a.Kpad >> 5;
+    const int KT = (g1 > g0) ? (g1 - g0) * kc : 0;
+
+    float4 ra[RA], rb[RB];
+    auto load_tile = [&](int kt) {
+        const int gi = kt / kc;
+        const int g = g0 + gi;
+        const int col = (kt - gi * kc) * 32 + lk;
+        const int oy = a.aoy[p][g], ox = a.aox[p][g];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int ya = ry[i] + oy, xa = rx[i] + ox;
+            const bool ok = rv[i] && (unsigned)ya < (unsigned)a.Ha && (unsigned)xa < (unsigned)a.Wa && col < a.Ca;
+            if (ok)
+                ra[i] = *(const float4*)(a.A + (size_t)(rn[i] + ya * a.Wa + xa) * a.Ca + col);
+            else
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float* bp = a.Bp + ((size_t)(p * a.G + g) * a.Npad + tile_n * BN + lrow) * a.Kpad + col;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) rb[i] = *(const float4*)(bp + (size_t)(32 * i) * a.Kpad);
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *(float4*)(As + buf * BM * LDK + (lrow + 32 * i) * LDK + lk) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *(float4*)(Bs + buf * BN * LDK + (lrow + 32 * i) * LDK + lk) = rb[i];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float* Ab = As + buf * BM * LDK + (wm * (BM / 2) + (lane & 31)) * LDK + (lane >> 5) * 4;
+        const float* Bb = Bs + buf * BN * LDK + (wn * (BN / 2) + (lane & 31)) * LDK + (lane >> 5) * 4;
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 8) {
+            float af[MI][4], bf[NI][4];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                float4 t = *(const float4*)(Ab + mi * 32 * LDK + kk);
+                af[mi][0] = t.x; af[mi][1] = t.y; af[mi][2] = t.z; af[mi][3] = t.w;
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                float4 t = *(const float4*)(Bb + ni * 32 * LDK + kk);
+                bf[ni][0] = t.x; bf[ni][1] = t.y; bf[ni][2] = t.z; bf[ni][3] = t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    if (KT > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool more = kt + 1 < KT;
+        if (more) load_tile(kt + 1);
+        compute(cur);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* outp = a.Out + (size_t)split * a.split_stride;
+    const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = tile_n * BN + wn * (BN / 2) + ni * 32 + (lane & 31);
+        const float bv = (add_bias && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int off = rowoff[row];
+                if (off >= 0 && col < a.N) outp[(size_t)off + col] = acc[mi][ni][r] + bv;
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+static int launch_igemm_t(fg_ctx* ctx, const IgemmArgs& a, int P) {
+    const size_t lds = (size_t)(2 * (BM + BN) * 36 + BM) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(fg_cdiv(a.M, BM) * (a.Npad / BN), a.splits, P);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN>), grid, dim3(256), lds, ctx->stream, a);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a, int P, int tile) {
+    if (a.Ca % 4 != 0 || a.Kpad % 32 != 0) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: Ca %% 4 / Kpad %% 32");
+    if (a.G > FG_MAX_GROUPS || P > 4 || a.splits < 1) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: G/P/splits");
+    switch (tile) {
+        case 0: if (a.Npad % 128) break; return launch_igemm_t<128, 128>(ctx, a, P);
+        case 1: if (a.Npad % 64) break; return launch_igemm_t<128, 64>(ctx, a, P);
+        case 2: if (a.Npad % 64) break; return launch_igemm_t<64, 64>(ctx, a, P);
+    }
+    return fg_set_err(ctx, FG_ERR_INVALID, "igemm: bad tile %d for Npad %d", tile, a.Npad);
+}
+
+__global__ void sum_splits_kernel(const float* __restrict__ part, int splits, long long stride,
+                                  const float* __restrict__ bias, int N, float* __restrict__ out, long long count4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (; i < count4; i += step) {
+        float4 s = ((const float4*)part)[i];
+        for (int k = 1; k < splits; ++k) {
+            float4 t = ((const float4*)(part + k * stride))[i];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        if (bias) {
+            int c = (int)((i * 4) % N);
+            s.x += bias[c]; s.y += bias[c + 1]; s.z += bias[c + 2]; s.w += bias[c + 3];
+        }
+        ((float4*)out)[i] = s;
+    }
+}
+
+int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long stride, const float* bias, int N,
+                         float* out, long long count) {
+    if (count % 4 || N % 4 || stride % 4) return fg_set_err(ctx, FG_ERR_INVALID, "sum_splits: alignment");
+    long long c4 = count / 4;
+    int blocks = (int)min((long long)2048, (c4 + 255) / 256);
+    hipLaunchKernelGGL(sum_splits_kernel, dim3(blocks), dim3(256), 0, ctx->stream, part, splits, stride, bias, N, out,
+                       c4);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------
+template <int BT>  // square tile BT x BT (rows = dY channels, cols = X channels)
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+    constexpr int BK = 32;
+    constexpr int R = BT / 32;   // float4 loads per thread per operand per K-step
+    constexpr int F4 = BT / 4;   // float4 per pixel row
+    constexpr int PSTEP = 256 / F4;
+    constexpr int MI = BT / 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ds = smem;                // [2][BK*BT]
+    float* Xs = smem + 2 * BK * BT;  // [2][BK*BT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int ntc = a.Cpad / BT;
+    const int tn = blockIdx.x / ntc, tc = blockIdx.x - tn * ntc;
+    const int s = blockIdx.y, pg = blockIdx.z;
+    const int p = pg / a.G, g = pg - p * a.G;
+    const int m0 = s * a.m_per_split;
+    const int m1 = min(a.M, m0 + a.m_per_split);
+    const int KT = (m1 > m0) ? (m1 - m0 + BK - 1) / BK : 0;
+
+    const int lpix = tid / F4, lc = (tid - lpix * F4) * 4;
+    const int chD = tn * BT + lc, chX = tc * BT + lc;
+    const bool okD = chD < a.Nd, okX = chX < a.Cx;
+    const int doy = a.doy[p], dox = a.dox[p], xoy = a.xoy[p][g], xox = a.xox[p][g];
+
+    float4 rd[R], rx[R];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int m = m0 + kt * BK + lpix + PSTEP * i;
+            const bool ok = m < m1;
+            int n, y, x;
+            fg_decode_m(ok ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
+            const int yd = y * a.dsy + doy, xd = x * a.dsx + dox;
+            const int yx = y * a.xsy + xoy, xx = x * a.xsx + xox;
+            if (ok && okD)
+                rd[i] = *(const float4*)(a.dY + (size_t)((n * a.Hd + yd) * a.Wd + xd) * a.Nd + chD);
+            else
+                rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && okX && (unsigned)yx < (unsigned)a.Hx && (unsigned)xx < (unsigned)a.Wx)
+                rx[i] = *(const float4*)(a.X + (size_t)((n * a.Hx + yx) * a.Wx + xx) * a.Cx + chX);
+            else
+                rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            *(float4*)(Ds + buf * BK * BT + (lpix + PSTEP * i) * BT + lc) = rd[i];
+            *(float4*)(Xs + buf * BK * BT + (lpix + PSTEP * i) * BT + lc) = rx[i];
+        }
+    };
+
+    f32x16 acc[MI][MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < MI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float* Db = Ds + buf * BK * BT + (lane >> 5) * BT + wm * (BT / 2) + (lane & 31);
+        const float* Xb = Xs + buf * BK * BT + (lane >> 5) * BT + wn * (BT / 2) + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float af[MI], bf[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[mi] = Db[kk * BT + mi * 32];
+#pragma unroll
+            for (int ni = 0; ni < MI; ++ni) bf[ni] = Xb[kk * BT + ni * 32];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < MI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    if (KT > 0) {
+        load_tile(0);
+        store_tile(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool more = kt + 1 < KT;
+        if (more) load_tile(kt + 1);
+        compute(cur);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* part = a.Part + ((size_t)pg * a.S + s) * a.Npad * a.Cpad;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < MI; ++ni) {
+            const int col = tc * BT + wn * (BT / 2) + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tn * BT + wm * (BT / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                part[(size_t)row * a.Cpad + col] = acc[mi][ni][r];
+            }
+        }
+}
+
+template <int BT>
+static int launch_wgrad_t(fg_ctx* ctx, const WgradArgs& a, int P) {
+    const size_t lds = (size_t)(4 * 32 * BT) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_kernel<BT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((a.Npad / BT) * (a.Cpad / BT), a.S, P * a.G);
+    hipLaunchKernelGGL((wgrad_kernel<BT>), grid, dim3(256), lds, ctx->stream, a);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+int fg_launch_wgrad(fg_ctx* ctx, const WgradArgs& a, int P, int tile) {
+    if (a.Nd % 4 || a.Cx % 4 || a.m_per_split % 32) return fg_set_err(ctx, FG_ERR_INVALID, "wgrad: alignment");
+    if (a.G > FG_MAX_GROUPS || P > 4) return fg_set_err(ctx, FG_ERR_INVALID, "wgrad: G/P");
+    if (tile == 0 && a.Npad % 128 == 0 && a.Cpad % 128 == 0) return launch_wgrad_t<128>(ctx, a, P);
+    if (tile == 2 && a.Npad % 64 == 0 && a.Cpad % 64 == 0) return launch_wgrad_t<64>(ctx, a, P);
+    return fg_set_err(ctx, FG_ERR_INVALID, "wgrad: bad tile %d for %dx%d", tile, a.Npad, a.Cpad);
+}
+
+// ---------------------------------------------------------------------------------
+// reference <-> packed weight layouts
+// ---------------------------------------------------------------------------------
+void fg_fold_window(int k, int pad, int* T, int* rmin) {
+    int lo = fg_fold_r(0, 0, pad), hi = fg_fold_r(1, k - 1, pad);
+    *rmin = lo;
+    *T = hi - lo + 1;
+}
+
+__device__ __forceinline__ int dev_fold_r(int parity, int d, int pad) {
+    int v = parity + d - pad;
+    return (v >= 0) ? (v >> 1) : -((-v + 1) >> 1);
+}
+
+// value of the (possibly tap-folded) weight for parity p, group g, reference out-channel o, in-channel i
+__device__ __forceinline__ float packed_weight_value(const WeightMap& wm, const float* __restrict__ W, int p, int g,
+                                                     int o, int i) {
+    const int kk = wm.k * wm.k;
+    const float* w = W + ((size_t)o * wm.I + i) * kk;
+    if (wm.kind == 0) return w[g];
+    const int py = p >> 1, px = p & 1, ty = g / wm.T, tx = g - ty * wm.T;
+    float s = 0.f;
+    for (int dy = 0; dy < wm.k; ++dy) {
+        if (dev_fold_r(py, dy, wm.pad) - wm.rmin != ty) continue;
+        for (int dx = 0; dx < wm.k; ++dx)
+            if (dev_fold_r(px, dx, wm.pad) - wm.rmin == tx) s += w[dy * wm.k + dx];
+    }
+    return s;
+}
+
+__global__ void pack_weights_kernel(const WeightMap wm, int mode, const float* __restrict__ W, float* __restrict__ Bp,
+                                    int rows_pad, int cols_pad, long long total) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int col = (int)(idx % cols_pad);
+    long long t = idx / cols_pad;
+    const int row = (int)(t % rows_pad);
+    const int pg = (int)(t / rows_pad);
+    const int p = pg / wm.G, g = pg - p * wm.G;
+    // packed (row, col) -> packed (o, i)
+    const int po = mode == 0 ? row : col, pi = mode == 0 ? col : row;
+    float v = 0.f;
+    if (po < wm.O && pi < wm.I) {
+        int o = po, i = pi;
+        if (wm.o_hw > 1) { int hw = po / wm.o_c, c = po - hw * wm.o_c; o = c * wm.o_hw + hw; }
+        if (wm.i_hw > 1) { int hw = pi / wm.i_c, c = pi - hw * wm.i_c; i = c * wm.i_hw + hw; }
+        v = packed_weight_value(wm, W, p, g, o, i);
+    }
+    Bp[idx] = v;
+}
+
+int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const float* W, float* Bp, int rows_pad,
+                           int cols_pad) {
+    long long total = (long long)wm.P * wm.G * rows_pad * cols_pad;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(fg_cdiv(total, 256)), dim3(256), 0, ctx->stream, wm, mode, W, Bp,
+                       rows_pad, cols_pad, total);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+__global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
+                                    float beta, float* __restrict__ gradW) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;  // packed in-channel
+    const int po = blockIdx.y;                              // packed out-channel
+    if (pi >= wm.I || po >= wm.O) return;
+    int o = po, i = pi;
+    if (wm.o_hw > 1) { int hw = po / wm.o_c, c = po - hw * wm.o_c; o = c * wm.o_hw + hw; }
+    if (wm.i_hw > 1) { int hw = pi / wm.i_c, c = pi - hw * wm.i_c; i = c * wm.i_hw + hw; }
+    const size_t tile = (size_t)Npad * Cpad;
+    const size_t e = (size_t)po * Cpad + pi;
+    float* gw = gradW + ((size_t)o * wm.I + i) * wm.k * wm.k;
+    for (int dy = 0; dy < wm.k; ++dy)
+        for (int dx = 0; dx < wm.k; ++dx) {
+            float sum = 0.f;
+            if (wm.kind == 0) {
+                const int g = dy * wm.k + dx;
+                for (int s = 0; s < S; ++s) sum += Part[((size_t)g * S + s) * tile + e];
+            } else {
+                for (int p = 0; p < 4; ++p) {
+                    const int ty = dev_fold_r(p >> 1, dy, wm.pad) - wm.rmin;
+                    const int tx = dev_fold_r(p & 1, dx, wm.pad) - wm.rmin;
+                    const int pg = p * wm.G + ty * wm.T + tx;
+                    for (int s = 0; s < S; ++s) sum += Part[((size_t)pg * S + s) * tile + e];
+                }
+            }
+            const int wi = dy * wm.k + dx;
+            gw[wi] = (beta == 0.f) ? sum : beta * gw[wi] + sum;
+        }
+}
+
+int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,
+                           float* gradW) {
+    dim3 grid(fg_cdiv(wm.I, 128), wm.O);
+    hipLaunchKernelGGL(wgrad_finish_kernel, grid, dim3(128), 0, ctx->stream, wm, Part, S, Npad, Cpad, beta, gradW);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}

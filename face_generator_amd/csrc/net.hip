@@ -1,0 +1,551 @@
+// fg_net: an nn.Sequential (models.lua:57-81 G, :382-416 D) compiled into a device plan.
+// The reference walks its module list calling one or more native kernels per module
+// (nn.Sequential:updateOutput / :backward).  Here adjacent modules are fused into stages:
+//   UpSamplingNearest(2)+Conv5x5  -> one tap-folded MFMA conv (4 output parities x 3x3 taps on the source)
+//   BatchNorm+PReLU               -> stats + one apply pass;  PReLU+SpatialDropout+AvgPool -> one pass
+//   PReLU+Dropout, Conv(->3)+Sigmoid, Linear(->1)+Sigmoid
+// Activations are NHWC and stay in the caller's workspace between forward and backward.
+#include "fg_internal.h"
+#include "conv_ops.h"
+#include "../../include/facegen_hip.h"
+#include <vector>
+#include <string.h>
+
+enum StageKind {
+    ST_CONV = 1,      // MFMA conv (fold optional) or Linear (H=W=1)
+    ST_GEMV,          // Linear(K->1) [+Sigmoid]
+    ST_THIN_IN,       // conv with <=4 input channels
+    ST_THIN_OUT,      // conv with <=4 output channels [+Sigmoid]
+    ST_BNPRELU,       // SpatialBatchNormalization [+PReLU]
+    ST_PRELU,         // PReLU [+Dropout]
+    ST_ACTPOOL,       // PReLU + SpatialDropout + AvgPool2
+    ST_SIGMOID,
+    ST_LEAKYRELU,
+    ST_UPSAMPLE,
+    ST_AVGPOOL,
+    ST_SDROPOUT
+};
+
+struct Stage {
+    int kind = 0;
+    int first_layer = 0, last_layer = 0;
+    int ic = 0, ih = 0, iw = 0, oc = 0, oh = 0, ow = 0;
+    long long w_off = -1, w_n = 0, b_off = -1, b_n = 0;
+    long long slope_off = -1, gamma_off = -1, beta_off = -1, buf_off = -1;
+    ConvGeom geom{};
+    float* wp_fwd = nullptr;
+    float* wp_bwd = nullptr;
+    float* bias_packed = nullptr;  // Linear followed by View(C,H,W): bias in NHWC feature order
+    int has_prelu = 0, has_sigmoid = 0;
+    int mask_idx = -1, mask_kind = 0;  // 1 spatial [B][C], 2 elementwise
+    float p = 0.f, eps = 1e-5f, momentum = 0.1f, negslope = 0.333f;
+    // per-forward plan
+    long long out_off = 0, aux_off = 0;
+};
+
+struct LayerInfo {
+    long long w_off = -1, w_n = 0, b_off = -1, b_n = 0;
+    int stage = -1;
+    int ends_stage = 0;
+};
+
+struct fg_net {
+    fg_ctx* ctx = nullptr;
+    std::vector<Stage> st;
+    std::vector<LayerInfo> layers;
+    int in_c = 0, in_h = 0, in_w = 0;
+    long long n_params = 0, n_buffers = 0;
+    int n_masks = 0;
+    std::vector<int> mask_stage;
+    float *params = nullptr, *grads = nullptr, *buffers = nullptr;
+    bool dirty = true;
+    // plan of the last forward
+    int plan_batch = -1;
+    long long grad_off[2] = {0, 0}, tmp_off = 0, scratch_off = 0, scratch_floats = 0, total_floats = 0;
+    const float* const* masks = nullptr;
+    std::vector<const float*> mask_ptrs;
+    int last_train = 1;
+};
+
+static inline long long align64(long long v) { return (v + 63) / 64 * 64; }
+
+static long long stage_scratch(const Stage& s, int B) {
+    long long need = 4096;
+    switch (s.kind) {
+        case ST_CONV: { ConvGeom g = s.geom; g.B = B; need = fg_conv_scratch_floats(g); break; }
+        case ST_BNPRELU: need = (long long)3 * CR_ROWBLOCKS_MAX * s.oc + 2 * s.oc + 64; break;
+        case ST_THIN_IN: case ST_THIN_OUT: {
+            const int cw = s.kind == ST_THIN_IN ? s.oc : s.ic, cs = s.kind == ST_THIN_IN ? s.ic : s.oc;
+            const long long na = (long long)s.geom.k * s.geom.k * cs;
+            need = 256 * na * cw + na * cw + (long long)CR_ROWBLOCKS_MAX * (s.oc > 64 ? s.oc : 64) + 64;
+            break;
+        }
+        default: break;
+    }
+    return need;
+}
+
+static void make_plan(fg_net* n, int B) {
+    long long off = 0, maxact = (long long)B * n->in_c * n->in_h * n->in_w, maxscr = 4096;
+    for (auto& s : n->st) {
+        const long long osz = (long long)B * s.oc * s.oh * s.ow;
+        s.out_off = off; off += align64(osz);
+        s.aux_off = off;
+        if (s.kind == ST_BNPRELU) off += align64(2 * s.oc);
+        if (osz > maxact) maxact = osz;
+        const long long isz = (long long)B * s.ic * s.ih * s.iw;
+        if (isz > maxact) maxact = isz;
+        const long long sc = stage_scratch(s, B);
+        if (sc > maxscr) maxscr = sc;
+    }
+    n->grad_off[0] = off; off += align64(maxact);
+    n->grad_off[1] = off; off += align64(maxact);
+    n->tmp_off = off; off += align64(maxact);
+    n->scratch_off = off; off += align64(maxscr);
+    n->scratch_floats = maxscr;
+    n->total_floats = off;
+    n->plan_batch = B;
+}
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_h, int in_w, fg_net** out) {
+    if (!ctx || !L || !out || nl <= 0) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_create: null/empty");
+    fg_net* n = new fg_net();
+    n->ctx = ctx; n->in_c = in_c; n->in_h = in_h; n->in_w = in_w;
+    n->layers.resize(nl);
+    int c = in_c, h = in_h, w = in_w;
+    int perm_c = 0, perm_hw = 0;  // pending NCHW-flatten permutation for the next Linear
+    long long poff = 0, boff = 0;
+    int rc = FG_OK;
+    auto fail = [&](int code, const char* msg, int i) {
+        rc = fg_set_err(ctx, code, "fg_net_create: layer %d: %s", i, msg);
+    };
+    for (int i = 0; i < nl && rc == FG_OK;) {
+        Stage s; s.first_layer = i; s.ic = c; s.ih = h; s.iw = w;
+        const fg_layer_spec& l = L[i];
+        int consumed = 1;
+        switch (l.type) {
+            case FG_LINEAR: {
+                if (h != 1 || w != 1 || l.a != c) { fail(FG_ERR_INVALID, "Linear input size mismatch", i); break; }
+                s.w_off = poff; s.w_n = (long long)l.a * l.b; s.b_off = poff + s.w_n; s.b_n = l.b;
+                poff += s.w_n + s.b_n;
+                n->layers[i].w_off = s.w_off; n->layers[i].w_n = s.w_n; n->layers[i].b_off = s.b_off; n->layers[i].b_n = s.b_n;
+                if (l.b == 1) {
+                    if (perm_hw > 1) { fail(FG_ERR_UNSUPPORTED, "Linear(->1) after a spatial flatten", i); break; }
+                    s.kind = ST_GEMV; s.oc = 1; s.oh = s.ow = 1;
+                    if (i + 1 < nl && L[i + 1].type == FG_SIGMOID) { s.has_sigmoid = 1; consumed = 2; }
+                } else {
+                    s.kind = ST_CONV;
+                    ConvGeom& g = s.geom; g.H = g.W = 1; g.Cin = l.a; g.Cout = l.b; g.k = 1; g.pad = 0; g.fold = 0;
+                    if (perm_hw > 1) { g.i_c = perm_c; g.i_hw = perm_hw; }
+                    s.oc = l.b; s.oh = s.ow = 1;
+                    if (i + 1 < nl && L[i + 1].type == FG_VIEW && L[i + 1].b > 0) {
+                        const fg_layer_spec& v = L[i + 1];
+                        if ((long long)v.a * v.b * v.c != l.b) { fail(FG_ERR_INVALID, "View size mismatch", i + 1); break; }
+                        if (v.b * v.c > 1) { g.o_c = v.a; g.o_hw = v.b * v.c; }
+                        s.oc = v.a; s.oh = v.b; s.ow = v.c;
+                        consumed = 2;
+                    }
+                    if (l.a % 4) { fail(FG_ERR_UNSUPPORTED, "Linear in_features % 4 != 0", i); break; }
+                }
+                perm_c = perm_hw = 0;
+                break;
+            }
+            case FG_VIEW: {
+                if (l.b > 0) {
+                    if ((long long)l.a * l.b * l.c != (long long)c * h * w) { fail(FG_ERR_INVALID, "View size mismatch", i); break; }
+                    if (l.a == c && l.b == h && l.c == w) { s.kind = 0; break; }
+                    fail(FG_ERR_UNSUPPORTED, "View(C,H,W) must directly follow a Linear", i);
+                } else {
+                    if ((long long)l.a != (long long)c * h * w) { fail(FG_ERR_INVALID, "View size mismatch", i); break; }
+                    if (h * w > 1) { perm_c = c; perm_hw = h * w; }
+                    c = c * h * w; h = w = 1;
+                    s.kind = 0;
+                }
+                break;
+            }
+            case FG_UPSAMPLE2X: {
+                if (i + 1 < nl && L[i + 1].type == FG_CONV && L[i + 1].a == c && L[i + 1].a > 4 && L[i + 1].b > 4 &&
+                    L[i + 1].c % 2 == 1 && L[i + 1].d == (L[i + 1].c - 1) / 2 && L[i + 1].a % 4 == 0) {
+                    const fg_layer_spec& cv = L[i + 1];
+                    int T, rmin; fg_fold_window(cv.c, cv.d, &T, &rmin);
+                    if (4 * T * T <= FG_MAX_GROUPS) {
+                        s.kind = ST_CONV;
+                        ConvGeom& g = s.geom; g.H = h; g.W = w; g.Cin = cv.a; g.Cout = cv.b; g.k = cv.c; g.pad = cv.d; g.fold = 1;
+                        s.w_n = (long long)cv.a * cv.b * cv.c * cv.c; s.b_n = cv.b;
+                        s.w_off = poff; s.b_off = poff + s.w_n; poff += s.w_n + s.b_n;
+                        n->layers[i + 1].w_off = s.w_off; n->layers[i + 1].w_n = s.w_n;
+                        n->layers[i + 1].b_off = s.b_off; n->layers[i + 1].b_n = s.b_n;
+                        s.oc = cv.b; s.oh = 2 * h; s.ow = 2 * w;
+                        consumed = 2;
+                        break;
+                    }
+                }
+                s.kind = ST_UPSAMPLE; s.oc = c; s.oh = 2 * h; s.ow = 2 * w;
+                break;
+            }
+            case FG_CONV: {
+                if (l.a != c) { fail(FG_ERR_INVALID, "conv nInputPlane mismatch", i); break; }
+                if (l.c % 2 != 1 || l.d != (l.c - 1) / 2) { fail(FG_ERR_UNSUPPORTED, "only odd-k 'same' stride-1 convs", i); break; }
+                s.w_n = (long long)l.a * l.b * l.c * l.c; s.b_n = l.b;
+                s.w_off = poff; s.b_off = poff + s.w_n; poff += s.w_n + s.b_n;
+                n->layers[i].w_off = s.w_off; n->layers[i].w_n = s.w_n; n->layers[i].b_off = s.b_off; n->layers[i].b_n = s.b_n;
+                ConvGeom& g = s.geom; g.H = h; g.W = w; g.Cin = l.a; g.Cout = l.b; g.k = l.c; g.pad = l.d; g.fold = 0;
+                s.oc = l.b; s.oh = h; s.ow = w;
+                if (l.a <= 4 && l.b % 64 == 0) s.kind = ST_THIN_IN;
+                else if (l.b <= 4 && l.a % 64 == 0) {
+                    s.kind = ST_THIN_OUT;
+                    if (i + 1 < nl && L[i + 1].type == FG_SIGMOID) { s.has_sigmoid = 1; consumed = 2; }
+                } else if (l.a % 4 == 0 && l.c * l.c <= FG_MAX_GROUPS) s.kind = ST_CONV;
+                else fail(FG_ERR_UNSUPPORTED, "conv channel counts not supported", i);
+                break;
+            }
+            case FG_BATCHNORM: {
+                if (l.a != c || c % 4) { fail(FG_ERR_INVALID, "BatchNorm nFeature mismatch / % 4", i); break; }
+                s.kind = ST_BNPRELU; s.oc = c; s.oh = h; s.ow = w;
+                s.gamma_off = poff; s.beta_off = poff + c; poff += 2 * c;
+                n->layers[i].w_off = s.gamma_off; n->layers[i].w_n = c; n->layers[i].b_off = s.beta_off; n->layers[i].b_n = c;
+                s.buf_off = boff; boff += 2 * c;
+                s.eps = l.p > 0.f ? l.p : 1e-5f; s.momentum = l.q > 0.f ? l.q : 0.1f;
+                if (i + 1 < nl && L[i + 1].type == FG_PRELU) {
+                    s.has_prelu = 1; s.slope_off = poff; poff += 1;
+                    n->layers[i + 1].w_off = s.slope_off; n->layers[i + 1].w_n = 1;
+                    consumed = 2;
+                }
+                break;
+            }
+            case FG_PRELU: {
+                s.slope_off = poff; poff += 1;
+                n->layers[i].w_off = s.slope_off; n->layers[i].w_n = 1;
+                s.has_prelu = 1; s.oc = c; s.oh = h; s.ow = w;
+                if (i + 2 < nl && L[i + 1].type == FG_SPATIAL_DROPOUT && L[i + 2].type == FG_AVGPOOL2 && c % 4 == 0 &&
+                    h % 2 == 0 && w % 2 == 0) {
+                    s.kind = ST_ACTPOOL; s.p = L[i + 1].p; s.mask_kind = 1; s.oh = h / 2; s.ow = w / 2; consumed = 3;
+                } else if (i + 1 < nl && L[i + 1].type == FG_DROPOUT) {
+                    s.kind = ST_PRELU; s.p = L[i + 1].p; s.mask_kind = 2; consumed = 2;
+                } else s.kind = ST_PRELU;
+                if (s.mask_kind) { s.mask_idx = n->n_masks++; }
+                break;
+            }
+            case FG_SIGMOID: s.kind = ST_SIGMOID; s.oc = c; s.oh = h; s.ow = w; break;
+            case FG_LEAKYRELU: s.kind = ST_LEAKYRELU; s.negslope = l.p; s.oc = c; s.oh = h; s.ow = w; break;
+            case FG_AVGPOOL2:
+                if (h % 2 || w % 2) { fail(FG_ERR_INVALID, "AvgPool on odd size", i); break; }
+                s.kind = ST_AVGPOOL; s.oc = c; s.oh = h / 2; s.ow = w / 2; break;
+            case FG_SPATIAL_DROPOUT:
+                s.kind = ST_SDROPOUT; s.p = l.p; s.mask_kind = 1; s.mask_idx = n->n_masks++; s.oc = c; s.oh = h; s.ow = w; break;
+            case FG_DROPOUT: fail(FG_ERR_UNSUPPORTED, "standalone Dropout (only PReLU+Dropout is built)", i); break;
+            default: fail(FG_ERR_INVALID, "unknown layer type", i); break;
+        }
+        if (rc != FG_OK) break;
+        s.last_layer = i + consumed - 1;
+        if (s.kind != 0) {
+            for (int j = i; j <= s.last_layer; ++j) n->layers[j].stage = (int)n->st.size();
+            n->layers[s.last_layer].ends_stage = 1;
+            if (s.mask_idx >= 0) n->mask_stage.push_back((int)n->st.size());
+            c = s.oc; h = s.oh; w = s.ow;
+            if (s.kind != ST_CONV && s.kind != ST_GEMV && perm_hw > 1 && l.type != FG_VIEW) {
+                // elementwise stages between the flatten and the Linear keep the pending permutation
+            }
+            n->st.push_back(s);
+        } else if (!n->st.empty()) {
+            n->layers[i].stage = (int)n->st.size() - 1;
+            n->layers[i].ends_stage = 1;
+        }
+        i += consumed;
+    }
+    if (rc == FG_OK && n->st.empty()) rc = fg_set_err(ctx, FG_ERR_INVALID, "fg_net_create: no compute stages");
+    n->n_params = poff; n->n_buffers = boff;
+    // packed-weight storage (owned by the net; allocated here, never on the hot path)
+    for (auto& s : n->st) {
+        if (rc != FG_OK) break;
+        if (s.kind == ST_CONV) {
+            ConvGeom g = s.geom; g.B = 1;
+            long long nf = fg_geom_pack_floats(g, 0), nb = fg_geom_pack_floats(g, 1);
+            if (hipMalloc((void**)&s.wp_fwd, nf * sizeof(float)) != hipSuccess ||
+                hipMalloc((void**)&s.wp_bwd, nb * sizeof(float)) != hipSuccess)
+                rc = fg_set_err(ctx, FG_ERR_NOMEM, "fg_net_create: packed weights");
+            if (rc == FG_OK && g.o_hw > 1 && hipMalloc((void**)&s.bias_packed, s.b_n * sizeof(float)) != hipSuccess)
+                rc = fg_set_err(ctx, FG_ERR_NOMEM, "fg_net_create: packed bias");
+        } else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT) {
+            if (hipMalloc((void**)&s.wp_fwd, s.w_n * sizeof(float)) != hipSuccess)
+                rc = fg_set_err(ctx, FG_ERR_NOMEM, "fg_net_create: packed weights");
+        }
+    }
+    if (rc != FG_OK) { fg_net_destroy(n); return rc; }
+    *out = n;
+    return FG_OK;
+}
+
+int fg_net_destroy(fg_net* n) {
+    if (!n) return FG_OK;
+    for (auto& s : n->st) {
+        if (s.wp_fwd) (void)hipFree(s.wp_fwd);
+        if (s.wp_bwd) (void)hipFree(s.wp_bwd);
+        if (s.bias_packed) (void)hipFree(s.bias_packed);
+    }
+    delete n;
+    return FG_OK;
+}
+
+long long fg_net_num_params(const fg_net* n) { return n ? n->n_params : 0; }
+long long fg_net_num_buffers(const fg_net* n) { return n ? n->n_buffers : 0; }
+int fg_net_num_masks(const fg_net* n) { return n ? n->n_masks : 0; }
+long long fg_net_mask_elems(const fg_net* n, int mi, int batch) {
+    if (!n || mi < 0 || mi >= n->n_masks) return -1;
+    const Stage& s = n->st[n->mask_stage[mi]];
+    return s.mask_kind == 1 ? (long long)batch * s.ic : (long long)batch * s.ic * s.ih * s.iw;
+}
+int fg_net_out_dims(const fg_net* n, int* c, int* h, int* w) {
+    if (!n) return FG_ERR_INVALID;
+    const Stage& s = n->st.back();
+    if (c) *c = s.oc; if (h) *h = s.oh; if (w) *w = s.ow;
+    return FG_OK;
+}
+size_t fg_net_workspace_bytes(const fg_net* n, int max_batch) {
+    if (!n) return 0;
+    fg_net tmp = *n;  // plan on a copy: const query
+    make_plan(&tmp, max_batch);
+    return (size_t)tmp.total_floats * sizeof(float) + 256;
+}
+int fg_net_param_offset(const fg_net* n, int li, long long* wo, long long* wn, long long* bo, long long* bn) {
+    if (!n || li < 0 || li >= (int)n->layers.size()) return FG_ERR_INVALID;
+    const LayerInfo& l = n->layers[li];
+    if (wo) *wo = l.w_off; if (wn) *wn = l.w_n; if (bo) *bo = l.b_off; if (bn) *bn = l.b_n;
+    return FG_OK;
+}
+int fg_net_bind(fg_net* n, float* params, float* grads, float* buffers) {
+    if (!n || !params) return fg_set_err(n ? n->ctx : nullptr, FG_ERR_INVALID, "fg_net_bind: params required");
+    n->params = params; n->grads = grads; n->buffers = buffers; n->dirty = true;
+    return FG_OK;
+}
+int fg_net_params_changed(fg_net* n) {
+    if (!n) return FG_ERR_INVALID;
+    n->dirty = true;
+    return FG_OK;
+}
+
+static int pack_all(fg_net* n) {
+    fg_ctx* ctx = n->ctx;
+    int rc;
+    for (auto& s : n->st) {
+        if (s.kind == ST_CONV) {
+            ConvGeom g = s.geom; g.B = 1;
+            if ((rc = fg_conv_pack(ctx, g, n->params + s.w_off, s.wp_fwd, s.wp_bwd))) return rc;
+            if (s.bias_packed &&
+                (rc = fg_launch_nchw_to_nhwc(ctx, n->params + s.b_off, s.bias_packed, 1, g.o_c, g.o_hw, 1))) return rc;
+        } else if (s.kind == ST_THIN_IN) {
+            if ((rc = fg_launch_thin_pack(ctx, n->params + s.w_off, s.wp_fwd, s.geom.Cout, s.geom.Cin, s.geom.k, 0))) return rc;
+        } else if (s.kind == ST_THIN_OUT) {
+            if ((rc = fg_launch_thin_pack(ctx, n->params + s.w_off, s.wp_fwd, s.geom.Cout, s.geom.Cin, s.geom.k, 1))) return rc;
+        }
+    }
+    n->dirty = false;
+    return FG_OK;
+}
+
+int fg_net_forward(fg_net* n, int B, const float* x, void* wsv, size_t ws_bytes, int train, const float* const* masks,
+                   int n_masks, long long* out_offset) {
+    if (!n || !x || !wsv) return fg_set_err(n ? n->ctx : nullptr, FG_ERR_INVALID, "fg_net_forward: null argument");
+    fg_ctx* ctx = n->ctx;
+    if (!n->params) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: fg_net_bind first");
+    if (B <= 0) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: batch %d", B);
+    if (((uintptr_t)wsv & 15) || ((uintptr_t)x & 15)) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: 16-byte alignment");
+    if (train && n->n_masks > 0 && (!masks || n_masks != n->n_masks))
+        return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: %d dropout masks required in training mode", n->n_masks);
+    if (n->n_buffers > 0 && !n->buffers) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: BN buffers not bound");
+    make_plan(n, B);
+    if ((size_t)n->total_floats * sizeof(float) > ws_bytes)
+        return fg_set_err(ctx, FG_ERR_WORKSPACE, "fg_net_forward: workspace %zu < %lld bytes", ws_bytes,
+                          n->total_floats * (long long)sizeof(float));
+    int rc;
+    if (n->dirty && (rc = pack_all(n))) return rc;
+    float* ws = (float*)wsv;
+    float* scratch = ws + n->scratch_off;
+    n->mask_ptrs.assign(n->n_masks, nullptr);
+    if (train) for (int i = 0; i < n->n_masks; ++i) n->mask_ptrs[i] = masks[i];
+    n->last_train = train;
+    const float* cur = x;
+    const float* P = n->params;
+    for (auto& s : n->st) {
+        float* y = ws + s.out_off;
+        const float* mask = (s.mask_idx >= 0) ? n->mask_ptrs[s.mask_idx] : nullptr;
+        switch (s.kind) {
+            case ST_CONV: {
+                ConvGeom g = s.geom; g.B = B;
+                rc = fg_conv_forward_run(ctx, g, cur, s.wp_fwd, s.bias_packed ? s.bias_packed : P + s.b_off, y, scratch,
+                                         n->scratch_floats);
+                break;
+            }
+            case ST_GEMV:
+                rc = fg_launch_gemv_forward(ctx, cur, P + s.w_off, P + s.b_off, y, B, s.ic, s.has_sigmoid);
+                break;
+            case ST_THIN_IN:
+                rc = fg_launch_thin_in_conv(ctx, cur, s.wp_fwd, P + s.b_off, y, B, s.ih, s.iw, s.ic, s.oc, s.geom.k, 0);
+                break;
+            case ST_THIN_OUT:
+                rc = fg_launch_thin_out_conv(ctx, cur, s.wp_fwd, P + s.b_off, y, B, s.ih, s.iw, s.ic, s.oc, s.geom.k, 0,
+                                             s.has_sigmoid);
+                break;
+            case ST_BNPRELU: {
+                BnArgs a; memset(&a, 0, sizeof(a));
+                a.x = cur; a.y = y; a.M = (long long)B * s.ih * s.iw; a.C = s.ic;
+                a.gamma = P + s.gamma_off; a.beta = P + s.beta_off; a.slope = s.has_prelu ? P + s.slope_off : nullptr;
+                a.mean = ws + s.aux_off; a.invstd = ws + s.aux_off + s.ic;
+                a.running_mean = n->buffers + s.buf_off; a.running_var = n->buffers + s.buf_off + s.ic;
+                a.eps = s.eps; a.momentum = s.momentum; a.train = train; a.scratch = scratch;
+                rc = fg_launch_bn_forward(ctx, a);
+                break;
+            }
+            case ST_PRELU: {
+                const long long cnt = (long long)B * s.ic * s.ih * s.iw;
+                const float sc = (s.mask_kind == 2 && train) ? 1.f / (1.f - s.p) : 1.f;
+                rc = fg_launch_prelu_forward(ctx, cur, P + s.slope_off, train ? mask : nullptr, sc, y, cnt);
+                break;
+            }
+            case ST_ACTPOOL: {
+                const float sc = train ? 1.f : (1.f - s.p);
+                rc = fg_launch_actpool_forward(ctx, cur, P + s.slope_off, train ? mask : nullptr, sc, y, B, s.ih, s.iw, s.ic);
+                break;
+            }
+            case ST_SIGMOID: rc = fg_launch_sigmoid_forward(ctx, cur, y, (long long)B * s.ic * s.ih * s.iw); break;
+            case ST_LEAKYRELU: rc = fg_launch_leakyrelu_forward(ctx, cur, s.negslope, y, (long long)B * s.ic * s.ih * s.iw); break;
+            case ST_UPSAMPLE: rc = fg_launch_upsample_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
+            case ST_AVGPOOL: rc = fg_launch_avgpool_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
+            case ST_SDROPOUT:
+                rc = fg_launch_scale_mask_nc(ctx, cur, train ? mask : nullptr, train ? 1.f : 1.f - s.p, y, B, s.ih * s.iw, s.ic);
+                break;
+            default: rc = fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: bad stage kind %d", s.kind);
+        }
+        if (rc) return rc;
+        cur = y;
+    }
+    if (out_offset) *out_offset = n->st.back().out_off;
+    return FG_OK;
+}
+
+int fg_net_backward(fg_net* n, int B, const float* x, const float* gy, void* wsv, size_t ws_bytes, int flags, float* gx) {
+    if (!n || !x || !gy || !wsv) return fg_set_err(n ? n->ctx : nullptr, FG_ERR_INVALID, "fg_net_backward: null argument");
+    fg_ctx* ctx = n->ctx;
+    if (n->plan_batch != B) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: batch %d != forward batch %d", B, n->plan_batch);
+    if (!n->last_train) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: last forward was in evaluate mode");
+    if ((size_t)n->total_floats * sizeof(float) > ws_bytes) return fg_set_err(ctx, FG_ERR_WORKSPACE, "fg_net_backward: workspace");
+    const bool want_p = (flags & FG_BWD_PARAM_GRADS) != 0, want_x = (flags & FG_BWD_INPUT_GRAD) != 0;
+    if (want_p && !n->grads) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: gradient vector not bound");
+    if (want_x && !gx) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: gx required");
+    float* ws = (float*)wsv;
+    float* scratch = ws + n->scratch_off;
+    float* tmp = ws + n->tmp_off;
+    const float* P = n->params;
+    float* Gp = n->grads;
+    const float* gcur = gy;
+    int pp = 0, rc = FG_OK;
+    for (int si = (int)n->st.size() - 1; si >= 0; --si) {
+        Stage& s = n->st[si];
+        const float* xin = si == 0 ? x : ws + n->st[si - 1].out_off;
+        const float* yout = ws + s.out_off;
+        const bool need_gx = si > 0 || want_x;
+        float* gxb = si == 0 ? gx : ws + n->grad_off[pp];
+        if (!need_gx) gxb = nullptr;
+        const float* mask = (s.mask_idx >= 0) ? n->mask_ptrs[s.mask_idx] : nullptr;
+        switch (s.kind) {
+            case ST_CONV: {
+                ConvGeom g = s.geom; g.B = B;
+                if (want_p) {
+                    rc = fg_conv_wgrad_run(ctx, g, xin, gcur, Gp + s.w_off, s.bias_packed ? nullptr : Gp + s.b_off, 0.f,
+                                           scratch, n->scratch_floats);
+                    if (!rc && s.bias_packed) {  // bias grad in NHWC feature order -> reference order
+                        float* tb = scratch + (long long)CR_ROWBLOCKS_MAX * g.Cout;
+                        rc = fg_launch_colsum(ctx, gcur, (long long)B, g.Cout, 0.f, tb, scratch);
+                        if (!rc) rc = fg_launch_nhwc_to_nchw(ctx, tb, Gp + s.b_off, 1, g.o_c, g.o_hw, 1);
+                    }
+                }
+                if (!rc && need_gx) rc = fg_conv_dgrad_run(ctx, g, gcur, s.wp_bwd, gxb, scratch, n->scratch_floats);
+                break;
+            }
+            case ST_GEMV:
+                rc = fg_launch_gemv_backward(ctx, xin, P + s.w_off, yout, gcur, gxb, want_p ? Gp + s.w_off : nullptr,
+                                             want_p ? Gp + s.b_off : nullptr, 0.f, B, s.ic, s.has_sigmoid);
+                break;
+            case ST_THIN_IN: {
+                const int k = s.geom.k;
+                if (want_p) {
+                    float* gw = scratch + (long long)256 * k * k * s.ic * s.oc;
+                    rc = fg_launch_thin_wgrad(ctx, xin, gcur, gw, B, s.ih, s.iw, s.ic, s.oc, k, +1, scratch);
+                    if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 0, 0.f);
+                    if (!rc) rc = fg_launch_colsum(ctx, gcur, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
+                }
+                if (!rc && need_gx)
+                    rc = fg_launch_thin_out_conv(ctx, gcur, s.wp_fwd, nullptr, gxb, B, s.ih, s.iw, s.oc, s.ic, k, 1, 0);
+                break;
+            }
+            case ST_THIN_OUT: {
+                const int k = s.geom.k;
+                const float* gpre = gcur;
+                if (s.has_sigmoid) {
+                    rc = fg_launch_sigmoid_backward(ctx, yout, gcur, tmp, (long long)B * s.oc * s.oh * s.ow);
+                    gpre = tmp;
+                }
+                if (!rc && want_p) {
+                    float* gw = scratch + (long long)256 * k * k * s.oc * s.ic;
+                    rc = fg_launch_thin_wgrad(ctx, gpre, xin, gw, B, s.ih, s.iw, s.oc, s.ic, k, -1, scratch);
+                    if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 1, 0.f);
+                    if (!rc) rc = fg_launch_colsum(ctx, gpre, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
+                }
+                if (!rc && need_gx)
+                    rc = fg_launch_thin_in_conv(ctx, gpre, s.wp_fwd, nullptr, gxb, B, s.ih, s.iw, s.oc, s.ic, k, 1);
+                break;
+            }
+            case ST_BNPRELU: {
+                BnBwdArgs a; memset(&a, 0, sizeof(a));
+                a.x = xin; a.gy = gcur; a.gx = gxb; a.M = (long long)B * s.ih * s.iw; a.C = s.ic;
+                a.gamma = P + s.gamma_off; a.beta = P + s.beta_off; a.slope = s.has_prelu ? P + s.slope_off : nullptr;
+                a.mean = ws + s.aux_off; a.invstd = ws + s.aux_off + s.ic;
+                a.ggamma = want_p ? Gp + s.gamma_off : nullptr; a.gbeta = want_p ? Gp + s.beta_off : nullptr;
+                a.gslope = (want_p && s.has_prelu) ? Gp + s.slope_off : nullptr; a.gbeta_acc = 0.f; a.scratch = scratch;
+                rc = fg_launch_bn_backward(ctx, a);
+                break;
+            }
+            case ST_PRELU: {
+                const long long cnt = (long long)B * s.ic * s.ih * s.iw;
+                const float sc = (s.mask_kind == 2) ? 1.f / (1.f - s.p) : 1.f;
+                rc = fg_launch_prelu_backward(ctx, xin, gcur, P + s.slope_off, mask, sc, gxb,
+                                              want_p ? Gp + s.slope_off : nullptr, 0.f, cnt, scratch);
+                break;
+            }
+            case ST_ACTPOOL:
+                rc = fg_launch_actpool_backward(ctx, xin, gcur, P + s.slope_off, mask, 1.f, gxb,
+                                                want_p ? Gp + s.slope_off : nullptr, 0.f, B, s.ih, s.iw, s.ic, scratch);
+                break;
+            case ST_SIGMOID:
+                if (need_gx) rc = fg_launch_sigmoid_backward(ctx, yout, gcur, gxb, (long long)B * s.ic * s.ih * s.iw);
+                break;
+            case ST_LEAKYRELU:
+                if (need_gx) rc = fg_launch_leakyrelu_backward(ctx, xin, gcur, s.negslope, gxb, (long long)B * s.ic * s.ih * s.iw);
+                break;
+            case ST_UPSAMPLE: if (need_gx) rc = fg_launch_upsample_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
+            case ST_AVGPOOL: if (need_gx) rc = fg_launch_avgpool_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
+            case ST_SDROPOUT: if (need_gx) rc = fg_launch_scale_mask_nc(ctx, gcur, mask, 1.f, gxb, B, s.ih * s.iw, s.ic); break;
+            default: rc = fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: bad stage kind %d", s.kind);
+        }
+        if (rc) return rc;
+        gcur = gxb;
+        if (si > 0) pp ^= 1;
+    }
+    return FG_OK;
+}
+
+int fg_net_layer_output(const fg_net* n, int li, long long* off, int* c, int* h, int* w) {
+    if (!n || li < 0 || li >= (int)n->layers.size()) return FG_ERR_INVALID;
+    const LayerInfo& l = n->layers[li];
+    if (l.stage < 0 || !l.ends_stage) return fg_set_err(n->ctx, FG_ERR_INVALID, "layer %d is fused inside a stage", li);
+    const Stage& s = n->st[l.stage];
+    if (off) *off = s.out_off;
+    if (c) *c = s.oc; if (h) *h = s.oh; if (w) *w = s.ow;
+    return FG_OK;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

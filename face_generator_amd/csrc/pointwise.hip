@@ -1,0 +1,864 @@
+// HBM-bound pointwise / reduction kernels of the GAN step for gfx950 (wave = 64):
+// layout conversion, column sums, SpatialBatchNormalization(+PReLU), PReLU(+Dropout),
+// PReLU+SpatialDropout+AvgPool, nearest upsample, sigmoid, LeakyReLU, Linear(K->1)+Sigmoid,
+// BCECriterion, fused penalty+clamp+Adam, norms, Philox RNG.
+// Reference semantics: SURVEY.md Appendix A (Torch7 nn modules; call sites models.lua:57-81, 382-416,
+// train.lua:148, interruptable_optimizers.lua:49-94, adversarial.lua:103-123).
+#include "fg_internal.h"
+
+#define FG_GRID(n, bs) dim3((unsigned)((((n) + (bs)-1) / (bs)) < 4096 ? (((n) + (bs)-1) / (bs)) : 4096))
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// block sum (256 threads), result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    return r;
+}
+
+// ------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ s, float* __restrict__ d, int N, int C, int H, int W) {
+    long long total = (long long)N * C * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long long t = i / C;
+        int w = (int)(t % W); t /= W;
+        int h = (int)(t % H);
+        int n = (int)(t / H);
+        d[i] = s[(((long long)n * C + c) * H + h) * W + w];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ s, float* __restrict__ d, int N, int C, int H, int W) {
+    long long total = (long long)N * C * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int w = (int)(i % W);
+        long long t = i / W;
+        int h = (int)(t % H); t /= H;
+        int c = (int)(t % C);
+        int n = (int)(t / C);
+        d[i] = s[(((long long)n * H + h) * W + w) * C + c];
+    }
+}
+int fg_launch_nchw_to_nhwc(fg_ctx* ctx, const float* s, float* d, int N, int C, int H, int W) {
+    long long n = (long long)N * C * H * W;
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, s, d, N, C, H, W);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_nhwc_to_nchw(fg_ctx* ctx, const float* s, float* d, int N, int C, int H, int W) {
+    long long n = (long long)N * C * H * W;
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, s, d, N, C, H, W);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+__global__ void fill_kernel(float* p, float v, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+int fg_launch_fill(fg_ctx* ctx, float* p, float v, long long n) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(fill_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, p, v, n);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ void axpby_kernel(float a, const float* __restrict__ x, float b, float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = (b == 0.f) ? a * x[i] : a * x[i] + b * y[i];
+}
+int fg_launch_axpby(fg_ctx* ctx, float a, const float* x, float b, float* y, long long n) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(axpby_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, a, x, b, y, n);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// ------------------------------------------------------------------ column reductions over [M][C]
+// block = (64 columns, 4 row lanes); grid = (row blocks, column blocks). K partial sums per element.
+#define CR_ROWBLOCKS 256
+static inline int cr_rowblocks(long long M) { return (int)((M + 63) / 64 < CR_ROWBLOCKS ? (M + 63) / 64 : CR_ROWBLOCKS); }
+
+template <int K, class F>
+__device__ __forceinline__ void colreduce_body(long long M, int C, float* __restrict__ part, F f) {
+    __shared__ float sh[K][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + tx;
+    const int nrb = gridDim.x;
+    const long long rows_per = (M + nrb - 1) / nrb;
+    const long long r0 = blockIdx.x * rows_per;
+    const long long r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    if (c < C)
+        for (long long r = r0 + ty; r < r1; r += 4) f(r, c, acc);
+#pragma unroll
+    for (int k = 0; k < K; ++k) sh[k][ty][tx] = acc[k];
+    __syncthreads();
+    if (ty == 0 && c < C) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            part[((size_t)k * nrb + blockIdx.x) * C + c] = (sh[k][0][tx] + sh[k][1][tx]) + (sh[k][2][tx] + sh[k][3][tx]);
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long long M, int C,
+                                                             float* __restrict__ part) {
+    colreduce_body<1>(M, C, part, [&](long long r, int c, float* acc) { acc[0] += x[r * C + c]; });
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nrb, int C, float beta, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nrb; ++b) s += (double)part[(size_t)b * C + c];
+    out[c] = (beta == 0.f) ? (float)s : beta * out[c] + (float)s;
+}
+int fg_launch_colsum(fg_ctx* ctx, const float* x, long long M, int N, float beta, float* out, float* scratch) {
+    const int nrb = cr_rowblocks(M);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nrb, fg_cdiv(N, 64)), dim3(256), 0, ctx->stream, x, M, N, scratch);
+    FG_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(N, 256)), dim3(256), 0, ctx->stream, scratch, nrb, N, beta, out);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// ------------------------------------------------------------------ SpatialBatchNormalization (+PReLU)
+// stats: shifted single pass (pivot = x[0][c]) -> S1 = sum(x-K), S2 = sum((x-K)^2); fp64 finalize.
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long long M, int C,
+                                                               float* __restrict__ part) {
+    colreduce_body<2>(M, C, part, [&](long long r, int c, float* acc) {
+        const float d = x[r * C + c] - x[c];
+        acc[0] += d;
+        acc[1] = fmaf(d, d, acc[1]);
+    });
+}
+__global__ void bn_stats_final_kernel(const float* __restrict__ part, const float* __restrict__ x, int nrb, long long M,
+                                      int C, float eps, float momentum, float* __restrict__ mean,
+                                      float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nrb; ++b) {
+        s1 += (double)part[(size_t)b * C + c];
+        s2 += (double)part[((size_t)nrb + b) * C + c];
+    }
+    const double n = (double)M;
+    const double mu = (double)x[c] + s1 / n;
+    double var = (s2 - s1 * s1 / n) / n;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        const double unb = var * n / (n > 1.0 ? n - 1.0 : 1.0);
+        rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mu);
+        rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unb);
+    }
+}
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar, int C, float eps,
+                                     float* __restrict__ mean, float* __restrict__ invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = rmean[c];
+    invstd[c] = (float)(1.0 / sqrt((double)rvar[c] + (double)eps));
+}
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       long long total4, int C, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ slope,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd) {
+    const float a = slope ? slope[0] : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        float4 v = ((const float4*)x)[i];
+        const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+        const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+        float z;
+        z = (v.x - mu.x) * is.x * g.x + b.x; v.x = z > 0.f ? z : a * z;
+        z = (v.y - mu.y) * is.y * g.y + b.y; v.y = z > 0.f ? z : a * z;
+        z = (v.z - mu.z) * is.z * g.z + b.z; v.z = z > 0.f ? z : a * z;
+        z = (v.w - mu.w) * is.w * g.w + b.w; v.w = z > 0.f ? z : a * z;
+        ((float4*)y)[i] = v;
+    }
+}
+int fg_launch_bn_forward(fg_ctx* ctx, const BnArgs& a) {
+    if (a.C % 4) return fg_set_err(ctx, FG_ERR_INVALID, "bn: C %% 4");
+    if (a.train) {
+        const int nrb = cr_rowblocks(a.M);
+        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nrb, fg_cdiv(a.C, 64)), dim3(256), 0, ctx->stream, a.x, a.M,
+                           a.C, a.scratch);
+        FG_CHECK_LAUNCH(ctx);
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(fg_cdiv(a.C, 256)), dim3(256), 0, ctx->stream, a.scratch, a.x,
+                           nrb, a.M, a.C, a.eps, a.momentum, a.mean, a.invstd, a.running_mean, a.running_var);
+        FG_CHECK_LAUNCH(ctx);
+    } else {
+        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(fg_cdiv(a.C, 256)), dim3(256), 0, ctx->stream, a.running_mean,
+                           a.running_var, a.C, a.eps, a.mean, a.invstd);
+        FG_CHECK_LAUNCH(ctx);
+    }
+    const long long t4 = a.M * a.C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, FG_GRID(t4, 256), dim3(256), 0, ctx->stream, a.x, a.y, t4, a.C, a.gamma,
+                       a.beta, a.slope, a.mean, a.invstd);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// backward: dz = PReLU'(z) * gy with z = gamma*xhat + beta; sums: S_dz, S_dz_xhat per channel, S_slope global
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                             long long M, int C, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ slope,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* __restrict__ part) {
+    const float a = slope ? slope[0] : 1.f;
+    colreduce_body<3>(M, C, part, [&](long long r, int c, float* acc) {
+        const float xh = (x[r * C + c] - mean[c]) * invstd[c];
+        const float z = xh * gamma[c] + beta[c];
+        const float g = gy[r * C + c];
+        const float dz = z > 0.f ? g : a * g;
+        acc[0] += dz;
+        acc[1] = fmaf(dz, xh, acc[1]);
+        if (!(z > 0.f)) acc[2] = fmaf(z, g, acc[2]);
+    });
+}
+// scratch layout: part[3][nrb][C], then coef[2][C]
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nrb, long long M, int C,
+                                    float* __restrict__ coef, float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                    float acc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nrb; ++b) {
+        s1 += (double)part[(size_t)b * C + c];
+        s2 += (double)part[((size_t)nrb + b) * C + c];
+    }
+    coef[c] = (float)(s1 / (double)M);
+    coef[C + c] = (float)(s2 / (double)M);
+    if (ggamma) ggamma[c] = (acc == 0.f ? 0.f : acc * ggamma[c]) + (float)s2;
+    if (gbeta) gbeta[c] = (acc == 0.f ? 0.f : acc * gbeta[c]) + (float)s1;
+}
+__global__ void scalar_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out, float acc) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)part[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = sh[0] + sh[1] + sh[2] + sh[3];
+        out[0] = (acc == 0.f ? 0.f : acc * out[0]) + (float)t;
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                           float* __restrict__ gx, long long total4, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ slope, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                           int train) {
+    const float a = slope ? slope[0] : 1.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * 4) % C);
+        const float4 xv = ((const float4*)x)[i], gv = ((const float4*)gy)[i];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float is = invstd[c + j], g = gamma[c + j];
+            const float xh = (xs[j] - mean[c + j]) * is;
+            const float z = xh * g + beta[c + j];
+            const float dz = z > 0.f ? gs[j] : a * gs[j];
+            o[j] = train ? g * is * (dz - coef[c + j] - xh * coef[C + c + j]) : g * is * dz;
+        }
+        ((float4*)gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
+    if (a.C % 4) return fg_set_err(ctx, FG_ERR_INVALID, "bn: C %% 4");
+    const int nrb = cr_rowblocks(a.M);
+    const int ncb = fg_cdiv(a.C, 64);
+    float* part = a.scratch;
+    float* coef = a.scratch + (size_t)3 * nrb * a.C;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb, ncb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
+                       a.beta, a.slope, a.mean, a.invstd, part);
+    FG_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fg_cdiv(a.C, 256)), dim3(256), 0, ctx->stream, part, nrb, a.M, a.C,
+                       coef, a.ggamma, a.gbeta, a.gbeta_acc);
+    FG_CHECK_LAUNCH(ctx);
+    if (a.slope && a.gslope) {
+        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, ctx->stream, part + (size_t)2 * nrb * a.C,
+                           nrb * a.C, a.gslope, a.gbeta_acc);
+        FG_CHECK_LAUNCH(ctx);
+    }
+    if (a.gx) {
+        const long long t4 = a.M * a.C / 4;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, FG_GRID(t4, 256), dim3(256), 0, ctx->stream, a.x, a.gy, a.gx, t4, a.C,
+                           a.gamma, a.beta, a.slope, a.mean, a.invstd, coef, 1);
+        FG_CHECK_LAUNCH(ctx);
+    }
+    return FG_OK;
+}
+
+// ------------------------------------------------------------------ PReLU (+ same-shape mask)
+__global__ __launch_bounds__(256) void prelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope,
+                                                        const float* __restrict__ mask, float mscale,
+                                                        float* __restrict__ y, long long n) {
+    const float a = slope[0];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        float r = v > 0.f ? v : a * v;
+        if (mask) r *= mask[i] * mscale;
+        y[i] = r;
+    }
+}
+int fg_launch_prelu_forward(fg_ctx* ctx, const float* x, const float* slope, const float* mask, float mscale, float* y,
+                            long long n) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(prelu_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, slope, mask, mscale, y, n);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ __launch_bounds__(256) void prelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                        const float* __restrict__ slope, const float* __restrict__ mask,
+                                                        float mscale, float* __restrict__ gx, float* __restrict__ part,
+                                                        long long n) {
+    __shared__ float sh[4];
+    const float a = slope[0];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        float g = gy[i];
+        if (mask) g *= mask[i] * mscale;
+        if (gx) gx[i] = v > 0.f ? g : a * g;
+        if (!(v > 0.f)) s = fmaf(v, g, s);
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+int fg_launch_prelu_backward(fg_ctx* ctx, const float* x, const float* gy, const float* slope, const float* mask,
+                             float mscale, float* gx, float* gslope, float acc, long long n, float* scratch) {
+    if (n == 0) return FG_OK;
+    dim3 grid = FG_GRID(n, 256);
+    if (grid.x > 1024) grid.x = 1024;
+    hipLaunchKernelGGL(prelu_bwd_kernel, grid, dim3(256), 0, ctx->stream, x, gy, slope, mask, mscale, gx, scratch, n);
+    FG_CHECK_LAUNCH(ctx);
+    if (gslope) {
+        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, ctx->stream, scratch, (int)grid.x, gslope, acc);
+        FG_CHECK_LAUNCH(ctx);
+    }
+    return FG_OK;
+}
+
+// ------------------------------------------------------------------ PReLU -> SpatialDropout -> AvgPool(2,2,2,2)
+__global__ __launch_bounds__(256) void actpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope,
+                                                          const float* __restrict__ mask, float mscale,
+                                                          float* __restrict__ y, int B, int H, int W, int C) {
+    const float a = slope ? slope[0] : 1.f;
+    const int H2 = H >> 1, W2 = W >> 1, C4 = C >> 2;
+    const long long total = (long long)B * H2 * W2 * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int w2 = (int)(t % W2); t /= W2;
+        const int h2 = (int)(t % H2);
+        const int b = (int)(t / H2);
+        const float4* px = (const float4*)(x + (((size_t)b * H + 2 * h2) * W + 2 * w2) * C) + c4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float4 v = px[((size_t)dy * W + dx) * C4];
+                s.x += v.x > 0.f ? v.x : a * v.x;
+                s.y += v.y > 0.f ? v.y : a * v.y;
+                s.z += v.z > 0.f ? v.z : a * v.z;
+                s.w += v.w > 0.f ? v.w : a * v.w;
+            }
+        float4 m = make_float4(mscale, mscale, mscale, mscale);
+        if (mask) {
+            const float4 mk = *(const float4*)(mask + (size_t)b * C + c4 * 4);
+            m.x *= mk.x; m.y *= mk.y; m.z *= mk.z; m.w *= mk.w;
+        }
+        s.x *= 0.25f * m.x; s.y *= 0.25f * m.y; s.z *= 0.25f * m.z; s.w *= 0.25f * m.w;
+        ((float4*)y)[i] = s;
+    }
+}
+int fg_launch_actpool_forward(fg_ctx* ctx, const float* x, const float* slope, const float* mask, float mscale,
+                              float* y, int B, int H, int W, int C) {
+    if (C % 4 || H % 2 || W % 2) return fg_set_err(ctx, FG_ERR_INVALID, "actpool: C%%4, even H/W");
+    long long n = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(actpool_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, slope, mask, mscale, y, B, H,
+                       W, C);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ __launch_bounds__(256) void actpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          const float* __restrict__ slope, const float* __restrict__ mask,
+                                                          float mscale, float* __restrict__ gx, float* __restrict__ part,
+                                                          int B, int H, int W, int C) {
+    __shared__ float sh[4];
+    const float a = slope ? slope[0] : 1.f;
+    const int H2 = H >> 1, W2 = W >> 1, C4 = C >> 2;
+    const long long total = (long long)B * H * W * C4;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int b = (int)(t / H);
+        const float4 v = ((const float4*)x)[i];
+        float4 g = *((const float4*)(gy + (((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * C) + c4);
+        float4 m = make_float4(mscale, mscale, mscale, mscale);
+        if (mask) {
+            const float4 mk = *(const float4*)(mask + (size_t)b * C + c4 * 4);
+            m.x *= mk.x; m.y *= mk.y; m.z *= mk.z; m.w *= mk.w;
+        }
+        g.x *= 0.25f * m.x; g.y *= 0.25f * m.y; g.z *= 0.25f * m.z; g.w *= 0.25f * m.w;
+        float4 o;
+        o.x = v.x > 0.f ? g.x : a * g.x; if (!(v.x > 0.f)) s = fmaf(v.x, g.x, s);
+        o.y = v.y > 0.f ? g.y : a * g.y; if (!(v.y > 0.f)) s = fmaf(v.y, g.y, s);
+        o.z = v.z > 0.f ? g.z : a * g.z; if (!(v.z > 0.f)) s = fmaf(v.z, g.z, s);
+        o.w = v.w > 0.f ? g.w : a * g.w; if (!(v.w > 0.f)) s = fmaf(v.w, g.w, s);
+        if (gx) ((float4*)gx)[i] = o;
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+int fg_launch_actpool_backward(fg_ctx* ctx, const float* x, const float* gy, const float* slope, const float* mask,
+                               float mscale, float* gx, float* gslope, float acc, int B, int H, int W, int C,
+                               float* scratch) {
+    if (C % 4 || H % 2 || W % 2) return fg_set_err(ctx, FG_ERR_INVALID, "actpool: C%%4, even H/W");
+    long long n = (long long)B * H * W * (C / 4);
+    if (n == 0) return FG_OK;
+    dim3 grid = FG_GRID(n, 256);
+    if (grid.x > 1024) grid.x = 1024;
+    hipLaunchKernelGGL(actpool_bwd_kernel, grid, dim3(256), 0, ctx->stream, x, gy, slope, mask, mscale, gx, scratch, B,
+                       H, W, C);
+    FG_CHECK_LAUNCH(ctx);
+    if (slope && gslope) {
+        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, ctx->stream, scratch, (int)grid.x, gslope, acc);
+        FG_CHECK_LAUNCH(ctx);
+    }
+    return FG_OK;
+}
+
+// ------------------------------------------------------------------ standalone module pieces
+__global__ void scale_mask_nc_kernel(const float* __restrict__ x, const float* __restrict__ mask, float mscale,
+                                     float* __restrict__ y, int B, int HW, int C) {
+    const long long total = (long long)B * HW * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((long long)HW * C));
+        y[i] = x[i] * (mask ? mask[(size_t)b * C + c] * mscale : mscale);
+    }
+}
+int fg_launch_scale_mask_nc(fg_ctx* ctx, const float* x, const float* mask, float mscale, float* y, int B, int HW,
+                            int C) {
+    long long n = (long long)B * HW * C;
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(scale_mask_nc_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, mask, mscale, y, B, HW, C);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long long total = (long long)B * H2 * W2 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int w2 = (int)(t % W2); t /= W2;
+        const int h2 = (int)(t % H2);
+        const int b = (int)(t / H2);
+        const float* p = x + (((size_t)b * H + 2 * h2) * W + 2 * w2) * C + c;
+        y[i] = 0.25f * ((p[0] + p[C]) + (p[(size_t)W * C] + p[(size_t)W * C + C]));
+    }
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int H, int W, int C) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long long total = (long long)B * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int b = (int)(t / H);
+        gx[i] = 0.25f * gy[(((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * C + c];
+    }
+}
+int fg_launch_avgpool_forward(fg_ctx* ctx, const float* x, float* y, int B, int H, int W, int C) {
+    long long n = (long long)B * (H / 2) * (W / 2) * C;
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(avgpool_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, y, B, H, W, C);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_avgpool_backward(fg_ctx* ctx, const float* gy, float* gx, int B, int H, int W, int C) {
+    long long n = (long long)B * H * W * C;
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(avgpool_bwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, gy, gx, B, H, W, C);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+    const int H2 = H * 2, W2 = W * 2;
+    const long long total = (long long)B * H2 * W2 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int w = (int)(t % W2); t /= W2;
+        const int h = (int)(t % H2);
+        const int b = (int)(t / H2);
+        y[i] = x[(((size_t)b * H + (h >> 1)) * W + (w >> 1)) * C + c];
+    }
+}
+__global__ void upsample_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int B, int H, int W, int C) {
+    const int W2 = W * 2;
+    const long long total = (long long)B * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const int b = (int)(t / H);
+        const float* p = gy + (((size_t)b * 2 * H + 2 * h) * W2 + 2 * w) * C + c;
+        gx[i] = (p[0] + p[C]) + (p[(size_t)W2 * C] + p[(size_t)W2 * C + C]);
+    }
+}
+int fg_launch_upsample_forward(fg_ctx* ctx, const float* x, float* y, int B, int H, int W, int C) {
+    long long n = (long long)B * H * W * C * 4;
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(upsample_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, y, B, H, W, C);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_upsample_backward(fg_ctx* ctx, const float* gy, float* gx, int B, int H, int W, int C) {
+    long long n = (long long)B * H * W * C;
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(upsample_bwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, gy, gx, B, H, W, C);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = 1.f / (1.f + expf(-x[i]));
+}
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy, float* __restrict__ gx,
+                                   long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = y[i];
+        gx[i] = gy[i] * v * (1.f - v);
+    }
+}
+int fg_launch_sigmoid_forward(fg_ctx* ctx, const float* x, float* y, long long n) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(sigmoid_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, y, n);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_sigmoid_backward(fg_ctx* ctx, const float* y, const float* gy, float* gx, long long n) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, y, gy, gx, n);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+// LeakyReLU.lua:13-31: y = (|x|+x)/2 + (-s/2)(|x|-x); backward: x >= 0 -> gy, else s*gy
+__global__ void leakyrelu_fwd_kernel(const float* __restrict__ x, float s, float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i], av = fabsf(v);
+        y[i] = (av + v) * 0.5f + (av - v) * (-s * 0.5f);
+    }
+}
+__global__ void leakyrelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float s,
+                                     float* __restrict__ gx, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        gx[i] = x[i] >= 0.f ? gy[i] : s * gy[i];
+}
+int fg_launch_leakyrelu_forward(fg_ctx* ctx, const float* x, float s, float* y, long long n) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(leakyrelu_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, s, y, n);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_leakyrelu_backward(fg_ctx* ctx, const float* x, const float* gy, float s, float* gx, long long n) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(leakyrelu_bwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, gy, s, gx, n);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// ------------------------------------------------------------------ Linear(K -> 1) [+ Sigmoid]
+__global__ __launch_bounds__(64) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ y, int B, int K,
+                                                      int sigmoid) {
+    const int row = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 64) s = fmaf(x[(size_t)row * K + k], w[k], s);
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        s += b[0];
+        y[row] = sigmoid ? 1.f / (1.f + expf(-s)) : s;
+    }
+}
+int fg_launch_gemv_forward(fg_ctx* ctx, const float* x, const float* w, const float* b, float* y, int B, int K,
+                           int sigmoid) {
+    if (B == 0) return FG_OK;
+    hipLaunchKernelGGL(gemv_fwd_kernel, dim3(B), dim3(64), 0, ctx->stream, x, w, b, y, B, K, sigmoid);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+// one block; dl[b] = gy[b]*y(1-y) (or gy); gx[b][k] = dl[b] w[k]; gw[k] = sum_b dl[b] x[b][k]; gb = sum dl
+__global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ y, const float* __restrict__ gy,
+                                                       float* __restrict__ gx, float* __restrict__ gw,
+                                                       float* __restrict__ gb, float acc, int B, int K, int sigmoid) {
+    extern __shared__ float dl[];  // [B]
+    __shared__ float sh[4];
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float v = y[b];
+        dl[b] = sigmoid ? gy[b] * v * (1.f - v) : gy[b];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        float s = 0.f;
+        const float wk = w[k];
+        for (int b = 0; b < B; ++b) {
+            s = fmaf(dl[b], x[(size_t)b * K + k], s);
+            if (gx) gx[(size_t)b * K + k] = dl[b] * wk;
+        }
+        if (gw) gw[k] = (acc == 0.f ? 0.f : acc * gw[k]) + s;
+    }
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) s += dl[b];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0 && gb) gb[0] = (acc == 0.f ? 0.f : acc * gb[0]) + s;
+}
+int fg_launch_gemv_backward(fg_ctx* ctx, const float* x, const float* w, const float* y, const float* gy, float* gx,
+                            float* gw, float* gb, float acc, int B, int K, int sigmoid) {
+    if (B == 0) return FG_OK;
+    hipLaunchKernelGGL(gemv_bwd_kernel, dim3(1), dim3(256), B * sizeof(float), ctx->stream, x, w, y, gy, gx, gw, gb,
+                       acc, B, K, sigmoid);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// ------------------------------------------------------------------ BCECriterion (train.lua:148), eps = 1e-12
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ prob, const float* __restrict__ target,
+                                                  float* __restrict__ loss, float* __restrict__ grad,
+                                                  int* __restrict__ conf, int B) {
+    __shared__ double shd[4];
+    __shared__ int shc[4];
+    const float eps = 1e-12f;
+    double s = 0.0;
+    if (threadIdx.x < 4) shc[threadIdx.x] = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float x = prob[b], t = target[b];
+        s += (double)(t * logf(x + eps) + (1.f - t) * logf((1.f - x) + eps));
+        if (grad) grad[b] = -(t - x) / (((1.f - x) + eps) * (x + eps)) / (float)B;
+        if (conf) atomicAdd(&shc[(x > 0.5f ? 2 : 0) + (t > 0.5f ? 1 : 0)], 1);
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) loss[0] = (float)(-(shd[0] + shd[1] + shd[2] + shd[3]) / (double)B);
+    if (threadIdx.x < 4 && conf) conf[threadIdx.x] = shc[threadIdx.x];
+}
+int fg_launch_bce(fg_ctx* ctx, const float* prob, const float* target, float* loss, float* grad, int* confusion,
+                  int B) {
+    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, ctx->stream, prob, target, loss, grad, confusion, B);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// ------------------------------------------------------------------ optimizers over the flat vector
+__device__ __forceinline__ float sgnf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+__device__ __forceinline__ float prep_grad(float g, float p, float gscale, float l1mul, float l2, float clamp) {
+    g *= gscale;
+    if (l1mul != 0.f || l2 != 0.f) g += sgnf(p) * l1mul + p * l2;   // adversarial.lua:109 / :223
+    if (clamp != 0.f) g = fminf(fmaxf(g, -clamp), clamp);           // adversarial.lua:121-123
+    return g;
+}
+__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a, float step) {
+    const float ob1 = 1.f - a.beta1, ob2 = 1.f - a.beta2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float p = a.p[i];
+        const float g = prep_grad(a.g[i], p, a.gscale, a.l1_mul, a.l2, a.clamp);
+        // interruptable_optimizers.lua:78-90 : m = b1*m + (1-b1) g ; v = b2*v + (1-b2) g*g ; denom = sqrt(v)+eps
+        const float m = a.m[i] * a.beta1 + ob1 * g;
+        const float v = a.v[i] * a.beta2 + ob2 * g * g;
+        const float denom = sqrtf(v) + a.eps;
+        a.m[i] = m;
+        a.v[i] = v;
+        a.p[i] = p - step * (m / denom);
+        if (a.gout) a.gout[i] = g;
+    }
+}
+int fg_launch_adam(fg_ctx* ctx, const AdamArgs& a) {
+    if (a.n == 0) return FG_OK;
+    const double bc1 = 1.0 - pow((double)a.beta1, (double)a.t);
+    const double bc2 = 1.0 - pow((double)a.beta2, (double)a.t);
+    const float step = (float)((double)a.lr * sqrt(bc2) / bc1);
+    hipLaunchKernelGGL(adam_kernel, FG_GRID(a.n, 256), dim3(256), 0, ctx->stream, a, step);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ void sgd_kernel(float* p, const float* g, float* mom, long long n, float gscale, float l1mul, float l2,
+                           float clamp, float lr, float momentum, float dampening, float wd, int nesterov, int first) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        float d = prep_grad(g[i], pv, gscale, l1mul, l2, clamp);
+        if (wd != 0.f) d += wd * pv;
+        if (momentum != 0.f) {
+            float mv = first ? d : mom[i] * momentum + (1.f - dampening) * d;
+            mom[i] = mv;
+            d = nesterov ? d + momentum * mv : mv;
+        }
+        p[i] = pv - lr * d;
+    }
+}
+int fg_launch_sgd(fg_ctx* ctx, float* p, const float* g, float* mom, long long n, float gscale, float l1mul, float l2,
+                  float clamp, float lr, float momentum, float dampening, float wd, int nesterov, int first) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(sgd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, p, g, mom, n, gscale, l1mul, l2, clamp,
+                       lr, momentum, dampening, wd, nesterov, first);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ void adagrad_kernel(float* p, const float* g, float* var, long long n, float gscale, float l1mul, float l2,
+                               float clamp, float clr) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        const float d = prep_grad(g[i], pv, gscale, l1mul, l2, clamp);
+        const float v = var[i] + d * d;
+        var[i] = v;
+        p[i] = pv - clr * (d / (sqrtf(v) + 1e-10f));
+    }
+}
+int fg_launch_adagrad(fg_ctx* ctx, float* p, const float* g, float* var, long long n, float gscale, float l1mul,
+                      float l2, float clamp, float clr) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(adagrad_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, p, g, var, n, gscale, l1mul, l2,
+                       clamp, clr);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ __launch_bounds__(256) void norms_partial_kernel(const float* __restrict__ p, long long n,
+                                                            float* __restrict__ part) {
+    __shared__ float sh[4];
+    float s1 = 0.f, s2 = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = p[i];
+        s1 += fabsf(v);
+        s2 = fmaf(v, v, s2);
+    }
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = s1;
+        part[gridDim.x + blockIdx.x] = s2;
+    }
+}
+__global__ void norms_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+    if (threadIdx.x < 2) {
+        double s = 0.0;
+        for (int i = 0; i < nb; ++i) s += (double)part[threadIdx.x * nb + i];
+        out[threadIdx.x] = (float)s;
+    }
+}
+int fg_launch_norms(fg_ctx* ctx, const float* p, long long n, float* out2, float* scratch) {
+    dim3 grid = FG_GRID(n > 0 ? n : 1, 256);
+    if (grid.x > 512) grid.x = 512;
+    hipLaunchKernelGGL(norms_partial_kernel, grid, dim3(256), 0, ctx->stream, p, n, scratch);
+    FG_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(norms_final_kernel, dim3(1), dim3(64), 0, ctx->stream, scratch, (int)grid.x, out2);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                           uint32_t* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// mode 0: uniform(lo,hi)  1: bernoulli(keep=lo)  2: normal(mean=lo, std=hi)
+__global__ void rng_kernel(uint64_t seed, uint64_t offset, float* __restrict__ out, long long n, float lo, float hi,
+                           int mode) {
+    const long long nq = (n + 3) / 4;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x) {
+        const uint64_t ctr = offset + (uint64_t)q;
+        uint32_t r[4];
+        philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        float v[4];
+        if (mode == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; j += 2) {
+                const float u1 = ((r[j] >> 8) + 1) * (1.f / 16777216.f), u2 = (r[j + 1] >> 8) * (1.f / 16777216.f);
+                const float rad = sqrtf(-2.f * logf(u1));
+                v[j] = lo + hi * rad * cosf(6.28318530718f * u2);
+                v[j + 1] = lo + hi * rad * sinf(6.28318530718f * u2);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float u = (r[j] >> 8) * (1.f / 16777216.f);
+                v[j] = mode == 0 ? lo + u * (hi - lo) : (u < lo ? 1.f : 0.f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) out[q * 4 + j] = v[j];
+    }
+}
+static int launch_rng(fg_ctx* ctx, uint64_t seed, uint64_t offset, float* out, long long n, float lo, float hi,
+                      int mode) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(rng_kernel, FG_GRID((n + 3) / 4, 256), dim3(256), 0, ctx->stream, seed, offset, out, n, lo, hi,
+                       mode);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_rng_uniform(fg_ctx* ctx, uint64_t seed, uint64_t offset, float* out, long long n, float lo, float hi) {
+    return launch_rng(ctx, seed, offset, out, n, lo, hi, 0);
+}
+int fg_launch_rng_bernoulli(fg_ctx* ctx, uint64_t seed, uint64_t offset, float* out, long long n, float keep_prob) {
+    return launch_rng(ctx, seed, offset, out, n, keep_prob, 0.f, 1);
+}
+int fg_launch_rng_normal(fg_ctx* ctx, uint64_t seed, uint64_t offset, float* out, long long n, float mean, float std) {
+    return launch_rng(ctx, seed, offset, out, n, mean, std, 2);
+}

@@ -1,0 +1,370 @@
+// "Thin" convolutions for gfx950: one side of the contraction has <= 4 channels (image side of the nets:
+// D's first conv 3->64 and G's last conv 128->3, models.lua:385 / :73, and their data / weight gradients).
+// N or K of the GEMM view is 3 (or 27), so MFMA tiles would be > 90 % padding: these are HBM/VALU-bound and
+// run on the vector ALU with coalesced NHWC accesses and weights held in registers.
+#include "fg_internal.h"
+
+__device__ __forceinline__ float wave_sum_x(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------
+// thin-in: out[pix][c] = bias[c] + sum_{tap,s} in[pix + off(tap)][s] * Wp[tap][s][c]     (Cs small, Cw wide)
+// block = 256 threads = CBLK channels x PL pixel lanes; weights for channel c live in registers.
+// ---------------------------------------------------------------------------------
+template <int K, int CS>
+__global__ __launch_bounds__(256) void thin_in_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                      const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                      int H, int W, int Cw, int flip, int cblk) {
+    constexpr int PAD = (K - 1) / 2;
+    const int pl = threadIdx.x / cblk, tc = threadIdx.x - pl * cblk;
+    const int PL = 256 / cblk;
+    const int c = blockIdx.y * cblk + tc;
+    float w[K * K * CS];
+#pragma unroll
+    for (int t = 0; t < K * K * CS; ++t) w[t] = Wp[(size_t)t * Cw + c];
+    const float bv = bias ? bias[c] : 0.f;
+    const int npix = B * H * W;
+    const int p0 = blockIdx.x * 128;
+    for (int j = pl; j < 128; j += PL) {
+        const int pix = p0 + j;
+        if (pix >= npix) break;
+        const int x = pix % W;
+        const int t = pix / W;
+        const int y = t % H;
+        const int b = t / H;
+        float acc = bv;
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy) {
+            const int yy = y + (flip ? PAD - dy : dy - PAD);
+            if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const int xx = x + (flip ? PAD - dx : dx - PAD);
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const float* ip = in + ((size_t)(b * H + yy) * W + xx) * CS;
+#pragma unroll
+                for (int s = 0; s < CS; ++s) acc = fmaf(ip[s], w[(dy * K + dx) * CS + s], acc);
+            }
+        }
+        out[(size_t)pix * Cw + c] = acc;
+    }
+}
+// generic fallback: runtime k / Cs, weights re-read through L1
+__global__ __launch_bounds__(256) void thin_in_generic_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int B, int H, int W, int Cs, int Cw, int K, int flip,
+                                                              int cblk) {
+    const int PAD = (K - 1) / 2;
+    const int pl = threadIdx.x / cblk, tc = threadIdx.x - pl * cblk;
+    const int PL = 256 / cblk;
+    const int c = blockIdx.y * cblk + tc;
+    const float bv = bias ? bias[c] : 0.f;
+    const int npix = B * H * W;
+    const int p0 = blockIdx.x * 128;
+    for (int j = pl; j < 128; j += PL) {
+        const int pix = p0 + j;
+        if (pix >= npix) break;
+        const int x = pix % W;
+        const int t = pix / W;
+        const int y = t % H;
+        const int b = t / H;
+        float acc = bv;
+        for (int dy = 0; dy < K; ++dy) {
+            const int yy = y + (flip ? PAD - dy : dy - PAD);
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int dx = 0; dx < K; ++dx) {
+                const int xx = x + (flip ? PAD - dx : dx - PAD);
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const float* ip = in + ((size_t)(b * H + yy) * W + xx) * Cs;
+                for (int s = 0; s < Cs; ++s) acc = fmaf(ip[s], Wp[(size_t)((dy * K + dx) * Cs + s) * Cw + c], acc);
+            }
+        }
+        out[(size_t)pix * Cw + c] = acc;
+    }
+}
+
+int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
+                           int W, int Cs, int Cw, int k, int flip) {
+    if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_in: Cw %% 64");
+    const int cblk = Cw >= 256 ? 256 : Cw;
+    if (Cw % cblk || 256 % cblk) return fg_set_err(ctx, FG_ERR_INVALID, "thin_in: Cw=%d unsupported", Cw);
+    const int npix = B * H * W;
+    if (npix == 0) return FG_OK;
+    dim3 grid(fg_cdiv(npix, 128), Cw / cblk);
+#define TI(KK, CC)                                                                                                  \
+    if (k == KK && Cs == CC) {                                                                                      \
+        hipLaunchKernelGGL((thin_in_kernel<KK, CC>), grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, Cw, \
+                           flip, cblk);                                                                             \
+        FG_CHECK_LAUNCH(ctx);                                                                                       \
+        return FG_OK;                                                                                               \
+    }
+    TI(3, 1) TI(3, 3) TI(3, 4)
+#undef TI
+    hipLaunchKernelGGL(thin_in_generic_kernel, grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, Cs, Cw, k,
+                       flip, cblk);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// thin-out: out[pix][s] = act(bias[s] + sum_{tap,c} in[pix + off(tap)][c] * Wp[tap][s][c])   (Cw wide, Cs small)
+// one wave per pixel; lane owns channels lane + 64 j; butterfly reduction of the Cs partials.
+// ---------------------------------------------------------------------------------
+template <int K, int CJ, int CS>
+__global__ __launch_bounds__(256) void thin_out_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                       int H, int W, int flip, int sigmoid) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int Cw = CJ * 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float w[K * K][CS][CJ];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t)
+#pragma unroll
+        for (int s = 0; s < CS; ++s)
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) w[t][s][j] = Wp[((size_t)t * CS + s) * Cw + lane + 64 * j];
+    const int npix = B * H * W;
+    const int p0 = blockIdx.x * 64;
+    for (int q = wid; q < 64; q += 4) {
+        const int pix = p0 + q;
+        if (pix >= npix) break;
+        const int x = pix % W;
+        const int t = pix / W;
+        const int y = t % H;
+        const int b = t / H;
+        float acc[CS];
+#pragma unroll
+        for (int s = 0; s < CS; ++s) acc[s] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy) {
+            const int yy = y + (flip ? PAD - dy : dy - PAD);
+            if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const int xx = x + (flip ? PAD - dx : dx - PAD);
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const float* ip = in + ((size_t)(b * H + yy) * W + xx) * Cw + lane;
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) {
+                    const float v = ip[64 * j];
+#pragma unroll
+                    for (int s = 0; s < CS; ++s) acc[s] = fmaf(v, w[dy * K + dx][s][j], acc[s]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < CS; ++s) acc[s] = wave_sum_x(acc[s]);
+        if (lane < CS) {
+            float r = acc[0];
+#pragma unroll
+            for (int s = 1; s < CS; ++s) r = (lane == s) ? acc[s] : r;
+            r += bias ? bias[lane] : 0.f;
+            if (sigmoid) r = 1.f / (1.f + expf(-r));
+            out[(size_t)pix * CS + lane] = r;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void thin_out_generic_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int B, int H, int W, int Cw, int Cs, int K, int flip,
+                                                               int sigmoid) {
+    const int PAD = (K - 1) / 2;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int npix = B * H * W;
+    const int p0 = blockIdx.x * 64;
+    for (int q = wid; q < 64; q += 4) {
+        const int pix = p0 + q;
+        if (pix >= npix) break;
+        const int x = pix % W;
+        const int t = pix / W;
+        const int y = t % H;
+        const int b = t / H;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int dy = 0; dy < K; ++dy) {
+            const int yy = y + (flip ? PAD - dy : dy - PAD);
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int dx = 0; dx < K; ++dx) {
+                const int xx = x + (flip ? PAD - dx : dx - PAD);
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const float* ip = in + ((size_t)(b * H + yy) * W + xx) * Cw;
+                const float* wp = Wp + (size_t)(dy * K + dx) * Cs * Cw;
+                for (int c = lane; c < Cw; c += 64) {
+                    const float v = ip[c];
+                    for (int s = 0; s < Cs; ++s) acc[s] = fmaf(v, wp[(size_t)s * Cw + c], acc[s]);
+                }
+            }
+        }
+        for (int s = 0; s < Cs; ++s) {
+            float r = wave_sum_x(acc[s]);
+            if (lane == 0) {
+                r += bias ? bias[s] : 0.f;
+                if (sigmoid) r = 1.f / (1.f + expf(-r));
+                out[(size_t)pix * Cs + s] = r;
+            }
+        }
+    }
+}
+
+int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
+                            int W, int Cw, int Cs, int k, int flip, int sigmoid) {
+    if (Cs > 4) return fg_set_err(ctx, FG_ERR_INVALID, "thin_out: Cs > 4");
+    const int npix = B * H * W;
+    if (npix == 0) return FG_OK;
+    dim3 grid(fg_cdiv(npix, 64));
+#define TO(KK, JJ, CC)                                                                                              \
+    if (k == KK && Cw == JJ * 64 && Cs == CC) {                                                                     \
+        hipLaunchKernelGGL((thin_out_kernel<KK, JJ, CC>), grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, \
+                           flip, sigmoid);                                                                          \
+        FG_CHECK_LAUNCH(ctx);                                                                                       \
+        return FG_OK;                                                                                               \
+    }
+    TO(3, 1, 1) TO(3, 1, 3) TO(3, 2, 1) TO(3, 2, 3)
+#undef TO
+    hipLaunchKernelGGL(thin_out_generic_kernel, grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, Cw, Cs, k,
+                       flip, sigmoid);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// thin wgrad: gw[tap][s][c] = sum_pix thin[pix + sgn*off(tap)][s] * wide[pix][c]
+// ---------------------------------------------------------------------------------
+#define TW_BLOCKS 256
+template <int K, int CS>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict__ thin, const float* __restrict__ wide,
+                                                         float* __restrict__ part, int B, int H, int W, int Cw, int sgn,
+                                                         int cblk) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int NA = K * K * CS;
+    extern __shared__ float sh[];  // [PL][NA][cblk] when PL > 1
+    const int pl = threadIdx.x / cblk, tc = threadIdx.x - pl * cblk;
+    const int PL = 256 / cblk;
+    const int c = blockIdx.y * cblk + tc;
+    const int npix = B * H * W;
+    const int per = (npix + gridDim.x - 1) / gridDim.x;
+    const int p0 = blockIdx.x * per;
+    const int p1 = min(npix, p0 + per);
+    float acc[NA];
+#pragma unroll
+    for (int t = 0; t < NA; ++t) acc[t] = 0.f;
+    for (int pix = p0 + pl; pix < p1; pix += PL) {
+        const int x = pix % W;
+        const int t = pix / W;
+        const int y = t % H;
+        const int b = t / H;
+        const float wv = wide[(size_t)pix * Cw + c];
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy) {
+            const int yy = y + sgn * (dy - PAD);
+            if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx) {
+                const int xx = x + sgn * (dx - PAD);
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const float* tp = thin + ((size_t)(b * H + yy) * W + xx) * CS;
+#pragma unroll
+                for (int s = 0; s < CS; ++s) acc[(dy * K + dx) * CS + s] = fmaf(tp[s], wv, acc[(dy * K + dx) * CS + s]);
+            }
+        }
+    }
+    float* dst = part + (size_t)blockIdx.x * NA * Cw;
+    if (PL == 1) {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) dst[(size_t)t * Cw + c] = acc[t];
+    } else {
+#pragma unroll
+        for (int t = 0; t < NA; ++t) sh[(pl * NA + t) * cblk + tc] = acc[t];
+        __syncthreads();
+        if (pl == 0) {
+#pragma unroll
+            for (int t = 0; t < NA; ++t) {
+                float s = 0.f;
+                for (int q = 0; q < PL; ++q) s += sh[(q * NA + t) * cblk + tc];
+                dst[(size_t)t * Cw + c] = s;
+            }
+        }
+    }
+}
+__global__ void thin_wgrad_final_kernel(const float* __restrict__ part, int nb, int total, float* __restrict__ gw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += (double)part[(size_t)b * total + i];
+    gw[i] = (float)s;
+}
+
+int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
+                         int Cw, int k, int shift_thin, float* scratch) {
+    if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_wgrad: Cw %% 64");
+    const int cblk = Cw >= 256 ? 256 : Cw;
+    if (Cw % cblk || 256 % cblk) return fg_set_err(ctx, FG_ERR_INVALID, "thin_wgrad: Cw=%d unsupported", Cw);
+    const int npix = B * H * W;
+    int nb = fg_cdiv(npix, 256);
+    if (nb > TW_BLOCKS) nb = TW_BLOCKS;
+    if (nb < 1) nb = 1;
+    const int PL = 256 / cblk;
+    const int NA = k * k * Cs;
+    dim3 grid(nb, Cw / cblk);
+    const size_t lds = PL > 1 ? (size_t)PL * NA * cblk * sizeof(float) : 0;
+#define TWG(KK, CC)                                                                                                  \
+    if (k == KK && Cs == CC) {                                                                                       \
+        hipLaunchKernelGGL((thin_wgrad_kernel<KK, CC>), grid, dim3(256), lds, ctx->stream, thin, wide, scratch, B, H, W, \
+                           Cw, shift_thin, cblk);                                                                    \
+        FG_CHECK_LAUNCH(ctx);                                                                                        \
+        hipLaunchKernelGGL(thin_wgrad_final_kernel, dim3(fg_cdiv(NA * Cw, 256)), dim3(256), 0, ctx->stream, scratch, nb, \
+                           NA * Cw, gw_tsc);                                                                         \
+        FG_CHECK_LAUNCH(ctx);                                                                                        \
+        return FG_OK;                                                                                                \
+    }
+    TWG(3, 1) TWG(3, 3) TWG(3, 4)
+#undef TWG
+    return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "thin_wgrad: k=%d Cs=%d not built", k, Cs);
+}
+
+// ---------------------------------------------------------------------------------
+// reference [O][I][k][k] <-> thin layouts
+// ---------------------------------------------------------------------------------
+__global__ void thin_pack_kernel(const float* __restrict__ Wr, float* __restrict__ Wp, int O, int I, int kk, int mode) {
+    const int total = O * I * kk;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    // idx enumerates packed [tap][s][c]
+    const int Cs = mode == 0 ? I : O, Cw = mode == 0 ? O : I;
+    const int c = idx % Cw;
+    const int t = idx / Cw;
+    const int s = t % Cs;
+    const int tap = t / Cs;
+    const int o = mode == 0 ? c : s, i = mode == 0 ? s : c;
+    Wp[idx] = Wr[((size_t)o * I + i) * kk + tap];
+}
+int fg_launch_thin_pack(fg_ctx* ctx, const float* W, float* Wp, int O, int I, int k, int mode) {
+    const int total = O * I * k * k;
+    hipLaunchKernelGGL(thin_pack_kernel, dim3(fg_cdiv(total, 256)), dim3(256), 0, ctx->stream, W, Wp, O, I, k * k, mode);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ void thin_unpack_grad_kernel(const float* __restrict__ gw, float* __restrict__ gradW, int O, int I, int kk,
+                                        int mode, float beta) {
+    const int total = O * I * kk;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int Cs = mode == 0 ? I : O, Cw = mode == 0 ? O : I;
+    const int c = idx % Cw;
+    const int t = idx / Cw;
+    const int s = t % Cs;
+    const int tap = t / Cs;
+    const int o = mode == 0 ? c : s, i = mode == 0 ? s : c;
+    const size_t r = ((size_t)o * I + i) * kk + tap;
+    gradW[r] = (beta == 0.f ? 0.f : beta * gradW[r]) + gw[idx];
+}
+int fg_launch_thin_unpack_grad(fg_ctx* ctx, const float* gw, float* gradW, int O, int I, int k, int mode, float beta) {
+    const int total = O * I * k * k;
+    hipLaunchKernelGGL(thin_unpack_grad_kernel, dim3(fg_cdiv(total, 256)), dim3(256), 0, ctx->stream, gw, gradW, O, I,
+                       k * k, mode, beta);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}

@@ -1,0 +1,401 @@
+"""Host-side mirror of the Torch7 `nn` surface the reference scripts touch (SURVEY.md 8(b) conformance list).
+
+Modules are descriptors holding host (torch CPU float) parameters in REFERENCE layout until the net is moved to
+the device (`:cuda()` / NN_UTILS.activateCuda), where one fg_net plan + one flat parameter vector take over and
+`module.weight` etc. become views into that flat device vector (== Module:getParameters(), train.lua:151-152).
+Compute always runs in libfacegen_hip.so; there is no CPU execution path (forward on a non-device net raises).
+"""
+import math
+
+import torch
+
+from ._lib import FgError
+
+
+class Module:
+    _typename = "nn.Module"
+
+    def __init__(self):
+        self.train = True
+        self.output = None
+        self.gradInput = None
+
+    # parameters in reference order: weight then bias (Module.lua)
+    def param_names(self):
+        return [n for n in ("weight", "bias") if getattr(self, n, None) is not None]
+
+    def spec(self):
+        raise NotImplementedError
+
+    def training(self):
+        self.train = True
+        return self
+
+    def evaluate(self):
+        self.train = False
+        return self
+
+    def forward(self, x):
+        raise FgError("%s: module-level forward needs the net on the device (use Sequential:cuda())" % self._typename)
+
+    def __repr__(self):
+        return self._typename
+
+
+def _uniform(shape, s, gen):
+    return (torch.rand(shape, generator=gen) * 2 - 1) * s
+
+
+class Linear(Module):
+    _typename = "nn.Linear"
+
+    def __init__(self, inputSize, outputSize, gen=None):
+        super().__init__()
+        s = 1.0 / math.sqrt(inputSize)
+        self.weight = _uniform((outputSize, inputSize), s, gen)
+        self.bias = _uniform((outputSize,), s, gen)
+        self.gradWeight = torch.zeros_like(self.weight)
+        self.gradBias = torch.zeros_like(self.bias)
+
+    def spec(self):
+        return ("LINEAR", self.weight.shape[1], self.weight.shape[0])
+
+    def __repr__(self):
+        return "nn.Linear(%d -> %d)" % (self.weight.shape[1], self.weight.shape[0])
+
+
+class View(Module):
+    _typename = "nn.View"
+
+    def __init__(self, *sizes):
+        super().__init__()
+        self.sizes = tuple(int(s) for s in sizes)
+
+    def spec(self):
+        if len(self.sizes) == 3:
+            return ("VIEW",) + self.sizes
+        if len(self.sizes) == 1:
+            return ("VIEW", self.sizes[0], 0, 0)
+        raise FgError("nn.View: only View(C,H,W) and View(features) are supported")
+
+    def __repr__(self):
+        return "nn.View(%s)" % ", ".join(map(str, self.sizes))
+
+
+class PReLU(Module):
+    _typename = "nn.PReLU"
+
+    def __init__(self, *ignored):  # models.lua passes (nil, nil, true); upstream ignores extra ctor args
+        super().__init__()
+        self.weight = torch.full((1,), 0.25)
+        self.gradWeight = torch.zeros(1)
+
+    def spec(self):
+        return ("PRELU",)
+
+
+class LeakyReLU(Module):
+    """LeakyReLU.lua:7-31."""
+    _typename = "nn.LeakyReLU"
+
+    def __init__(self, negval=0.333):
+        super().__init__()
+        self.negval = negval
+
+    def spec(self):
+        return ("LEAKYRELU", 0, 0, 0, 0, self.negval)
+
+
+class SpatialUpSamplingNearest(Module):
+    _typename = "nn.SpatialUpSamplingNearest"
+
+    def __init__(self, scale):
+        super().__init__()
+        if scale != 2:
+            raise FgError("nn.SpatialUpSamplingNearest: only scale 2 is built (models.lua:63, 68)")
+
+    def spec(self):
+        return ("UPSAMPLE2X",)
+
+
+class SpatialConvolution(Module):
+    """nn.SpatialConvolution / cudnn.SpatialConvolution(nIn, nOut, kW, kH, dW, dH, padW[, padH])."""
+    _typename = "nn.SpatialConvolution"
+
+    def __init__(self, nInputPlane, nOutputPlane, kW, kH, dW=1, dH=1, padW=0, padH=None, gen=None):
+        super().__init__()
+        padH = padW if padH is None else padH
+        if kW != kH or dW != 1 or dH != 1 or padW != padH or kW % 2 != 1 or padW != (kW - 1) // 2:
+            raise FgError("SpatialConvolution: only square odd kernels, stride 1, 'same' padding are built")
+        self.nInputPlane, self.nOutputPlane, self.kW, self.padW = nInputPlane, nOutputPlane, kW, int(padW)
+        s = 1.0 / math.sqrt(kW * kH * nInputPlane)
+        self.weight = _uniform((nOutputPlane, nInputPlane, kH, kW), s, gen)
+        self.bias = _uniform((nOutputPlane,), s, gen)
+        self.gradWeight = torch.zeros_like(self.weight)
+        self.gradBias = torch.zeros_like(self.bias)
+
+    def spec(self):
+        return ("CONV", self.nInputPlane, self.nOutputPlane, self.kW, self.padW)
+
+    def __repr__(self):
+        return "%s(%d -> %d, %dx%d, 1,1, %d,%d)" % (self._typename, self.nInputPlane, self.nOutputPlane, self.kW,
+                                                    self.kW, self.padW, self.padW)
+
+
+class SpatialBatchNormalization(Module):
+    _typename = "nn.SpatialBatchNormalization"
+
+    def __init__(self, nFeature, eps=1e-5, momentum=0.1, gen=None):
+        super().__init__()
+        self.nFeature, self.eps, self.momentum = nFeature, eps, momentum
+        self.weight = torch.rand(nFeature, generator=gen)   # reset(): gamma ~ U(0,1)
+        self.bias = torch.zeros(nFeature)
+        self.gradWeight = torch.zeros(nFeature)
+        self.gradBias = torch.zeros(nFeature)
+        self.running_mean = torch.zeros(nFeature)
+        self.running_var = torch.ones(nFeature)
+
+    def spec(self):
+        return ("BATCHNORM", self.nFeature, 0, 0, 0, self.eps, self.momentum)
+
+
+class SpatialDropout(Module):
+    _typename = "nn.SpatialDropout"
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def spec(self):
+        return ("SPATIAL_DROPOUT", 0, 0, 0, 0, self.p)
+
+
+class Dropout(Module):
+    _typename = "nn.Dropout"
+
+    def __init__(self, p=0.5):
+        super().__init__()
+        self.p = p
+
+    def spec(self):
+        return ("DROPOUT", 0, 0, 0, 0, self.p)
+
+
+class SpatialAveragePooling(Module):
+    _typename = "nn.SpatialAveragePooling"
+
+    def __init__(self, kW, kH, dW=None, dH=None):
+        super().__init__()
+        if (kW, kH, dW or kW, dH or kH) != (2, 2, 2, 2):
+            raise FgError("nn.SpatialAveragePooling: only (2,2,2,2) is built (models.lua:388-403)")
+
+    def spec(self):
+        return ("AVGPOOL2",)
+
+
+class Sigmoid(Module):
+    _typename = "nn.Sigmoid"
+
+    def spec(self):
+        return ("SIGMOID",)
+
+
+class Copy(Module):
+    """nn.Copy(inType, outType): the host<->device (and NCHW<->NHWC) boundary of NN_UTILS.activateCuda."""
+    _typename = "nn.Copy"
+
+    def __init__(self, intype, outtype):
+        super().__init__()
+        self.intype, self.outtype = intype, outtype
+
+    def __repr__(self):
+        return "nn.Copy(%s -> %s)" % (self.intype, self.outtype)
+
+
+class Sequential(Module):
+    _typename = "nn.Sequential"
+
+    def __init__(self):
+        super().__init__()
+        self.modules = []
+        self.input_dims = None     # (C, H, W) of one input sample; set by MODELS.create_*
+        self.device_net = None     # runtime.DeviceNet once on the device
+        self._flat = None
+
+    def add(self, m):
+        self.modules.append(m)
+        return self
+
+    def get(self, i):
+        return self.modules[i - 1]   # 1-based like Lua
+
+    def size(self):
+        return len(self.modules)
+
+    def listModules(self):
+        out = [self]
+        for m in self.modules:
+            out.extend(m.listModules() if isinstance(m, Sequential) else [m])
+        return out
+
+    def training(self):
+        self.train = True
+        for m in self.modules:
+            m.training()
+        if self.device_net is not None:
+            self.device_net.train = True
+        return self
+
+    def evaluate(self):
+        self.train = False
+        for m in self.modules:
+            m.evaluate()
+        if self.device_net is not None:
+            self.device_net.train = False
+        return self
+
+    def _inner(self):
+        """The compute Sequential: self, or the middle of {Copy, net, Copy}."""
+        if len(self.modules) == 3 and isinstance(self.modules[0], Copy) and isinstance(self.modules[1], Sequential):
+            return self.modules[1]
+        return self
+
+    def layer_specs(self):
+        return [m.spec() for m in self.modules]
+
+    def parameter_list(self):
+        """[(module, 'weight'|'bias')...] in Module:parameters() order."""
+        out = []
+        for m in self.modules:
+            if isinstance(m, Sequential):
+                out.extend(m.parameter_list())
+            elif not isinstance(m, Copy):
+                out.extend((m, n) for n in m.param_names())
+        return out
+
+    def is_cuda(self):
+        return self._inner().device_net is not None
+
+    def cuda(self, ctx=None, max_batch=32):
+        """:cuda() -- compile to an fg_net and move parameters / BN buffers to the device."""
+        from . import runtime
+        inner = self._inner()
+        if inner.device_net is not None:
+            return self
+        if inner.input_dims is None:
+            raise FgError("Sequential:cuda(): input_dims unknown (build the net through MODELS.create_*)")
+        ctx = ctx or runtime.get_context()
+        dn = runtime.DeviceNet(ctx, inner.layer_specs(), inner.input_dims, max_batch)
+        off = 0
+        boff = 0
+        for (m, name) in inner.parameter_list():
+            w = getattr(m, name)
+            n = w.numel()
+            dn.params[off:off + n] = w.reshape(-1).to(ctx.device)
+            setattr(m, name, dn.params[off:off + n].view(w.shape))
+            gname = "gradWeight" if name == "weight" else "gradBias"
+            setattr(m, gname, dn.grads[off:off + n].view(w.shape))
+            off += n
+        assert off == dn.n_params, (off, dn.n_params)
+        for m in inner.modules:
+            if isinstance(m, SpatialBatchNormalization):
+                nf = m.nFeature
+                dn.buffers[boff:boff + nf] = m.running_mean.to(ctx.device)
+                dn.buffers[boff + nf:boff + 2 * nf] = m.running_var.to(ctx.device)
+                m.running_mean = dn.buffers[boff:boff + nf]
+                m.running_var = dn.buffers[boff + nf:boff + 2 * nf]
+                boff += 2 * nf
+        dn.train = inner.train
+        dn.params_changed()
+        inner.device_net = dn
+        return self
+
+    def float(self):
+        """:float() -- pull parameters back to host tensors and drop the device plan."""
+        inner = self._inner()
+        if inner.device_net is None:
+            return self
+        for (m, name) in inner.parameter_list():
+            setattr(m, name, getattr(m, name).detach().cpu().clone())
+            gname = "gradWeight" if name == "weight" else "gradBias"
+            setattr(m, gname, getattr(m, gname).detach().cpu().clone())
+        for m in inner.modules:
+            if isinstance(m, SpatialBatchNormalization):
+                m.running_mean = m.running_mean.cpu().clone()
+                m.running_var = m.running_var.cpu().clone()
+        inner.device_net = None
+        return self
+
+    def getParameters(self):
+        """-> (flatParameters, flatGradParameters): the net's two flat vectors (device tensors)."""
+        inner = self._inner()
+        if inner.device_net is None:
+            raise FgError("getParameters(): move the net to the device first (NN_UTILS.activateCuda / :cuda())")
+        return inner.device_net.params, inner.device_net.grads
+
+    # ---- Module:forward / :backward on host NCHW tensors (the reference's GPU mode returns Float tensors too)
+    def forward(self, x, masks=None):
+        inner = self._inner()
+        dn = inner.device_net
+        if dn is None:
+            raise FgError("Sequential:forward: no CPU path -- call NN_UTILS.activateCuda(net) / net:cuda() first")
+        ctx = dn.ctx
+        xd = ctx.to_device_nhwc(x)
+        y = dn.forward(xd, masks=masks, train=inner.train)
+        self.output = ctx.to_nchw(y).cpu()
+        return self.output
+
+    def backward(self, x, gradOutput):
+        inner = self._inner()
+        dn = inner.device_net
+        if dn is None:
+            raise FgError("Sequential:backward: no CPU path")
+        ctx = dn.ctx
+        gy = ctx.to_device_nhwc(gradOutput)
+        gx = dn.backward(gy, param_grads=True, input_grad=True)
+        self.gradInput = ctx.to_nchw(gx).cpu()
+        if self is not inner:
+            self.modules[0].gradInput = self.gradInput   # adversarial.lua:210 reads MODEL_D.modules[1].gradInput
+        return self.gradInput
+
+    def __repr__(self):
+        lines = ["nn.Sequential {"]
+        for i, m in enumerate(self.modules):
+            lines.append("  (%d): %s" % (i + 1, repr(m).replace("\n", "\n  ")))
+        lines.append("}")
+        return "\n".join(lines)
+
+
+class BCECriterion:
+    """nn.BCECriterion() (train.lua:148) on device tensors; forward returns a python float like Torch."""
+
+    def __init__(self):
+        self.sizeAverage = True
+        self.output = None
+        self.gradInput = None
+
+    def forward_backward_device(self, ctx, prob, target, want_confusion=True):
+        """prob, target: device [B].  -> (loss device scalar, grad device [B], confusion device int32[4])."""
+        B = prob.numel()
+        loss = ctx.empty(1)
+        grad = ctx.empty(B)
+        conf = torch.zeros(4, dtype=torch.int32, device=ctx.device)
+        ctx.check(ctx.lib.fg_bce_forward_backward(ctx.h, prob.data_ptr(), target.data_ptr(), B, loss.data_ptr(),
+                                                  grad.data_ptr(), conf.data_ptr() if want_confusion else None))
+        return loss, grad, conf
+
+    def forward(self, input, target):
+        from . import runtime
+        ctx = runtime.get_context()
+        p = torch.as_tensor(input, dtype=torch.float32).reshape(-1).to(ctx.device)
+        t = torch.as_tensor(target, dtype=torch.float32).reshape(-1).to(ctx.device)
+        loss, grad, _ = self.forward_backward_device(ctx, p, t, False)
+        self.output = float(loss.item())
+        self._grad = grad.cpu().reshape(torch.as_tensor(input).shape)
+        return self.output
+
+    def backward(self, input, target):
+        if getattr(self, "_grad", None) is None:
+            self.forward(input, target)
+        self.gradInput = self._grad
+        return self.gradInput

@@ -1,0 +1,225 @@
+"""Device runtime glue: one fg_ctx per process/GPU, torch tensors as device memory, DeviceNet = fg_net + buffers.
+
+Replaces the reference's `cutorch.setDevice` / `:cuda()` / `nn.Copy` plumbing (train.lua:79-80,
+nn_utils.lua:328-363).  Everything numerical happens inside libfacegen_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import FgError, LayerSpec, LAYER_TYPES
+
+_CTX = {}
+
+
+class Context:
+    """fg_ctx bound to one HIP device; launches go to torch's current stream of that device."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise FgError("no HIP device visible: the face_generator_amd compute path needs an MI355X "
+                          "(there is no CPU fallback)")
+        self.lib = _lib.load_library()
+        self.device = torch.device("cuda", device)
+        h = ctypes.c_void_p()
+        rc = self.lib.fg_ctx_create(device, ctypes.byref(h))
+        if rc != 0:
+            raise FgError("fg_ctx_create: %s" % self.lib.fg_last_error(None).decode())
+        self.h = h
+        torch.cuda.set_device(self.device)
+        self.bind_stream()
+
+    def bind_stream(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self.check(self.lib.fg_ctx_set_stream(self.h, ctypes.c_void_p(s.cuda_stream)))
+
+    def check(self, rc):
+        if rc != 0:
+            raise FgError("libfacegen_hip error %d: %s" % (rc, self.lib.fg_last_error(self.h).decode()))
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+    def sync(self):
+        self.check(self.lib.fg_stream_sync(self.h))
+
+    # ---- boundary helpers (the nn.Copy Float<->device modules) ----
+    def to_device_nhwc(self, x_nchw):
+        """host/any NCHW float tensor -> device NHWC tensor."""
+        x = torch.as_tensor(x_nchw, dtype=torch.float32)
+        if x.dim() == 2:
+            return x.to(self.device).contiguous()
+        n, c, h, w = x.shape
+        xd = x.to(self.device).contiguous()
+        out = self.empty(n, h, w, c)
+        self.check(self.lib.fg_nchw_to_nhwc(self.h, xd.data_ptr(), out.data_ptr(), n, c, h, w))
+        return out
+
+    def to_nchw(self, x_nhwc):
+        if x_nhwc.dim() == 2:
+            return x_nhwc.clone()
+        n, h, w, c = x_nhwc.shape
+        out = self.empty(n, c, h, w)
+        self.check(self.lib.fg_nhwc_to_nchw(self.h, x_nhwc.contiguous().data_ptr(), out.data_ptr(), n, c, h, w))
+        return out
+
+    def uniform(self, shape, lo, hi, seed, offset=0):
+        out = self.empty(*shape)
+        self.check(self.lib.fg_rng_uniform(self.h, seed, offset, out.data_ptr(), out.numel(), lo, hi))
+        return out
+
+    def bernoulli(self, shape, keep, seed, offset=0):
+        out = self.empty(*shape)
+        self.check(self.lib.fg_rng_bernoulli(self.h, seed, offset, out.data_ptr(), out.numel(), keep))
+        return out
+
+    def normal(self, shape, mean, std, seed, offset=0):
+        out = self.empty(*shape)
+        self.check(self.lib.fg_rng_normal(self.h, seed, offset, out.data_ptr(), out.numel(), mean, std))
+        return out
+
+
+def get_context(device=None):
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if device not in _CTX:
+        _CTX[device] = Context(device)
+    return _CTX[device]
+
+
+def make_specs(layers):
+    """layers: list of tuples (TYPE, a, b, c, d, p, q) -> ctypes array of fg_layer_spec."""
+    arr = (LayerSpec * len(layers))()
+    for i, l in enumerate(layers):
+        l = tuple(l) + (0,) * (7 - len(l))
+        arr[i].type = LAYER_TYPES[l[0]] if isinstance(l[0], str) else int(l[0])
+        arr[i].a, arr[i].b, arr[i].c, arr[i].d = int(l[1]), int(l[2]), int(l[3]), int(l[4])
+        arr[i].p, arr[i].q = float(l[5]), float(l[6])
+    return arr
+
+
+class DeviceNet:
+    """An nn.Sequential compiled by fg_net_create, with its flat parameter / gradient vectors
+    (== Module:getParameters(), train.lua:151-152), BN running stats and workspace as torch device tensors."""
+
+    def __init__(self, ctx, layers, in_dims, max_batch):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.layers = list(layers)
+        self.in_c, self.in_h, self.in_w = in_dims
+        self.specs = make_specs(self.layers)
+        h = ctypes.c_void_p()
+        ctx.check(self.lib.fg_net_create(ctx.h, self.specs, len(self.layers), self.in_c, self.in_h, self.in_w,
+                                         ctypes.byref(h)))
+        self.h = h
+        self.n_params = self.lib.fg_net_num_params(h)
+        self.n_buffers = self.lib.fg_net_num_buffers(h)
+        self.n_masks = self.lib.fg_net_num_masks(h)
+        c, hh, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self.lib.fg_net_out_dims(h, ctypes.byref(c), ctypes.byref(hh), ctypes.byref(w))
+        self.out_c, self.out_h, self.out_w = c.value, hh.value, w.value
+        self.params = ctx.zeros(self.n_params)
+        self.grads = ctx.zeros(self.n_params)
+        self.buffers = ctx.zeros(max(self.n_buffers, 1))
+        self._init_bn_buffers()
+        self.max_batch = 0
+        self.ws = None
+        self.reserve(max_batch)
+        ctx.check(self.lib.fg_net_bind(h, self.params.data_ptr(), self.grads.data_ptr(), self.buffers.data_ptr()))
+        self.train = True
+        self.mask_seed, self.mask_offset = 1, 0
+        self._masks = None
+        self._batch = 0
+        self._x = None
+
+    def __del__(self):
+        try:
+            self.lib.fg_net_destroy(self.h)
+        except Exception:
+            pass
+
+    def _init_bn_buffers(self):
+        off = 0
+        for l in self.layers:
+            if l[0] == "BATCHNORM":
+                nf = l[1]
+                self.buffers[off + nf: off + 2 * nf] = 1.0  # running_var = 1
+                off += 2 * nf
+
+    def reserve(self, batch):
+        if batch > self.max_batch:
+            nbytes = self.lib.fg_net_workspace_bytes(self.h, batch)
+            self.ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.ctx.device)
+            self.max_batch = batch
+
+    def param_offsets(self, layer_index):
+        wo, wn, bo, bn = (ctypes.c_longlong() for _ in range(4))
+        self.ctx.check(self.lib.fg_net_param_offset(self.h, layer_index, ctypes.byref(wo), ctypes.byref(wn),
+                                                    ctypes.byref(bo), ctypes.byref(bn)))
+        return wo.value, wn.value, bo.value, bn.value
+
+    def params_changed(self):
+        self.ctx.check(self.lib.fg_net_params_changed(self.h))
+
+    def mask_shape(self, i, batch):
+        return (self.lib.fg_net_mask_elems(self.h, i, batch),)
+
+    def draw_masks(self, batch):
+        """Bernoulli keep masks for every dropout layer (Philox, seed/offset advance per call)."""
+        masks = []
+        k = 0
+        for l in self.layers:
+            if l[0] in ("SPATIAL_DROPOUT", "DROPOUT"):
+                n = self.lib.fg_net_mask_elems(self.h, k, batch)
+                masks.append(self.ctx.bernoulli((n,), 1.0 - float(l[5]), self.mask_seed, self.mask_offset))
+                self.mask_offset += (n + 3) // 4
+                k += 1
+        return masks
+
+    def forward(self, x, masks=None, train=None):
+        """x: device NHWC [B,H,W,C] (or [B,F]).  Returns a VIEW into the workspace (NHWC)."""
+        train = self.train if train is None else train
+        B = x.shape[0]
+        self.reserve(B)
+        x = x.contiguous()
+        if train and self.n_masks:
+            if masks is None:
+                masks = self.draw_masks(B)
+            assert len(masks) == self.n_masks
+            self._masks = [m.contiguous() for m in masks]
+            mp = (ctypes.c_void_p * self.n_masks)(*[m.data_ptr() for m in self._masks])
+        else:
+            self._masks, mp = None, None
+        off = ctypes.c_longlong()
+        self.ctx.check(self.lib.fg_net_forward(self.h, B, x.data_ptr(), self.ws.data_ptr(), self.ws.numel() * 4,
+                                               1 if train else 0, mp, self.n_masks if mp is not None else 0,
+                                               ctypes.byref(off)))
+        self._batch, self._x = B, x
+        n = B * self.out_c * self.out_h * self.out_w
+        out = self.ws[off.value: off.value + n]
+        if self.out_h * self.out_w == 1:
+            return out.view(B, self.out_c)
+        return out.view(B, self.out_h, self.out_w, self.out_c)
+
+    def backward(self, gy, param_grads=True, input_grad=False):
+        """gy: device grad wrt the output (NHWC).  Returns gx (NHWC) if input_grad."""
+        B = self._batch
+        gy = gy.contiguous()
+        gx = None
+        if input_grad:
+            gx = self.ctx.empty(*self._x.shape)
+        flags = (_lib.FG_BWD_PARAM_GRADS if param_grads else 0) | (_lib.FG_BWD_INPUT_GRAD if input_grad else 0)
+        self.ctx.check(self.lib.fg_net_backward(self.h, B, self._x.data_ptr(), gy.data_ptr(), self.ws.data_ptr(),
+                                                self.ws.numel() * 4, flags, gx.data_ptr() if gx is not None else None))
+        return gx
+
+    def layer_output(self, layer_index):
+        off, c, h, w = ctypes.c_longlong(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self.ctx.check(self.lib.fg_net_layer_output(self.h, layer_index, ctypes.byref(off), ctypes.byref(c),
+                                                    ctypes.byref(h), ctypes.byref(w)))
+        n = self._batch * c.value * h.value * w.value
+        t = self.ws[off.value: off.value + n]
+        return t.view(self._batch, h.value, w.value, c.value)

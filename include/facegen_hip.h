@@ -1,0 +1,183 @@
+/* libfacegen_hip.so -- C ABI of the MI355X-native (gfx950) GAN training hot path of aleju/face-generator.
+ *
+ * This is the drop-in boundary: the reference has no native code of its own; its Lua
+ * modules dispatch into Torch7's THNN/THCUNN/cuDNN through LuaJIT FFI (upstream convention:
+ *   THNN_(SpatialConvolutionMM_updateOutput)(state, input, output, weight, bias, finput, ...)
+ * called as input.THNN.X(input:cdata(), ...)).  The entry points below are what a LuaJIT `ffi.cdef` (or the
+ * ctypes mirror in face_generator_amd/_lib.py) binds instead.  Plain C: opaque context, caller-owned device
+ * buffers (raw pointers + explicit workspace), status-code returns, message via fg_last_error().
+ * No C++ exceptions cross the ABI; nothing here names a torch type.
+ *
+ * Conventions
+ *   - all tensors fp32; device activations are NHWC ("internal layout"); the reference's NCHW appears only at
+ *     the boundary (fg_nchw_to_nhwc / fg_nhwc_to_nchw = the nn.Copy modules of nn_utils.lua:355-362).
+ *   - parameter and gradient vectors are ONE flat fp32 vector per net in REFERENCE order and layout
+ *     (module order, weight then bias; conv [O][I][kH][kW], linear [out][in]) == Module:getParameters()
+ *     (train.lua:151-152).  Tile-packed / tap-folded weight copies are internal.
+ *   - every entry is asynchronous on the context's stream; only fg_d2h / fg_stream_sync block.
+ *   - a context is bound to one device and is not thread-safe.
+ */
+#ifndef FACEGEN_HIP_H
+#define FACEGEN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fg_ctx fg_ctx;
+typedef struct fg_net fg_net;
+
+enum {
+    FG_OK = 0,
+    FG_ERR_INVALID = -1,      /* bad argument / shape (the Lua shim turns this into error()) */
+    FG_ERR_HIP = -2,          /* HIP runtime error, text in fg_last_error */
+    FG_ERR_NOMEM = -3,
+    FG_ERR_UNSUPPORTED = -4,  /* layer pattern or kernel variant not built */
+    FG_ERR_WORKSPACE = -5     /* caller workspace too small */
+};
+
+/* ---- context / memory (replaces cutorch.setDevice / cutorch streams, train.lua:79-80) ---- */
+int fg_ctx_create(int device, fg_ctx** out);
+int fg_ctx_destroy(fg_ctx* ctx);
+int fg_ctx_set_stream(fg_ctx* ctx, void* hip_stream); /* NULL = default stream */
+const char* fg_last_error(const fg_ctx* ctx);
+const char* fg_version(void);
+int fg_stream_sync(fg_ctx* ctx);
+int fg_malloc(fg_ctx* ctx, size_t bytes, void** out);
+int fg_free(fg_ctx* ctx, void* p);
+int fg_h2d(fg_ctx* ctx, void* dst, const void* src, size_t bytes);
+int fg_d2h(fg_ctx* ctx, void* dst, const void* src, size_t bytes); /* synchronises */
+int fg_d2d(fg_ctx* ctx, void* dst, const void* src, size_t bytes);
+int fg_fill(fg_ctx* ctx, float* p, float value, long long n);
+int fg_axpby(fg_ctx* ctx, float a, const float* x, float b, float* y, long long n); /* y = a*x + b*y */
+
+/* ---- layout boundary: nn.Copy Float<->device of NN_UTILS.activateCuda (nn_utils.lua:355-362) ---- */
+int fg_nchw_to_nhwc(fg_ctx* ctx, const float* src, float* dst, int n, int c, int h, int w);
+int fg_nhwc_to_nchw(fg_ctx* ctx, const float* src, float* dst, int n, int c, int h, int w);
+
+/* ---- RNG: torch.Tensor:uniform / :bernoulli / randn (nn_utils.lua:9, 37; nn.Dropout) -- Philox4x32-10 ---- */
+int fg_rng_uniform(fg_ctx* ctx, uint64_t seed, uint64_t offset, float* out, long long n, float lo, float hi);
+int fg_rng_bernoulli(fg_ctx* ctx, uint64_t seed, uint64_t offset, float* out, long long n, float keep_prob);
+int fg_rng_normal(fg_ctx* ctx, uint64_t seed, uint64_t offset, float* out, long long n, float mean, float std);
+
+/* ---- net-level: an nn.Sequential compiled to a device plan (models.lua:57-81, 382-416) ---- */
+enum fg_layer_type {
+    FG_LINEAR = 1,          /* nn.Linear(a=in, b=out) */
+    FG_VIEW = 2,            /* nn.View(a=C, b=H, c=W)  or nn.View(a=features) with b=c=0 */
+    FG_PRELU = 3,           /* nn.PReLU() -- one shared slope */
+    FG_UPSAMPLE2X = 4,      /* nn.SpatialUpSamplingNearest(2) */
+    FG_CONV = 5,            /* (cudnn|nn).SpatialConvolution(a=nIn, b=nOut, c=k, k, 1, 1, d=pad, pad) */
+    FG_BATCHNORM = 6,       /* nn.SpatialBatchNormalization(a=nF), p=eps, q=momentum */
+    FG_SPATIAL_DROPOUT = 7, /* nn.SpatialDropout(p) */
+    FG_AVGPOOL2 = 8,        /* nn.SpatialAveragePooling(2,2,2,2) */
+    FG_DROPOUT = 9,         /* nn.Dropout(p) (v2) */
+    FG_SIGMOID = 10,        /* nn.Sigmoid */
+    FG_LEAKYRELU = 11       /* LeakyReLU.lua, p = negative slope */
+};
+typedef struct fg_layer_spec {
+    int type;
+    int a, b, c, d;
+    float p, q;
+} fg_layer_spec;
+
+int fg_net_create(fg_ctx* ctx, const fg_layer_spec* layers, int n_layers, int in_c, int in_h, int in_w, fg_net** out);
+int fg_net_destroy(fg_net* net);
+long long fg_net_num_params(const fg_net* net);   /* length of the flat parameter vector (reference order) */
+long long fg_net_num_buffers(const fg_net* net);  /* BN running_mean||running_var per BN layer, module order */
+int fg_net_num_masks(const fg_net* net);          /* dropout layers, module order */
+long long fg_net_mask_elems(const fg_net* net, int mask_index, int batch);
+int fg_net_out_dims(const fg_net* net, int* c, int* h, int* w);
+size_t fg_net_workspace_bytes(const fg_net* net, int max_batch);
+/* offsets (in floats) of layer `layer_index`'s weight / bias inside the flat vector; -1 if it has none */
+int fg_net_param_offset(const fg_net* net, int layer_index, long long* weight_off, long long* weight_n,
+                        long long* bias_off, long long* bias_n);
+/* persistent device pointers: flat params, flat grads (may be NULL for inference), BN buffers (may be NULL) */
+int fg_net_bind(fg_net* net, float* params, float* grads, float* buffers);
+int fg_net_params_changed(fg_net* net); /* call after the optimizer touched `params` (re-packs lazily) */
+/* Module:forward.  x: NHWC [batch][in_h][in_w][in_c].  masks: one device pointer per dropout layer
+ * (0/1 keep masks: SpatialDropout [batch][C]; Dropout [batch][features in internal NHWC order]); ignored when
+ * train == 0.  Activations stay in `ws` for fg_net_backward.  *out_offset = float offset of the output
+ * (NHWC [batch][out_h][out_w][out_c]) inside ws. */
+int fg_net_forward(fg_net* net, int batch, const float* x, void* ws, size_t ws_bytes, int train,
+                   const float* const* masks, int n_masks, long long* out_offset);
+enum { FG_BWD_PARAM_GRADS = 1, FG_BWD_INPUT_GRAD = 2 };
+/* Module:backward after a train-mode forward with the same (batch, x, ws).  gy: grad wrt the output.
+ * FG_BWD_PARAM_GRADS writes (overwrites: the reference zeroes before every feval, adversarial.lua:92, 193)
+ * the flat gradient vector; FG_BWD_INPUT_GRAD writes gx (NHWC like x). */
+int fg_net_backward(fg_net* net, int batch, const float* x, const float* gy, void* ws, size_t ws_bytes, int flags,
+                    float* gx);
+/* debugging / parity: activation after reference layer `layer_index` of the last forward (must end a stage) */
+int fg_net_layer_output(const fg_net* net, int layer_index, long long* ws_offset, int* c, int* h, int* w);
+
+/* ---- criterion: nn.BCECriterion() (train.lua:148) fused forward+backward, plus D's confusion counts
+ *      (adversarial.lua:112-117): confusion[pred*2 + target] ---- */
+int fg_bce_forward_backward(fg_ctx* ctx, const float* prob, const float* target, int n, float* loss_dev,
+                            float* grad_dev, int* confusion_dev);
+
+/* ---- optimizers on the flat vectors (interruptable_optimizers.lua:7-167) with the penalty and clamp of
+ *      adversarial.lua:103-123 / 218-228 fused in:  g' = clamp(gscale*g + l1_mul*sign(p) + l2*p, +-clamp) ---- */
+int fg_adam_fused(fg_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float gscale, float l1_mul,
+                  float l2, float clamp, float lr, float beta1, float beta2, float eps, int t, float* g_out);
+int fg_sgd_fused(fg_ctx* ctx, float* p, const float* g, float* mom_buf, long long n, float gscale, float l1_mul,
+                 float l2, float clamp, float lr, float momentum, float dampening, float weight_decay, int nesterov,
+                 int first_step);
+int fg_adagrad_fused(fg_ctx* ctx, float* p, const float* g, float* variance, long long n, float gscale, float l1_mul,
+                     float l2, float clamp, float clr);
+/* out2[0] = ||p||_1, out2[1] = ||p||_2^2 (torch.norm of adversarial.lua:105-106); scratch >= 1024 floats */
+int fg_norms(fg_ctx* ctx, const float* p, long long n, float* out2_dev, float* scratch);
+
+/* ---- module-level ops (nn.Module protocol: updateOutput / updateGradInput / accGradParameters), NHWC ----
+ * conv / linear take REFERENCE-layout weights and pack them into `ws` on the fly. */
+size_t fg_conv2d_workspace_bytes(int batch, int h, int w, int cin, int cout, int k, int upsample2x);
+int fg_conv2d_forward(fg_ctx* ctx, const float* x, const float* w_oihw, const float* bias, float* y, int batch, int h,
+                      int w, int cin, int cout, int k, int pad, int upsample2x, void* ws, size_t ws_bytes);
+int fg_conv2d_backward_data(fg_ctx* ctx, const float* gy, const float* w_oihw, float* gx, int batch, int h, int w,
+                            int cin, int cout, int k, int pad, int upsample2x, void* ws, size_t ws_bytes);
+/* gw = beta*gw + dW, gb = beta*gb + db (beta = 1: Torch's accumulate semantics) */
+int fg_conv2d_backward_weight(fg_ctx* ctx, const float* x, const float* gy, float* gw_oihw, float* gb, float beta,
+                              int batch, int h, int w, int cin, int cout, int k, int pad, int upsample2x, void* ws,
+                              size_t ws_bytes);
+size_t fg_linear_workspace_bytes(int batch, int in_f, int out_f);
+int fg_linear_forward(fg_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int batch, int in_f,
+                      int out_f, void* ws, size_t ws_bytes);
+int fg_linear_backward_data(fg_ctx* ctx, const float* gy, const float* w, float* gx, int batch, int in_f, int out_f,
+                            void* ws, size_t ws_bytes);
+int fg_linear_backward_weight(fg_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, float beta,
+                              int batch, int in_f, int out_f, void* ws, size_t ws_bytes);
+/* SpatialBatchNormalization; slope != NULL fuses the following PReLU.  scratch >= fg_bn_scratch_floats(c) floats */
+long long fg_bn_scratch_floats(int c);
+int fg_batchnorm_forward(fg_ctx* ctx, const float* x, float* y, long long rows, int c, const float* gamma,
+                         const float* beta, const float* slope, float* save_mean, float* save_invstd,
+                         float* running_mean, float* running_var, float eps, float momentum, int train,
+                         float* scratch);
+int fg_batchnorm_backward(fg_ctx* ctx, const float* x, const float* gy, float* gx, long long rows, int c,
+                          const float* gamma, const float* beta, const float* slope, const float* save_mean,
+                          const float* save_invstd, float* ggamma, float* gbeta, float* gslope, float acc,
+                          float* scratch);
+/* PReLU with an optional same-shape keep mask (x mscale): nn.PReLU [+ nn.Dropout]; scratch >= 1024 floats */
+int fg_prelu_forward(fg_ctx* ctx, const float* x, const float* slope, const float* mask, float mscale, float* y,
+                     long long n);
+int fg_prelu_backward(fg_ctx* ctx, const float* x, const float* gy, const float* slope, const float* mask,
+                      float mscale, float* gx, float* gslope, float acc, long long n, float* scratch);
+/* fused nn.PReLU -> nn.SpatialDropout(mask [batch][c]) -> nn.SpatialAveragePooling(2,2,2,2) (models.lua:386-388) */
+int fg_actpool_forward(fg_ctx* ctx, const float* x, const float* slope, const float* mask, float mscale, float* y,
+                       int batch, int h, int w, int c);
+int fg_actpool_backward(fg_ctx* ctx, const float* x, const float* gy, const float* slope, const float* mask,
+                        float mscale, float* gx, float* gslope, float acc, int batch, int h, int w, int c,
+                        float* scratch);
+int fg_spatial_dropout_apply(fg_ctx* ctx, const float* x, const float* mask, float mscale, float* y, int batch, int hw,
+                             int c);
+int fg_avgpool2x2_forward(fg_ctx* ctx, const float* x, float* y, int batch, int h, int w, int c);
+int fg_avgpool2x2_backward(fg_ctx* ctx, const float* gy, float* gx, int batch, int h, int w, int c);
+int fg_upsample_nearest2x_forward(fg_ctx* ctx, const float* x, float* y, int batch, int h, int w, int c);
+int fg_upsample_nearest2x_backward(fg_ctx* ctx, const float* gy, float* gx, int batch, int h, int w, int c);
+int fg_sigmoid_forward(fg_ctx* ctx, const float* x, float* y, long long n);
+int fg_sigmoid_backward(fg_ctx* ctx, const float* y, const float* gy, float* gx, long long n);
+int fg_leakyrelu_forward(fg_ctx* ctx, const float* x, float negslope, float* y, long long n);
+int fg_leakyrelu_backward(fg_ctx* ctx, const float* x, const float* gy, float negslope, float* gx, long long n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACEGEN_HIP_H */

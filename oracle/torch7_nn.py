@@ -743,6 +743,7 @@ def feval_D(st, inputs, targets):
     st.gD[...] = 0
     out = st.D.forward(inputs)
     f = st.crit.forward(out, targets)
+    st.last_f_bce = f
     df = st.crit.backward(out, targets)
     st.D.backward(inputs, df)
     if o['D_L1'] != 0 or o['D_L2'] != 0:
@@ -767,6 +768,7 @@ def feval_G_on_D(st, noise, targets):
     samples = st.G.forward(noise)
     out = st.D.forward(samples)
     f = st.crit.forward(out, targets)
+    st.last_f_bce = f
     df = st.crit.backward(out, targets)
     st.D.backward(samples, df)
     df_do = st.D.modules[0].gradInput
@@ -794,7 +796,7 @@ def step_D(st, real, noise_half, masks=None):
 
     def op(x):
         f, g, out, conf = feval_D(st, inputs, targets)
-        res.update(f=f, out=out.copy(), conf=conf, grad=g.copy(), inputs=inputs)
+        res.update(f=f, f_bce=st.last_f_bce, out=out.copy(), conf=conf, grad=g.copy(), inputs=inputs)
         return f, g
     interruptable_adam(op, st.pD, st.adamD)
     return res
@@ -809,7 +811,7 @@ def step_G(st, noise, masks=None):
 
     def op(x):
         f, g, samples, out = feval_G_on_D(st, noise, targets)
-        res.update(f=f, out=out.copy(), grad=g.copy(), samples=samples.copy())
+        res.update(f=f, f_bce=st.last_f_bce, out=out.copy(), grad=g.copy(), samples=samples.copy())
         return f, g
     interruptable_adam(op, st.pG, st.adamG)
     return res

@@ -1,0 +1,152 @@
+"""Net-level and step-level parity of the device plan (fg_net_*) against the oracle's restatement of
+models.lua / adversarial.lua, on the same seeded inputs, weights and injected dropout masks."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch7_nn as O
+from gpu_util import nhwc, nchw, dev, close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from face_generator_amd.runtime import get_context
+    return get_context(0)
+
+
+def build(ctx, C, B, seed, init="default"):
+    """oracle nets + device nets holding identical parameters."""
+    from face_generator_amd import models
+    rng = np.random.default_rng(seed)
+    G = O.create_G32((C, 32, 32), 100, rng)
+    D = O.create_D32b((C, 32, 32), rng)
+    if init == "reference":      # train.lua:137-138 -> N(0,0.005^2) / N(0,0.001^2), incl. BN gamma and PReLU slope
+        O.initialize_weights(G, rng=rng); O.initialize_weights(D, rng=rng)
+    else:
+        for net in (G, D):       # well-conditioned init + non-trivial BN beta / PReLU slopes
+            for m in net.modules:
+                if isinstance(m, O.SpatialBatchNormalization):
+                    m.bias[...] = rng.standard_normal(m.bias.shape).astype(np.float32) * 0.2
+                    m.weight[...] = rng.uniform(0.5, 1.5, m.weight.shape).astype(np.float32)
+                if isinstance(m, O.PReLU):
+                    m.weight[0] = np.float32(rng.uniform(0.1, 0.4))
+    st = O.GanState(G, D)
+    Gd = models.create_G((C, 32, 32), 100).cuda(ctx, max_batch=B)
+    Dd = models.create_D((C, 32, 32)).cuda(ctx, max_batch=B)
+    pG, gG = Gd.getParameters(); pD, gD = Dd.getParameters()
+    assert pG.numel() == st.pG.size and pD.numel() == st.pD.size
+    pG.copy_(torch.tensor(st.pG)); pD.copy_(torch.tensor(st.pD))
+    Gd.device_net.params_changed(); Dd.device_net.params_changed()
+    return st, Gd, Dd, rng
+
+
+def d_masks(rng, B):
+    return [(rng.random((B, c)) < 0.8).astype(np.float32) for c in (64, 128, 256, 512)] + \
+           [(rng.random((B, 512)) < 0.5).astype(np.float32) for _ in range(2)]
+
+
+@pytest.mark.parametrize("C,B", [(3, 4), (1, 6), (3, 18)])
+def test_G_forward_backward(ctx, C, B):
+    st, Gd, Dd, rng = build(ctx, C, B, seed=100 + C + B)
+    noise = rng.uniform(-1, 1, (B, 100)).astype(np.float32)
+    img = st.G.forward(noise)
+    gy = rng.standard_normal(img.shape).astype(np.float32)
+    st.gG[...] = 0
+    st.G.backward(noise, gy)
+    dn = Gd.device_net
+    y = dn.forward(dev(noise, ctx.device))
+    close(nchw(dn.layer_output(2)), st.G.modules[2].output, atol=2e-5, what="G prelu(view(linear))")
+    close(nchw(dn.layer_output(6)), st.G.modules[6].output, atol=5e-5, what="G conv5+bn+prelu")
+    close(nchw(dn.layer_output(10)), st.G.modules[10].output, atol=5e-5, what="G conv9+bn+prelu")
+    close(nchw(y), img, atol=1e-5, what="G images")                    # bar: 1e-4 (north_star)
+    dn.backward(nhwc(gy, ctx.device), param_grads=True, input_grad=False)
+    g = dn.grads.cpu().numpy()
+    offs = 0
+    for i, m in enumerate(st.G.modules):                               # per-parameter report for localisation
+        for (mm, pn, gn) in m.parameters():
+            ref = getattr(mm, gn).reshape(-1)
+            close(g[offs:offs + ref.size], ref, atol=1e-4 * np.abs(ref).max() + 1e-7,
+                  what="G grad module %d %s" % (i + 1, pn))
+            offs += ref.size
+    # BN running statistics (evaluate-mode state) follow the THNN update
+    rm = dn.buffers.cpu().numpy()
+    close(rm[:256], st.G.modules[5].running_mean, atol=1e-6, what="running_mean")
+    close(rm[256:512], st.G.modules[5].running_var, atol=0, rtol=1e-5, what="running_var")
+
+
+@pytest.mark.parametrize("C,B", [(3, 4), (1, 6), (3, 18)])
+def test_D_forward_backward(ctx, C, B):
+    st, Gd, Dd, rng = build(ctx, C, B, seed=200 + C + B)
+    x = rng.uniform(0, 1, (B, C, 32, 32)).astype(np.float32)
+    masks = d_masks(rng, B)
+    O.set_dropout_masks(st.D, masks)
+    out = st.D.forward(x)
+    gy = rng.standard_normal(out.shape).astype(np.float32)
+    st.gD[...] = 0
+    gx = st.D.backward(x, gy)
+    dn = Dd.device_net
+    y = dn.forward(nhwc(x, ctx.device), masks=[dev(m.reshape(-1), ctx.device) for m in masks])
+    close(nchw(dn.layer_output(3)), st.D.modules[3].output, atol=1e-5, what="D block1")
+    close(nchw(dn.layer_output(15)), st.D.modules[15].output, atol=2e-5, what="D block4")
+    close(y.cpu().numpy(), out, atol=1e-5, what="D probabilities")      # bar: 1e-4
+    gxd = dn.backward(dev(gy, ctx.device), param_grads=True, input_grad=True)
+    close(nchw(gxd), gx, atol=1e-4 * np.abs(gx).max() + 1e-8, what="D input grad")
+    g = dn.grads.cpu().numpy()
+    offs = 0
+    for i, m in enumerate(st.D.modules):
+        for (mm, pn, gn) in m.parameters():
+            ref = getattr(mm, gn).reshape(-1)
+            close(g[offs:offs + ref.size], ref, atol=1e-4 * np.abs(ref).max() + 1e-7,
+                  what="D grad module %d %s" % (i + 1, pn))
+            offs += ref.size
+
+
+def test_evaluate_mode_forward(ctx):
+    """sample.lua / visualizeProgress path: BN running stats, SpatialDropout x(1-p), Dropout identity."""
+    st, Gd, Dd, rng = build(ctx, 3, 8, seed=300)
+    noise = rng.uniform(-1, 1, (8, 100)).astype(np.float32)
+    st.G.forward(noise)                    # one train-mode pass to move the running stats
+    Gd.device_net.forward(dev(noise, ctx.device))
+    st.G.evaluate(); st.D.evaluate(); Gd.evaluate(); Dd.evaluate()
+    img = st.G.forward(noise)
+    p = st.D.forward(img)
+    y = Gd.device_net.forward(dev(noise, ctx.device))
+    close(nchw(y), img, atol=2e-5, what="G eval images")
+    pd = Dd.device_net.forward(y.clone())
+    close(pd.cpu().numpy(), p, atol=2e-5, what="D eval probabilities")
+
+
+@pytest.mark.parametrize("init", ["default", "reference"])
+def test_full_D_step_and_G_step(ctx, init):
+    """adversarial.lua:240-288 with Adam: outputs, loss, flat gradients, post-Adam parameters."""
+    from face_generator_amd import adversarial
+    B, C = 8, 3
+    st, Gd, Dd, rng = build(ctx, C, B, seed=400, init=init)
+    tr = adversarial.Trainer(ctx, Gd, Dd, dict(batchSize=B, noiseDim=100, D_L1=0.0, D_L2=1e-4, G_L1=0.0, G_L2=0.0,
+                                              D_clamp=1.0, G_clamp=5.0))
+    real = rng.uniform(0, 1, (B // 2, C, 32, 32)).astype(np.float32)
+    nz = rng.uniform(-1, 1, (B // 2, 100)).astype(np.float32)
+    masks = d_masks(rng, B)
+    ref = O.step_D(st, real, nz, masks)
+    got = tr.step_D(nhwc(real, ctx.device), dev(nz, ctx.device), [dev(m.reshape(-1), ctx.device) for m in masks],
+                    keep_grad=True)
+    close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what="D-step D outputs")
+    assert abs(got["loss"].item() - ref["f_bce"]) <= 1e-5 * abs(ref["f_bce"])      # loss: rel 1e-5
+    assert abs(got["f"] - ref["f"]) <= 1e-5 * abs(ref["f"])                           # incl. the L2 penalty term
+    close(got["grad"].cpu().numpy(), ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what="D-step flat grad")
+    close(Dd.getParameters()[0].cpu().numpy(), st.pD, atol=2e-6, what="D params after Adam")
+    assert (got["confusion"].cpu().numpy().reshape(2, 2) == ref["conf"]).all()
+    # G-step on the updated D
+    nz2 = rng.uniform(-1, 1, (B, 100)).astype(np.float32)
+    masks2 = d_masks(rng, B)
+    ref = O.step_G(st, nz2, masks2)
+    got = tr.step_G(dev(nz2, ctx.device), [dev(m.reshape(-1), ctx.device) for m in masks2], keep_grad=True)
+    close(nchw(got["samples"]), ref["samples"], atol=1e-5, what="G-step samples")
+    close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what="G-step D outputs")
+    assert abs(got["loss"].item() - ref["f_bce"]) <= 1e-5 * abs(ref["f_bce"])
+    close(got["grad"].cpu().numpy(), ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what="G-step flat grad")
+    close(Gd.getParameters()[0].cpu().numpy(), st.pG, atol=2e-6, what="G params after Adam")
+
+
