@@ -1,0 +1,191 @@
+#!/usr/bin/env python
+"""bench.py -- GAN train images/sec (G+D step) at 32x32x3, batch 128 per GPU (BASELINE.json config 2 / 3).
+
+One "step" = one iteration of adversarial.lua:54-288: D_iterations x D-step (G forward on B/2 noises in train
+mode -> D forward/BCE/backward on B/2 real || B/2 fake -> L2 penalty -> clamp -> Adam on D) + G_iterations x
+G-step (G forward on B noises -> D forward/BCE(target 1)/backward-to-input -> G backward -> clamp -> Adam on G).
+Synthetic inputs resident in HBM before the timed region (real ~ U[0,1), noise ~ U(-1,1) drawn on device by
+Philox inside the step, dropout masks drawn on device), reference init N(0,0.005^2)/N(0,0.001^2) (train.lua:137).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  N > 1: weak scaling (B=128 per GPU), RCCL all-reduce (sum) of the flat D / G
+gradient vectors each update, replicas stay identical.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+# algorithmic FLOPs per image for cfg2/3: 7.962 GFLOP/img, 1019.19 GFLOP per B=128 iteration
+MG, MD, G1, D1 = 1052934144, 59703808, 819200, 1769472
+
+
+def alg_flops_per_iter(B, d_it=1, g_it=1):
+    return 2.0 * (d_it * (B / 2 * MG + 3 * B * MD - B * D1) + g_it * (3 * B * MG - B * G1 + 2 * B * MD))
+
+
+def parse_prof(text):
+    rows = {}
+    for line in text.strip().splitlines():
+        parts = line.split()
+        if len(parts) != 6:
+            continue
+        name = parts[0]
+        rows[name] = dict(calls=int(parts[1]), ms=float(parts[2]), alg=float(parts[3]), exe=float(parts[4]))
+    return rows
+
+
+def cpu_baseline(sample_batch=32):
+    """The oracle (numpy restatement of the Torch7 nn CPU path: im2col + sgemm per layer) timed on this host's
+    cores: ONE iteration at batch `sample_batch` of the same nets / inputs / optimizer."""
+    import numpy as np
+    from oracle import torch7_nn as O
+    rng = np.random.default_rng(1)
+    G = O.create_G32((3, 32, 32), 100, rng)
+    D = O.create_D32b((3, 32, 32), rng)
+    O.initialize_weights(G, rng=rng)
+    O.initialize_weights(D, rng=rng)
+    st = O.GanState(G, D)
+    B = sample_batch
+    real = rng.uniform(0, 1, (B // 2, 3, 32, 32)).astype(np.float32)
+    t0 = time.time()
+    O.step_D(st, real, rng.uniform(-1, 1, (B // 2, 100)).astype(np.float32))
+    O.step_G(st, rng.uniform(-1, 1, (B, 100)).astype(np.float32))
+    dt = time.time() - t0
+    return dict(value=B / dt, unit="images/sec", cores=os.cpu_count(), kind="port",
+                sample="1 iteration (D-step + G-step) at batch %d, numpy/OpenBLAS oracle, %.1f s" % (B, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (OPT.batchSize)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prof-iters", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (one process per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from face_generator_amd import models, nn_utils, adversarial
+    from face_generator_amd.runtime import get_context
+    from face_generator_amd.state import S
+
+    ctx = get_context(local_rank)
+    B = args.batch
+    C = 3
+    gen = torch.Generator().manual_seed(1)              # identical initial replicas on every rank
+    G = models.create_G((C, 32, 32), 100)
+    D = models.create_D((C, 32, 32))
+    nn_utils.initializeWeights(D, gen=gen)
+    nn_utils.initializeWeights(G, gen=gen)
+    G.cuda(ctx, max_batch=B)
+    D.cuda(ctx, max_batch=B)
+    S.OPT.update(batchSize=B, noiseDim=100)
+    S.noise_seed = 1 + rank                             # each rank draws its own shard of the global batch
+    G.device_net.mask_seed = D.device_net.mask_seed = 1000 + rank
+    tr = adversarial.Trainer(ctx, G, D, S.OPT, dist=dist if world > 1 else None)
+    real = ctx.uniform((B // 2, 32, 32, C), 0.0, 1.0, seed=77 + rank)
+
+    def iteration():
+        tr.step_D(real, S.next_noise(ctx, B // 2, 100))
+        tr.step_G(S.next_noise(ctx, B, 100))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        iteration()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iteration()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = 1000.0 * dt / args.steps
+    value = world * B * args.steps / dt
+
+    out = {
+        "metric": "GAN train images/sec (G+D step) at 32x32x3 bs128",
+        "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (U[0,1) images, U(-1,1) noise, reference init N(0,.005^2)/N(0,.001^2))",
+        "config": {"workload": "configs[1]: 32x32 color, noiseDim=100, batch 128 per GPU, Adam, D_it=G_it=1"
+                               + ("" if world == 1 else "; configs[2]-style weak scaling, RCCL grad all-reduce"),
+                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world},
+        "reference_accounting_images_per_sec": value / 2,   # adversarial.lua:305 counts B/2 per iteration
+    }
+    flops = alg_flops_per_iter(B)
+    out["step_roofline"] = {"algorithmic_gflop_per_iter": flops / 1e9, "achieved_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
+                            "frac_of_f32_mfma_peak": flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+
+    if rank == 0 and not args.no_roofline:
+        import ctypes
+        ctx.check(ctx.lib.fg_prof_enable(ctx.h, 1))
+        for _ in range(args.prof_iters):
+            iteration()
+        buf = ctypes.create_string_buffer(1 << 16)
+        ctx.check(ctx.lib.fg_prof_report(ctx.h, buf, len(buf), 1))
+        ctx.check(ctx.lib.fg_prof_enable(ctx.h, 0))
+        rows = parse_prof(buf.value.decode())
+        # aggregate by kernel symbol (what rocprofv3 --stats reports)
+        sym = {}
+        for name, r in rows.items():
+            k = name.split("/")[0]
+            a = sym.setdefault(k, dict(calls=0, ms=0.0, alg=0.0, exe=0.0))
+            for f in ("calls", "ms", "alg", "exe"):
+                a[f] += r[f]
+        if sym:
+            dom = max(sym, key=lambda k: sym[k]["ms"])
+            a = sym[dom]
+            ach = a["alg"] / (a["ms"] * 1e-3) / 1e12
+            exe = a["exe"] / (a["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": dom,
+                               "avg_launch_ms": a["ms"] / a["calls"], "launches_per_iter": a["calls"] / args.prof_iters,
+                               "executed_tflops": exe, "executed_frac": exe / PEAK_F32_MFMA_TFLOPS,
+                               "note": "achieved = reference-formulation (un-folded 5x5) conv FLOPs / kernel time; "
+                                       "executed = MFMA FLOPs actually issued (nearest-x2 tap folding: 9/25 of the taps)"}
+            out["kernels"] = {k: {"calls_per_iter": v["calls"] / args.prof_iters, "ms_per_iter": v["ms"] / args.prof_iters,
+                                  "executed_tflops": v["exe"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0}
+                              for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

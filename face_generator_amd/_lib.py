@@ -31,12 +31,14 @@ _CTYPES = [
     (r"^const float\* const\*$", ctypes.POINTER(ctypes.c_void_p)),
     (r"^(fg_ctx|fg_net|void)\*\*$", ctypes.POINTER(ctypes.c_void_p)),
     (r"^const char\*$", ctypes.c_char_p),
+    (r"^char\*$", ctypes.c_char_p),
     (r"^long long\*$", ctypes.POINTER(ctypes.c_longlong)),
     (r"^(const )?(fg_ctx|fg_net|void|float|int)\*$", ctypes.c_void_p),
     (r"^int$", ctypes.c_int),
     (r"^long long$", ctypes.c_longlong),
     (r"^size_t$", ctypes.c_size_t),
     (r"^float$", ctypes.c_float),
+    (r"^double$", ctypes.c_double),
     (r"^uint64_t$", ctypes.c_uint64),
 ]
 

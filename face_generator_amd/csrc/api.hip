@@ -17,6 +17,28 @@ int fg_set_err(fg_ctx* c, int code, const char* fmt, ...) {
     return code;
 }
 
+const char* fg_intern(fg_ctx* ctx, const char* s) {
+    if (!ctx || !ctx->prof) return "";
+    for (auto* n : ctx->names) if (*n == s) return n->c_str();
+    ctx->names.push_back(new std::string(s));
+    return ctx->names.back()->c_str();
+}
+FgProfScope::FgProfScope(fg_ctx* c, const char* name, double alg, double exec, double bytes) : ctx(c), idx(-1) {
+    if (!c || !c->prof) return;
+    hipEvent_t e[2];
+    for (int i = 0; i < 2; ++i) {
+        if (!c->prof_pool.empty()) { e[i] = c->prof_pool.back(); c->prof_pool.pop_back(); }
+        else if (hipEventCreate(&e[i]) != hipSuccess) return;
+    }
+    FgProfRec r{name, e[0], e[1], alg, exec, bytes};
+    (void)hipEventRecord(r.e0, c->stream);
+    c->prof_recs.push_back(r);
+    idx = (int)c->prof_recs.size() - 1;
+}
+FgProfScope::~FgProfScope() {
+    if (idx >= 0) (void)hipEventRecord(ctx->prof_recs[idx].e1, ctx->stream);
+}
+
 #define NEED(ctx, cond, msg) \
     do { if (!(cond)) return fg_set_err((ctx), FG_ERR_INVALID, "%s: %s", __func__, msg); } while (0)
 
@@ -45,6 +67,34 @@ int fg_ctx_create(int device, fg_ctx** out) {
     return FG_OK;
 }
 int fg_ctx_destroy(fg_ctx* ctx) { delete ctx; return FG_OK; }
+int fg_prof_enable(fg_ctx* ctx, int on) { NEED(ctx, ctx, "null ctx"); ctx->prof = on != 0; return FG_OK; }
+// Synchronises, then writes one line per kernel label: "name calls total_ms alg_flops exec_flops bytes\n".
+int fg_prof_report(fg_ctx* ctx, char* buf, size_t len, int reset) {
+    NEED(ctx, ctx && buf && len > 0, "bad argument");
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    struct Agg { const char* name; long calls; double ms, alg, exec, bytes; };
+    std::vector<Agg> aggs;
+    for (auto& r : ctx->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = 0.f;
+        Agg* a = nullptr;
+        for (auto& x : aggs) if (strcmp(x.name, r.name) == 0) { a = &x; break; }
+        if (!a) { aggs.push_back(Agg{r.name, 0, 0, 0, 0, 0}); a = &aggs.back(); }
+        a->calls++; a->ms += ms; a->alg += r.alg_flops; a->exec += r.exec_flops; a->bytes += r.bytes;
+    }
+    size_t off = 0;
+    buf[0] = 0;
+    for (auto& a : aggs) {
+        int n = snprintf(buf + off, len - off, "%s %ld %.6f %.6e %.6e %.6e\n", a.name, a.calls, a.ms, a.alg, a.exec, a.bytes);
+        if (n < 0 || (size_t)n >= len - off) break;
+        off += n;
+    }
+    if (reset) {
+        for (auto& r : ctx->prof_recs) { ctx->prof_pool.push_back(r.e0); ctx->prof_pool.push_back(r.e1); }
+        ctx->prof_recs.clear();
+    }
+    return FG_OK;
+}
 int fg_ctx_set_stream(fg_ctx* ctx, void* s) { NEED(ctx, ctx, "null ctx"); ctx->stream = (hipStream_t)s; return FG_OK; }
 const char* fg_last_error(const fg_ctx* ctx) { return ctx ? ctx->err : g_err; }
 int fg_stream_sync(fg_ctx* ctx) { NEED(ctx, ctx, "null ctx"); FG_HIP(ctx, hipStreamSynchronize(ctx->stream)); return FG_OK; }
@@ -102,21 +152,23 @@ int fg_bce_forward_backward(fg_ctx* ctx, const float* prob, const float* target,
 }
 
 int fg_adam_fused(fg_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float gscale, float l1_mul,
-                  float l2, float clamp, float lr, float beta1, float beta2, float eps, int t, float* g_out) {
+                  float l2, float clamp, double lr, double beta1, double beta2, double eps, int t, float* g_out) {
     NEED(ctx, ctx && p && g && m && v && n >= 0 && t >= 1, "bad argument");
     AdamArgs a; a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.gscale = gscale; a.l1 = 0.f; a.l1_mul = l1_mul; a.l2 = l2;
-    a.clamp = clamp; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.t = t; a.gout = g_out;
+    a.clamp = clamp; a.lr_d = lr; a.beta1_d = beta1; a.beta2_d = beta2; a.beta1 = (float)beta1; a.beta2 = (float)beta2;
+    a.eps = (float)eps; a.t = t; a.gout = g_out;
     return fg_launch_adam(ctx, a);
 }
 int fg_sgd_fused(fg_ctx* ctx, float* p, const float* g, float* mom, long long n, float gscale, float l1_mul, float l2,
-                 float clamp, float lr, float momentum, float dampening, float wd, int nesterov, int first) {
-    NEED(ctx, ctx && p && g && n >= 0 && (momentum == 0.f || mom), "bad argument");
-    return fg_launch_sgd(ctx, p, g, mom, n, gscale, l1_mul, l2, clamp, lr, momentum, dampening, wd, nesterov, first);
+                 float clamp, double lr, double momentum, double dampening, double wd, int nesterov, int first) {
+    NEED(ctx, ctx && p && g && n >= 0 && (momentum == 0.0 || mom), "bad argument");
+    return fg_launch_sgd(ctx, p, g, mom, n, gscale, l1_mul, l2, clamp, (float)lr, (float)momentum, (float)(1.0 - dampening),
+                         (float)wd, nesterov, first);
 }
 int fg_adagrad_fused(fg_ctx* ctx, float* p, const float* g, float* var, long long n, float gscale, float l1_mul, float l2,
-                     float clamp, float clr) {
+                     float clamp, double clr) {
     NEED(ctx, ctx && p && g && var && n >= 0, "bad argument");
-    return fg_launch_adagrad(ctx, p, g, var, n, gscale, l1_mul, l2, clamp, clr);
+    return fg_launch_adagrad(ctx, p, g, var, n, gscale, l1_mul, l2, clamp, (float)clr);
 }
 int fg_norms(fg_ctx* ctx, const float* p, long long n, float* out2, float* scratch) {
     NEED(ctx, ctx && p && out2 && scratch && n >= 0, "bad argument");
@@ -149,7 +201,11 @@ static int conv_check(fg_ctx* ctx, int cin, int cout, int k, int pad, int up) {
         return FG_OK;
     }
     if (cin % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: nInputPlane %% 4 != 0");
-    if (k * k * (up ? 4 : 1) > FG_MAX_GROUPS && up) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: fold groups");
+    if (up) {
+        int T, rmin;
+        fg_fold_window(k, pad, &T, &rmin);
+        if (4 * T * T > FG_MAX_GROUPS) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: fold groups");
+    } else if (k * k > FG_MAX_GROUPS) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: k too large");
     return FG_OK;
 }
 

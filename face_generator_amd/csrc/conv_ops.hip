@@ -105,6 +105,19 @@ long long fg_conv_scratch_floats(const ConvGeom& g) {
     return need + 64;
 }
 
+// reference-formulation FLOPs of one pass over this layer (2 x MACs of the un-folded convolution)
+static double alg_flops(const ConvGeom& g) {
+    const double outpix = (double)g.B * g.H * g.W * (g.fold ? 4.0 : 1.0);
+    return 2.0 * outpix * g.Cout * g.Cin * g.k * g.k;
+}
+static const char* tag_of(const ConvGeom& g, int pass) {
+    static const char* names[3][3] = {{"linear_fwd", "linear_dgrad", "linear_wgrad"},
+                                      {"conv_fwd", "conv_dgrad", "conv_wgrad"},
+                                      {"convup_fwd", "convup_dgrad", "convup_wgrad"}};
+    const int kind = (g.k == 1 && g.H == 1 && g.W == 1) ? 0 : (g.fold ? 2 : 1);
+    return names[kind][pass];
+}
+
 static void fill_mspace(IgemmArgs& a, int B, int H, int W) {
     a.Nb = B; a.Hm = H; a.Wm = W; a.M = B * H * W;
     a.lgH = ilog2_exact(H); a.lgW = ilog2_exact(W);
@@ -119,6 +132,7 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
     IgemmArgs a; memset(&a, 0, sizeof(a));
     fill_mspace(a, g.B, g.H, g.W);
     a.A = x; a.Bp = wp_fwd; a.bias = bias; a.Out = y;
+    a.alg_flops = alg_flops(g); a.tag = tag_of(g, 0);
     a.Ha = g.H; a.Wa = g.W; a.Ca = g.Cin; a.Kpad = cf; a.asy = a.asx = 1;
     a.N = g.Cout; a.G = wm.G; a.Npad = rf;
     if (g.fold) {
@@ -159,6 +173,7 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
     IgemmArgs a; memset(&a, 0, sizeof(a));
     fill_mspace(a, g.B, g.H, g.W);
     a.A = gy; a.Bp = wp_bwd; a.bias = nullptr; a.Out = gx;
+    a.alg_flops = alg_flops(g); a.tag = tag_of(g, 1);
     a.Ca = g.Cout; a.Kpad = cb;
     a.Ho = g.H; a.Wo = g.W; a.osy = a.osx = 1; a.N = g.Cin; a.Npad = rb;
     a.G = wm.G * wm.P;
@@ -198,6 +213,7 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
     WeightMap wm; fg_geom_weightmap(g, &wm);
     WgradArgs a; memset(&a, 0, sizeof(a));
     a.dY = gy; a.X = x; a.Part = scratch;
+    a.alg_flops = alg_flops(g); a.tag = tag_of(g, 2);
     a.Nb = g.B; a.Hm = g.H; a.Wm = g.W; a.M = g.B * g.H * g.W;
     a.lgH = ilog2_exact(g.H); a.lgW = ilog2_exact(g.W);
     if (a.lgH < 0 || a.lgW < 0) a.lgH = a.lgW = -1;

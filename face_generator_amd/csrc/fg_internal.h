@@ -8,11 +8,26 @@
 
 #define FG_MAX_GROUPS 64   // (parity,tap) groups per launch table (7x7 plain = 49, folded dgrad = 36)
 
+#include <vector>
+#include <string>
+struct FgProfRec { const char* name; hipEvent_t e0, e1; double alg_flops, exec_flops, bytes; };
 struct fg_ctx {
     int device;
     hipStream_t stream;
     char err[512];
     int sm_count;
+    // optional per-launch HIP-event timing of the contraction kernels (bench.py roofline leg)
+    bool prof = false;
+    std::vector<FgProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    std::vector<std::string*> names;
+};
+const char* fg_intern(fg_ctx* ctx, const char* s);  // stable pointer for a profile label
+// RAII helper: records an event pair around one launch when profiling is on
+struct FgProfScope {
+    fg_ctx* ctx; int idx;
+    FgProfScope(fg_ctx* c, const char* name, double alg, double exec, double bytes);
+    ~FgProfScope();
 };
 
 
@@ -52,6 +67,8 @@ struct IgemmArgs {
     long long split_stride;
     signed char aoy[4][FG_MAX_GROUPS], aox[4][FG_MAX_GROUPS];
     signed char ooy[4], oox[4];
+    double alg_flops;    // host-side bookkeeping only: reference-formulation FLOPs of this launch
+    const char* tag;     // host-side: profile label
 };
 // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64.  P = gridDim.z parities.
 int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a, int P, int tile);
@@ -73,6 +90,8 @@ struct WgradArgs {
     int m_per_split;     // multiple of 32
     signed char doy[4], dox[4];
     signed char xoy[4][FG_MAX_GROUPS], xox[4][FG_MAX_GROUPS];
+    double alg_flops;
+    const char* tag;
 };
 int fg_launch_wgrad(fg_ctx* ctx, const WgradArgs& a, int P, int tile);  // tile: 0 = 128x128, 2 = 64x64
 
@@ -180,7 +199,8 @@ struct AdamArgs {
     float gscale;            // gradient pre-scale (1/world after an all-reduce sum)
     float l1, l1_mul, l2;    // g += l1_mul*sign(p) + l2*p   (l1_mul: quirk C4 lets G use G_L2 here)
     float clamp;             // 0 = off
-    float lr, beta1, beta2, eps; int t;  // t already incremented
+    float beta1, beta2, eps; int t;      // t already incremented; float copies used inside the kernel
+    double lr_d, beta1_d, beta2_d;       // Lua-number (double) hyper-parameters for the host-side scalars
     float* gout;             // optional: write the penalised+clamped gradient back (feval's return value)
 };
 int fg_launch_adam(fg_ctx*, const AdamArgs& a);

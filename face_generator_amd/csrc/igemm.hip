@@ -12,6 +12,7 @@
 // per 16-lane group).  Lane l of an MFMA holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; one ds_read_b128 per
 // 32-row fragment feeds 4 MFMAs (k = kk+j for lanes<32, kk+4+j for lanes>=32 -- same permutation on A and B).
 #include "fg_internal.h"
+#include <stdio.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -176,6 +177,11 @@ static int launch_igemm_t(fg_ctx* ctx, const IgemmArgs& a, int P) {
         attr_set = true;
     }
     dim3 grid(fg_cdiv(a.M, BM) * (a.Npad / BN), a.splits, P);
+    // executed FLOPs: every tile runs the full padded contraction
+    const double exec = 2.0 * (double)grid.x * BM * BN * (double)P * a.G * a.Kpad;
+    char label[96];
+    snprintf(label, sizeof(label), "igemm_kernel<%d,%d>/%s", BM, BN, a.tag ? a.tag : "?");
+    FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
     hipLaunchKernelGGL((igemm_kernel<BM, BN>), grid, dim3(256), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
@@ -343,6 +349,10 @@ static int launch_wgrad_t(fg_ctx* ctx, const WgradArgs& a, int P) {
         attr_set = true;
     }
     dim3 grid((a.Npad / BT) * (a.Cpad / BT), a.S, P * a.G);
+    const double exec = 2.0 * (double)a.Npad * a.Cpad * (double)P * a.G * (double)a.S * fg_round_up(a.m_per_split, 32);
+    char label[96];
+    snprintf(label, sizeof(label), "wgrad_kernel<%d>/%s", BT, a.tag ? a.tag : "?");
+    FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
     hipLaunchKernelGGL((wgrad_kernel<BT>), grid, dim3(256), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;

@@ -142,6 +142,12 @@ int fg_launch_colsum(fg_ctx* ctx, const float* x, long long M, int N, float beta
 }
 
 // ------------------------------------------------------------------ SpatialBatchNormalization (+PReLU)
+// z = ((x - mean) * invstd) * gamma + beta with every operation rounded separately (no FMA contraction): the sign of
+// z decides the PReLU branch in forward AND backward, so it must not depend on how the compiler fuses the expression.
+__device__ __forceinline__ float bn_xhat(float x, float mu, float is) { return __fmul_rn(__fsub_rn(x, mu), is); }
+__device__ __forceinline__ float bn_z(float x, float mu, float is, float g, float b) {
+    return __fadd_rn(__fmul_rn(bn_xhat(x, mu, is), g), b);
+}
 // stats: shifted single pass (pivot = x[0][c]) -> S1 = sum(x-K), S2 = sum((x-K)^2); fp64 finalize.
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long long M, int C,
                                                                float* __restrict__ part) {
@@ -192,10 +198,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
         const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
         float z;
-        z = (v.x - mu.x) * is.x * g.x + b.x; v.x = z > 0.f ? z : a * z;
-        z = (v.y - mu.y) * is.y * g.y + b.y; v.y = z > 0.f ? z : a * z;
-        z = (v.z - mu.z) * is.z * g.z + b.z; v.z = z > 0.f ? z : a * z;
-        z = (v.w - mu.w) * is.w * g.w + b.w; v.w = z > 0.f ? z : a * z;
+        z = bn_z(v.x, mu.x, is.x, g.x, b.x); v.x = z > 0.f ? z : a * z;
+        z = bn_z(v.y, mu.y, is.y, g.y, b.y); v.y = z > 0.f ? z : a * z;
+        z = bn_z(v.z, mu.z, is.z, g.z, b.z); v.z = z > 0.f ? z : a * z;
+        z = bn_z(v.w, mu.w, is.w, g.w, b.w); v.w = z > 0.f ? z : a * z;
         ((float4*)y)[i] = v;
     }
 }
@@ -230,8 +236,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ invstd, float* __restrict__ part) {
     const float a = slope ? slope[0] : 1.f;
     colreduce_body<3>(M, C, part, [&](long long r, int c, float* acc) {
-        const float xh = (x[r * C + c] - mean[c]) * invstd[c];
-        const float z = xh * gamma[c] + beta[c];
+        const float xh = bn_xhat(x[r * C + c], mean[c], invstd[c]);
+        const float z = __fadd_rn(__fmul_rn(xh, gamma[c]), beta[c]);
         const float g = gy[r * C + c];
         const float dz = z > 0.f ? g : a * g;
         acc[0] += dz;
@@ -283,8 +289,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float is = invstd[c + j], g = gamma[c + j];
-            const float xh = (xs[j] - mean[c + j]) * is;
-            const float z = xh * g + beta[c + j];
+            const float xh = bn_xhat(xs[j], mean[c + j], is);
+            const float z = __fadd_rn(__fmul_rn(xh, g), beta[c + j]);
             const float dz = z > 0.f ? gs[j] : a * gs[j];
             o[j] = train ? g * is * (dz - coef[c + j] - xh * coef[C + c + j]) : g * is * dz;
         }
@@ -705,8 +711,7 @@ __device__ __forceinline__ float prep_grad(float g, float p, float gscale, float
     if (clamp != 0.f) g = fminf(fmaxf(g, -clamp), clamp);           // adversarial.lua:121-123
     return g;
 }
-__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a, float step) {
-    const float ob1 = 1.f - a.beta1, ob2 = 1.f - a.beta2;
+__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a, float step, float ob1, float ob2) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
          i += (long long)gridDim.x * blockDim.x) {
         const float p = a.p[i];
@@ -723,10 +728,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a, float step)
 }
 int fg_launch_adam(fg_ctx* ctx, const AdamArgs& a) {
     if (a.n == 0) return FG_OK;
-    const double bc1 = 1.0 - pow((double)a.beta1, (double)a.t);
-    const double bc2 = 1.0 - pow((double)a.beta2, (double)a.t);
-    const float step = (float)((double)a.lr * sqrt(bc2) / bc1);
-    hipLaunchKernelGGL(adam_kernel, FG_GRID(a.n, 256), dim3(256), 0, ctx->stream, a, step);
+    const double bc1 = 1.0 - pow(a.beta1_d, (double)a.t);
+    const double bc2 = 1.0 - pow(a.beta2_d, (double)a.t);
+    const float step = (float)(a.lr_d * sqrt(bc2) / bc1);
+    hipLaunchKernelGGL(adam_kernel, FG_GRID(a.n, 256), dim3(256), 0, ctx->stream, a, step, (float)(1.0 - a.beta1_d),
+                       (float)(1.0 - a.beta2_d));
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
@@ -737,7 +743,7 @@ __global__ void sgd_kernel(float* p, const float* g, float* mom, long long n, fl
         float d = prep_grad(g[i], pv, gscale, l1mul, l2, clamp);
         if (wd != 0.f) d += wd * pv;
         if (momentum != 0.f) {
-            float mv = first ? d : mom[i] * momentum + (1.f - dampening) * d;
+            float mv = first ? d : mom[i] * momentum + dampening * d;   // `dampening` holds (1 - dampening)
             mom[i] = mv;
             d = nesterov ? d + momentum * mv : mv;
         }

@@ -44,6 +44,10 @@ int fg_ctx_set_stream(fg_ctx* ctx, void* hip_stream); /* NULL = default stream *
 const char* fg_last_error(const fg_ctx* ctx);
 const char* fg_version(void);
 int fg_stream_sync(fg_ctx* ctx);
+/* per-launch HIP-event timing of the contraction kernels on the context's stream (measurement only).
+ * fg_prof_report synchronises and writes "label calls total_ms algorithmic_flops executed_flops bytes" lines. */
+int fg_prof_enable(fg_ctx* ctx, int on);
+int fg_prof_report(fg_ctx* ctx, char* buf, size_t len, int reset);
 int fg_malloc(fg_ctx* ctx, size_t bytes, void** out);
 int fg_free(fg_ctx* ctx, void* p);
 int fg_h2d(fg_ctx* ctx, void* dst, const void* src, size_t bytes);
@@ -116,14 +120,16 @@ int fg_bce_forward_backward(fg_ctx* ctx, const float* prob, const float* target,
                             float* grad_dev, int* confusion_dev);
 
 /* ---- optimizers on the flat vectors (interruptable_optimizers.lua:7-167) with the penalty and clamp of
- *      adversarial.lua:103-123 / 218-228 fused in:  g' = clamp(gscale*g + l1_mul*sign(p) + l2*p, +-clamp) ---- */
+ *      adversarial.lua:103-123 / 218-228 fused in:  g' = clamp(gscale*g + l1_mul*sign(p) + l2*p, +-clamp).
+ *      Hyper-parameters are doubles (Lua numbers): 1-beta, the bias corrections and the step size are evaluated in
+ *      double on the host exactly like interruptable_optimizers.lua:78-88, then rounded to fp32 once. ---- */
 int fg_adam_fused(fg_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float gscale, float l1_mul,
-                  float l2, float clamp, float lr, float beta1, float beta2, float eps, int t, float* g_out);
+                  float l2, float clamp, double lr, double beta1, double beta2, double eps, int t, float* g_out);
 int fg_sgd_fused(fg_ctx* ctx, float* p, const float* g, float* mom_buf, long long n, float gscale, float l1_mul,
-                 float l2, float clamp, float lr, float momentum, float dampening, float weight_decay, int nesterov,
+                 float l2, float clamp, double lr, double momentum, double dampening, double weight_decay, int nesterov,
                  int first_step);
 int fg_adagrad_fused(fg_ctx* ctx, float* p, const float* g, float* variance, long long n, float gscale, float l1_mul,
-                     float l2, float clamp, float clr);
+                     float l2, float clamp, double clr);
 /* out2[0] = ||p||_1, out2[1] = ||p||_2^2 (torch.norm of adversarial.lua:105-106); scratch >= 1024 floats */
 int fg_norms(fg_ctx* ctx, const float* p, long long n, float* out2_dev, float* scratch);
 

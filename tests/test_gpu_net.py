@@ -42,6 +42,28 @@ def build(ctx, C, B, seed, init="default"):
     return st, Gd, Dd, rng
 
 
+def check_flat_grads(g, net, name):
+    """Flat gradient vector vs the oracle, reported per parameter tensor (all failures listed).
+    Tolerance: 1e-4 * max|g| + 1e-7 per tensor; a bias uses its module's weight-grad scale as well,
+    because the bias grad of a conv feeding a BatchNorm is pure rounding noise around an exact zero."""
+    offs, msgs = 0, []
+    for i, m in enumerate(net.modules):
+        wscale = 0.0
+        for (mm, pn, gn) in m.parameters():
+            ref = getattr(mm, gn).reshape(-1)
+            scale = np.abs(ref).max()
+            if pn == 'weight':
+                wscale = scale
+            got = g[offs:offs + ref.size]
+            tol = 1e-4 * max(scale, wscale if pn == 'bias' else 0.0) + 1e-7
+            err = np.abs(got.astype(np.float64) - ref)
+            if not (err <= tol).all():
+                msgs.append("%s module %d %s %s: %d/%d off, max err %.3g (tol %.3g, max|ref| %.3g)"
+                            % (name, i + 1, type(m).__name__, pn, (err > tol).sum(), ref.size, err.max(), tol, scale))
+            offs += ref.size
+    assert not msgs, "\n".join(msgs)
+
+
 def d_masks(rng, B):
     return [(rng.random((B, c)) < 0.8).astype(np.float32) for c in (64, 128, 256, 512)] + \
            [(rng.random((B, 512)) < 0.5).astype(np.float32) for _ in range(2)]
@@ -62,14 +84,7 @@ def test_G_forward_backward(ctx, C, B):
     close(nchw(dn.layer_output(10)), st.G.modules[10].output, atol=5e-5, what="G conv9+bn+prelu")
     close(nchw(y), img, atol=1e-5, what="G images")                    # bar: 1e-4 (north_star)
     dn.backward(nhwc(gy, ctx.device), param_grads=True, input_grad=False)
-    g = dn.grads.cpu().numpy()
-    offs = 0
-    for i, m in enumerate(st.G.modules):                               # per-parameter report for localisation
-        for (mm, pn, gn) in m.parameters():
-            ref = getattr(mm, gn).reshape(-1)
-            close(g[offs:offs + ref.size], ref, atol=1e-4 * np.abs(ref).max() + 1e-7,
-                  what="G grad module %d %s" % (i + 1, pn))
-            offs += ref.size
+    check_flat_grads(dn.grads.cpu().numpy(), st.G, "G")
     # BN running statistics (evaluate-mode state) follow the THNN update
     rm = dn.buffers.cpu().numpy()
     close(rm[:256], st.G.modules[5].running_mean, atol=1e-6, what="running_mean")
@@ -93,14 +108,7 @@ def test_D_forward_backward(ctx, C, B):
     close(y.cpu().numpy(), out, atol=1e-5, what="D probabilities")      # bar: 1e-4
     gxd = dn.backward(dev(gy, ctx.device), param_grads=True, input_grad=True)
     close(nchw(gxd), gx, atol=1e-4 * np.abs(gx).max() + 1e-8, what="D input grad")
-    g = dn.grads.cpu().numpy()
-    offs = 0
-    for i, m in enumerate(st.D.modules):
-        for (mm, pn, gn) in m.parameters():
-            ref = getattr(mm, gn).reshape(-1)
-            close(g[offs:offs + ref.size], ref, atol=1e-4 * np.abs(ref).max() + 1e-7,
-                  what="D grad module %d %s" % (i + 1, pn))
-            offs += ref.size
+    check_flat_grads(dn.grads.cpu().numpy(), st.D, "D")
 
 
 def test_evaluate_mode_forward(ctx):
