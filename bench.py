@@ -43,7 +43,7 @@ def parse_prof(text):
     return rows
 
 
-def cpu_baseline(sample_batch=32):
+def cpu_baseline(sample_batch=None):
     """The oracle (numpy restatement of the Torch7 nn CPU path: im2col + sgemm per layer) timed on this host's
     cores: ONE iteration at batch `sample_batch` of the same nets / inputs / optimizer."""
     import numpy as np
@@ -54,7 +54,7 @@ def cpu_baseline(sample_batch=32):
     O.initialize_weights(G, rng=rng)
     O.initialize_weights(D, rng=rng)
     st = O.GanState(G, D)
-    B = sample_batch
+    B = sample_batch or (128 if (os.cpu_count() or 1) >= 64 else 32)   # ~10-30 s of CPU work
     real = rng.uniform(0, 1, (B // 2, 3, 32, 32)).astype(np.float32)
     t0 = time.time()
     O.step_D(st, real, rng.uniform(-1, 1, (B // 2, 100)).astype(np.float32))

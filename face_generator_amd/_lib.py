@@ -84,6 +84,10 @@ def load_library():
     if not os.path.exists(path):
         raise FgError("libfacegen_hip.so not found at %s -- run `python -m face_generator_amd.build` "
                       "(there is no CPU fallback)" % path)
+    # Share ONE HIP runtime with torch: torch ships its own libamdhip64.so.7 / libhsa-runtime64 and must be loaded
+    # first so that libfacegen_hip.so binds to the same instance (device pointers, streams and the KFD handle are
+    # per-runtime; a second runtime in the process sees no device).  A Lua host has no torch and simply uses /opt/rocm.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(path)
     for name, (ret, argtypes, _) in parse_header().items():
         try:

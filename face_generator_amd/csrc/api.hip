@@ -188,7 +188,7 @@ static inline long long a64(long long v) { return (v + 63) / 64 * 64; }
 size_t fg_conv2d_workspace_bytes(int batch, int h, int w, int cin, int cout, int k, int up) {
     if (thin_in(cin, cout) || thin_out(cin, cout)) {
         const long long na = (long long)k * k * (cin <= 4 ? cin : cout), cw = cin <= 4 ? cout : cin;
-        return (size_t)(a64((long long)cin * cout * k * k) + 257 * na * cw + 258LL * (cout > 64 ? cout : 64) + 256) * 4;
+        return (size_t)(a64((long long)cin * cout * k * k) + (FG_THIN_WGRAD_BLOCKS + 1) * na * cw + 258LL * (cout > 64 ? cout : 64) + 256) * 4;
     }
     ConvGeom g = mk_geom(batch, h, w, cin, cout, k, (k - 1) / 2, up);
     long long pf = fg_geom_pack_floats(g, 0), pb = fg_geom_pack_floats(g, 1);
@@ -259,7 +259,7 @@ int fg_conv2d_backward_weight(fg_ctx* ctx, const float* x, const float* gy, floa
     if (thin_in(cin, cout) || thin_out(cin, cout)) {
         const bool tin = thin_in(cin, cout);
         const int cs = tin ? cin : cout, cw = tin ? cout : cin;
-        float* gwt = ws + (long long)256 * k * k * cs * cw;
+        float* gwt = ws + (long long)FG_THIN_WGRAD_BLOCKS * k * k * cs * cw;
         rc = tin ? fg_launch_thin_wgrad(ctx, x, gy, gwt, batch, h, w, cs, cw, k, +1, ws)
                  : fg_launch_thin_wgrad(ctx, gy, x, gwt, batch, h, w, cs, cw, k, -1, ws);
         if (rc) return rc;

@@ -50,7 +50,7 @@ int fg_conv_pack(fg_ctx* ctx, const ConvGeom& g, const float* W, float* wp_fwd, 
 }
 
 // ---- tile / split heuristics: fill >= 2 blocks per CU (256 CUs) where the problem allows ----
-static void choose_igemm(long long M, int Npad, int G, int P, int* tile, int* splits) {
+static void choose_igemm(long long M, int Npad, int ksteps, int P, int* tile, int* splits) {
     const long long target = 512;
     long long b0 = (Npad % 128 == 0) ? (long long)fg_cdiv(M, 128) * (Npad / 128) * P : 0;
     long long b1 = (long long)fg_cdiv(M, 128) * (Npad / 64) * P;
@@ -59,14 +59,13 @@ static void choose_igemm(long long M, int Npad, int G, int P, int* tile, int* sp
     if (b0 >= target) { *tile = 0; return; }
     if (b1 >= target) { *tile = 1; return; }
     *tile = 2;
-    if (b2 < 384 && G > 1) {
+    if (b2 < 384 && ksteps >= 4) {      // split-K over K-steps, >= 2 steps per split
         int s = fg_cdiv(target, b2 > 0 ? b2 : 1);
-        if (s > G) s = G;
-        if (s > 12) s = 12;
-        // make every split non-empty
-        int gper = (G + s - 1) / s;
-        s = (G + gper - 1) / gper;
-        *splits = s;
+        if (s > ksteps / 2) s = ksteps / 2;
+        if (s > 16) s = 16;
+        int per = (ksteps + s - 1) / s;
+        s = (ksteps + per - 1) / per;   // every split non-empty
+        *splits = s < 1 ? 1 : s;
     }
 }
 static void choose_wgrad(long long M, int Cout, int Cin, int G, int P, int* tile, int* S, int* mper, int* Npad, int* Cpad) {
@@ -91,10 +90,10 @@ long long fg_conv_scratch_floats(const ConvGeom& g) {
     long long need = 0;
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
     int tile, splits;
-    choose_igemm(M, rf, wm.G, wm.P, &tile, &splits);
+    choose_igemm(M, rf, wm.G * (cf / 32), wm.P, &tile, &splits);
     const long long outM = g.fold ? M * 4 : M;
     if (splits > 1) need = (long long)splits * outM * g.Cout;
-    choose_igemm(M, rb, wm.G * wm.P, 1, &tile, &splits);
+    choose_igemm(M, rb, wm.G * wm.P * (cb / 32), 1, &tile, &splits);
     if (splits > 1) { long long n2 = (long long)splits * M * g.Cin; if (n2 > need) need = n2; }
     int wt, S, mper, Np, Cp;
     choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
@@ -152,7 +151,7 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
         }
     }
     int tile, splits;
-    choose_igemm(a.M, rf, wm.G, wm.P, &tile, &splits);
+    choose_igemm(a.M, rf, wm.G * (cf / 32), wm.P, &tile, &splits);
     const long long out_count = (long long)a.M * (g.fold ? 4 : 1) * g.Cout;
     a.splits = splits;
     if (splits > 1) {
@@ -194,7 +193,7 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
         }
     }
     int tile, splits;
-    choose_igemm(a.M, rb, a.G, 1, &tile, &splits);
+    choose_igemm(a.M, rb, a.G * (cb / 32), 1, &tile, &splits);
     const long long out_count = (long long)a.M * g.Cin;
     a.splits = splits;
     if (splits > 1) {

@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include "../../include/facegen_hip.h"
 
+#define FG_THIN_WGRAD_BLOCKS 512   // max partial slabs of the thin weight-gradient kernel
 #define FG_MAX_GROUPS 64   // (parity,tap) groups per launch table (7x7 plain = 49, folded dgrad = 36)
 
 #include <vector>

@@ -44,9 +44,6 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     const int ntn = a.Npad / BN;
     const int tile_m = blockIdx.x / ntn, tile_n = blockIdx.x - tile_m * ntn;
     const int p = blockIdx.z, split = blockIdx.y;
-    const int gper = (a.G + a.splits - 1) / a.splits;
-    const int g0 = split * gper;
-    const int g1 = min(a.G, g0 + gper);
 
     if (tid < BM) {
         int m = tile_m * BM + tid, off = -1;
@@ -72,13 +69,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         rx[i] = x * a.asx;
     }
     const int kc = a.Kpad >> 5;
-    const int KT = (g1 > g0) ? (g1 - g0) * kc : 0;
+    const int kt_all = a.G * kc;                       // K-steps of the whole contraction
+    const int kt_per = (kt_all + a.splits - 1) / a.splits;
+    const int kt0 = split * kt_per;                    // this split's K-step range
+    const int KT = max(0, min(kt_all, kt0 + kt_per) - kt0);
 
     float4 ra[RA], rb[RB];
-    auto load_tile = [&](int kt) {
-        const int gi = kt / kc;
-        const int g = g0 + gi;
-        const int col = (kt - gi * kc) * 32 + lk;
+    auto load_tile = [&](int ktl) {
+        const int kt = kt0 + ktl;
+        const int g = kt / kc;
+        const int col = (kt - g * kc) * 32 + lk;
         const int oy = a.aoy[p][g], ox = a.aox[p][g];
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -428,37 +428,34 @@ int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const flo
 
 __global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
                                     float beta, float* __restrict__ gradW) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;  // packed in-channel
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;  // packed in-channel (coalesced partial reads)
     const int po = blockIdx.y;                              // packed out-channel
+    const int wi = blockIdx.z;                              // tap dy*k+dx
     if (pi >= wm.I || po >= wm.O) return;
     int o = po, i = pi;
     if (wm.o_hw > 1) { int hw = po / wm.o_c, c = po - hw * wm.o_c; o = c * wm.o_hw + hw; }
     if (wm.i_hw > 1) { int hw = pi / wm.i_c, c = pi - hw * wm.i_c; i = c * wm.i_hw + hw; }
     const size_t tile = (size_t)Npad * Cpad;
     const size_t e = (size_t)po * Cpad + pi;
-    float* gw = gradW + ((size_t)o * wm.I + i) * wm.k * wm.k;
-    for (int dy = 0; dy < wm.k; ++dy)
-        for (int dx = 0; dx < wm.k; ++dx) {
-            float sum = 0.f;
-            if (wm.kind == 0) {
-                const int g = dy * wm.k + dx;
-                for (int s = 0; s < S; ++s) sum += Part[((size_t)g * S + s) * tile + e];
-            } else {
-                for (int p = 0; p < 4; ++p) {
-                    const int ty = dev_fold_r(p >> 1, dy, wm.pad) - wm.rmin;
-                    const int tx = dev_fold_r(p & 1, dx, wm.pad) - wm.rmin;
-                    const int pg = p * wm.G + ty * wm.T + tx;
-                    for (int s = 0; s < S; ++s) sum += Part[((size_t)pg * S + s) * tile + e];
-                }
-            }
-            const int wi = dy * wm.k + dx;
-            gw[wi] = (beta == 0.f) ? sum : beta * gw[wi] + sum;
+    const int dy = wi / wm.k, dx = wi - dy * wm.k;
+    float sum = 0.f;
+    if (wm.kind == 0) {
+        for (int s = 0; s < S; ++s) sum += Part[((size_t)wi * S + s) * tile + e];
+    } else {
+        for (int p = 0; p < 4; ++p) {
+            const int ty = dev_fold_r(p >> 1, dy, wm.pad) - wm.rmin;
+            const int tx = dev_fold_r(p & 1, dx, wm.pad) - wm.rmin;
+            const int pg = p * wm.G + ty * wm.T + tx;
+            for (int s = 0; s < S; ++s) sum += Part[((size_t)pg * S + s) * tile + e];
         }
+    }
+    float* gw = gradW + ((size_t)o * wm.I + i) * wm.k * wm.k + wi;
+    *gw = (beta == 0.f) ? sum : beta * (*gw) + sum;
 }
 
 int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,
                            float* gradW) {
-    dim3 grid(fg_cdiv(wm.I, 128), wm.O);
+    dim3 grid(fg_cdiv(wm.I, 128), wm.O, wm.k * wm.k);
     hipLaunchKernelGGL(wgrad_finish_kernel, grid, dim3(128), 0, ctx->stream, wm, Part, S, Npad, Cpad, beta, gradW);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;

@@ -77,7 +77,7 @@ static long long stage_scratch(const Stage& s, int B) {
         case ST_THIN_IN: case ST_THIN_OUT: {
             const int cw = s.kind == ST_THIN_IN ? s.oc : s.ic, cs = s.kind == ST_THIN_IN ? s.ic : s.oc;
             const long long na = (long long)s.geom.k * s.geom.k * cs;
-            need = 256 * na * cw + na * cw + (long long)CR_ROWBLOCKS_MAX * (s.oc > 64 ? s.oc : 64) + 64;
+            need = (FG_THIN_WGRAD_BLOCKS + 1) * na * cw + (long long)CR_ROWBLOCKS_MAX * (s.oc > 64 ? s.oc : 64) + 64;
             break;
         }
         default: break;
@@ -472,7 +472,7 @@ int fg_net_backward(fg_net* n, int B, const float* x, const float* gy, void* wsv
             case ST_THIN_IN: {
                 const int k = s.geom.k;
                 if (want_p) {
-                    float* gw = scratch + (long long)256 * k * k * s.ic * s.oc;
+                    float* gw = scratch + (long long)FG_THIN_WGRAD_BLOCKS * k * k * s.ic * s.oc;
                     rc = fg_launch_thin_wgrad(ctx, xin, gcur, gw, B, s.ih, s.iw, s.ic, s.oc, k, +1, scratch);
                     if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 0, 0.f);
                     if (!rc) rc = fg_launch_colsum(ctx, gcur, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
@@ -489,7 +489,7 @@ int fg_net_backward(fg_net* n, int B, const float* x, const float* gy, void* wsv
                     gpre = tmp;
                 }
                 if (!rc && want_p) {
-                    float* gw = scratch + (long long)256 * k * k * s.oc * s.ic;
+                    float* gw = scratch + (long long)FG_THIN_WGRAD_BLOCKS * k * k * s.oc * s.ic;
                     rc = fg_launch_thin_wgrad(ctx, gpre, xin, gw, B, s.ih, s.iw, s.oc, s.ic, k, -1, scratch);
                     if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 1, 0.f);
                     if (!rc) rc = fg_launch_colsum(ctx, gpre, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);

@@ -125,18 +125,34 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
                                                              float* __restrict__ part) {
     colreduce_body<1>(M, C, part, [&](long long r, int c, float* acc) { acc[0] += x[r * C + c]; });
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nrb, int C, float beta, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// final stage of every column reduction: block = 64 columns x 16 partial lanes, fp64 accumulate
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nrb, int C, float beta,
+                                                            float* __restrict__ out) {
+    __shared__ double sh[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     double s = 0.0;
-    for (int b = 0; b < nrb; ++b) s += (double)part[(size_t)b * C + c];
-    out[c] = (beta == 0.f) ? (float)s : beta * out[c] + (float)s;
+    if (c < C)
+        for (int b = ty; b < nrb; b += 16) s += (double)part[(size_t)b * C + c];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sh[i][tx];
+        out[c] = (beta == 0.f) ? (float)t : beta * out[c] + (float)t;
+    }
+}
+int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(C, 64)), dim3(1024), 0, ctx->stream, part, nrb, C, beta, out);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
 }
 int fg_launch_colsum(fg_ctx* ctx, const float* x, long long M, int N, float beta, float* out, float* scratch) {
     const int nrb = cr_rowblocks(M);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nrb, fg_cdiv(N, 64)), dim3(256), 0, ctx->stream, x, M, N, scratch);
     FG_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(N, 256)), dim3(256), 0, ctx->stream, scratch, nrb, N, beta, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(N, 64)), dim3(1024), 0, ctx->stream, scratch, nrb, N, beta, out);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
@@ -157,16 +173,25 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
         acc[1] = fmaf(d, d, acc[1]);
     });
 }
-__global__ void bn_stats_final_kernel(const float* __restrict__ part, const float* __restrict__ x, int nrb, long long M,
-                                      int C, float eps, float momentum, float* __restrict__ mean,
-                                      float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ part, const float* __restrict__ x,
+                                                              int nrb, long long M, int C, float eps, float momentum,
+                                                              float* __restrict__ mean, float* __restrict__ invstd,
+                                                              float* __restrict__ rmean, float* __restrict__ rvar) {
+    __shared__ double sh[2][16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nrb; ++b) {
-        s1 += (double)part[(size_t)b * C + c];
-        s2 += (double)part[((size_t)nrb + b) * C + c];
-    }
+    if (c < C)
+        for (int b = ty; b < nrb; b += 16) {
+            s1 += (double)part[(size_t)b * C + c];
+            s2 += (double)part[((size_t)nrb + b) * C + c];
+        }
+    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s1 += sh[0][i][tx]; s2 += sh[1][i][tx]; }
     const double n = (double)M;
     const double mu = (double)x[c] + s1 / n;
     double var = (s2 - s1 * s1 / n) / n;
@@ -212,7 +237,7 @@ int fg_launch_bn_forward(fg_ctx* ctx, const BnArgs& a) {
         hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nrb, fg_cdiv(a.C, 64)), dim3(256), 0, ctx->stream, a.x, a.M,
                            a.C, a.scratch);
         FG_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(fg_cdiv(a.C, 256)), dim3(256), 0, ctx->stream, a.scratch, a.x,
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(fg_cdiv(a.C, 64)), dim3(1024), 0, ctx->stream, a.scratch, a.x,
                            nrb, a.M, a.C, a.eps, a.momentum, a.mean, a.invstd, a.running_mean, a.running_var);
         FG_CHECK_LAUNCH(ctx);
     } else {
@@ -246,30 +271,40 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     });
 }
 // scratch layout: part[3][nrb][C], then coef[2][C]
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nrb, long long M, int C,
-                                    float* __restrict__ coef, float* __restrict__ ggamma, float* __restrict__ gbeta,
-                                    float acc) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ part, int nrb, long long M, int C,
+                                                            float* __restrict__ coef, float* __restrict__ ggamma,
+                                                            float* __restrict__ gbeta, float acc) {
+    __shared__ double sh[2][16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nrb; ++b) {
-        s1 += (double)part[(size_t)b * C + c];
-        s2 += (double)part[((size_t)nrb + b) * C + c];
-    }
+    if (c < C)
+        for (int b = ty; b < nrb; b += 16) {
+            s1 += (double)part[(size_t)b * C + c];
+            s2 += (double)part[((size_t)nrb + b) * C + c];
+        }
+    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s1 += sh[0][i][tx]; s2 += sh[1][i][tx]; }
     coef[c] = (float)(s1 / (double)M);
     coef[C + c] = (float)(s2 / (double)M);
     if (ggamma) ggamma[c] = (acc == 0.f ? 0.f : acc * ggamma[c]) + (float)s2;
     if (gbeta) gbeta[c] = (acc == 0.f ? 0.f : acc * gbeta[c]) + (float)s1;
 }
-__global__ void scalar_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out, float acc) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void scalar_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out,
+                                                            float acc) {
+    __shared__ double sh[16];
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)part[i];
     s = wave_sum_d(s);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t = sh[0] + sh[1] + sh[2] + sh[3];
+        double t = 0.0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
         out[0] = (acc == 0.f ? 0.f : acc * out[0]) + (float)t;
     }
 }
@@ -306,11 +341,11 @@ int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb, ncb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
                        a.beta, a.slope, a.mean, a.invstd, part);
     FG_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fg_cdiv(a.C, 256)), dim3(256), 0, ctx->stream, part, nrb, a.M, a.C,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fg_cdiv(a.C, 64)), dim3(1024), 0, ctx->stream, part, nrb, a.M, a.C,
                        coef, a.ggamma, a.gbeta, a.gbeta_acc);
     FG_CHECK_LAUNCH(ctx);
     if (a.slope && a.gslope) {
-        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, ctx->stream, part + (size_t)2 * nrb * a.C,
+        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, part + (size_t)2 * nrb * a.C,
                            nrb * a.C, a.gslope, a.gbeta_acc);
         FG_CHECK_LAUNCH(ctx);
     }
@@ -367,7 +402,7 @@ int fg_launch_prelu_backward(fg_ctx* ctx, const float* x, const float* gy, const
     hipLaunchKernelGGL(prelu_bwd_kernel, grid, dim3(256), 0, ctx->stream, x, gy, slope, mask, mscale, gx, scratch, n);
     FG_CHECK_LAUNCH(ctx);
     if (gslope) {
-        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, ctx->stream, scratch, (int)grid.x, gslope, acc);
+        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, scratch, (int)grid.x, gslope, acc);
         FG_CHECK_LAUNCH(ctx);
     }
     return FG_OK;
@@ -464,7 +499,7 @@ int fg_launch_actpool_backward(fg_ctx* ctx, const float* x, const float* gy, con
                        H, W, C);
     FG_CHECK_LAUNCH(ctx);
     if (slope && gslope) {
-        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, ctx->stream, scratch, (int)grid.x, gslope, acc);
+        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, scratch, (int)grid.x, gslope, acc);
         FG_CHECK_LAUNCH(ctx);
     }
     return FG_OK;

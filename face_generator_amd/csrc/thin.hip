@@ -233,42 +233,54 @@ int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const
 // ---------------------------------------------------------------------------------
 // thin wgrad: gw[tap][s][c] = sum_pix thin[pix + sgn*off(tap)][s] * wide[pix][c]
 // ---------------------------------------------------------------------------------
-#define TW_BLOCKS 256
+#define TW_BLOCKS FG_THIN_WGRAD_BLOCKS
+#define TW_ROWS 4   // image rows per staged strip
+// Block = cblk wide channels x PL pixel lanes.  A strip of TW_ROWS image rows of the THIN operand (+ halo, zero
+// padded) is staged in LDS, so the 27 thin reads per pixel are conflict-free LDS broadcasts without bounds checks;
+// the wide operand streams from HBM, coalesced over channels.  Strips are distributed grid-stride; every block
+// writes one partial [taps*CS][Cw] slab, reduced by colsum_final_kernel (fp64).
 template <int K, int CS>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict__ thin, const float* __restrict__ wide,
                                                          float* __restrict__ part, int B, int H, int W, int Cw, int sgn,
                                                          int cblk) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int NA = K * K * CS;
-    extern __shared__ float sh[];  // [PL][NA][cblk] when PL > 1
+    extern __shared__ float sh[];
+    const int WP = W + 2 * PAD;
+    float* tile = sh;                                  // [(TW_ROWS + 2 PAD)][WP][CS]
+    float* red = sh + (TW_ROWS + 2 * PAD) * WP * CS;   // [PL][NA][cblk] (PL > 1 only)
     const int pl = threadIdx.x / cblk, tc = threadIdx.x - pl * cblk;
     const int PL = 256 / cblk;
     const int c = blockIdx.y * cblk + tc;
-    const int npix = B * H * W;
-    const int per = (npix + gridDim.x - 1) / gridDim.x;
-    const int p0 = blockIdx.x * per;
-    const int p1 = min(npix, p0 + per);
+    const int strips_per_img = (H + TW_ROWS - 1) / TW_ROWS;
+    const int nstrips = B * strips_per_img;
     float acc[NA];
 #pragma unroll
     for (int t = 0; t < NA; ++t) acc[t] = 0.f;
-    for (int pix = p0 + pl; pix < p1; pix += PL) {
-        const int x = pix % W;
-        const int t = pix / W;
-        const int y = t % H;
-        const int b = t / H;
-        const float wv = wide[(size_t)pix * Cw + c];
+    for (int st = blockIdx.x; st < nstrips; st += gridDim.x) {
+        const int b = st / strips_per_img, y0 = (st - b * strips_per_img) * TW_ROWS;
+        __syncthreads();
+        for (int i = threadIdx.x; i < (TW_ROWS + 2 * PAD) * WP * CS; i += 256) {
+            const int s = i % CS;
+            const int t = i / CS;
+            const int xx = t % WP - PAD, yy = y0 + t / WP - PAD;
+            float v = 0.f;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = thin[((size_t)(b * H + yy) * W + xx) * CS + s];
+            tile[i] = v;
+        }
+        __syncthreads();
+        const int rows = min(TW_ROWS, H - y0);
+        for (int j = pl; j < rows * W; j += PL) {
+            const int ry = j / W, rx = j - ry * W;
+            const float wv = wide[((size_t)(b * H + y0 + ry) * W + rx) * Cw + c];
 #pragma unroll
-        for (int dy = 0; dy < K; ++dy) {
-            const int yy = y + sgn * (dy - PAD);
-            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int dy = 0; dy < K; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) {
-                const int xx = x + sgn * (dx - PAD);
-                if ((unsigned)xx >= (unsigned)W) continue;
-                const float* tp = thin + ((size_t)(b * H + yy) * W + xx) * CS;
+                for (int dx = 0; dx < K; ++dx) {
+                    const float* tp = tile + ((ry + PAD + sgn * (dy - PAD)) * WP + rx + PAD + sgn * (dx - PAD)) * CS;
 #pragma unroll
-                for (int s = 0; s < CS; ++s) acc[(dy * K + dx) * CS + s] = fmaf(tp[s], wv, acc[(dy * K + dx) * CS + s]);
-            }
+                    for (int s = 0; s < CS; ++s) acc[(dy * K + dx) * CS + s] = fmaf(tp[s], wv, acc[(dy * K + dx) * CS + s]);
+                }
         }
     }
     float* dst = part + (size_t)blockIdx.x * NA * Cw;
@@ -276,49 +288,42 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 #pragma unroll
         for (int t = 0; t < NA; ++t) dst[(size_t)t * Cw + c] = acc[t];
     } else {
+        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < NA; ++t) sh[(pl * NA + t) * cblk + tc] = acc[t];
+        for (int t = 0; t < NA; ++t) red[(pl * NA + t) * cblk + tc] = acc[t];
         __syncthreads();
         if (pl == 0) {
 #pragma unroll
             for (int t = 0; t < NA; ++t) {
                 float s = 0.f;
-                for (int q = 0; q < PL; ++q) s += sh[(q * NA + t) * cblk + tc];
+                for (int q = 0; q < PL; ++q) s += red[(q * NA + t) * cblk + tc];
                 dst[(size_t)t * Cw + c] = s;
             }
         }
     }
 }
-__global__ void thin_wgrad_final_kernel(const float* __restrict__ part, int nb, int total, float* __restrict__ gw) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += (double)part[(size_t)b * total + i];
-    gw[i] = (float)s;
-}
+
+int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);
 
 int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
                          int Cw, int k, int shift_thin, float* scratch) {
     if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_wgrad: Cw %% 64");
     const int cblk = Cw >= 256 ? 256 : Cw;
     if (Cw % cblk || 256 % cblk) return fg_set_err(ctx, FG_ERR_INVALID, "thin_wgrad: Cw=%d unsupported", Cw);
-    const int npix = B * H * W;
-    int nb = fg_cdiv(npix, 256);
-    if (nb > TW_BLOCKS) nb = TW_BLOCKS;
+    const int nstrips = B * ((H + TW_ROWS - 1) / TW_ROWS);
+    int nb = nstrips < TW_BLOCKS ? nstrips : TW_BLOCKS;
     if (nb < 1) nb = 1;
     const int PL = 256 / cblk;
     const int NA = k * k * Cs;
+    const int pad = (k - 1) / 2;
     dim3 grid(nb, Cw / cblk);
-    const size_t lds = PL > 1 ? (size_t)PL * NA * cblk * sizeof(float) : 0;
+    const size_t lds = ((size_t)(TW_ROWS + 2 * pad) * (W + 2 * pad) * Cs + (PL > 1 ? (size_t)PL * NA * cblk : 0)) * sizeof(float);
 #define TWG(KK, CC)                                                                                                  \
     if (k == KK && Cs == CC) {                                                                                       \
         hipLaunchKernelGGL((thin_wgrad_kernel<KK, CC>), grid, dim3(256), lds, ctx->stream, thin, wide, scratch, B, H, W, \
                            Cw, shift_thin, cblk);                                                                    \
         FG_CHECK_LAUNCH(ctx);                                                                                        \
-        hipLaunchKernelGGL(thin_wgrad_final_kernel, dim3(fg_cdiv(NA * Cw, 256)), dim3(256), 0, ctx->stream, scratch, nb, \
-                           NA * Cw, gw_tsc);                                                                         \
-        FG_CHECK_LAUNCH(ctx);                                                                                        \
-        return FG_OK;                                                                                                \
+        return fg_launch_colsum_final(ctx, scratch, nb, NA * Cw, 0.f, gw_tsc);                                       \
     }
     TWG(3, 1) TWG(3, 3) TWG(3, 4)
 #undef TWG

@@ -1,0 +1,37 @@
+"""Summarise a rocprofv3 rocpd SQLite database (kernel trace) per kernel name: calls, total/avg ms, % of GPU time.
+usage: python scripts/rocpd_stats.py <results.db> [iters]   -> markdown table on stdout"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*$", "", name)
+    name = name.replace("void ", "")
+    return name[:90]
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    iters = float(sys.argv[2]) if len(sys.argv) > 2 else None
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
+    rows = list(cur.execute("select %s, start, end from kernels" % namecol))
+    agg = {}
+    for name, s, e in rows:
+        a = agg.setdefault(short(name), [0, 0.0])
+        a[0] += 1
+        a[1] += (e - s) / 1e6
+    total = sum(v[1] for v in agg.values())
+    span = (max(r[2] for r in rows) - min(r[1] for r in rows)) / 1e6
+    print("| kernel | calls | total ms | avg us | % of kernel time |" + (" ms/iter |" if iters else ""))
+    print("|---|---|---|---|---|" + ("---|" if iters else ""))
+    for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("| %s | %d | %.3f | %.1f | %.1f |" % (k, n, ms, 1000 * ms / n, 100 * ms / total)
+              + (" %.3f |" % (ms / iters) if iters else ""))
+    print("\ntotal kernel time %.3f ms over %d dispatches; first-to-last span %.3f ms" % (total, len(rows), span))
+
+
+if __name__ == "__main__":
+    main()
