@@ -55,7 +55,8 @@ class Trainer:
 
     def _allreduce(self, grads):
         if self.world > 1:
-            self.dist.all_reduce(grads, op=self.dist.ReduceOp.SUM)
+            from .distributed import allreduce_sum_
+            allreduce_sum_(grads)
 
     def _update(self, which, params, grads, f):
         o = self.opt

@@ -1,0 +1,109 @@
+"""CPU-only: the C-ABI library loads, exports every symbol include/facegen_hip.h declares, fails loudly without a
+GPU; the host-side mirror (models / nn / nn_utils) reproduces the reference's structure."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch7_nn as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from face_generator_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load_library()
+
+
+def test_header_symbols_all_exported(lib):
+    from face_generator_amd import _lib
+    decls = _lib.parse_header()
+    names = set(re.findall(r"\b(fg_[a-z0-9_]+)\s*\(", open(_lib.HEADER).read()))
+    names -= {"fg_layer_spec", "fg_layer_type"}
+    assert names == set(decls), names ^ set(decls)       # the ctypes binding covers the whole header
+    assert len(decls) >= 60
+    for n in decls:
+        assert hasattr(lib, n), n
+    assert lib.fg_version().startswith(b"facegen_hip")
+
+
+def test_no_gpu_fails_loudly_not_silently(lib):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = ctypes.c_void_p()
+    rc = lib.fg_ctx_create(0, ctypes.byref(h))
+    assert rc == -2 and b"no HIP device" in lib.fg_last_error(None)
+    from face_generator_amd import models, nn_utils, FgError
+    from face_generator_amd.state import S
+    G = models.create_G((3, 32, 32), 100)
+    with pytest.raises(FgError):
+        G.forward(torch.zeros(2, 100))                     # no CPU fallback anywhere in the product path
+    with pytest.raises(FgError):
+        nn_utils.activateCuda(G)
+    with pytest.raises(FgError):
+        G.getParameters()
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "face_generator_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("# oracle", ""), os.path.join(dp, f)
+
+
+def test_models_mirror_reference_structure_and_parameter_order():
+    from face_generator_amd import models, nn_utils
+    for C in (3, 1):
+        G = models.create_G((C, 32, 32), 100)
+        D = models.create_D((C, 32, 32))
+        oG = O.create_G32((C, 32, 32), 100)
+        oD = O.create_D32b((C, 32, 32))
+        for net, onet in ((G, oG), (D, oD)):
+            assert [type(m).__name__ for m in net.modules] == [type(m).__name__ for m in onet.modules]
+            sizes = [tuple(getattr(m, n).shape) for m, n in net.parameter_list()]
+            osizes = [tuple(getattr(m, p).shape) for (m, p, g) in onet.parameters()]
+            assert sizes == osizes                        # getParameters() order: module order, weight then bias
+    assert sum(getattr(m, n).numel() for m, n in G.parameter_list()) == 2468100
+    G3 = models.create_G((3, 32, 32), 100)
+    assert sum(getattr(m, n).numel() for m, n in G3.parameter_list()) == 2470406
+    assert nn_utils.getNumberOfParameters(D) == sum(
+        m.weight.numel() for m in D.modules if getattr(m, "weight", None) is not None)  # biases excluded (nn_utils.lua:281)
+    with pytest.raises(NotImplementedError):
+        models.create_G((3, 16, 16), 100)
+
+
+def test_initialize_weights_semantics():
+    """nn_utils.lua:17-29: every top-level .weight ~ N(0, 0.005^2) (incl. BN gamma and PReLU slope), .bias ~ N(0, 0.001^2)."""
+    from face_generator_amd import models, nn_utils
+    G = models.create_G((3, 32, 32), 100)
+    nn_utils.initializeWeights(G, gen=torch.Generator().manual_seed(3))
+    lin = G.modules[0]
+    assert abs(lin.weight.std().item() - 0.005) < 2e-4 and abs(lin.bias.std().item() - 0.001) < 1e-4
+    bn = G.modules[5]
+    assert abs(bn.weight.std().item() - 0.005) < 1.5e-3 and abs(bn.weight.mean().item()) < 2e-3   # gamma no longer U(0,1)
+    assert abs(G.modules[2].weight.item()) < 0.05                                                 # PReLU slope re-drawn
+    assert isinstance(repr(G), str) and "nn.SpatialConvolution(128 -> 256, 5x5" in repr(G)       # print(MODEL_G), train.lua:155
+
+
+def test_layer_specs_cover_reference_constructors():
+    from face_generator_amd import models
+    D = models.create_D((3, 32, 32))
+    specs = D.layer_specs()
+    assert specs[0] == ("CONV", 3, 64, 3, 1) and specs[2][0] == "SPATIAL_DROPOUT" and abs(specs[2][5] - 0.2) < 1e-9
+    assert specs[16] == ("VIEW", 2048, 0, 0) and specs[17] == ("LINEAR", 2048, 512)
+    assert specs[19][0] == "DROPOUT" and specs[19][5] == 0.5
+    G = models.create_G((3, 32, 32), 100)
+    assert G.layer_specs()[1] == ("VIEW", 128, 8, 8) and G.layer_specs()[5][0] == "BATCHNORM"
+
+
+def test_bench_flop_accounting_matches_survey():
+    import bench
+    assert abs(bench.alg_flops_per_iter(128) / 1e9 - 1019.19) < 0.01      # cfg2
+    assert abs(bench.alg_flops_per_iter(128) / 128 / 1e9 - 7.962) < 0.001

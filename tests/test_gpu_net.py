@@ -77,7 +77,11 @@ def prelu_margin(net):
 
 def draw_kink_safe(rng, draw, forward, nets, tries=80, margin=1e-7):
     """Re-draw the random input until no PReLU input of the oracle sits within `margin` (relative) of zero."""
+    bns = [m for n in nets for m in n.modules if isinstance(m, O.SpatialBatchNormalization)]
+    saved = [(m.running_mean.copy(), m.running_var.copy()) for m in bns]
     for _ in range(tries):
+        for m, (rm, rv) in zip(bns, saved):          # every try starts from the same running statistics
+            m.running_mean, m.running_var = rm.copy(), rv.copy()
         x = draw()
         y = forward(x)
         if min(prelu_margin(n) for n in nets) > margin:
