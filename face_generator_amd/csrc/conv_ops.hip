@@ -117,6 +117,7 @@ static const char* tag_of(const ConvGeom& g, int pass) {
     return names[kind][pass];
 }
 
+static inline int pack_off(int oy, int ox) { return (oy & 0xffff) | (ox << 16); }
 static void fill_mspace(IgemmArgs& a, int B, int H, int W) {
     a.Nb = B; a.Hm = H; a.Wm = W; a.M = B * H * W;
     a.lgH = ilog2_exact(H); a.lgW = ilog2_exact(W);
@@ -139,17 +140,16 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
         for (int p = 0; p < 4; ++p) {
             a.ooy[p] = (signed char)(p >> 1); a.oox[p] = (signed char)(p & 1);
             for (int t = 0; t < wm.G; ++t) {
-                a.aoy[p][t] = (signed char)(t / wm.T + wm.rmin);
-                a.aox[p][t] = (signed char)(t % wm.T + wm.rmin);
+                a.goff[p][t] = pack_off(t / wm.T + wm.rmin, t % wm.T + wm.rmin);
             }
         }
     } else {
         a.Ho = g.H; a.Wo = g.W; a.osy = a.osx = 1;
         for (int t = 0; t < wm.G; ++t) {
-            a.aoy[0][t] = (signed char)(t / g.k - g.pad);
-            a.aox[0][t] = (signed char)(t % g.k - g.pad);
+            a.goff[0][t] = pack_off(t / g.k - g.pad, t % g.k - g.pad);
         }
     }
+    a.a_bytes = (long long)g.B * g.H * g.W * g.Cin * 4;
     int tile, splits;
     choose_igemm(a.M, rf, wm.G * (cf / 32), wm.P, &tile, &splits);
     const long long out_count = (long long)a.M * (g.fold ? 4 : 1) * g.Cout;
@@ -182,16 +182,15 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
         for (int p = 0; p < 4; ++p)
             for (int t = 0; t < wm.G; ++t) {
                 const int ry = t / wm.T + wm.rmin, rx = t % wm.T + wm.rmin;
-                a.aoy[0][p * wm.G + t] = (signed char)((p >> 1) - 2 * ry);
-                a.aox[0][p * wm.G + t] = (signed char)((p & 1) - 2 * rx);
+                a.goff[0][p * wm.G + t] = pack_off((p >> 1) - 2 * ry, (p & 1) - 2 * rx);
             }
     } else {
         a.Ha = g.H; a.Wa = g.W; a.asy = a.asx = 1;
         for (int t = 0; t < wm.G; ++t) {
-            a.aoy[0][t] = (signed char)(g.pad - t / g.k);
-            a.aox[0][t] = (signed char)(g.pad - t % g.k);
+            a.goff[0][t] = pack_off(g.pad - t / g.k, g.pad - t % g.k);
         }
     }
+    a.a_bytes = (long long)g.B * g.H * g.W * (g.fold ? 4 : 1) * g.Cout * 4;
     int tile, splits;
     choose_igemm(a.M, rb, a.G * (cb / 32), 1, &tile, &splits);
     const long long out_count = (long long)a.M * g.Cin;
@@ -234,6 +233,8 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
             a.xox[0][t] = (signed char)(t % g.k - g.pad);
         }
     }
+    a.d_bytes = (long long)g.B * a.Hd * a.Wd * g.Cout * 4;
+    a.x_bytes = (long long)g.B * g.H * g.W * g.Cin * 4;
     int tile;
     choose_wgrad(a.M, g.Cout, g.Cin, wm.G, wm.P, &tile, &a.S, &a.m_per_split, &a.Npad, &a.Cpad);
     const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;

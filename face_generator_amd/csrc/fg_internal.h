@@ -66,8 +66,9 @@ struct IgemmArgs {
     int G, Npad;
     int splits;          // split-K over groups (gridDim.y); partials at Out + s*split_stride
     long long split_stride;
-    signed char aoy[4][FG_MAX_GROUPS], aox[4][FG_MAX_GROUPS];
+    int goff[4][FG_MAX_GROUPS];   // per (parity, group): (oy & 0xffff) | (ox << 16) pixel offsets into A
     signed char ooy[4], oox[4];
+    long long a_bytes;   // size of the A tensor in bytes (< 2 GiB: raw-buffer addressing)
     double alg_flops;    // host-side bookkeeping only: reference-formulation FLOPs of this launch
     const char* tag;     // host-side: profile label
 };
@@ -91,6 +92,7 @@ struct WgradArgs {
     int m_per_split;     // multiple of 32
     signed char doy[4], dox[4];
     signed char xoy[4][FG_MAX_GROUPS], xox[4][FG_MAX_GROUPS];
+    long long d_bytes, x_bytes;   // operand sizes (< 2 GiB: raw-buffer addressing)
     double alg_flops;
     const char* tag;
 };

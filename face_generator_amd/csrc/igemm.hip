@@ -29,6 +29,14 @@ __device__ __forceinline__ void fg_decode_m(int m, int lgH, int lgW, int Hm, int
     }
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define FG_OOB 0x7FFFFFF0   // voffset marker: beyond any buffer (< 2 GiB) -> the buffer load returns zeros
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's float4 struct array went to scratch)
+__device__ __forceinline__ f32x4 fg_buffer_load4(__amdgpu_buffer_rsrc_t r, int voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     constexpr int LDK = 36;
@@ -55,17 +63,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         rowoff[tid] = off;
     }
 
+    // A operand through a raw buffer resource: out-of-image taps / ragged rows / K tail read as hardware zeros
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)a.a_bytes, 0x00020000);
     const int lrow = tid >> 3, lk = (tid & 7) * 4;
     int ry[RA], rx[RA], rn[RA];
-    bool rv[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        int m = tile_m * BM + lrow + 32 * i;
-        rv[i] = m < a.M;
+        const int m = tile_m * BM + lrow + 32 * i;
         int n, y, x;
-        fg_decode_m(rv[i] ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
+        fg_decode_m(m < a.M ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
         rn[i] = n * a.Ha * a.Wa;
-        ry[i] = y * a.asy;
+        ry[i] = m < a.M ? y * a.asy : -(1 << 20);   // ragged rows: never in range
         rx[i] = x * a.asx;
     }
     const int kc = a.Kpad >> 5;
@@ -73,32 +81,44 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     const int kt_per = (kt_all + a.splits - 1) / a.splits;
     const int kt0 = split * kt_per;                    // this split's K-step range
     const int KT = max(0, min(kt_all, kt0 + kt_per) - kt0);
+    const bool ktail = a.Ca != a.Kpad;
 
-    float4 ra[RA], rb[RB];
-    auto load_tile = [&](int ktl) {
-        const int kt = kt0 + ktl;
-        const int g = kt / kc;
-        const int col = (kt - g * kc) * 32 + lk;
-        const int oy = a.aoy[p][g], ox = a.aox[p][g];
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int ya = ry[i] + oy, xa = rx[i] + ox;
-            const bool ok = rv[i] && (unsigned)ya < (unsigned)a.Ha && (unsigned)xa < (unsigned)a.Wa && col < a.Ca;
-            if (ok)
-                ra[i] = *(const float4*)(a.A + (size_t)(rn[i] + ya * a.Wa + xa) * a.Ca + col);
-            else
-                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const float* bp = a.Bp + ((size_t)(p * a.G + g) * a.Npad + tile_n * BN + lrow) * a.Kpad + col;
-#pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = *(const float4*)(bp + (size_t)(32 * i) * a.Kpad);
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) *(float4*)(As + buf * BM * LDK + (lrow + 32 * i) * LDK + lk) = ra[i];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) *(float4*)(Bs + buf * BN * LDK + (lrow + 32 * i) * LDK + lk) = rb[i];
-    };
+    int g = kt0 / kc;
+    int col0 = (kt0 - g * kc) * 32;
+    int voff[RA];
+#define FG_SET_GROUP()                                                                                   \
+    {                                                                                                    \
+        const int go = a.goff[p][g < a.G ? g : 0];                                                       \
+        const int oy = (int)(short)(go & 0xffff), ox = go >> 16;                                         \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                                 \
+            const int ya = ry[i] + oy, xa = rx[i] + ox;                                                  \
+            const bool ok = (unsigned)ya < (unsigned)a.Ha && (unsigned)xa < (unsigned)a.Wa;              \
+            voff[i] = ok ? ((rn[i] + ya * a.Wa + xa) * a.Ca + lk) * 4 : FG_OOB;                          \
+        }                                                                                                \
+    }
+    FG_SET_GROUP();
+    const float* bptr = a.Bp + ((size_t)(p * a.G + g) * a.Npad + tile_n * BN + lrow) * a.Kpad + col0 + lk;
+    const size_t brow = (size_t)32 * a.Kpad;
+    const size_t bjump = (size_t)(a.Npad - 1) * a.Kpad;
+
+    f32x4 ra[RA], rb[RB];
+#define FG_LOAD_TILE()                                                                                   \
+    {                                                                                                    \
+        const int cb = col0 * 4;                                                                         \
+        const bool kin = !ktail || (col0 + lk < a.Ca);                                                   \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                   \
+            ra[i] = fg_buffer_load4(arsrc, kin ? voff[i] + cb : FG_OOB);                                 \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) rb[i] = *(const f32x4*)(bptr + i * brow);         \
+        col0 += 32; bptr += 32;                                                                          \
+        if (col0 == a.Kpad) { col0 = 0; ++g; bptr += bjump; FG_SET_GROUP(); }                            \
+    }
+#define FG_STORE_TILE(buf)                                                                               \
+    {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                   \
+            *(f32x4*)(As + (buf) * BM * LDK + (lrow + 32 * i) * LDK + lk) = ra[i];                       \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                   \
+            *(f32x4*)(Bs + (buf) * BN * LDK + (lrow + 32 * i) * LDK + lk) = rb[i];                       \
+    }
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -108,46 +128,51 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    auto compute = [&](int buf) {
-        const float* Ab = As + buf * BM * LDK + (wm * (BM / 2) + (lane & 31)) * LDK + (lane >> 5) * 4;
-        const float* Bb = Bs + buf * BN * LDK + (wn * (BN / 2) + (lane & 31)) * LDK + (lane >> 5) * 4;
-#pragma unroll
-        for (int kk = 0; kk < 32; kk += 8) {
-            float af[MI][4], bf[NI][4];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                float4 t = *(const float4*)(Ab + mi * 32 * LDK + kk);
-                af[mi][0] = t.x; af[mi][1] = t.y; af[mi][2] = t.z; af[mi][3] = t.w;
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                float4 t = *(const float4*)(Bb + ni * 32 * LDK + kk);
-                bf[ni][0] = t.x; bf[ni][1] = t.y; bf[ni][2] = t.z; bf[ni][3] = t.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][j], bf[ni][j], acc[mi][ni], 0, 0, 0);
-        }
-    };
+    const int a_lds = (wm * (BM / 2) + (lane & 31)) * LDK + (lane >> 5) * 4;
+    const int b_lds = (wn * (BN / 2) + (lane & 31)) * LDK + (lane >> 5) * 4;
 
     if (KT > 0) {
-        load_tile(0);
-        store_tile(0);
+        FG_LOAD_TILE();
+        FG_STORE_TILE(0);
     }
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < KT; ++kt) {
         const bool more = kt + 1 < KT;
-        if (more) load_tile(kt + 1);
-        compute(cur);
-        if (more) store_tile(cur ^ 1);
+        if (more) FG_LOAD_TILE();
+        {
+            const float* Ab = As + cur * BM * LDK + a_lds;
+            const float* Bb = Bs + cur * BN * LDK + b_lds;
+            f32x4 af[2][MI], bf[2][NI];   // fragment double buffer: chunk kk+8 is read while chunk kk multiplies
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) af[0][mi] = *(const f32x4*)(Ab + mi * 32 * LDK);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *(const f32x4*)(Bb + ni * 32 * LDK);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < 3) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) af[(c + 1) & 1][mi] = *(const f32x4*)(Ab + mi * 32 * LDK + (c + 1) * 8);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) bf[(c + 1) & 1][ni] = *(const f32x4*)(Bb + ni * 32 * LDK + (c + 1) * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][mi][j], bf[c & 1][ni][j],
+                                                                               acc[mi][ni], 0, 0, 0);
+            }
+        }
+        if (more) FG_STORE_TILE(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+#undef FG_SET_GROUP
+#undef FG_LOAD_TILE
+#undef FG_STORE_TILE
 
     float* outp = a.Out + (size_t)split * a.split_stride;
     const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
@@ -189,6 +214,7 @@ static int launch_igemm_t(fg_ctx* ctx, const IgemmArgs& a, int P) {
 
 int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a, int P, int tile) {
     if (a.Ca % 4 != 0 || a.Kpad % 32 != 0) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: Ca %% 4 / Kpad %% 32");
+    if (a.a_bytes <= 0 || a.a_bytes >= (long long)FG_OOB) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "igemm: A operand of %lld bytes (must be < 2 GiB per launch)", a.a_bytes);
     if (a.G > FG_MAX_GROUPS || P > 4 || a.splits < 1) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: G/P/splits");
     switch (tile) {
         case 0: if (a.Npad % 128) break; return launch_igemm_t<128, 128>(ctx, a, P);
@@ -251,38 +277,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int m1 = min(a.M, m0 + a.m_per_split);
     const int KT = (m1 > m0) ? (m1 - m0 + BK - 1) / BK : 0;
 
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)a.d_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
     const int lpix = tid / F4, lc = (tid - lpix * F4) * 4;
     const int chD = tn * BT + lc, chX = tc * BT + lc;
     const bool okD = chD < a.Nd, okX = chX < a.Cx;
     const int doy = a.doy[p], dox = a.dox[p], xoy = a.xoy[p][g], xox = a.xox[p][g];
 
-    float4 rd[R], rx[R];
-    auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            const int m = m0 + kt * BK + lpix + PSTEP * i;
-            const bool ok = m < m1;
-            int n, y, x;
-            fg_decode_m(ok ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
-            const int yd = y * a.dsy + doy, xd = x * a.dsx + dox;
-            const int yx = y * a.xsy + xoy, xx = x * a.xsx + xox;
-            if (ok && okD)
-                rd[i] = *(const float4*)(a.dY + (size_t)((n * a.Hd + yd) * a.Wd + xd) * a.Nd + chD);
-            else
-                rd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && okX && (unsigned)yx < (unsigned)a.Hx && (unsigned)xx < (unsigned)a.Wx)
-                rx[i] = *(const float4*)(a.X + (size_t)((n * a.Hx + yx) * a.Wx + xx) * a.Cx + chX);
-            else
-                rx[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            *(float4*)(Ds + buf * BK * BT + (lpix + PSTEP * i) * BT + lc) = rd[i];
-            *(float4*)(Xs + buf * BK * BT + (lpix + PSTEP * i) * BT + lc) = rx[i];
-        }
-    };
+    f32x4 rd[R], rx[R];
+    int mcur = m0;
+#define FG_WLOAD()                                                                                          \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < R; ++i) {                                                     \
+            const int m = mcur + lpix + PSTEP * i;                                                          \
+            const bool ok = m < m1;                                                                         \
+            int n, y, x;                                                                                    \
+            fg_decode_m(ok ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                                     \
+            const int yd = y * a.dsy + doy, xd = x * a.dsx + dox;                                           \
+            const int yx = y * a.xsy + xoy, xx = x * a.xsx + xox;                                           \
+            const int od = (((n * a.Hd + yd) * a.Wd + xd) * a.Nd + chD) * 4;                                \
+            const int ox = (((n * a.Hx + yx) * a.Wx + xx) * a.Cx + chX) * 4;                                \
+            const bool inx = (unsigned)yx < (unsigned)a.Hx && (unsigned)xx < (unsigned)a.Wx;                \
+            rd[i] = fg_buffer_load4(drsrc, (ok && okD) ? od : FG_OOB);                                      \
+            rx[i] = fg_buffer_load4(xrsrc, (ok && okX && inx) ? ox : FG_OOB);                               \
+        }                                                                                                   \
+        mcur += BK;                                                                                         \
+    }
+#define FG_WSTORE(buf)                                                                                      \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < R; ++i) {                                                     \
+            *(f32x4*)(Ds + (buf) * BK * BT + (lpix + PSTEP * i) * BT + lc) = rd[i];                         \
+            *(f32x4*)(Xs + (buf) * BK * BT + (lpix + PSTEP * i) * BT + lc) = rx[i];                         \
+        }                                                                                                   \
+    }
 
     f32x16 acc[MI][MI];
 #pragma unroll
@@ -292,38 +319,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    auto compute = [&](int buf) {
-        const float* Db = Ds + buf * BK * BT + (lane >> 5) * BT + wm * (BT / 2) + (lane & 31);
-        const float* Xb = Xs + buf * BK * BT + (lane >> 5) * BT + wn * (BT / 2) + (lane & 31);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float af[MI], bf[MI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) af[mi] = Db[kk * BT + mi * 32];
-#pragma unroll
-            for (int ni = 0; ni < MI; ++ni) bf[ni] = Xb[kk * BT + ni * 32];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < MI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
-        }
-    };
+    const int d_lds = (lane >> 5) * BT + wm * (BT / 2) + (lane & 31);
+    const int x_lds = (lane >> 5) * BT + wn * (BT / 2) + (lane & 31);
 
     if (KT > 0) {
-        load_tile(0);
-        store_tile(0);
+        FG_WLOAD();
+        FG_WSTORE(0);
     }
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < KT; ++kt) {
         const bool more = kt + 1 < KT;
-        if (more) load_tile(kt + 1);
-        compute(cur);
-        if (more) store_tile(cur ^ 1);
+        if (more) FG_WLOAD();
+        {
+            const float* Db = Ds + cur * BK * BT + d_lds;
+            const float* Xb = Xs + cur * BK * BT + x_lds;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                float af[MI], bf[MI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[mi] = Db[kk * BT + mi * 32];
+#pragma unroll
+                for (int ni = 0; ni < MI; ++ni) bf[ni] = Xb[kk * BT + ni * 32];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < MI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        if (more) FG_WSTORE(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+#undef FG_WLOAD
+#undef FG_WSTORE
 
     float* part = a.Part + ((size_t)pg * a.S + s) * a.Npad * a.Cpad;
 #pragma unroll
@@ -361,6 +391,8 @@ static int launch_wgrad_t(fg_ctx* ctx, const WgradArgs& a, int P) {
 int fg_launch_wgrad(fg_ctx* ctx, const WgradArgs& a, int P, int tile) {
     if (a.Nd % 4 || a.Cx % 4 || a.m_per_split % 32) return fg_set_err(ctx, FG_ERR_INVALID, "wgrad: alignment");
     if (a.G > FG_MAX_GROUPS || P > 4) return fg_set_err(ctx, FG_ERR_INVALID, "wgrad: G/P");
+    if (a.d_bytes <= 0 || a.x_bytes <= 0 || a.d_bytes >= (long long)FG_OOB || a.x_bytes >= (long long)FG_OOB)
+        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad: operands must be < 2 GiB per launch");
     if (tile == 0 && a.Npad % 128 == 0 && a.Cpad % 128 == 0) return launch_wgrad_t<128>(ctx, a, P);
     if (tile == 2 && a.Npad % 64 == 0 && a.Cpad % 64 == 0) return launch_wgrad_t<64>(ctx, a, P);
     return fg_set_err(ctx, FG_ERR_INVALID, "wgrad: bad tile %d for %dx%d", tile, a.Npad, a.Cpad);
