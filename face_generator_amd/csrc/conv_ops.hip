@@ -73,13 +73,20 @@ static void choose_wgrad(long long M, int Cout, int Cin, int G, int P, int* tile
     *tile = bt == 128 ? 0 : 2;
     *Npad = fg_round_up(Cout, bt);
     *Cpad = fg_round_up(Cin, bt);
-    long long base = (long long)(*Npad / bt) * (*Cpad / bt) * G * P;
-    long long s = (768 + base - 1) / base;
-    long long maxs = (M + 63) / 64;  // at least 2 K-steps per split
-    if (s > maxs) s = maxs;
-    if (s > 64) s = 64;
-    if (s < 1) s = 1;
-    int mp = fg_round_up((int)((M + s - 1) / s), 32);
+    const long long base = (long long)(*Npad / bt) * (*Cpad / bt) * G * P;
+    // pick the split count whose grid fills whole waves of 512 resident blocks (2 per CU) best
+    const long long maxs = (M + 63) / 64 < 64 ? (M + 63) / 64 : 64;   // >= 2 K-steps per split
+    long long best = 1;
+    double best_eff = 0.0;
+    for (long long s = 1; s <= maxs; ++s) {
+        const long long blocks = base * s;
+        if (blocks > 2048 && s > 1) break;
+        const long long waves = (blocks + 511) / 512;
+        const double eff = (double)blocks / (double)(waves * 512);
+        // prefer fuller waves; among equals prefer fewer splits (less partial traffic)
+        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
+    }
+    int mp = fg_round_up((int)((M + best - 1) / best), 32);
     *mper = mp;
     *S = (int)((M + mp - 1) / mp);
 }

@@ -334,18 +334,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         {
             const float* Db = Ds + cur * BK * BT + d_lds;
             const float* Xb = Xs + cur * BK * BT + x_lds;
+            float af[2][MI], bf[2][MI];   // fragment double buffer
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) { af[0][mi] = Db[mi * 32]; bf[0][mi] = Xb[mi * 32]; }
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
-                float af[MI], bf[MI];
+                const int c = (kk >> 1) & 1;
+                if (kk + 2 < BK) {
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) af[mi] = Db[kk * BT + mi * 32];
-#pragma unroll
-                for (int ni = 0; ni < MI; ++ni) bf[ni] = Xb[kk * BT + ni * 32];
+                    for (int mi = 0; mi < MI; ++mi) {
+                        af[c ^ 1][mi] = Db[(kk + 2) * BT + mi * 32];
+                        bf[c ^ 1][mi] = Xb[(kk + 2) * BT + mi * 32];
+                    }
+                }
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < MI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][mi], bf[c][ni], acc[mi][ni], 0, 0, 0);
             }
         }
         if (more) FG_WSTORE(cur ^ 1);

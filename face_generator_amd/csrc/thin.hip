@@ -14,28 +14,35 @@ __device__ __forceinline__ float wave_sum_x(float v) {
 // thin-in: out[pix][c] = bias[c] + sum_{tap,s} in[pix + off(tap)][s] * Wp[tap][s][c]     (Cs small, Cw wide)
 // block = 256 threads = CBLK channels x PL pixel lanes; weights for channel c live in registers.
 // ---------------------------------------------------------------------------------
-template <int K, int CS>
+// One wave per pixel (wave-uniform pixel index): the CS-channel input taps are the same for all 64 lanes, so they
+// are fetched through the scalar cache (s_load) and feed v_fmac as SGPR operands; each lane owns CJ output channels
+// whose weights stay in registers.  Stores are 256 B coalesced per wave.
+template <int K, int CS, int CJ>
 __global__ __launch_bounds__(256) void thin_in_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
                                                       const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                      int H, int W, int Cw, int flip, int cblk) {
+                                                      int H, int W, int flip) {
     constexpr int PAD = (K - 1) / 2;
-    const int pl = threadIdx.x / cblk, tc = threadIdx.x - pl * cblk;
-    const int PL = 256 / cblk;
-    const int c = blockIdx.y * cblk + tc;
-    float w[K * K * CS];
+    constexpr int Cw = CJ * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float w[K * K * CS][CJ];
 #pragma unroll
-    for (int t = 0; t < K * K * CS; ++t) w[t] = Wp[(size_t)t * Cw + c];
-    const float bv = bias ? bias[c] : 0.f;
+    for (int t = 0; t < K * K * CS; ++t)
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) w[t][j] = Wp[(size_t)t * Cw + lane + 64 * j];
+    float bv[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) bv[j] = bias ? bias[lane + 64 * j] : 0.f;
     const int npix = B * H * W;
-    const int p0 = blockIdx.x * 128;
-    for (int j = pl; j < 128; j += PL) {
-        const int pix = p0 + j;
-        if (pix >= npix) break;
+    const int nwaves = gridDim.x * 4;
+    for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += nwaves) {
         const int x = pix % W;
         const int t = pix / W;
         const int y = t % H;
         const int b = t / H;
-        float acc = bv;
+        float acc[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) acc[j] = bv[j];
 #pragma unroll
         for (int dy = 0; dy < K; ++dy) {
             const int yy = y + (flip ? PAD - dy : dy - PAD);
@@ -44,12 +51,17 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const float* __restrict__ 
             for (int dx = 0; dx < K; ++dx) {
                 const int xx = x + (flip ? PAD - dx : dx - PAD);
                 if ((unsigned)xx >= (unsigned)W) continue;
-                const float* ip = in + ((size_t)(b * H + yy) * W + xx) * CS;
+                const float* ip = in + ((size_t)(b * H + yy) * W + xx) * CS;   // wave-uniform address
 #pragma unroll
-                for (int s = 0; s < CS; ++s) acc = fmaf(ip[s], w[(dy * K + dx) * CS + s], acc);
+                for (int s = 0; s < CS; ++s) {
+                    const float v = ip[s];
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j) acc[j] = fmaf(v, w[(dy * K + dx) * CS + s][j], acc[j]);
+                }
             }
         }
-        out[(size_t)pix * Cw + c] = acc;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) out[(size_t)pix * Cw + lane + 64 * j] = acc[j];
     }
 }
 // generic fallback: runtime k / Cs, weights re-read through L1
@@ -94,14 +106,18 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
     const int npix = B * H * W;
     if (npix == 0) return FG_OK;
     dim3 grid(fg_cdiv(npix, 128), Cw / cblk);
-#define TI(KK, CC)                                                                                                  \
-    if (k == KK && Cs == CC) {                                                                                      \
-        hipLaunchKernelGGL((thin_in_kernel<KK, CC>), grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, Cw, \
-                           flip, cblk);                                                                             \
+    {
+        int nblk = fg_cdiv(npix, 4);
+        if (nblk > 4096) nblk = 4096;
+#define TI(KK, CC, JJ)                                                                                               \
+    if (k == KK && Cs == CC && Cw == JJ * 64) {                                                                     \
+        hipLaunchKernelGGL((thin_in_kernel<KK, CC, JJ>), dim3(nblk), dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, \
+                           W, flip);                                                                                \
         FG_CHECK_LAUNCH(ctx);                                                                                       \
         return FG_OK;                                                                                               \
     }
-    TI(3, 1) TI(3, 3) TI(3, 4)
+        TI(3, 1, 1) TI(3, 3, 1) TI(3, 4, 1) TI(3, 1, 2) TI(3, 3, 2) TI(3, 4, 2)
+    }
 #undef TI
     hipLaunchKernelGGL(thin_in_generic_kernel, grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, Cs, Cw, k,
                        flip, cblk);
@@ -113,13 +129,19 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
 // thin-out: out[pix][s] = act(bias[s] + sum_{tap,c} in[pix + off(tap)][c] * Wp[tap][s][c])   (Cw wide, Cs small)
 // one wave per pixel; lane owns channels lane + 64 j; butterfly reduction of the Cs partials.
 // ---------------------------------------------------------------------------------
-template <int K, int CJ, int CS>
+#define FG_OOB_T 0x7FFFFFF0
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+// NP pixels per wave iteration; every tap is fetched with a raw-buffer load whose offset is pushed out of range for
+// padding taps (hardware returns 0), so the NP*K*K*CJ loads of one iteration are branch-free and all in flight.
+template <int K, int CJ, int CS, int NP>
 __global__ __launch_bounds__(256) void thin_out_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
                                                        const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                       int H, int W, int flip, int sigmoid) {
+                                                       int H, int W, int flip, int sigmoid, int in_bytes) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int Cw = CJ * 64;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
     float w[K * K][CS][CJ];
 #pragma unroll
     for (int t = 0; t < K * K; ++t)
@@ -128,43 +150,54 @@ __global__ __launch_bounds__(256) void thin_out_kernel(const float* __restrict__
 #pragma unroll
             for (int j = 0; j < CJ; ++j) w[t][s][j] = Wp[((size_t)t * CS + s) * Cw + lane + 64 * j];
     const int npix = B * H * W;
-    const int p0 = blockIdx.x * 64;
-    for (int q = wid; q < 64; q += 4) {
-        const int pix = p0 + q;
-        if (pix >= npix) break;
-        const int x = pix % W;
-        const int t = pix / W;
-        const int y = t % H;
-        const int b = t / H;
-        float acc[CS];
+    const int ngrp = (npix + NP - 1) / NP;
+    const int nwaves = gridDim.x * 4;
+    for (int grp = blockIdx.x * 4 + wave; grp < ngrp; grp += nwaves) {
+        float acc[NP][CS];
 #pragma unroll
-        for (int s = 0; s < CS; ++s) acc[s] = 0.f;
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
-        for (int dy = 0; dy < K; ++dy) {
-            const int yy = y + (flip ? PAD - dy : dy - PAD);
-            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int s = 0; s < CS; ++s) acc[q][s] = 0.f;
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) {
-                const int xx = x + (flip ? PAD - dx : dx - PAD);
-                if ((unsigned)xx >= (unsigned)W) continue;
-                const float* ip = in + ((size_t)(b * H + yy) * W + xx) * Cw + lane;
+        for (int q = 0; q < NP; ++q) {
+            const int pix = grp * NP + q;
+            const bool pv = pix < npix;
+            const int x = pix % W;
+            const int t = pix / W;
+            const int y = t % H;
+            const int b = t / H;
 #pragma unroll
-                for (int j = 0; j < CJ; ++j) {
-                    const float v = ip[64 * j];
+            for (int dy = 0; dy < K; ++dy) {
+                const int yy = y + (flip ? PAD - dy : dy - PAD);
 #pragma unroll
-                    for (int s = 0; s < CS; ++s) acc[s] = fmaf(v, w[dy * K + dx][s][j], acc[s]);
+                for (int dx = 0; dx < K; ++dx) {
+                    const int xx = x + (flip ? PAD - dx : dx - PAD);
+                    const bool ok = pv && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+                    const int base = ok ? (((b * H + yy) * W + xx) * Cw + lane) * 4 : FG_OOB_T;
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j) {
+                        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 256 * j, 0, 0));
+#pragma unroll
+                        for (int s = 0; s < CS; ++s) acc[q][s] = fmaf(v, w[dy * K + dx][s][j], acc[q][s]);
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int s = 0; s < CS; ++s) acc[s] = wave_sum_x(acc[s]);
-        if (lane < CS) {
-            float r = acc[0];
+        for (int q = 0; q < NP; ++q)
 #pragma unroll
-            for (int s = 1; s < CS; ++s) r = (lane == s) ? acc[s] : r;
-            r += bias ? bias[lane] : 0.f;
+            for (int s = 0; s < CS; ++s) acc[q][s] = wave_sum_x(acc[q][s]);
+        if (lane < NP * CS) {
+            float r = 0.f;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int s = 0; s < CS; ++s) r = (lane == q * CS + s) ? acc[q][s] : r;
+            const int s = lane % CS;
+            r += bias ? bias[s] : 0.f;
             if (sigmoid) r = 1.f / (1.f + expf(-r));
-            out[(size_t)pix * CS + lane] = r;
+            const int pix = grp * NP + lane / CS;
+            if (pix < npix) out[(size_t)pix * CS + s] = r;     // NP*CS consecutive floats per group
         }
     }
 }
@@ -215,14 +248,19 @@ int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const
     const int npix = B * H * W;
     if (npix == 0) return FG_OK;
     dim3 grid(fg_cdiv(npix, 64));
+    const long long in_bytes = (long long)npix * Cw * 4;
+    if (in_bytes < (long long)FG_OOB_T) {
+        int nblk = fg_cdiv(fg_cdiv(npix, 4), 4);
+        if (nblk > 4096) nblk = 4096;
 #define TO(KK, JJ, CC)                                                                                              \
     if (k == KK && Cw == JJ * 64 && Cs == CC) {                                                                     \
-        hipLaunchKernelGGL((thin_out_kernel<KK, JJ, CC>), grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, \
-                           flip, sigmoid);                                                                          \
+        hipLaunchKernelGGL((thin_out_kernel<KK, JJ, CC, 4>), dim3(nblk), dim3(256), 0, ctx->stream, in, Wp, bias, out, B, \
+                           H, W, flip, sigmoid, (int)in_bytes);                                                     \
         FG_CHECK_LAUNCH(ctx);                                                                                       \
         return FG_OK;                                                                                               \
     }
-    TO(3, 1, 1) TO(3, 1, 3) TO(3, 2, 1) TO(3, 2, 3)
+        TO(3, 1, 1) TO(3, 1, 3) TO(3, 2, 1) TO(3, 2, 3)
+    }
 #undef TO
     hipLaunchKernelGGL(thin_out_generic_kernel, grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, Cw, Cs, k,
                        flip, sigmoid);
@@ -270,17 +308,29 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
         }
         __syncthreads();
         const int rows = min(TW_ROWS, H - y0);
-        for (int j = pl; j < rows * W; j += PL) {
-            const int ry = j / W, rx = j - ry * W;
-            const float wv = wide[((size_t)(b * H + y0 + ry) * W + rx) * Cw + c];
+        const int npx = rows * W;
+        for (int j0 = pl; j0 < npx; j0 += 4 * PL) {
+            float wv[4];
 #pragma unroll
-            for (int dy = 0; dy < K; ++dy)
+            for (int u = 0; u < 4; ++u) {      // 4 independent coalesced loads in flight
+                const int j = j0 + u * PL;
+                wv[u] = j < npx ? wide[((size_t)(b * H + y0) * W + j) * Cw + c] : 0.f;
+            }
 #pragma unroll
-                for (int dx = 0; dx < K; ++dx) {
-                    const float* tp = tile + ((ry + PAD + sgn * (dy - PAD)) * WP + rx + PAD + sgn * (dx - PAD)) * CS;
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u * PL;
+                if (j >= npx) break;
+                const int ry = j / W, rx = j - ry * W;
 #pragma unroll
-                    for (int s = 0; s < CS; ++s) acc[(dy * K + dx) * CS + s] = fmaf(tp[s], wv, acc[(dy * K + dx) * CS + s]);
-                }
+                for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < K; ++dx) {
+                        const float* tp = tile + ((ry + PAD + sgn * (dy - PAD)) * WP + rx + PAD + sgn * (dx - PAD)) * CS;
+#pragma unroll
+                        for (int s = 0; s < CS; ++s)
+                            acc[(dy * K + dx) * CS + s] = fmaf(tp[s], wv[u], acc[(dy * K + dx) * CS + s]);
+                    }
+            }
         }
     }
     float* dst = part + (size_t)blockIdx.x * NA * Cw;

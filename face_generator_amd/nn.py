@@ -379,7 +379,7 @@ class BCECriterion:
         B = prob.numel()
         loss = ctx.empty(1)
         grad = ctx.empty(B)
-        conf = torch.zeros(4, dtype=torch.int32, device=ctx.device)
+        conf = torch.empty(4, dtype=torch.int32, device=ctx.device)   # fully overwritten by the kernel
         ctx.check(ctx.lib.fg_bce_forward_backward(ctx.h, prob.data_ptr(), target.data_ptr(), B, loss.data_ptr(),
                                                   grad.data_ptr(), conf.data_ptr() if want_confusion else None))
         return loss, grad, conf

@@ -168,15 +168,25 @@ class DeviceNet:
         return (self.lib.fg_net_mask_elems(self.h, i, batch),)
 
     def draw_masks(self, batch):
-        """Bernoulli keep masks for every dropout layer (Philox, seed/offset advance per call)."""
-        masks = []
+        """Bernoulli keep masks for every dropout layer: ONE Philox launch per distinct keep probability (the masks
+        of equal-p layers are slices of one buffer); seed/offset advance per call."""
+        sizes, keeps = [], []
         k = 0
         for l in self.layers:
             if l[0] in ("SPATIAL_DROPOUT", "DROPOUT"):
-                n = self.lib.fg_net_mask_elems(self.h, k, batch)
-                masks.append(self.ctx.bernoulli((n,), 1.0 - float(l[5]), self.mask_seed, self.mask_offset))
-                self.mask_offset += (n + 3) // 4
+                sizes.append(self.lib.fg_net_mask_elems(self.h, k, batch))
+                keeps.append(1.0 - float(l[5]))
                 k += 1
+        masks = [None] * len(sizes)
+        for kp in sorted(set(keeps)):
+            idx = [i for i, v in enumerate(keeps) if v == kp]
+            padded = [(sizes[i] + 3) // 4 * 4 for i in idx]       # 16-byte aligned slices
+            buf = self.ctx.bernoulli((sum(padded),), kp, self.mask_seed, self.mask_offset)
+            self.mask_offset += sum(padded) // 4
+            off = 0
+            for i, n in zip(idx, padded):
+                masks[i] = buf[off:off + sizes[i]]
+                off += n
         return masks
 
     def forward(self, x, masks=None, train=None):
