@@ -169,8 +169,15 @@ def main():
             a = sym[dom]
             ach = a["alg"] / (a["ms"] * 1e-3) / 1e12
             exe = a["exe"] / (a["ms"] * 1e-3) / 1e12
+            traffic, tnote = None, None
+            try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected in-process)
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                if tj["kernel"] == dom:
+                    traffic, tnote = tj["hbm_bytes_per_launch"], tj["launch"] + "; " + tj["source"]
+            except Exception:
+                pass
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": dom,
+                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": tnote, "kernel": dom,
                                "avg_launch_ms": a["ms"] / a["calls"], "launches_per_iter": a["calls"] / args.prof_iters,
                                "executed_tflops": exe, "executed_frac": exe / PEAK_F32_MFMA_TFLOPS,
                                "note": "achieved = reference-formulation (un-folded 5x5) conv FLOPs / kernel time; "

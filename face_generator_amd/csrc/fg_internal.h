@@ -63,7 +63,7 @@ struct IgemmArgs {
     int asy, asx;        // A coord = y*asy + aoy[p][g]
     int Ho, Wo, N;
     int osy, osx;        // out coord = y*osy + ooy[p]
-    int G, Npad;
+    int G, Npad, P;      // P = output parities (1 plain, 4 nearest-x2 folded forward)
     int splits;          // split-K over groups (gridDim.y); partials at Out + s*split_stride
     long long split_stride;
     int goff[4][FG_MAX_GROUPS];   // per (parity, group): (oy & 0xffff) | (ox << 16) pixel offsets into A

@@ -13,6 +13,7 @@
 // 32-row fragment feeds 4 MFMAs (k = kk+j for lanes<32, kk+4+j for lanes>=32 -- same permutation on A and B).
 #include "fg_internal.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -37,10 +38,12 @@ __device__ __forceinline__ f32x4 fg_buffer_load4(__amdgpu_buffer_rsrc_t r, int v
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
-    constexpr int LDK = 36;
-    constexpr int RA = BM / 32, RB = BN / 32;  // float4 loads per thread per K-step
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void igemm_kernel(const IgemmArgs a) {
+    constexpr int LDK = BK + 4;                 // padded row: conflict-free ds_read_b128 fragment reads
+    constexpr int LPR = BK / 4;                 // lanes (float4) per tile row
+    constexpr int RPP = 256 / LPR;              // rows per load pass
+    constexpr int RA = BM / RPP, RB = BN / RPP; // float4 loads per thread per K-step
     constexpr int MI = BM / 64, NI = BN / 64;  // 32x32 MFMA tiles per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -49,9 +52,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
+    // XCD-aware block -> (tile, parity) map.  The dispatcher places block b on XCD b % 8 (speed only, never relied on
+    // for correctness): give every XCD a contiguous range of M-tiles and make the N-tile / output parity the fastest
+    // index, so the blocks that re-read one input neighbourhood (all parities, all N-tiles, 3x3 halo of adjacent
+    // M-tiles) share one L2 instead of pulling the activation through all eight.
     const int ntn = a.Npad / BN;
-    const int tile_m = blockIdx.x / ntn, tile_n = blockIdx.x - tile_m * ntn;
-    const int p = blockIdx.z, split = blockIdx.y;
+    const int np = a.P;
+    const int per_m = ntn * np;                       // blocks sharing one M-tile
+    const int nmt = (a.M + BM - 1) / BM;
+    int lin = blockIdx.x;
+    if ((nmt & 7) == 0) {
+        const int xcd = lin & 7, loc = lin >> 3;
+        const int mt_per_xcd = nmt >> 3;
+        lin = (xcd * mt_per_xcd + loc / per_m) * per_m + loc % per_m;
+    }
+    const int tile_m = lin / per_m;
+    const int rem = lin - tile_m * per_m;
+    const int tile_n = rem / np, p = rem - tile_n * np;
+    const int split = blockIdx.y;
 
     if (tid < BM) {
         int m = tile_m * BM + tid, off = -1;
@@ -65,18 +83,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 
     // A operand through a raw buffer resource: out-of-image taps / ragged rows / K tail read as hardware zeros
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)a.a_bytes, 0x00020000);
-    const int lrow = tid >> 3, lk = (tid & 7) * 4;
+    const int lrow = tid / LPR, lk = (tid % LPR) * 4;
     int ry[RA], rx[RA], rn[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = tile_m * BM + lrow + 32 * i;
+        const int m = tile_m * BM + lrow + RPP * i;
         int n, y, x;
         fg_decode_m(m < a.M ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
         rn[i] = n * a.Ha * a.Wa;
         ry[i] = m < a.M ? y * a.asy : -(1 << 20);   // ragged rows: never in range
         rx[i] = x * a.asx;
     }
-    const int kc = a.Kpad >> 5;
+    const int kc = a.Kpad / BK;
     const int kt_all = a.G * kc;                       // K-steps of the whole contraction
     const int kt_per = (kt_all + a.splits - 1) / a.splits;
     const int kt0 = split * kt_per;                    // this split's K-step range
@@ -84,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     const bool ktail = a.Ca != a.Kpad;
 
     int g = kt0 / kc;
-    int col0 = (kt0 - g * kc) * 32;
+    int col0 = (kt0 - g * kc) * BK;
     int voff[RA];
 #define FG_SET_GROUP()                                                                                   \
     {                                                                                                    \
@@ -98,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     }
     FG_SET_GROUP();
     const float* bptr = a.Bp + ((size_t)(p * a.G + g) * a.Npad + tile_n * BN + lrow) * a.Kpad + col0 + lk;
-    const size_t brow = (size_t)32 * a.Kpad;
+    const size_t brow = (size_t)RPP * a.Kpad;
     const size_t bjump = (size_t)(a.Npad - 1) * a.Kpad;
 
     f32x4 ra[RA], rb[RB];
@@ -109,15 +127,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
         _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                   \
             ra[i] = fg_buffer_load4(arsrc, kin ? voff[i] + cb : FG_OOB);                                 \
         _Pragma("unroll") for (int i = 0; i < RB; ++i) rb[i] = *(const f32x4*)(bptr + i * brow);         \
-        col0 += 32; bptr += 32;                                                                          \
+        col0 += BK; bptr += BK;                                                                          \
         if (col0 == a.Kpad) { col0 = 0; ++g; bptr += bjump; FG_SET_GROUP(); }                            \
     }
 #define FG_STORE_TILE(buf)                                                                               \
     {                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                   \
-            *(f32x4*)(As + (buf) * BM * LDK + (lrow + 32 * i) * LDK + lk) = ra[i];                       \
+            *(f32x4*)(As + (buf) * BM * LDK + (lrow + RPP * i) * LDK + lk) = ra[i];                       \
         _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                   \
-            *(f32x4*)(Bs + (buf) * BN * LDK + (lrow + 32 * i) * LDK + lk) = rb[i];                       \
+            *(f32x4*)(Bs + (buf) * BN * LDK + (lrow + RPP * i) * LDK + lk) = rb[i];                       \
     }
 
     f32x16 acc[MI][NI];
@@ -149,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *(const f32x4*)(Bb + ni * 32 * LDK);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (c < 3) {
+            for (int c = 0; c < BK / 8; ++c) {
+                if (c < BK / 8 - 1) {
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) af[(c + 1) & 1][mi] = *(const f32x4*)(Ab + mi * 32 * LDK + (c + 1) * 8);
 #pragma unroll
@@ -192,34 +210,40 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 static int launch_igemm_t(fg_ctx* ctx, const IgemmArgs& a, int P) {
-    const size_t lds = (size_t)(2 * (BM + BN) * 36 + BM) * sizeof(float);
+    const size_t lds = (size_t)(2 * (BM + BN) * (BK + 4) + BM) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
         attr_set = true;
     }
-    dim3 grid(fg_cdiv(a.M, BM) * (a.Npad / BN), a.splits, P);
+    dim3 grid(fg_cdiv(a.M, BM) * (a.Npad / BN) * P, a.splits, 1);
     // executed FLOPs: every tile runs the full padded contraction
-    const double exec = 2.0 * (double)grid.x * BM * BN * (double)P * a.G * a.Kpad;
+    const double exec = 2.0 * (double)grid.x * BM * BN * (double)a.G * a.Kpad;
     char label[96];
-    snprintf(label, sizeof(label), "igemm_kernel<%d,%d>/%s", BM, BN, a.tag ? a.tag : "?");
+    snprintf(label, sizeof(label), "igemm_kernel<%d,%d,%d>/%s", BM, BN, BK, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN>), grid, dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK>), grid, dim3(256), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
 
-int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a, int P, int tile) {
+int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
+    IgemmArgs a = a_in;
+    a.P = P;
     if (a.Ca % 4 != 0 || a.Kpad % 32 != 0) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: Ca %% 4 / Kpad %% 32");
     if (a.a_bytes <= 0 || a.a_bytes >= (long long)FG_OOB) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "igemm: A operand of %lld bytes (must be < 2 GiB per launch)", a.a_bytes);
     if (a.G > FG_MAX_GROUPS || P > 4 || a.splits < 1) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: G/P/splits");
+    static int force = -2;
+    if (force == -2) { const char* e = getenv("FG_IGEMM_TILE"); force = e ? atoi(e) : -1; }   // tuning aid
+    if (force >= 0 && tile == 0) tile = force;
     switch (tile) {
-        case 0: if (a.Npad % 128) break; return launch_igemm_t<128, 128>(ctx, a, P);
-        case 1: if (a.Npad % 64) break; return launch_igemm_t<128, 64>(ctx, a, P);
-        case 2: if (a.Npad % 64) break; return launch_igemm_t<64, 64>(ctx, a, P);
+        case 0: if (a.Npad % 128) break; return launch_igemm_t<128, 128, 32>(ctx, a, P);
+        case 1: if (a.Npad % 64) break; return launch_igemm_t<128, 64, 32>(ctx, a, P);
+        case 2: if (a.Npad % 64) break; return launch_igemm_t<64, 64, 32>(ctx, a, P);
+        case 3: if (a.Npad % 128) break; return launch_igemm_t<128, 128, 16>(ctx, a, P);
     }
     return fg_set_err(ctx, FG_ERR_INVALID, "igemm: bad tile %d for Npad %d", tile, a.Npad);
 }

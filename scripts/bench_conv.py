@@ -2,7 +2,7 @@
 profiler).  usage: python scripts/bench_conv.py [iters]"""
 import ctypes, sys
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from face_generator_amd import ops
 from face_generator_amd.runtime import get_context
 
