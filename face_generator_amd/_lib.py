@@ -14,7 +14,7 @@ FG_BWD_PARAM_GRADS = 1
 FG_BWD_INPUT_GRAD = 2
 
 LAYER_TYPES = dict(LINEAR=1, VIEW=2, PRELU=3, UPSAMPLE2X=4, CONV=5, BATCHNORM=6, SPATIAL_DROPOUT=7, AVGPOOL2=8,
-                   DROPOUT=9, SIGMOID=10, LEAKYRELU=11)
+                   DROPOUT=9, SIGMOID=10, LEAKYRELU=11, MAXPOOL2=12)
 
 
 class FgError(RuntimeError):

@@ -372,6 +372,30 @@ int fg_upsample_nearest2x_backward(fg_ctx* ctx, const float* gy, float* gx, int 
     NEED(ctx, ctx && gy && gx, "null argument");
     return fg_launch_upsample_backward(ctx, gy, gx, b, h, w, c);
 }
+int fg_maxpool2x2_forward(fg_ctx* ctx, const float* x, float* y, int b, int h, int w, int c) {
+    NEED(ctx, ctx && x && y, "null argument");
+    return fg_launch_maxpool_forward(ctx, x, y, b, h, w, c);
+}
+int fg_maxpool2x2_backward(fg_ctx* ctx, const float* x, const float* gy, float* gx, int b, int h, int w, int c) {
+    NEED(ctx, ctx && x && gy && gx, "null argument");
+    return fg_launch_maxpool_backward(ctx, x, gy, gx, b, h, w, c);
+}
+int fg_dropout_apply(fg_ctx* ctx, const float* x, const float* mask, float scale, float* y, long long n) {
+    NEED(ctx, ctx && x && y && n >= 0, "bad argument");
+    return fg_launch_mul_mask(ctx, x, mask, scale, y, n);
+}
+int fg_concat_channels(fg_ctx* ctx, const float* a, const float* b, float* out, long long npix, int ca, int cb) {
+    NEED(ctx, ctx && a && b && out && npix >= 0 && ca > 0 && cb > 0, "bad argument");
+    return fg_launch_concat(ctx, a, b, out, npix, ca, cb);
+}
+int fg_split_channels(fg_ctx* ctx, const float* g, float* ga, float* gb, long long npix, int ca, int cb) {
+    NEED(ctx, ctx && g && npix >= 0 && ca > 0 && cb > 0, "bad argument");
+    return fg_launch_split(ctx, g, ga, gb, npix, ca, cb);
+}
+int fg_add(fg_ctx* ctx, const float* a, const float* b, float* out, long long n) {
+    NEED(ctx, ctx && a && b && out && n >= 0, "bad argument");
+    return fg_launch_add(ctx, a, b, out, n);
+}
 int fg_sigmoid_forward(fg_ctx* ctx, const float* x, float* y, long long n) { NEED(ctx, ctx && x && y, "null argument"); return fg_launch_sigmoid_forward(ctx, x, y, n); }
 int fg_sigmoid_backward(fg_ctx* ctx, const float* y, const float* gy, float* gx, long long n) {
     NEED(ctx, ctx && y && gy && gx, "null argument");

@@ -169,6 +169,12 @@ int fg_launch_sigmoid_backward(fg_ctx*, const float* y, const float* gy, float* 
 int fg_launch_leakyrelu_forward(fg_ctx*, const float* x, float s, float* y, long long n);
 int fg_launch_leakyrelu_backward(fg_ctx*, const float* x, const float* gy, float s, float* gx, long long n);
 int fg_launch_axpby(fg_ctx*, float a, const float* x, float b, float* y, long long n);  // y = a*x + b*y
+int fg_launch_maxpool_forward(fg_ctx*, const float* x, float* y, int B, int H, int W, int C);
+int fg_launch_maxpool_backward(fg_ctx*, const float* x, const float* gy, float* gx, int B, int H, int W, int C);
+int fg_launch_mul_mask(fg_ctx*, const float* x, const float* mask, float scale, float* y, long long n);
+int fg_launch_concat(fg_ctx*, const float* a, const float* b, float* out, long long npix, int ca, int cb);
+int fg_launch_split(fg_ctx*, const float* g, float* ga, float* gb, long long npix, int ca, int cb);
+int fg_launch_add(fg_ctx*, const float* a, const float* b, float* out, long long n);
 
 // thin convolutions (3 <-> wide channels), NHWC, stride 1, "same" pad, odd k <= 7
 // thin-in : out[pix][c<Cw] = bias[c] + sum_{tap, s<Cs} in[pix+off(tap)][s] * Wp[tap][s][c]

@@ -23,7 +23,9 @@ enum StageKind {
     ST_LEAKYRELU,
     ST_UPSAMPLE,
     ST_AVGPOOL,
-    ST_SDROPOUT
+    ST_SDROPOUT,
+    ST_MAXPOOL,
+    ST_DROPOUT        // standalone nn.Dropout (any shape)
 };
 
 struct Stage {
@@ -236,7 +238,11 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
                 s.kind = ST_AVGPOOL; s.oc = c; s.oh = h / 2; s.ow = w / 2; break;
             case FG_SPATIAL_DROPOUT:
                 s.kind = ST_SDROPOUT; s.p = l.p; s.mask_kind = 1; s.mask_idx = n->n_masks++; s.oc = c; s.oh = h; s.ow = w; break;
-            case FG_DROPOUT: fail(FG_ERR_UNSUPPORTED, "standalone Dropout (only PReLU+Dropout is built)", i); break;
+            case FG_DROPOUT:
+                s.kind = ST_DROPOUT; s.p = l.p; s.mask_kind = 2; s.mask_idx = n->n_masks++; s.oc = c; s.oh = h; s.ow = w; break;
+            case FG_MAXPOOL2:
+                if (h % 2 || w % 2 || c % 4) { fail(FG_ERR_INVALID, "MaxPool needs even H/W and C % 4 == 0", i); break; }
+                s.kind = ST_MAXPOOL; s.oc = c; s.oh = h / 2; s.ow = w / 2; break;
             default: fail(FG_ERR_INVALID, "unknown layer type", i); break;
         }
         if (rc != FG_OK) break;
@@ -417,6 +423,11 @@ int fg_net_forward(fg_net* n, int B, const float* x, void* wsv, size_t ws_bytes,
             case ST_SDROPOUT:
                 rc = fg_launch_scale_mask_nc(ctx, cur, train ? mask : nullptr, train ? 1.f : 1.f - s.p, y, B, s.ih * s.iw, s.ic);
                 break;
+            case ST_MAXPOOL: rc = fg_launch_maxpool_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
+            case ST_DROPOUT:
+                rc = fg_launch_mul_mask(ctx, cur, train ? mask : nullptr, train ? 1.f / (1.f - s.p) : 1.f, y,
+                                        (long long)B * s.ic * s.ih * s.iw);
+                break;
             default: rc = fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: bad stage kind %d", s.kind);
         }
         if (rc) return rc;
@@ -528,6 +539,10 @@ int fg_net_backward(fg_net* n, int B, const float* x, const float* gy, void* wsv
             case ST_UPSAMPLE: if (need_gx) rc = fg_launch_upsample_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
             case ST_AVGPOOL: if (need_gx) rc = fg_launch_avgpool_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
             case ST_SDROPOUT: if (need_gx) rc = fg_launch_scale_mask_nc(ctx, gcur, mask, 1.f, gxb, B, s.ih * s.iw, s.ic); break;
+            case ST_MAXPOOL: if (need_gx) rc = fg_launch_maxpool_backward(ctx, xin, gcur, gxb, B, s.ih, s.iw, s.ic); break;
+            case ST_DROPOUT:
+                if (need_gx) rc = fg_launch_mul_mask(ctx, gcur, mask, 1.f / (1.f - s.p), gxb, (long long)B * s.ic * s.ih * s.iw);
+                break;
             default: rc = fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: bad stage kind %d", s.kind);
         }
         if (rc) return rc;

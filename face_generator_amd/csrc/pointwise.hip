@@ -654,6 +654,124 @@ int fg_launch_leakyrelu_backward(fg_ctx* ctx, const float* x, const float* gy, f
     return FG_OK;
 }
 
+// ------------------------------------------------------------------ SpatialMaxPooling(2,2) (models_c2f.lua:251, 256)
+// ties: first max in scan order (dy, dx); backward recomputes the argmax from the saved input (no index tensor)
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                          int W, int C) {
+    const int H2 = H >> 1, W2 = W >> 1, C4 = C >> 2;
+    const long long total = (long long)B * H2 * W2 * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int w2 = (int)(t % W2); t /= W2;
+        const int h2 = (int)(t % H2);
+        const int b = (int)(t / H2);
+        const float4* px = (const float4*)(x + (((size_t)b * H + 2 * h2) * W + 2 * w2) * C) + c4;
+        float4 m = px[0];
+        const float4 v1 = px[C4], v2 = px[(size_t)W * C4], v3 = px[(size_t)W * C4 + C4];
+        m.x = fmaxf(fmaxf(m.x, v1.x), fmaxf(v2.x, v3.x)); m.y = fmaxf(fmaxf(m.y, v1.y), fmaxf(v2.y, v3.y));
+        m.z = fmaxf(fmaxf(m.z, v1.z), fmaxf(v2.z, v3.z)); m.w = fmaxf(fmaxf(m.w, v1.w), fmaxf(v2.w, v3.w));
+        ((float4*)y)[i] = m;
+    }
+}
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                          float* __restrict__ gx, int B, int H, int W, int C) {
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long long total = (long long)B * H2 * W2 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int w2 = (int)(t % W2); t /= W2;
+        const int h2 = (int)(t % H2);
+        const int b = (int)(t / H2);
+        const size_t base = (((size_t)b * H + 2 * h2) * W + 2 * w2) * C + c;
+        const size_t o[4] = {base, base + C, base + (size_t)W * C, base + (size_t)W * C + C};
+        int am = 0;
+        float m = x[o[0]];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { const float v = x[o[k]]; if (v > m) { m = v; am = k; } }
+        const float g = gy[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gx[o[k]] = (k == am) ? g : 0.f;
+    }
+}
+int fg_launch_maxpool_forward(fg_ctx* ctx, const float* x, float* y, int B, int H, int W, int C) {
+    if (C % 4 || H % 2 || W % 2) return fg_set_err(ctx, FG_ERR_INVALID, "maxpool: C%%4, even H/W");
+    long long n = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, y, B, H, W, C);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_maxpool_backward(fg_ctx* ctx, const float* x, const float* gy, float* gx, int B, int H, int W, int C) {
+    if (H % 2 || W % 2) return fg_set_err(ctx, FG_ERR_INVALID, "maxpool: even H/W");
+    long long n = (long long)B * (H / 2) * (W / 2) * C;
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, gy, gx, B, H, W, C);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+// y = x * mask * scale (elementwise, nn.Dropout on any shape; mask nullptr -> y = x * scale)
+__global__ void mul_mask_kernel(const float* __restrict__ x, const float* __restrict__ mask, float scale,
+                                float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        y[i] = x[i] * (mask ? mask[i] * scale : scale);
+}
+int fg_launch_mul_mask(fg_ctx* ctx, const float* x, const float* mask, float scale, float* y, long long n) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(mul_mask_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, mask, scale, y, n);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+// nn.JoinTable(2,2) on NHWC: out[pix][0..ca) = a, [ca..ca+cb) = b ; nn.CAddTable: out = a + b
+__global__ void concat_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                              long long npix, int ca, int cb) {
+    const int c = ca + cb;
+    const long long total = npix * c;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % c);
+        const long long p = i / c;
+        out[i] = k < ca ? a[p * ca + k] : b[p * cb + (k - ca)];
+    }
+}
+__global__ void split_kernel(const float* __restrict__ g, float* __restrict__ ga, float* __restrict__ gb,
+                             long long npix, int ca, int cb) {
+    const int c = ca + cb;
+    const long long total = npix * c;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % c);
+        const long long p = i / c;
+        if (k < ca) { if (ga) ga[p * ca + k] = g[i]; }
+        else if (gb) gb[p * cb + (k - ca)] = g[i];
+    }
+}
+int fg_launch_concat(fg_ctx* ctx, const float* a, const float* b, float* out, long long npix, int ca, int cb) {
+    if (npix == 0) return FG_OK;
+    hipLaunchKernelGGL(concat_kernel, FG_GRID(npix * (ca + cb), 256), dim3(256), 0, ctx->stream, a, b, out, npix, ca, cb);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_split(fg_ctx* ctx, const float* g, float* ga, float* gb, long long npix, int ca, int cb) {
+    if (npix == 0) return FG_OK;
+    hipLaunchKernelGGL(split_kernel, FG_GRID(npix * (ca + cb), 256), dim3(256), 0, ctx->stream, g, ga, gb, npix, ca, cb);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+int fg_launch_add(fg_ctx* ctx, const float* a, const float* b, float* out, long long n) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(add_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, a, b, out, n);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
 // ------------------------------------------------------------------ Linear(K -> 1) [+ Sigmoid]
 __global__ __launch_bounds__(64) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ b, float* __restrict__ y, int B, int K,

@@ -20,19 +20,19 @@ __device__ __forceinline__ float wave_sum_x(float v) {
 template <int K, int CS, int CJ>
 __global__ __launch_bounds__(256) void thin_in_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
                                                       const float* __restrict__ bias, float* __restrict__ out, int B,
-                                                      int H, int W, int flip) {
+                                                      int H, int W, int flip, int Cw) {
     constexpr int PAD = (K - 1) / 2;
-    constexpr int Cw = CJ * 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb = blockIdx.y * (CJ * 64) + lane;       // this lane's first output channel
     float w[K * K * CS][CJ];
 #pragma unroll
     for (int t = 0; t < K * K * CS; ++t)
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) w[t][j] = Wp[(size_t)t * Cw + lane + 64 * j];
+        for (int j = 0; j < CJ; ++j) w[t][j] = Wp[(size_t)t * Cw + cb + 64 * j];
     float bv[CJ];
 #pragma unroll
-    for (int j = 0; j < CJ; ++j) bv[j] = bias ? bias[lane + 64 * j] : 0.f;
+    for (int j = 0; j < CJ; ++j) bv[j] = bias ? bias[cb + 64 * j] : 0.f;
     const int npix = B * H * W;
     const int nwaves = gridDim.x * 4;
     for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += nwaves) {
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const float* __restrict__ 
             }
         }
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) out[(size_t)pix * Cw + lane + 64 * j] = acc[j];
+        for (int j = 0; j < CJ; ++j) out[(size_t)pix * Cw + cb + 64 * j] = acc[j];
     }
 }
 // generic fallback: runtime k / Cs, weights re-read through L1
@@ -110,13 +110,13 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         int nblk = fg_cdiv(npix, 4);
         if (nblk > 4096) nblk = 4096;
 #define TI(KK, CC, JJ)                                                                                               \
-    if (k == KK && Cs == CC && Cw == JJ * 64) {                                                                     \
-        hipLaunchKernelGGL((thin_in_kernel<KK, CC, JJ>), dim3(nblk), dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, \
-                           W, flip);                                                                                \
+    if (k == KK && Cs == CC && Cw % (JJ * 64) == 0 && (JJ == 1 || Cw == JJ * 64)) {                                 \
+        hipLaunchKernelGGL((thin_in_kernel<KK, CC, JJ>), dim3(nblk, Cw / (JJ * 64)), dim3(256), 0, ctx->stream, in, Wp, \
+                           bias, out, B, H, W, flip, Cw);                                                           \
         FG_CHECK_LAUNCH(ctx);                                                                                       \
         return FG_OK;                                                                                               \
     }
-        TI(3, 1, 1) TI(3, 3, 1) TI(3, 4, 1) TI(3, 1, 2) TI(3, 3, 2) TI(3, 4, 2)
+        TI(3, 1, 2) TI(3, 3, 2) TI(3, 4, 2) TI(3, 1, 1) TI(3, 3, 1) TI(3, 4, 1) TI(5, 3, 1) TI(7, 3, 1) TI(7, 1, 1)
     }
 #undef TI
     hipLaunchKernelGGL(thin_in_generic_kernel, grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, Cs, Cw, k,
@@ -201,6 +201,74 @@ __global__ __launch_bounds__(256) void thin_out_kernel(const float* __restrict__
         }
     }
 }
+// LDS-tiled thin-out for large kernels / many input channels (c2f generator head: 7x7, 256 -> 3, models_c2f.lua:131).
+// Block = 16x16 output pixels (4 waves x 8x8), lane = pixel.  Per 32-channel chunk the (16+K-1)^2 input halo tile is
+// staged in LDS (rows padded to 36 floats); each lane reads its taps as ds_read_b128 (4 channels) and multiplies them
+// with wave-uniform weights (scalar loads -> SGPR operands): 4*CS FMAs per LDS read.
+template <int K, int CS>
+__global__ __launch_bounds__(256) void thin_out_tiled_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int B, int H, int W, int Cw, int flip, int sigmoid) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int TP = 16 + K - 1;   // tile edge incl. halo
+    constexpr int LDC = 36;
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [TP*TP][LDC]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    int bid = blockIdx.x;
+    const int txi = bid % tiles_x; bid /= tiles_x;
+    const int tyi = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = txi * 16, y0 = tyi * 16;
+    const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
+    float acc[CS];
+#pragma unroll
+    for (int s = 0; s < CS; ++s) acc[s] = 0.f;
+    for (int c0 = 0; c0 < Cw; c0 += 32) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < TP * TP * 8; i += 256) {
+            const int c4 = i & 7, pp = i >> 3;
+            const int px = pp % TP, py = pp / TP;
+            const int xx = x0 + px - PAD, yy = y0 + py - PAD;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H)
+                v = *(const float4*)(in + ((size_t)(b * H + yy) * W + xx) * Cw + c0 + c4 * 4);
+            *(float4*)(tile + pp * LDC + c4 * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int dy = 0; dy < K; ++dy) {
+#pragma unroll 1
+            for (int dx = 0; dx < K; ++dx) {
+                const int ty = ly + (flip ? 2 * PAD - dy : dy), tx = lx + (flip ? 2 * PAD - dx : dx);
+                const float* tp = tile + (ty * TP + tx) * LDC;
+                const float* wp = Wp + (size_t)(dy * K + dx) * CS * Cw + c0;   // wave-uniform
+#pragma unroll
+                for (int c4 = 0; c4 < 8; ++c4) {
+                    const float4 v = *(const float4*)(tp + c4 * 4);
+#pragma unroll
+                    for (int s = 0; s < CS; ++s) {
+                        const float* ws = wp + (size_t)s * Cw + c4 * 4;
+                        acc[s] = fmaf(v.x, ws[0], acc[s]);
+                        acc[s] = fmaf(v.y, ws[1], acc[s]);
+                        acc[s] = fmaf(v.z, ws[2], acc[s]);
+                        acc[s] = fmaf(v.w, ws[3], acc[s]);
+                    }
+                }
+            }
+        }
+    }
+    const int ox = x0 + lx, oy = y0 + ly;
+    if (ox < W && oy < H) {
+#pragma unroll
+        for (int s = 0; s < CS; ++s) {
+            float r = acc[s] + (bias ? bias[s] : 0.f);
+            if (sigmoid) r = 1.f / (1.f + expf(-r));
+            out[((size_t)(b * H + oy) * W + ox) * CS + s] = r;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void thin_out_generic_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
                                                                const float* __restrict__ bias, float* __restrict__ out,
                                                                int B, int H, int W, int Cw, int Cs, int K, int flip,
@@ -262,6 +330,26 @@ int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const
         TO(3, 1, 1) TO(3, 1, 3) TO(3, 2, 1) TO(3, 2, 3)
     }
 #undef TO
+    if (Cw % 32 == 0 && (k == 3 || k == 5 || k == 7) && (Cs == 1 || Cs == 3)) {
+        const int tp = 16 + k - 1;
+        const size_t lds = (size_t)tp * tp * 36 * sizeof(float);
+        dim3 tgrid(B * ((H + 15) / 16) * ((W + 15) / 16));
+#define TOT(KK, CC)                                                                                                  \
+    if (k == KK && Cs == CC) {                                                                                       \
+        static bool attr = false;                                                                                    \
+        if (!attr) {                                                                                                 \
+            FG_HIP(ctx, hipFuncSetAttribute((const void*)thin_out_tiled_kernel<KK, CC>,                              \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+            attr = true;                                                                                             \
+        }                                                                                                            \
+        hipLaunchKernelGGL((thin_out_tiled_kernel<KK, CC>), tgrid, dim3(256), lds, ctx->stream, in, Wp, bias, out, B, H, \
+                           W, Cw, flip, sigmoid);                                                                    \
+        FG_CHECK_LAUNCH(ctx);                                                                                        \
+        return FG_OK;                                                                                                \
+    }
+        TOT(3, 1) TOT(3, 3) TOT(5, 1) TOT(5, 3) TOT(7, 1) TOT(7, 3)
+#undef TOT
+    }
     hipLaunchKernelGGL(thin_out_generic_kernel, grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, Cw, Cs, k,
                        flip, sigmoid);
     FG_CHECK_LAUNCH(ctx);
@@ -375,7 +463,7 @@ int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, floa
         FG_CHECK_LAUNCH(ctx);                                                                                        \
         return fg_launch_colsum_final(ctx, scratch, nb, NA * Cw, 0.f, gw_tsc);                                       \
     }
-    TWG(3, 1) TWG(3, 3) TWG(3, 4)
+    TWG(3, 1) TWG(3, 3) TWG(3, 4) TWG(5, 3) TWG(7, 3) TWG(7, 1)
 #undef TWG
     return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "thin_wgrad: k=%d Cs=%d not built", k, Cs);
 }

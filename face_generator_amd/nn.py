@@ -193,6 +193,48 @@ class SpatialAveragePooling(Module):
         return ("AVGPOOL2",)
 
 
+class SpatialMaxPooling(Module):
+    """nn.SpatialMaxPooling(2,2) (models_c2f.lua:251, 256)."""
+    _typename = "nn.SpatialMaxPooling"
+
+    def __init__(self, kW, kH, dW=None, dH=None):
+        super().__init__()
+        if (kW, kH, dW or kW, dH or kH) != (2, 2, 2, 2):
+            raise FgError("nn.SpatialMaxPooling: only (2,2) is built")
+
+    def spec(self):
+        return ("MAXPOOL2",)
+
+
+class SpatialConvolutionUpsample(SpatialConvolution):
+    """layers/cudnnSpatialConvolutionUpsample.lua:4-58.  The reference always passes factor = 1 (models_c2f.lua:123-131),
+    which is exactly a 'same' convolution; factor > 1 (flat NCHW re-view, not pixel-shuffle) is not on any config."""
+    _typename = "cudnn.SpatialConvolutionUpsample"
+
+    def __init__(self, nInputPlane, nOutputPlane, kW, kH, factor=2, groups=None, gen=None):
+        if kW % 2 != 1 or kH % 2 != 1:
+            raise FgError("kW has to be odd / kH has to be odd")          # cudnnSpatialConvolutionUpsample.lua:7-8
+        if factor != 1:
+            raise FgError("SpatialConvolutionUpsample: factor %d not built (the reference only uses factor 1)" % factor)
+        super().__init__(nInputPlane, nOutputPlane, kW, kH, 1, 1, (kW - 1) // 2, (kH - 1) // 2, gen=gen)
+        self.factor = factor
+
+
+class JoinTable(Module):
+    """nn.JoinTable(2, 2): concat along channels (models_c2f.lua:116)."""
+    _typename = "nn.JoinTable"
+
+    def __init__(self, dimension=2, nInputDims=2):
+        super().__init__()
+        if dimension != 2:
+            raise FgError("nn.JoinTable: only the channel dimension is built")
+
+
+class CAddTable(Module):
+    """nn.CAddTable (models_c2f.lua:240)."""
+    _typename = "nn.CAddTable"
+
+
 class Sigmoid(Module):
     _typename = "nn.Sigmoid"
 
@@ -364,6 +406,75 @@ class Sequential(Module):
             lines.append("  (%d): %s" % (i + 1, repr(m).replace("\n", "\n  ")))
         lines.append("}")
         return "\n".join(lines)
+
+
+class TableSequential(Sequential):
+    """models_c2f.lua nets: {JoinTable | CAddTable, [Copy], inner Sequential, [Copy]} taking a table of two tensors.
+    `modules` mirrors the reference's outer container; the compute net is `inner`."""
+
+    def __init__(self, first, inner):
+        super().__init__()
+        self.first, self.inner = first, inner
+        self.modules = [first, inner]
+
+    def _inner(self):
+        return self.inner
+
+    def cuda(self, ctx=None, max_batch=32):
+        self.inner.cuda(ctx, max_batch)
+        if not isinstance(self.modules[1], Copy):
+            self.modules = [self.first, Copy("torch.FloatTensor", "hip.NHWC"), self.inner, Copy("hip.NHWC", "torch.FloatTensor")]
+        return self
+
+    def is_cuda(self):
+        return self.inner.device_net is not None
+
+    def combine_device(self, ctx, a, b):
+        """JoinTable / CAddTable on device NHWC tensors."""
+        if isinstance(self.first, JoinTable):
+            out = ctx.empty(a.shape[0], a.shape[1], a.shape[2], a.shape[3] + b.shape[3])
+            ctx.check(ctx.lib.fg_concat_channels(ctx.h, a.data_ptr(), b.data_ptr(), out.data_ptr(),
+                                                 a.shape[0] * a.shape[1] * a.shape[2], a.shape[3], b.shape[3]))
+        else:
+            out = torch.empty_like(a)
+            ctx.check(ctx.lib.fg_add(ctx.h, a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel()))
+        return out
+
+    def forward(self, xs, masks=None):
+        dn = self.inner.device_net
+        if dn is None:
+            raise FgError("TableSequential:forward: no CPU path -- build with cuda=true / call :cuda() first")
+        ctx = dn.ctx
+        a, b = ctx.to_device_nhwc(xs[0]), ctx.to_device_nhwc(xs[1])
+        y = dn.forward(self.combine_device(ctx, a.contiguous(), b.contiguous()), masks=masks, train=self.inner.train)
+        self.output = ctx.to_nchw(y).cpu()
+        return self.output
+
+    def backward(self, xs, gradOutput):
+        dn = self.inner.device_net
+        ctx = dn.ctx
+        g = dn.backward(ctx.to_device_nhwc(gradOutput), param_grads=True, input_grad=True)
+        if isinstance(self.first, JoinTable):
+            ca = torch.as_tensor(xs[0]).shape[1]
+            cb = g.shape[3] - ca
+            ga, gb = ctx.empty(*g.shape[:3], ca), ctx.empty(*g.shape[:3], cb)
+            ctx.check(ctx.lib.fg_split_channels(ctx.h, g.data_ptr(), ga.data_ptr(), gb.data_ptr(),
+                                                g.shape[0] * g.shape[1] * g.shape[2], ca, cb))
+            self.gradInput = [ctx.to_nchw(ga).cpu(), ctx.to_nchw(gb).cpu()]
+        else:
+            gh = ctx.to_nchw(g).cpu()
+            self.gradInput = [gh, gh]           # CAddTable: the same gradient for both inputs
+        return self.gradInput
+
+    def training(self):
+        self.train = True
+        self.inner.training()
+        return self
+
+    def evaluate(self):
+        self.train = False
+        self.inner.evaluate()
+        return self
 
 
 class BCECriterion:

