@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-iters", type=int, default=3)
+    ap.add_argument("--workload", choices=["cfg2", "c2f"], default="cfg2",
+                    help="cfg2: 32x32 G32+D32b (BASELINE configs[1], the headline); c2f: 64x64 coarse-to-fine (configs[3])")
     args = ap.parse_args()
 
     import torch
@@ -96,6 +98,8 @@ def main():
     ctx = get_context(local_rank)
     B = args.batch
     C = 3
+    if args.workload == "c2f":
+        return main_c2f(args, ctx, dist, world, rank, torch)
     gen = torch.Generator().manual_seed(1)              # identical initial replicas on every rank
     G = models.create_G((C, 32, 32), 100)
     D = models.create_D((C, 32, 32))
@@ -187,6 +191,62 @@ def main():
                               for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def main_c2f(args, ctx, dist, world, rank, torch):
+    """BASELINE configs[3]: 64x64 colour coarse-to-fine (models_c2f.lua G_d / D_c, adversarial_c2f.lua), B=128/GPU.
+    Algorithmic FLOPs: 37.220 GFLOP/img, 4764.19 GFLOP per B=128 iteration (D_it = G_it = 1)."""
+    from face_generator_amd import models_c2f, adversarial_c2f
+    from face_generator_amd.state import S
+    B, Sz = args.batch, 64
+    gen = torch.Generator().manual_seed(1)
+    G = models_c2f.create_G((3, Sz, Sz), gen=gen).cuda(ctx, max_batch=B)
+    D = models_c2f.create_D((3, Sz, Sz), gen=gen).cuda(ctx, max_batch=B)
+    S.noise_seed = 1 + rank
+    G.inner.device_net.mask_seed = D.inner.device_net.mask_seed = 1000 + rank
+    tr = adversarial_c2f.TrainerC2F(ctx, G, D, dict(batchSize=B), dist=dist if world > 1 else None)
+    fine = ctx.uniform((B, Sz, Sz, 3), 0.0, 1.0, seed=70 + rank)
+    coarse = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(fine.permute(0, 3, 1, 2), 2), scale_factor=2)
+    coarse = coarse.permute(0, 2, 3, 1).contiguous()          # synthetic-input preparation (dataset_c2f.lua:49-61)
+    diff = (fine - coarse).contiguous()
+    h = B // 2
+
+    def iteration():
+        tr.step_D(diff[:h], coarse[:h], S.next_noise(ctx, h, Sz * Sz).view(h, Sz, Sz, 1), coarse[h:])
+        tr.step_G(S.next_noise(ctx, B, Sz * Sz).view(B, Sz, Sz, 1), coarse)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        iteration()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iteration()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = 1000.0 * dt / args.steps
+    flops = 37.220e9 * B
+    out = {"metric": "GAN train images/sec (G+D step), c2f 64x64x3 bs128", "value": world * B * args.steps / dt,
+           "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[3]: 64x64 color coarse-to-fine G_d/D_c, batch 128 per GPU, Adam",
+                      "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world},
+           "step_roofline": {"algorithmic_gflop_per_iter": flops / 1e9,
+                             "achieved_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
+                             "frac_of_f32_mfma_peak": flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

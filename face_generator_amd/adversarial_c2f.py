@@ -121,3 +121,38 @@ def train(trainData):
     print("Confusion of D: [pred][target] = %s  totalValid = %.4f" % (cl, tV))
     S.EPOCH += 1
     return tV
+
+
+best_dist = None
+
+
+def approxParzen(ds, nsamples, nneighbors):
+    """adversarial.approxParzen (adversarial_c2f.lua:305-344): nearest-neighbour distance of the ground truth fine
+    image to `nneighbors` generations G(noise, coarse) + coarse; saves the .bestnet checkpoint on improvement."""
+    global best_dist
+    best_dist = 1e10 if best_dist is None else best_dist
+    print("<trainer> evaluating approximate parzen ")
+    from .runtime import get_context
+    ctx = get_context()
+    c, h, w = S.IMG_DIMENSIONS
+    distances = torch.empty(nsamples)
+    G = S.MODEL_G
+    for n in range(nsamples):
+        example = ds[S.rng.randrange(ds.size())]
+        cond = ctx.to_device_nhwc(torch.as_tensor(example.coarse, dtype=torch.float32).unsqueeze(0).repeat(nneighbors, 1, 1, 1))
+        noise = S.next_noise(ctx, nneighbors, h * w).view(nneighbors, h, w, 1)
+        neighbors = G.inner.device_net.forward(G.combine_device(ctx, noise, cond), train=G.inner.train)
+        full = ctx.to_nchw(neighbors).add_(ctx.to_nchw(cond))                 # neighbors:add(condInputs)
+        fine = torch.as_tensor(example.fine, dtype=torch.float32).to(ctx.device)
+        d = (full - fine.unsqueeze(0)).flatten(1).norm(dim=1)                   # torch.dist(neighbors[i], fine)
+        distances[n] = float(d.min())
+    mean = float(distances.mean())
+    print("average || x_%s - G(x_%s) || = %f" % (S.OPT.get("fineSize", h), S.OPT.get("coarseSize", h // 2), mean))
+    if mean < best_dist:
+        best_dist = mean
+        from . import nn_utils
+        import os
+        fn = os.path.join(S.OPT.get("save", "logs"), "adversarial_c2f_%d_to_%d.bestnet" % (S.OPT.get("coarseSize", h // 2),
+                                                                                        S.OPT.get("fineSize", h)))
+        nn_utils.save_checkpoint(fn)
+    return distances

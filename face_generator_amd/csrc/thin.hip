@@ -64,6 +64,66 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const float* __restrict__ 
         for (int j = 0; j < CJ; ++j) out[(size_t)pix * Cw + cb + 64 * j] = acc[j];
     }
 }
+// Large-kernel thin-in (c2f generator head data-grad: 7x7, 3 -> 256): a strip of TR image rows (+ halo, zero padded) of
+// the thin operand is staged in LDS; each wave computes NPX consecutive output pixels per step for its 64 channels,
+// reading every halo row segment once (uniform-address LDS broadcast) and re-using it for the NPX pixels; the K*K*CS
+// weights of the lane's channel stay in registers (pre-flipped for the data-grad form).
+template <int K, int CS>
+__global__ __launch_bounds__(256) void thin_in_rows_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int B, int H, int W, int flip, int Cw) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int TR = 4, NPX = 4;
+    constexpr int SEG = (NPX + K - 1) * CS;            // floats of one halo row segment
+    constexpr int SEG4 = (SEG + 3) / 4 * 4;
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int WP = (W + 2 * PAD + 3) / 4 * 4 + 4;      // padded row length in pixels (room for the last float4)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + lane;
+    float w[K * K * CS];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t)
+#pragma unroll
+        for (int s = 0; s < CS; ++s) w[t * CS + s] = Wp[(size_t)((flip ? K * K - 1 - t : t) * CS + s) * Cw + c];
+    const float bv = bias ? bias[c] : 0.f;
+    const int strips_per_img = (H + TR - 1) / TR;
+    const int b = blockIdx.x / strips_per_img, y0 = (blockIdx.x - b * strips_per_img) * TR;
+    for (int i = threadIdx.x; i < (TR + 2 * PAD) * WP * CS; i += 256) {
+        const int s = i % CS;
+        const int t = i / CS;
+        const int xx = t % WP - PAD, yy = y0 + t / WP - PAD;
+        float v = 0.f;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = in[((size_t)(b * H + yy) * W + xx) * CS + s];
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int rows = min(TR, H - y0);
+    const int gpr = (W + NPX - 1) / NPX;               // pixel groups per row
+    for (int grp = wave; grp < rows * gpr; grp += 4) {
+        const int r = grp / gpr, x0 = (grp - r * gpr) * NPX;
+        float acc[NPX];
+#pragma unroll
+        for (int q = 0; q < NPX; ++q) acc[q] = bv;
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy) {
+            float seg[SEG4];
+            const float* sp = tile + ((r + dy) * WP + x0) * CS;     // wave-uniform address
+#pragma unroll
+            for (int i = 0; i < SEG4; ++i) seg[i] = sp[i];
+#pragma unroll
+            for (int dx = 0; dx < K; ++dx)
+#pragma unroll
+                for (int s = 0; s < CS; ++s)
+#pragma unroll
+                    for (int q = 0; q < NPX; ++q) acc[q] = fmaf(seg[(q + dx) * CS + s], w[(dy * K + dx) * CS + s], acc[q]);
+            __builtin_amdgcn_sched_barrier(0);   // keep one row segment live at a time (else 7 x 32 VGPRs get hoisted)
+        }
+#pragma unroll
+        for (int q = 0; q < NPX; ++q)
+            if (x0 + q < W) out[((size_t)(b * H + y0 + r) * W + x0 + q) * Cw + c] = acc[q];
+    }
+}
+
 // generic fallback: runtime k / Cs, weights re-read through L1
 __global__ __launch_bounds__(256) void thin_in_generic_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
                                                               const float* __restrict__ bias, float* __restrict__ out,
@@ -116,7 +176,22 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         FG_CHECK_LAUNCH(ctx);                                                                                       \
         return FG_OK;                                                                                               \
     }
-        TI(3, 1, 2) TI(3, 3, 2) TI(3, 4, 2) TI(3, 1, 1) TI(3, 3, 1) TI(3, 4, 1) TI(5, 3, 1) TI(7, 3, 1) TI(7, 1, 1)
+        TI(3, 1, 2) TI(3, 3, 2) TI(3, 4, 2) TI(3, 1, 1) TI(3, 3, 1) TI(3, 4, 1)
+    }
+    if ((k == 5 || k == 7) && (Cs == 1 || Cs == 3)) {
+        const int pad = (k - 1) / 2;
+        const int wp = (W + 2 * pad + 3) / 4 * 4 + 4;
+        const size_t lds = (size_t)(4 + 2 * pad) * wp * Cs * sizeof(float) + 64;
+        dim3 rgrid(B * ((H + 3) / 4), Cw / 64);
+#define TIR(KK, CC)                                                                                                  \
+    if (k == KK && Cs == CC) {                                                                                       \
+        hipLaunchKernelGGL((thin_in_rows_kernel<KK, CC>), rgrid, dim3(256), lds, ctx->stream, in, Wp, bias, out, B, H, W, \
+                           flip, Cw);                                                                                \
+        FG_CHECK_LAUNCH(ctx);                                                                                        \
+        return FG_OK;                                                                                                \
+    }
+        TIR(5, 1) TIR(5, 3) TIR(7, 1) TIR(7, 3)
+#undef TIR
     }
 #undef TI
     hipLaunchKernelGGL(thin_in_generic_kernel, grid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, Cs, Cw, k,

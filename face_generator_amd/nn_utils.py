@@ -123,6 +123,28 @@ def state_dict(net):
     return sd
 
 
+def load_state_dict(net, sd):
+    """Write a saved state dict back into a net (host modules or device-resident flat vectors alike)."""
+    inner = net._inner()
+    plist = inner.parameter_list()
+    assert len(plist) == len(sd["params"]), "checkpoint does not match the network structure"
+    with torch.no_grad():
+        for (m, name), w in zip(plist, sd["params"]):
+            getattr(m, name).copy_(w.reshape(getattr(m, name).shape))
+        bns = [m for m in inner.modules if isinstance(m, nn.SpatialBatchNormalization)]
+        for m, (rm, rv) in zip(bns, sd["bn"]):
+            m.running_mean.copy_(rm)
+            m.running_var.copy_(rv)
+    if inner.device_net is not None:
+        inner.device_net.params_changed()
+    return net
+
+
+def load_checkpoint(filename):
+    """train.lua:114-129 `--network`: -> {D, G, opt, epoch} (optimizer state is NOT restored, like the reference)."""
+    return torch.load(filename, weights_only=False)
+
+
 def save_checkpoint(filename=None):
     """adversarial.lua:319-329: rotate adversarial.net -> .old, save {D, G, opt, epoch}."""
     filename = filename or os.path.join(S.OPT.get("save", "logs"), "adversarial.net")

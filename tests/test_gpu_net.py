@@ -72,6 +72,10 @@ def prelu_margin(net):
     for mod, xin in zip(net.modules, net._inputs):
         if isinstance(mod, O.PReLU):
             m = min(m, float(np.abs(xin).min() / max(np.abs(xin).max(), 1e-30)))
+        if isinstance(mod, O.SpatialMaxPooling):      # near-tie in a 2x2 block: the argmax (gradient routing) is ill-defined
+            n, c, h, w = xin.shape
+            blk = np.sort(xin.reshape(n, c, h // 2, 2, w // 2, 2).transpose(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4), -1)
+            m = min(m, float((blk[..., 3] - blk[..., 2]).min() / max(np.abs(xin).max(), 1e-30)))
     return m
 
 
