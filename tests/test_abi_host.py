@@ -107,3 +107,33 @@ def test_bench_flop_accounting_matches_survey():
     import bench
     assert abs(bench.alg_flops_per_iter(128) / 1e9 - 1019.19) < 0.01      # cfg2
     assert abs(bench.alg_flops_per_iter(128) / 128 / 1e9 - 7.962) < 0.001
+
+
+def test_checkpoint_roundtrip_and_c2f_dataset(tmp_path):
+    """adversarial.lua:319-329 / train.lua:114-129: {D, G, opt, epoch} saved with .old rotation and restored."""
+    from face_generator_amd import models, nn_utils, dataset_c2f
+    from face_generator_amd.state import S
+    S.reset()
+    S.MODEL_G = models.create_G((3, 32, 32), 100)
+    S.MODEL_D = models.create_D((3, 32, 32))
+    nn_utils.initializeWeights(S.MODEL_G, gen=torch.Generator().manual_seed(5))
+    S.MODEL_G.modules[5].running_mean += 0.25
+    S.EPOCH = 7
+    fn = str(tmp_path / "logs" / "adversarial.net")
+    nn_utils.save_checkpoint(fn)
+    nn_utils.save_checkpoint(fn)
+    assert os.path.isfile(fn) and os.path.isfile(fn + ".old")          # mv adversarial.net adversarial.net.old
+    ck = nn_utils.load_checkpoint(fn)
+    assert ck["epoch"] == 7 and ck["opt"]["batchSize"] == S.OPT["batchSize"]
+    G2 = models.create_G((3, 32, 32), 100)
+    nn_utils.load_state_dict(G2, ck["G"])
+    for (m, n), (m2, n2) in zip(S.MODEL_G.parameter_list(), G2.parameter_list()):
+        assert torch.equal(getattr(m, n), getattr(m2, n2))
+    assert torch.equal(G2.modules[5].running_mean, S.MODEL_G.modules[5].running_mean)
+    # dataset_c2f._toResult: coarse = down/up scaled fine, diff = fine - coarse
+    fine = torch.rand(5, 3, 64, 64)
+    res = dataset_c2f.toResult(fine, 32, 64)
+    assert res.size() == 5 and res[2].coarse.shape == (3, 64, 64)
+    assert torch.allclose(res[1].diff + res[1].coarse, fine[1], atol=1e-6)
+    assert (res.coarse - fine).abs().mean() > 1e-3 and res.getDiff(0, 2).shape[0] == 2
+    S.reset()
