@@ -310,20 +310,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 
     f32x4 rd[R], rx[R];
     int mcur = m0;
+    // Fast path (all hot-path shapes): Hm, Wm powers of two and a 32-pixel K-step never straddles two samples.  Then a
+    // row's offsets are  (wave-uniform base of this K-step) + (per-thread constant), so the per-step address math is
+    // scalar except one add and one bounds compare per row.
+    const bool fast = a.lgW >= 0 && ((a.Hm * a.Wm) & 31) == 0;
+    int cD[R], cX[R], cy[R];
+    bool xin[R];
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const int j = lpix + PSTEP * i;
+            const int x = j & (a.Wm - 1), yr = j >> a.lgW;          // pixel inside the K-step (Wm < 32: several rows)
+            const int xx = x * a.xsx + xox;
+            xin[i] = okX && (unsigned)xx < (unsigned)a.Wx;
+            cy[i] = yr * a.xsy + xoy;
+            cD[i] = (((yr * a.dsy + doy) * a.Wd + x * a.dsx + dox) * a.Nd + chD) * 4;
+            cX[i] = (((yr * a.xsy + xoy) * a.Wx + xx) * a.Cx + chX) * 4;
+        }
+    }
+    const int sDn = a.Hd * a.Wd * a.Nd * 4, sDy = a.dsy * a.Wd * a.Nd * 4;   // byte strides per sample / per M-space row
+    const int sXn = a.Hx * a.Wx * a.Cx * 4, sXy = a.xsy * a.Wx * a.Cx * 4;
 #define FG_WLOAD()                                                                                          \
     {                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < R; ++i) {                                                     \
-            const int m = mcur + lpix + PSTEP * i;                                                          \
-            const bool ok = m < m1;                                                                         \
-            int n, y, x;                                                                                    \
-            fg_decode_m(ok ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                                     \
-            const int yd = y * a.dsy + doy, xd = x * a.dsx + dox;                                           \
-            const int yx = y * a.xsy + xoy, xx = x * a.xsx + xox;                                           \
-            const int od = (((n * a.Hd + yd) * a.Wd + xd) * a.Nd + chD) * 4;                                \
-            const int ox = (((n * a.Hx + yx) * a.Wx + xx) * a.Cx + chX) * 4;                                \
-            const bool inx = (unsigned)yx < (unsigned)a.Hx && (unsigned)xx < (unsigned)a.Wx;                \
-            rd[i] = fg_buffer_load4(drsrc, (ok && okD) ? od : FG_OOB);                                      \
-            rx[i] = fg_buffer_load4(xrsrc, (ok && okX && inx) ? ox : FG_OOB);                               \
+        if (fast) {                                                                                         \
+            const int rowi = mcur >> a.lgW;                 /* wave-uniform */                              \
+            const int yb = rowi & (a.Hm - 1), nb = rowi >> a.lgH;                                           \
+            const int bD = nb * sDn + yb * sDy, bX = nb * sXn + yb * sXy, ybx = yb * a.xsy;                 \
+            _Pragma("unroll") for (int i = 0; i < R; ++i) {                                                 \
+                const bool ok = mcur + lpix + PSTEP * i < m1;                                               \
+                const bool iny = (unsigned)(ybx + cy[i]) < (unsigned)a.Hx;                                  \
+                rd[i] = fg_buffer_load4(drsrc, (ok && okD) ? bD + cD[i] : FG_OOB);                          \
+                rx[i] = fg_buffer_load4(xrsrc, (ok && xin[i] && iny) ? bX + cX[i] : FG_OOB);                \
+            }                                                                                               \
+        } else {                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < R; ++i) {                                                 \
+                const int m = mcur + lpix + PSTEP * i;                                                      \
+                const bool ok = m < m1;                                                                     \
+                int n, y, x;                                                                                \
+                fg_decode_m(ok ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                                 \
+                const int yd = y * a.dsy + doy, xd = x * a.dsx + dox;                                       \
+                const int yx = y * a.xsy + xoy, xx = x * a.xsx + xox;                                       \
+                const int od = (((n * a.Hd + yd) * a.Wd + xd) * a.Nd + chD) * 4;                            \
+                const int ox = (((n * a.Hx + yx) * a.Wx + xx) * a.Cx + chX) * 4;                            \
+                const bool inx = (unsigned)yx < (unsigned)a.Hx && (unsigned)xx < (unsigned)a.Wx;            \
+                rd[i] = fg_buffer_load4(drsrc, (ok && okD) ? od : FG_OOB);                                  \
+                rx[i] = fg_buffer_load4(xrsrc, (ok && okX && inx) ? ox : FG_OOB);                           \
+            }                                                                                               \
         }                                                                                                   \
         mcur += BK;                                                                                         \
     }
