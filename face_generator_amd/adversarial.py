@@ -32,8 +32,11 @@ class Trainer:
         self.optstate = dict(adam=dict(D={}, G={}), sgd=dict(D={}, G={}), adagrad=dict(D={}, G={}))
         self.dist = dist          # torch.distributed module (initialised) or None
         self.world = dist.get_world_size() if dist is not None else 1
+        self.gscale = 1.0 / self.world   # BCE averages over the local batch: global mean = all-reduced sum / world
         self._targets = {}
         self._inputs = {}
+        self._pending_D = None    # (async all-reduce handle, loss) of a D update deferred behind the next G forward
+        self.overlap = True       # N > 1: hide D's gradient all-reduce under the G-step's generator forward
 
     # -- helpers -----------------------------------------------------------------------------
     def _targets_for(self, B, kind):
@@ -66,7 +69,7 @@ class Trainer:
         else:
             # adversarial.lua:109 (D: sign*D_L1) vs :223 (G: sign*G_L2 -- quirk C4, preserved)
             l1_mul = l1 if which == "D" else l2
-        fused = dict(gscale=1.0 / self.world, l1_mul=l1_mul, l2=l2 if (l1 != 0 or l2 != 0) else 0.0, clamp=clamp)
+        fused = dict(gscale=self.gscale, l1_mul=l1_mul, l2=l2 if (l1 != 0 or l2 != 0) else 0.0, clamp=clamp)
         method = o[which + "_optmethod"]
         fn = dict(adam=IO.interruptableAdam, sgd=IO.interruptableSgd, adagrad=IO.interruptableAdagrad)[method]
         fn(lambda x: (f, grads), params, self.optstate[method][which], fused=fused)
@@ -87,6 +90,7 @@ class Trainer:
     def step_D(self, real_nhwc, noise_half, masks=None, keep_grad=False, gate=None):
         """adversarial.lua:240-268 + fevalD (:83-179).  real_nhwc: device [B/2,H,W,C]; noise_half: [B/2,noiseDim].
         gate(accuracy)->bool reproduces the maxAccuracyD interrupt (host sync only when a gate is given)."""
+        self.finish_pending()
         half = real_nhwc.shape[0]
         B = 2 * half
         fake = self.dnG.forward(noise_half, train=True)          # C5: G in TRAIN mode, BN batch stats over B/2
@@ -114,16 +118,32 @@ class Trainer:
             acc = (c[0] + c[3]) / max(1, sum(c))     # [pred0,t0] + [pred1,t1]
             do_train = gate(acc)
         if do_train:
-            self._allreduce(gD)
-            self._update("D", pD, gD, loss)
-            self.dnD.params_changed()
+            if self.world > 1 and self.overlap:
+                # xGMI all-reduce of the 11.45 MB D gradient runs on RCCL's stream while the G-step's generator
+                # forward (no dependency on D's parameters) computes; the update lands before D is next used.
+                work = self.dist.all_reduce(gD, op=self.dist.ReduceOp.SUM, async_op=True)
+                self._pending_D = (work, loss)
+            else:
+                self._allreduce(gD)
+                self._update("D", pD, gD, loss)
+                self.dnD.params_changed()
         res["trained"] = do_train
         return res
+
+    def finish_pending(self):
+        """Complete a deferred D update (wait for its all-reduce, fused Adam, re-pack)."""
+        if self._pending_D is not None:
+            work, loss = self._pending_D
+            self._pending_D = None
+            work.wait()
+            self._update("D", self.dnD.params, self.dnD.grads, loss)
+            self.dnD.params_changed()
 
     def step_G(self, noise, masks=None, keep_grad=False):
         """adversarial.lua:275-288 + fevalG_on_D (:187-231)."""
         B = noise.shape[0]
         samples = self.dnG.forward(noise, train=True)
+        self.finish_pending()                                     # D's update must land before D is evaluated
         targets = self._targets_for(B, "G")
         out = self.dnD.forward(samples, masks=masks, train=True)
         loss, dprob, _ = self.crit.forward_backward_device(self.ctx, out.reshape(-1), targets, want_confusion=False)

@@ -17,6 +17,7 @@ class TrainerC2F(Trainer):
 
     def step_D(self, diff_real, cond_real, noise_half, cond_fake, masks=None, keep_grad=False):
         """adversarial_c2f.lua:123-160 + fevalD (:40-80).  All inputs device NHWC; *_real/*_fake have B/2 rows."""
+        self.finish_pending()
         half = diff_real.shape[0]
         B = 2 * half
         ctx = self.ctx
