@@ -115,6 +115,16 @@ int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const flo
 // gradW_ref = beta*gradW_ref + sum over splits / parities of Part ([P*G][S][Npad][Cpad], n = O, c = I)
 int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,
                            float* gradW);
+// One launch re-packs every layer of a net after an optimizer step.
+struct PackJob {
+    WeightMap wm;
+    int mode;             // 0 forward pack, 1 data-grad pack, 2 thin pack [tap][I][O], 3 thin pack [tap][O][I], 4 bias NCHW->NHWC perm
+    long long src_off;    // offset into the flat parameter vector
+    float* dst;
+    int rows, cols;       // padded tile dims (modes 0/1)
+    long long start, count;
+};
+int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params);
 void fg_fold_window(int k, int pad, int* T, int* rmin);
 static inline int fg_fold_r(int parity, int d, int pad) {  // floor((parity + d - pad)/2)
     int v = parity + d - pad;

@@ -520,6 +520,51 @@ int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const flo
     return FG_OK;
 }
 
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int njobs, long long total,
+                                                        const float* __restrict__ params) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int j = 0;
+    while (j + 1 < njobs && idx >= jobs[j + 1].start) ++j;
+    const PackJob& jb = jobs[j];
+    const long long loc = idx - jb.start;
+    const WeightMap& wm = jb.wm;
+    const float* W = params + jb.src_off;
+    if (jb.mode <= 1) {
+        const int col = (int)(loc % jb.cols);
+        long long t = loc / jb.cols;
+        const int row = (int)(t % jb.rows);
+        const int pg = (int)(t / jb.rows);
+        const int p = pg / wm.G, g = pg - p * wm.G;
+        const int po = jb.mode == 0 ? row : col, pi = jb.mode == 0 ? col : row;
+        float v = 0.f;
+        if (po < wm.O && pi < wm.I) {
+            int o = po, i = pi;
+            if (wm.o_hw > 1) { int hw = po / wm.o_c, c = po - hw * wm.o_c; o = c * wm.o_hw + hw; }
+            if (wm.i_hw > 1) { int hw = pi / wm.i_c, c = pi - hw * wm.i_c; i = c * wm.i_hw + hw; }
+            v = packed_weight_value(wm, W, p, g, o, i);
+        }
+        jb.dst[loc] = v;
+    } else if (jb.mode <= 3) {   // thin layouts [tap][s][c]
+        const int kk = wm.k * wm.k;
+        const int Cs = jb.mode == 2 ? wm.I : wm.O, Cw = jb.mode == 2 ? wm.O : wm.I;
+        const int c = (int)(loc % Cw);
+        const int t = (int)(loc / Cw);
+        const int sidx = t % Cs, tap = t / Cs;
+        const int o = jb.mode == 2 ? c : sidx, i = jb.mode == 2 ? sidx : c;
+        jb.dst[loc] = W[((size_t)o * wm.I + i) * kk + tap];
+    } else {                     // bias: packed[hw*C + c] = ref[c*HW + hw]
+        const int c = (int)(loc % wm.o_c), hw = (int)(loc / wm.o_c);
+        jb.dst[loc] = W[(size_t)c * wm.o_hw + hw];
+    }
+}
+int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params) {
+    if (total == 0 || njobs == 0) return FG_OK;
+    hipLaunchKernelGGL(pack_jobs_kernel, dim3(fg_cdiv(total, 256)), dim3(256), 0, ctx->stream, jobs_dev, njobs, total, params);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
 __global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
                                     float beta, float* __restrict__ gradW) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;  // packed in-channel (coalesced partial reads)

@@ -67,6 +67,10 @@ struct fg_net {
     const float* const* masks = nullptr;
     std::vector<const float*> mask_ptrs;
     int last_train = 1;
+    // one-launch weight re-pack
+    PackJob* jobs_dev = nullptr;
+    int n_jobs = 0;
+    long long jobs_total = 0;
 };
 
 static inline long long align64(long long v) { return (v + 63) / 64 * 64; }
@@ -108,6 +112,8 @@ static void make_plan(fg_net* n, int B) {
     n->total_floats = off;
     n->plan_batch = B;
 }
+
+static int build_pack_jobs(fg_net* n);
 
 extern "C" {
 #pragma GCC visibility push(default)
@@ -280,6 +286,7 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
                 rc = fg_set_err(ctx, FG_ERR_NOMEM, "fg_net_create: packed weights");
         }
     }
+    if (rc == FG_OK) rc = build_pack_jobs(n);
     if (rc != FG_OK) { fg_net_destroy(n); return rc; }
     *out = n;
     return FG_OK;
@@ -292,6 +299,7 @@ int fg_net_destroy(fg_net* n) {
         if (s.wp_bwd) (void)hipFree(s.wp_bwd);
         if (s.bias_packed) (void)hipFree(s.bias_packed);
     }
+    if (n->jobs_dev) (void)hipFree(n->jobs_dev);
     delete n;
     return FG_OK;
 }
@@ -333,21 +341,41 @@ int fg_net_params_changed(fg_net* n) {
     return FG_OK;
 }
 
-static int pack_all(fg_net* n) {
-    fg_ctx* ctx = n->ctx;
-    int rc;
+static int build_pack_jobs(fg_net* n) {
+    std::vector<PackJob> jobs;
+    long long start = 0;
+    auto add = [&](const WeightMap& wm, int mode, long long src, float* dst, int rows, int cols, long long count) {
+        PackJob j; memset(&j, 0, sizeof(j));
+        j.wm = wm; j.mode = mode; j.src_off = src; j.dst = dst; j.rows = rows; j.cols = cols; j.start = start; j.count = count;
+        jobs.push_back(j);
+        start += count;
+    };
     for (auto& s : n->st) {
         if (s.kind == ST_CONV) {
             ConvGeom g = s.geom; g.B = 1;
-            if ((rc = fg_conv_pack(ctx, g, n->params + s.w_off, s.wp_fwd, s.wp_bwd))) return rc;
-            if (s.bias_packed &&
-                (rc = fg_launch_nchw_to_nhwc(ctx, n->params + s.b_off, s.bias_packed, 1, g.o_c, g.o_hw, 1))) return rc;
-        } else if (s.kind == ST_THIN_IN) {
-            if ((rc = fg_launch_thin_pack(ctx, n->params + s.w_off, s.wp_fwd, s.geom.Cout, s.geom.Cin, s.geom.k, 0))) return rc;
-        } else if (s.kind == ST_THIN_OUT) {
-            if ((rc = fg_launch_thin_pack(ctx, n->params + s.w_off, s.wp_fwd, s.geom.Cout, s.geom.Cin, s.geom.k, 1))) return rc;
+            WeightMap wm; fg_geom_weightmap(g, &wm);
+            int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
+            add(wm, 0, s.w_off, s.wp_fwd, rf, cf, (long long)wm.P * wm.G * rf * cf);
+            add(wm, 1, s.w_off, s.wp_bwd, rb, cb, (long long)wm.P * wm.G * rb * cb);
+            if (s.bias_packed) add(wm, 4, s.b_off, s.bias_packed, 0, 0, s.b_n);
+        } else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT) {
+            WeightMap wm; memset(&wm, 0, sizeof(wm));
+            wm.O = s.geom.Cout; wm.I = s.geom.Cin; wm.k = s.geom.k;
+            add(wm, s.kind == ST_THIN_IN ? 2 : 3, s.w_off, s.wp_fwd, 0, 0, s.w_n);
         }
     }
+    n->n_jobs = (int)jobs.size();
+    n->jobs_total = start;
+    if (jobs.empty()) return FG_OK;
+    if (hipMalloc((void**)&n->jobs_dev, jobs.size() * sizeof(PackJob)) != hipSuccess)
+        return fg_set_err(n->ctx, FG_ERR_NOMEM, "fg_net_create: pack jobs");
+    FG_HIP(n->ctx, hipMemcpy(n->jobs_dev, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+    return FG_OK;
+}
+
+static int pack_all(fg_net* n) {
+    int rc = fg_launch_pack_jobs(n->ctx, n->jobs_dev, n->n_jobs, n->jobs_total, n->params);
+    if (rc) return rc;
     n->dirty = false;
     return FG_OK;
 }

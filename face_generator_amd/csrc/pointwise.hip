@@ -121,6 +121,45 @@ __device__ __forceinline__ void colreduce_body(long long M, int C, float* __rest
     }
 }
 
+// float4 variant: thread = 4 consecutive channels x one row lane; needs C % 4 == 0 and 256 % (C/4) == 0 (C <= 1024).
+// 16 B per lane per load (1 KiB per wave instruction), rows of a block reduced through LDS.
+static inline bool cr4_ok(int C) { return C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0; }
+template <int K, class F>
+__device__ __forceinline__ void colreduce4_body(long long M, int C, float* __restrict__ part, F f) {
+    __shared__ float4 sh4[K][256];
+    const int c4n = C >> 2;
+    const int cx = threadIdx.x % c4n, ry = threadIdx.x / c4n, RY = 256 / c4n;
+    const int nrb = gridDim.x;
+    const long long rows_per = (M + nrb - 1) / nrb;
+    const long long r0 = blockIdx.x * rows_per;
+    const long long r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
+    float4 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long r = r0 + ry; r < r1; r += RY) f(r, cx, acc);
+#pragma unroll
+    for (int k = 0; k < K; ++k) sh4[k][threadIdx.x] = acc[k];
+    __syncthreads();
+    if (ry == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float4 t = sh4[k][cx];
+            for (int j = 1; j < RY; ++j) {
+                const float4 u = sh4[k][j * c4n + cx];
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            *(float4*)(part + ((size_t)k * nrb + blockIdx.x) * C + cx * 4) = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum4_partial_kernel(const float* __restrict__ x, long long M, int C,
+                                                              float* __restrict__ part) {
+    colreduce4_body<1>(M, C, part, [&](long long r, int cx, float4* acc) {
+        const float4 v = *((const float4*)(x + r * C) + cx);
+        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+    });
+}
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, long long M, int C,
                                                              float* __restrict__ part) {
     colreduce_body<1>(M, C, part, [&](long long r, int c, float* acc) { acc[0] += x[r * C + c]; });
@@ -150,7 +189,10 @@ int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float
 }
 int fg_launch_colsum(fg_ctx* ctx, const float* x, long long M, int N, float beta, float* out, float* scratch) {
     const int nrb = cr_rowblocks(M);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nrb, fg_cdiv(N, 64)), dim3(256), 0, ctx->stream, x, M, N, scratch);
+    if (cr4_ok(N))
+        hipLaunchKernelGGL(colsum4_partial_kernel, dim3(nrb), dim3(256), 0, ctx->stream, x, M, N, scratch);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(nrb, fg_cdiv(N, 64)), dim3(256), 0, ctx->stream, x, M, N, scratch);
     FG_CHECK_LAUNCH(ctx);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(N, 64)), dim3(1024), 0, ctx->stream, scratch, nrb, N, beta, out);
     FG_CHECK_LAUNCH(ctx);
@@ -171,6 +213,17 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
         const float d = x[r * C + c] - x[c];
         acc[0] += d;
         acc[1] = fmaf(d, d, acc[1]);
+    });
+}
+__global__ __launch_bounds__(256) void bn_stats4_partial_kernel(const float* __restrict__ x, long long M, int C,
+                                                                float* __restrict__ part) {
+    const float4 piv = *((const float4*)x + threadIdx.x % (C >> 2));
+    colreduce4_body<2>(M, C, part, [&](long long r, int cx, float4* acc) {
+        const float4 v = *((const float4*)(x + r * C) + cx);
+        const float dx = v.x - piv.x, dy = v.y - piv.y, dz = v.z - piv.z, dw = v.w - piv.w;
+        acc[0].x += dx; acc[0].y += dy; acc[0].z += dz; acc[0].w += dw;
+        acc[1].x = fmaf(dx, dx, acc[1].x); acc[1].y = fmaf(dy, dy, acc[1].y);
+        acc[1].z = fmaf(dz, dz, acc[1].z); acc[1].w = fmaf(dw, dw, acc[1].w);
     });
 }
 __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ part, const float* __restrict__ x,
@@ -211,17 +264,19 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rmean, const floa
     mean[c] = rmean[c];
     invstd[c] = (float)(1.0 / sqrt((double)rvar[c] + (double)eps));
 }
+// apply: the grid is sized so that (gridDim * 256 * 4) % C == 0 -> a thread always owns the same 4 channels and keeps
+// their statistics / affine parameters in registers
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                        long long total4, int C, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ slope,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd) {
     const float a = slope ? slope[0] : 1.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)((i0 * 4) % C);
+    const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    for (long long i = i0; i < total4; i += (long long)gridDim.x * blockDim.x) {
         float4 v = ((const float4*)x)[i];
-        const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
-        const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
         float z;
         z = bn_z(v.x, mu.x, is.x, g.x, b.x); v.x = z > 0.f ? z : a * z;
         z = bn_z(v.y, mu.y, is.y, g.y, b.y); v.y = z > 0.f ? z : a * z;
@@ -230,12 +285,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         ((float4*)y)[i] = v;
     }
 }
+// grid with (blocks * 1024) % C == 0 (C % 4 == 0): blocks = multiple of C / gcd(C, 1024)
+static inline int bn_apply_blocks(long long total4, int C) {
+    int g = 1024, t = C;
+    while (t) { int r = g % t; g = t; t = r; }       // g = gcd(1024, C)
+    const int unit = C / g;
+    long long want = (total4 + 255) / 256;
+    if (want > 4096) want = 4096;
+    long long blocks = (want + unit - 1) / unit * unit;
+    return (int)(blocks < unit ? unit : blocks);
+}
 int fg_launch_bn_forward(fg_ctx* ctx, const BnArgs& a) {
     if (a.C % 4) return fg_set_err(ctx, FG_ERR_INVALID, "bn: C %% 4");
     if (a.train) {
         const int nrb = cr_rowblocks(a.M);
-        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nrb, fg_cdiv(a.C, 64)), dim3(256), 0, ctx->stream, a.x, a.M,
-                           a.C, a.scratch);
+        if (cr4_ok(a.C))
+            hipLaunchKernelGGL(bn_stats4_partial_kernel, dim3(nrb), dim3(256), 0, ctx->stream, a.x, a.M, a.C, a.scratch);
+        else
+            hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nrb, fg_cdiv(a.C, 64)), dim3(256), 0, ctx->stream, a.x, a.M,
+                               a.C, a.scratch);
         FG_CHECK_LAUNCH(ctx);
         hipLaunchKernelGGL(bn_stats_final_kernel, dim3(fg_cdiv(a.C, 64)), dim3(1024), 0, ctx->stream, a.scratch, a.x,
                            nrb, a.M, a.C, a.eps, a.momentum, a.mean, a.invstd, a.running_mean, a.running_var);
@@ -246,8 +314,8 @@ int fg_launch_bn_forward(fg_ctx* ctx, const BnArgs& a) {
         FG_CHECK_LAUNCH(ctx);
     }
     const long long t4 = a.M * a.C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, FG_GRID(t4, 256), dim3(256), 0, ctx->stream, a.x, a.y, t4, a.C, a.gamma,
-                       a.beta, a.slope, a.mean, a.invstd);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.y, t4, a.C,
+                       a.gamma, a.beta, a.slope, a.mean, a.invstd);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
@@ -268,6 +336,31 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         acc[0] += dz;
         acc[1] = fmaf(dz, xh, acc[1]);
         if (!(z > 0.f)) acc[2] = fmaf(z, g, acc[2]);
+    });
+}
+__global__ __launch_bounds__(256) void bn_bwd4_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                              long long M, int C, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ slope,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* __restrict__ part) {
+    const float a = slope ? slope[0] : 1.f;
+    const int cq = (threadIdx.x % (C >> 2)) * 4;
+    const float4 mu = *(const float4*)(mean + cq), is = *(const float4*)(invstd + cq);
+    const float4 g4 = *(const float4*)(gamma + cq), b4 = *(const float4*)(beta + cq);
+    colreduce4_body<3>(M, C, part, [&](long long r, int cx, float4* acc) {
+        const float4 xv = *((const float4*)(x + r * C) + cx), gv = *((const float4*)(gy + r * C) + cx);
+#define FG_BNB(f)                                                                       \
+        {                                                                               \
+            const float xh = bn_xhat(xv.f, mu.f, is.f);                                 \
+            const float z = __fadd_rn(__fmul_rn(xh, g4.f), b4.f);                       \
+            const float dz = z > 0.f ? gv.f : a * gv.f;                                 \
+            acc[0].f += dz;                                                             \
+            acc[1].f = fmaf(dz, xh, acc[1].f);                                          \
+            if (!(z > 0.f)) acc[2].f = fmaf(z, gv.f, acc[2].f);                         \
+        }
+        FG_BNB(x) FG_BNB(y) FG_BNB(z) FG_BNB(w)
+#undef FG_BNB
     });
 }
 // scratch layout: part[3][nrb][C], then coef[2][C]
@@ -315,21 +408,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
                                                            int train) {
     const float a = slope ? slope[0] : 1.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)((i * 4) % C);
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)((i0 * 4) % C);
+    const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+    const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    const float4 m1 = *(const float4*)(coef + c), m2 = *(const float4*)(coef + C + c);
+    for (long long i = i0; i < total4; i += (long long)gridDim.x * blockDim.x) {
         const float4 xv = ((const float4*)x)[i], gv = ((const float4*)gy)[i];
-        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float is = invstd[c + j], g = gamma[c + j];
-            const float xh = bn_xhat(xs[j], mean[c + j], is);
-            const float z = __fadd_rn(__fmul_rn(xh, g), beta[c + j]);
-            const float dz = z > 0.f ? gs[j] : a * gs[j];
-            o[j] = train ? g * is * (dz - coef[c + j] - xh * coef[C + c + j]) : g * is * dz;
+        float4 o;
+#define FG_BNA(f)                                                                                   \
+        {                                                                                           \
+            const float xh = bn_xhat(xv.f, mu.f, is.f);                                             \
+            const float z = __fadd_rn(__fmul_rn(xh, g.f), b.f);                                     \
+            const float dz = z > 0.f ? gv.f : a * gv.f;                                             \
+            o.f = train ? g.f * is.f * (dz - m1.f - xh * m2.f) : g.f * is.f * dz;                   \
         }
-        ((float4*)gx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+        FG_BNA(x) FG_BNA(y) FG_BNA(z) FG_BNA(w)
+#undef FG_BNA
+        ((float4*)gx)[i] = o;
     }
 }
 int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
@@ -338,8 +434,12 @@ int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
     const int ncb = fg_cdiv(a.C, 64);
     float* part = a.scratch;
     float* coef = a.scratch + (size_t)3 * nrb * a.C;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb, ncb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
-                       a.beta, a.slope, a.mean, a.invstd, part);
+    if (cr4_ok(a.C))
+        hipLaunchKernelGGL(bn_bwd4_partial_kernel, dim3(nrb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
+                           a.beta, a.slope, a.mean, a.invstd, part);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb, ncb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
+                           a.beta, a.slope, a.mean, a.invstd, part);
     FG_CHECK_LAUNCH(ctx);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fg_cdiv(a.C, 64)), dim3(1024), 0, ctx->stream, part, nrb, a.M, a.C,
                        coef, a.ggamma, a.gbeta, a.gbeta_acc);
@@ -351,7 +451,7 @@ int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
     }
     if (a.gx) {
         const long long t4 = a.M * a.C / 4;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, FG_GRID(t4, 256), dim3(256), 0, ctx->stream, a.x, a.gy, a.gx, t4, a.C,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.gy, a.gx, t4, a.C,
                            a.gamma, a.beta, a.slope, a.mean, a.invstd, coef, 1);
         FG_CHECK_LAUNCH(ctx);
     }
