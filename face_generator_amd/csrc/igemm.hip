@@ -13,7 +13,6 @@
 // 32-row fragment feeds 4 MFMAs (k = kk+j for lanes<32, kk+4+j for lanes>=32 -- same permutation on A and B).
 #include "fg_internal.h"
 #include <stdio.h>
-#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -39,7 +38,7 @@ __device__ __forceinline__ f32x4 fg_buffer_load4(__amdgpu_buffer_rsrc_t r, int v
 }
 
 template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256, (BK == 16 ? 3 : 2)) void igemm_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     constexpr int LDK = BK + 4;                 // padded row: conflict-free ds_read_b128 fragment reads
     constexpr int LPR = BK / 4;                 // lanes (float4) per tile row
     constexpr int RPP = 256 / LPR;              // rows per load pass
@@ -236,14 +235,10 @@ int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
     if (a.Ca % 4 != 0 || a.Kpad % 32 != 0) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: Ca %% 4 / Kpad %% 32");
     if (a.a_bytes <= 0 || a.a_bytes >= (long long)FG_OOB) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "igemm: A operand of %lld bytes (must be < 2 GiB per launch)", a.a_bytes);
     if (a.G > FG_MAX_GROUPS || P > 4 || a.splits < 1) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: G/P/splits");
-    static int force = -2;
-    if (force == -2) { const char* e = getenv("FG_IGEMM_TILE"); force = e ? atoi(e) : -1; }   // tuning aid
-    if (force >= 0 && tile == 0) tile = force;
     switch (tile) {
         case 0: if (a.Npad % 128) break; return launch_igemm_t<128, 128, 32>(ctx, a, P);
         case 1: if (a.Npad % 64) break; return launch_igemm_t<128, 64, 32>(ctx, a, P);
         case 2: if (a.Npad % 64) break; return launch_igemm_t<64, 64, 32>(ctx, a, P);
-        case 3: if (a.Npad % 128) break; return launch_igemm_t<128, 128, 16>(ctx, a, P);
     }
     return fg_set_err(ctx, FG_ERR_INVALID, "igemm: bad tile %d for Npad %d", tile, a.Npad);
 }
