@@ -292,6 +292,7 @@ int fg_linear_forward(fg_ctx* ctx, const float* x, const float* wt, const float*
 int fg_linear_backward_data(fg_ctx* ctx, const float* gy, const float* wt, float* gx, int batch, int in_f, int out_f,
                             void* wsv, size_t ws_bytes) {
     NEED(ctx, ctx && gy && wt && gx && wsv, "null argument");
+    if (out_f == 1) return fg_launch_gemv_backward(ctx, nullptr, wt, nullptr, gy, gx, nullptr, nullptr, 0.f, batch, in_f, 0);
     if (out_f % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "linear dgrad: out_features %% 4 != 0");
     if (ws_bytes < fg_linear_workspace_bytes(batch, in_f, out_f)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "linear: workspace");
     ConvGeom g = mk_geom(batch, 1, 1, in_f, out_f, 1, 0, 0);
@@ -304,6 +305,7 @@ int fg_linear_backward_data(fg_ctx* ctx, const float* gy, const float* wt, float
 int fg_linear_backward_weight(fg_ctx* ctx, const float* x, const float* gy, float* gw, float* gb, float beta, int batch,
                               int in_f, int out_f, void* wsv, size_t ws_bytes) {
     NEED(ctx, ctx && x && gy && gw && wsv, "null argument");
+    if (out_f == 1) return fg_launch_gemv_backward(ctx, x, gw /*unused as w*/, nullptr, gy, nullptr, gw, gb, beta, batch, in_f, 0);
     if (in_f % 4 || out_f % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "linear wgrad: features %% 4 != 0");
     if (ws_bytes < fg_linear_workspace_bytes(batch, in_f, out_f)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "linear: workspace");
     ConvGeom g = mk_geom(batch, 1, 1, in_f, out_f, 1, 0, 0);

@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__
     extern __shared__ float dl[];  // [B]
     __shared__ float sh[4];
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const float v = y[b];
+        const float v = sigmoid ? y[b] : 0.f;
         dl[b] = sigmoid ? gy[b] * v * (1.f - v) : gy[b];
     }
     __syncthreads();
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__
         float s = 0.f;
         const float wk = w[k];
         for (int b = 0; b < B; ++b) {
-            s = fmaf(dl[b], x[(size_t)b * K + k], s);
+            if (gw) s = fmaf(dl[b], x[(size_t)b * K + k], s);
             if (gx) gx[(size_t)b * K + k] = dl[b] * wk;
         }
         if (gw) gw[k] = (acc == 0.f ? 0.f : acc * gw[k]) + s;

@@ -35,8 +35,34 @@ class Module:
         self.train = False
         return self
 
+    # ---- nn.Module protocol on DEVICE tensors (internal NHWC layout), one C entry per call (SURVEY 8(b) level i) ----
+    def _dev(self, x):
+        if not (torch.is_tensor(x) and x.is_cuda):
+            raise FgError("%s: module-level calls take device (NHWC) tensors -- go through nn.Copy / "
+                          "Sequential:forward for host tensors; there is no CPU path" % self._typename)
+        return x.contiguous()
+
+    def updateOutput(self, input):
+        raise FgError("%s:updateOutput is not built" % self._typename)
+
+    def updateGradInput(self, input, gradOutput):
+        raise FgError("%s:updateGradInput is not built" % self._typename)
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        pass
+
     def forward(self, x):
-        raise FgError("%s: module-level forward needs the net on the device (use Sequential:cuda())" % self._typename)
+        return self.updateOutput(x)
+
+    def backward(self, input, gradOutput, scale=1.0):
+        gi = self.updateGradInput(input, gradOutput)
+        self.accGradParameters(input, gradOutput, scale)
+        return gi
+
+    def zeroGradParameters(self):
+        for n in ("gradWeight", "gradBias"):
+            if getattr(self, n, None) is not None:
+                getattr(self, n).zero_()
 
     def __repr__(self):
         return self._typename
@@ -60,6 +86,21 @@ class Linear(Module):
     def spec(self):
         return ("LINEAR", self.weight.shape[1], self.weight.shape[0])
 
+    def updateOutput(self, input):
+        from . import ops
+        self.output = ops.linear_forward(self._dev(input), self.weight, self.bias)
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from . import ops
+        self.gradInput = ops.linear_backward_data(self._dev(gradOutput), self.weight)
+        return self.gradInput
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        from . import ops
+        gy = self._dev(gradOutput) if scale == 1.0 else self._dev(gradOutput) * scale
+        ops.linear_backward_weight(self._dev(input), gy, gw=self.gradWeight, gb=self.gradBias, beta=1.0)
+
     def __repr__(self):
         return "nn.Linear(%d -> %d)" % (self.weight.shape[1], self.weight.shape[0])
 
@@ -78,6 +119,35 @@ class View(Module):
             return ("VIEW", self.sizes[0], 0, 0)
         raise FgError("nn.View: only View(C,H,W) and View(features) are supported")
 
+    def updateOutput(self, input):
+        """The reference reshapes NCHW-contiguous memory; device tensors are NHWC, so a View between a feature
+        vector (NCHW flatten order) and a spatial tensor is a real permutation here."""
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        x = self._dev(input)
+        B = x.shape[0]
+        if len(self.sizes) == 3 and x.dim() == 2:
+            c, h, w = self.sizes
+            self.output = ctx.to_device_nhwc(x.view(B, c, h, w))
+        elif len(self.sizes) == 1 and x.dim() == 4:
+            self.output = ctx.to_nchw(x).view(B, -1)
+        else:
+            self.output = x.view((B,) + self.sizes)
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        g = self._dev(gradOutput)
+        if input.dim() == 2 and g.dim() == 4:
+            self.gradInput = ctx.to_nchw(g).view(input.shape)
+        elif input.dim() == 4 and g.dim() == 2:
+            B, h, w, c = input.shape
+            self.gradInput = ctx.to_device_nhwc(g.view(B, c, h, w))
+        else:
+            self.gradInput = g.view(input.shape)
+        return self.gradInput
+
     def __repr__(self):
         return "nn.View(%s)" % ", ".join(map(str, self.sizes))
 
@@ -93,6 +163,22 @@ class PReLU(Module):
     def spec(self):
         return ("PRELU",)
 
+    def updateOutput(self, input):
+        from . import ops
+        self.output = ops.prelu_forward(self._dev(input), self.weight)
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from . import ops
+        self.gradInput, self._gs = ops.prelu_backward(self._dev(input), self._dev(gradOutput), self.weight)
+        return self.gradInput
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        if getattr(self, "_gs", None) is None:
+            self.updateGradInput(input, gradOutput)
+        self.gradWeight.add_(self._gs, alpha=scale)
+        self._gs = None
+
 
 class LeakyReLU(Module):
     """LeakyReLU.lua:7-31."""
@@ -105,6 +191,22 @@ class LeakyReLU(Module):
     def spec(self):
         return ("LEAKYRELU", 0, 0, 0, 0, self.negval)
 
+    def updateOutput(self, input):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        x = self._dev(input)
+        self.output = torch.empty_like(x)
+        ctx.check(ctx.lib.fg_leakyrelu_forward(ctx.h, x.data_ptr(), self.negval, self.output.data_ptr(), x.numel()))
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        x, g = self._dev(input), self._dev(gradOutput)
+        self.gradInput = torch.empty_like(x)
+        ctx.check(ctx.lib.fg_leakyrelu_backward(ctx.h, x.data_ptr(), g.data_ptr(), self.negval, self.gradInput.data_ptr(), x.numel()))
+        return self.gradInput
+
 
 class SpatialUpSamplingNearest(Module):
     _typename = "nn.SpatialUpSamplingNearest"
@@ -116,6 +218,24 @@ class SpatialUpSamplingNearest(Module):
 
     def spec(self):
         return ("UPSAMPLE2X",)
+
+    def updateOutput(self, input):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        x = self._dev(input)
+        B, H, W, C = x.shape
+        self.output = ctx.empty(B, 2 * H, 2 * W, C)
+        ctx.check(ctx.lib.fg_upsample_nearest2x_forward(ctx.h, x.data_ptr(), self.output.data_ptr(), B, H, W, C))
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        B, H, W, C = input.shape
+        g = self._dev(gradOutput)
+        self.gradInput = ctx.empty(B, H, W, C)
+        ctx.check(ctx.lib.fg_upsample_nearest2x_backward(ctx.h, g.data_ptr(), self.gradInput.data_ptr(), B, H, W, C))
+        return self.gradInput
 
 
 class SpatialConvolution(Module):
@@ -136,6 +256,21 @@ class SpatialConvolution(Module):
 
     def spec(self):
         return ("CONV", self.nInputPlane, self.nOutputPlane, self.kW, self.padW)
+
+    def updateOutput(self, input):
+        from . import ops
+        self.output = ops.conv2d_forward(self._dev(input), self.weight, self.bias, pad=self.padW)
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from . import ops
+        self.gradInput = ops.conv2d_backward_data(self._dev(gradOutput), self.weight, tuple(input.shape[1:3]), pad=self.padW)
+        return self.gradInput
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        from . import ops
+        gy = self._dev(gradOutput) if scale == 1.0 else self._dev(gradOutput) * scale
+        ops.conv2d_backward_weight(self._dev(input), gy, self.kW, pad=self.padW, gw=self.gradWeight, gb=self.gradBias, beta=1.0)
 
     def __repr__(self):
         return "%s(%d -> %d, %dx%d, 1,1, %d,%d)" % (self._typename, self.nInputPlane, self.nOutputPlane, self.kW,
@@ -158,6 +293,28 @@ class SpatialBatchNormalization(Module):
     def spec(self):
         return ("BATCHNORM", self.nFeature, 0, 0, 0, self.eps, self.momentum)
 
+    def updateOutput(self, input):
+        from . import ops
+        self.output, self.save_mean, self.save_invstd = ops.batchnorm_forward(
+            self._dev(input), self.weight, self.bias, None, self.running_mean, self.running_var, self.eps, self.momentum,
+            train=self.train)
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from . import ops
+        if not self.train:
+            raise FgError("nn.SpatialBatchNormalization: backward in evaluate mode is not built")
+        self.gradInput, self._gg, self._gb, _ = ops.batchnorm_backward(self._dev(input), self._dev(gradOutput), self.weight,
+                                                                        self.bias, self.save_mean, self.save_invstd)
+        return self.gradInput
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        if getattr(self, "_gg", None) is None:
+            self.updateGradInput(input, gradOutput)
+        self.gradWeight.add_(self._gg, alpha=scale)
+        self.gradBias.add_(self._gb, alpha=scale)
+        self._gg = None
+
 
 class SpatialDropout(Module):
     _typename = "nn.SpatialDropout"
@@ -169,6 +326,37 @@ class SpatialDropout(Module):
     def spec(self):
         return ("SPATIAL_DROPOUT", 0, 0, 0, 0, self.p)
 
+    def _apply(self, x, train):
+        from .runtime import get_context
+        ctx = get_context(x.device.index)
+        B, H, W, C = x.shape
+        y = torch.empty_like(x)
+        ctx.check(ctx.lib.fg_spatial_dropout_apply(ctx.h, x.data_ptr(), self.noise.data_ptr() if train else None,
+                                                   1.0 if train else 1.0 - self.p, y.data_ptr(), B, H * W, C))
+        return y
+
+    def updateOutput(self, input):
+        from .runtime import get_context
+        x = self._dev(input)
+        if self.train and getattr(self, "_injected", None) is None:
+            ctx = get_context(x.device.index)
+            self._seed = getattr(self, "_seed", 0) + 1
+            self.noise = ctx.bernoulli((x.shape[0] * x.shape[3],), 1.0 - self.p, 7919, self._seed * 65536)
+        elif self.train:
+            self.noise = self._injected
+        self.output = self._apply(x, self.train)
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        if not self.train:
+            raise FgError("nn.SpatialDropout: backward is an error in evaluate mode (upstream)")
+        self.gradInput = self._apply(self._dev(gradOutput), True)
+        return self.gradInput
+
+    def set_mask(self, mask_dev):
+        """Inject the [B][C] keep mask (reproducible runs / parity tests)."""
+        self._injected = mask_dev.contiguous().reshape(-1)
+
 
 class Dropout(Module):
     _typename = "nn.Dropout"
@@ -179,6 +367,33 @@ class Dropout(Module):
 
     def spec(self):
         return ("DROPOUT", 0, 0, 0, 0, self.p)
+
+    def _apply(self, x, train):
+        from .runtime import get_context
+        ctx = get_context(x.device.index)
+        y = torch.empty_like(x)
+        ctx.check(ctx.lib.fg_dropout_apply(ctx.h, x.data_ptr(), self.noise.data_ptr() if train else None,
+                                           1.0 / (1.0 - self.p) if train else 1.0, y.data_ptr(), x.numel()))
+        return y
+
+    def updateOutput(self, input):
+        from .runtime import get_context
+        x = self._dev(input)
+        if self.train and getattr(self, "_injected", None) is None:
+            ctx = get_context(x.device.index)
+            self._seed = getattr(self, "_seed", 0) + 1
+            self.noise = ctx.bernoulli((x.numel(),), 1.0 - self.p, 7907, self._seed * 1048576)
+        elif self.train:
+            self.noise = self._injected
+        self.output = self._apply(x, self.train)
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        self.gradInput = self._apply(self._dev(gradOutput), self.train)
+        return self.gradInput
+
+    def set_mask(self, mask_dev):
+        self._injected = mask_dev.contiguous().reshape(-1)
 
 
 class SpatialAveragePooling(Module):
@@ -192,6 +407,23 @@ class SpatialAveragePooling(Module):
     def spec(self):
         return ("AVGPOOL2",)
 
+    def updateOutput(self, input):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        x = self._dev(input)
+        B, H, W, C = x.shape
+        self.output = ctx.empty(B, H // 2, W // 2, C)
+        ctx.check(ctx.lib.fg_avgpool2x2_forward(ctx.h, x.data_ptr(), self.output.data_ptr(), B, H, W, C))
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        B, H, W, C = input.shape
+        self.gradInput = ctx.empty(B, H, W, C)
+        ctx.check(ctx.lib.fg_avgpool2x2_backward(ctx.h, self._dev(gradOutput).data_ptr(), self.gradInput.data_ptr(), B, H, W, C))
+        return self.gradInput
+
 
 class SpatialMaxPooling(Module):
     """nn.SpatialMaxPooling(2,2) (models_c2f.lua:251, 256)."""
@@ -204,6 +436,25 @@ class SpatialMaxPooling(Module):
 
     def spec(self):
         return ("MAXPOOL2",)
+
+    def updateOutput(self, input):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        x = self._dev(input)
+        B, H, W, C = x.shape
+        self.output = ctx.empty(B, H // 2, W // 2, C)
+        ctx.check(ctx.lib.fg_maxpool2x2_forward(ctx.h, x.data_ptr(), self.output.data_ptr(), B, H, W, C))
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        x = self._dev(input)
+        B, H, W, C = x.shape
+        self.gradInput = ctx.empty(B, H, W, C)
+        ctx.check(ctx.lib.fg_maxpool2x2_backward(ctx.h, x.data_ptr(), self._dev(gradOutput).data_ptr(),
+                                                 self.gradInput.data_ptr(), B, H, W, C))
+        return self.gradInput
 
 
 class SpatialConvolutionUpsample(SpatialConvolution):
@@ -241,6 +492,22 @@ class Sigmoid(Module):
     def spec(self):
         return ("SIGMOID",)
 
+    def updateOutput(self, input):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        x = self._dev(input)
+        self.output = torch.empty_like(x)
+        ctx.check(ctx.lib.fg_sigmoid_forward(ctx.h, x.data_ptr(), self.output.data_ptr(), x.numel()))
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from .runtime import get_context
+        ctx = get_context(input.device.index)
+        g = self._dev(gradOutput)
+        self.gradInput = torch.empty_like(g)
+        ctx.check(ctx.lib.fg_sigmoid_backward(ctx.h, self.output.data_ptr(), g.data_ptr(), self.gradInput.data_ptr(), g.numel()))
+        return self.gradInput
+
 
 class Copy(Module):
     """nn.Copy(inType, outType): the host<->device (and NCHW<->NHWC) boundary of NN_UTILS.activateCuda."""
@@ -249,6 +516,21 @@ class Copy(Module):
     def __init__(self, intype, outtype):
         super().__init__()
         self.intype, self.outtype = intype, outtype
+
+    def updateOutput(self, input):
+        from .runtime import get_context
+        ctx = get_context()
+        if self.outtype.startswith("hip"):
+            self.output = ctx.to_device_nhwc(input)
+        else:
+            self.output = ctx.to_nchw(input).cpu()
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        from .runtime import get_context
+        ctx = get_context()
+        self.gradInput = ctx.to_nchw(gradOutput).cpu() if self.outtype.startswith("hip") else ctx.to_device_nhwc(gradOutput)
+        return self.gradInput
 
     def __repr__(self):
         return "nn.Copy(%s -> %s)" % (self.intype, self.outtype)
@@ -399,6 +681,26 @@ class Sequential(Module):
         if self is not inner:
             self.modules[0].gradInput = self.gradInput   # adversarial.lua:210 reads MODEL_D.modules[1].gradInput
         return self.gradInput
+
+    # ---- module-by-module execution (nn.Sequential:updateOutput / :backward of upstream nn): one C entry per module
+    #      call, no fusion.  Same results as the compiled plan; used for per-module access and as a cross-check.
+    def forward_modules(self, x_dev):
+        self._mod_inputs = []
+        for m in self.modules:
+            self._mod_inputs.append(x_dev)
+            x_dev = m.updateOutput(x_dev)
+        self.output = x_dev
+        return x_dev
+
+    def backward_modules(self, gy_dev, scale=1.0):
+        for m, xi in zip(reversed(self.modules), reversed(self._mod_inputs)):
+            gy_dev = m.backward(xi, gy_dev, scale)
+        self.gradInput = gy_dev
+        return gy_dev
+
+    def zeroGradParameters(self):
+        for m in self.modules:
+            m.zeroGradParameters()
 
     def __repr__(self):
         lines = ["nn.Sequential {"]
