@@ -476,11 +476,18 @@ __device__ __forceinline__ float packed_weight_value(const WeightMap& wm, const 
     const float* w = W + ((size_t)o * wm.I + i) * kk;
     if (wm.kind == 0) return w[g];
     const int py = p >> 1, px = p & 1, ty = g / wm.T, tx = g - ty * wm.T;
+    // source offset r = t + rmin collects the taps d with floor((parity + d - pad)/2) == r, i.e. d in {2r-parity+pad, +1}
+    const int dy0 = 2 * (ty + wm.rmin) - py + wm.pad, dx0 = 2 * (tx + wm.rmin) - px + wm.pad;
     float s = 0.f;
-    for (int dy = 0; dy < wm.k; ++dy) {
-        if (dev_fold_r(py, dy, wm.pad) - wm.rmin != ty) continue;
-        for (int dx = 0; dx < wm.k; ++dx)
-            if (dev_fold_r(px, dx, wm.pad) - wm.rmin == tx) s += w[dy * wm.k + dx];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int dy = dy0 + a;
+        if ((unsigned)dy >= (unsigned)wm.k) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int dx = dx0 + b;
+            if ((unsigned)dx < (unsigned)wm.k) s += w[dy * wm.k + dx];
+        }
     }
     return s;
 }

@@ -892,37 +892,48 @@ int fg_launch_gemv_forward(fg_ctx* ctx, const float* x, const float* w, const fl
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
-// one block; dl[b] = gy[b]*y(1-y) (or gy); gx[b][k] = dl[b] w[k]; gw[k] = sum_b dl[b] x[b][k]; gb = sum dl
+// dl[b] = gy[b]*y(1-y) (or gy); gx[b][k] = dl[b] w[k]; gw[k] = sum_b dl[b] x[b][k]; gb = sum dl.
+// block = 64 columns x 4 batch lanes, grid over K; block 0 also reduces the bias gradient.
 __global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ y, const float* __restrict__ gy,
                                                        float* __restrict__ gx, float* __restrict__ gw,
                                                        float* __restrict__ gb, float acc, int B, int K, int sigmoid) {
-    extern __shared__ float dl[];  // [B]
+    extern __shared__ float dl[];  // [B] then [4][64] partials
+    float* red = dl + B;
     __shared__ float sh[4];
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const float v = sigmoid ? y[b] : 0.f;
         dl[b] = sigmoid ? gy[b] * v * (1.f - v) : gy[b];
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        float s = 0.f;
-        const float wk = w[k];
-        for (int b = 0; b < B; ++b) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (k < K) {
+        const float wk = gx ? w[k] : 0.f;
+        for (int b = ty; b < B; b += 4) {
             if (gw) s = fmaf(dl[b], x[(size_t)b * K + k], s);
             if (gx) gx[(size_t)b * K + k] = dl[b] * wk;
         }
-        if (gw) gw[k] = (acc == 0.f ? 0.f : acc * gw[k]) + s;
     }
-    float s = 0.f;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) s += dl[b];
-    s = block_sum(s, sh);
-    if (threadIdx.x == 0 && gb) gb[0] = (acc == 0.f ? 0.f : acc * gb[0]) + s;
+    red[ty * 64 + tx] = s;
+    __syncthreads();
+    if (ty == 0 && k < K && gw) {
+        const float t = (red[tx] + red[64 + tx]) + (red[128 + tx] + red[192 + tx]);
+        gw[k] = (acc == 0.f ? 0.f : acc * gw[k]) + t;
+    }
+    if (blockIdx.x == 0 && gb) {
+        float sb = 0.f;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) sb += dl[b];
+        sb = block_sum(sb, sh);
+        if (threadIdx.x == 0) gb[0] = (acc == 0.f ? 0.f : acc * gb[0]) + sb;
+    }
 }
 int fg_launch_gemv_backward(fg_ctx* ctx, const float* x, const float* w, const float* y, const float* gy, float* gx,
                             float* gw, float* gb, float acc, int B, int K, int sigmoid) {
     if (B == 0) return FG_OK;
-    hipLaunchKernelGGL(gemv_bwd_kernel, dim3(1), dim3(256), B * sizeof(float), ctx->stream, x, w, y, gy, gx, gw, gb,
-                       acc, B, K, sigmoid);
+    hipLaunchKernelGGL(gemv_bwd_kernel, dim3(fg_cdiv(K, 64)), dim3(256), (B + 256) * sizeof(float), ctx->stream, x, w, y,
+                       gy, gx, gw, gb, acc, B, K, sigmoid);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }

@@ -35,35 +35,122 @@ __global__ __launch_bounds__(256) void thin_in_kernel(const float* __restrict__ 
     for (int j = 0; j < CJ; ++j) bv[j] = bias ? bias[cb + 64 * j] : 0.f;
     const int npix = B * H * W;
     const int nwaves = gridDim.x * 4;
-    for (int pix = blockIdx.x * 4 + wave; pix < npix; pix += nwaves) {
-        const int x = pix % W;
-        const int t = pix / W;
-        const int y = t % H;
-        const int b = t / H;
-        float acc[CJ];
+    // two pixels per iteration; every tap is loaded from a clamped (always valid) wave-uniform address and zeroed by a
+    // scalar select, so all 2*K*K scalar loads of an iteration are issued before the first use (one latency, not K)
+    for (int pix0 = blockIdx.x * 4 + wave; pix0 < npix; pix0 += 2 * nwaves) {
+        float v[2][K * K * CS];
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) acc[j] = bv[j];
+        for (int u = 0; u < 2; ++u) {
+            const int pix = min(pix0 + u * nwaves, npix - 1);
+            const int x = pix % W;
+            const int t = pix / W;
+            const int y = t % H;
+            const int b = t / H;
 #pragma unroll
-        for (int dy = 0; dy < K; ++dy) {
-            const int yy = y + (flip ? PAD - dy : dy - PAD);
-            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int dy = 0; dy < K; ++dy) {
+                const int yy = y + (flip ? PAD - dy : dy - PAD);
+                const int yc = min(max(yy, 0), H - 1);
 #pragma unroll
-            for (int dx = 0; dx < K; ++dx) {
-                const int xx = x + (flip ? PAD - dx : dx - PAD);
-                if ((unsigned)xx >= (unsigned)W) continue;
-                const float* ip = in + ((size_t)(b * H + yy) * W + xx) * CS;   // wave-uniform address
+                for (int dx = 0; dx < K; ++dx) {
+                    const int xx = x + (flip ? PAD - dx : dx - PAD);
+                    const int xc = min(max(xx, 0), W - 1);
+                    const bool ok = yy == yc && xx == xc;
+                    const float* ip = in + ((size_t)(b * H + yc) * W + xc) * CS;   // wave-uniform address
 #pragma unroll
-                for (int s = 0; s < CS; ++s) {
-                    const float v = ip[s];
-#pragma unroll
-                    for (int j = 0; j < CJ; ++j) acc[j] = fmaf(v, w[(dy * K + dx) * CS + s][j], acc[j]);
+                    for (int s = 0; s < CS; ++s) {
+                        const float tv = ip[s];
+                        v[u][(dy * K + dx) * CS + s] = ok ? tv : 0.f;
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) out[(size_t)pix * Cw + cb + 64 * j] = acc[j];
+        for (int u = 0; u < 2; ++u) {
+            const int pix = pix0 + u * nwaves;
+            if (pix >= npix) break;
+            float acc[CJ];
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) acc[j] = bv[j];
+#pragma unroll
+            for (int t = 0; t < K * K * CS; ++t)
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) acc[j] = fmaf(v[u][t], w[t][j], acc[j]);
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) out[(size_t)pix * Cw + cb + 64 * j] = acc[j];
+        }
     }
 }
+
+// 3x3 thin-in, one wave per image ROW: the wave walks x with a sliding 3x3xCS window held in scalar registers (one new
+// column = 3 scalar loads per pixel, no per-pixel index arithmetic); the x loop is unrolled by 3 so the window slots
+// rotate statically.  Weights are pre-flipped for the data-grad form, so the loop body is always a correlation.
+template <int CS, int CJ>
+__global__ __launch_bounds__(256) void thin_in_row3_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int B, int H, int W, int flip, int Cw) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb = blockIdx.y * (CJ * 64) + lane;
+    float w[9 * CS][CJ];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < CS; ++s)
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) w[t * CS + s][j] = Wp[(size_t)((flip ? 8 - t : t) * CS + s) * Cw + cb + 64 * j];
+    float bv[CJ];
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) bv[j] = bias ? bias[cb + 64 * j] : 0.f;
+    const int row = blockIdx.x * 4 + wave;            // (b, y), wave-uniform
+    if (row >= B * H) return;
+    const int y = row % H;
+    const float* rp[3];
+    bool rok[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        rok[dy] = (unsigned)yy < (unsigned)H;
+        rp[dy] = in + (size_t)(row + (rok[dy] ? dy - 1 : 0)) * W * CS;
+    }
+    float win[3][3][CS];                               // [column slot][row][channel]
+#define FG_LOADCOL(slot, xc)                                                                        \
+    {                                                                                               \
+        const bool cok = (unsigned)(xc) < (unsigned)W;                                              \
+        const int xcl = cok ? (xc) : 0;                                                             \
+        _Pragma("unroll") for (int dy = 0; dy < 3; ++dy)                                            \
+            _Pragma("unroll") for (int s = 0; s < CS; ++s) {                                        \
+                const float tv = rp[dy][xcl * CS + s];                                              \
+                win[slot][dy][s] = (cok && rok[dy]) ? tv : 0.f;                                     \
+            }                                                                                       \
+    }
+    FG_LOADCOL(2, -1)                                  // column -1 lives in slot (-1 mod 3) = 2
+    FG_LOADCOL(0, 0)
+    float* orow = out + (size_t)row * W * Cw + cb;
+    for (int x0 = 0; x0 < W; x0 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int x = x0 + u;
+            if (x >= W) break;
+            FG_LOADCOL((u + 1) % 3, x + 1)
+            float acc[CJ];
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) acc[j] = bv[j];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int s = 0; s < CS; ++s)
+#pragma unroll
+                        for (int j = 0; j < CJ; ++j)
+                            acc[j] = fmaf(win[(u + dx + 2) % 3][dy][s], w[(dy * 3 + dx) * CS + s][j], acc[j]);
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) orow[(size_t)x * Cw + 64 * j] = acc[j];
+        }
+    }
+#undef FG_LOADCOL
+}
+
 // Large-kernel thin-in (c2f generator head data-grad: 7x7, 3 -> 256): a strip of TR image rows (+ halo, zero padded) of
 // the thin operand is staged in LDS; each wave computes NPX consecutive output pixels per step for its 64 channels,
 // reading every halo row segment once (uniform-address LDS broadcast) and re-using it for the NPX pixels; the K*K*CS
@@ -166,6 +253,18 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
     const int npix = B * H * W;
     if (npix == 0) return FG_OK;
     dim3 grid(fg_cdiv(npix, 128), Cw / cblk);
+    if (k == 3 && (Cs == 1 || Cs == 3 || Cs == 4) && (Cw == 64 || Cw == 128)) {
+        dim3 rgrid(fg_cdiv(B * H, 4), 1);
+#define TIR3(CC, JJ)                                                                                                 \
+    if (Cs == CC && Cw == JJ * 64) {                                                                                 \
+        hipLaunchKernelGGL((thin_in_row3_kernel<CC, JJ>), rgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, W, \
+                           flip, Cw);                                                                                \
+        FG_CHECK_LAUNCH(ctx);                                                                                        \
+        return FG_OK;                                                                                                \
+    }
+        TIR3(1, 1) TIR3(3, 1) TIR3(4, 1) TIR3(1, 2) TIR3(3, 2) TIR3(4, 2)
+#undef TIR3
+    }
     {
         int nblk = fg_cdiv(npix, 4);
         if (nblk > 4096) nblk = 4096;
