@@ -129,6 +129,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         iteration()
+    tr.finish_pending()          # N > 1: the last D update is deferred behind the next G forward -- complete it in-region
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -152,11 +153,16 @@ def main():
     out["step_roofline"] = {"algorithmic_gflop_per_iter": flops / 1e9, "achieved_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
                             "frac_of_f32_mfma_peak": flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
 
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # every rank runs the extra iterations (they contain collectives); only rank 0 records HIP events
         import ctypes
-        ctx.check(ctx.lib.fg_prof_enable(ctx.h, 1))
+        if rank == 0:
+            ctx.check(ctx.lib.fg_prof_enable(ctx.h, 1))
         for _ in range(args.prof_iters):
             iteration()
+        tr.finish_pending()
+        sync_all()
+    if rank == 0 and not args.no_roofline:
         buf = ctypes.create_string_buffer(1 << 16)
         ctx.check(ctx.lib.fg_prof_report(ctx.h, buf, len(buf), 1))
         ctx.check(ctx.lib.fg_prof_enable(ctx.h, 0))

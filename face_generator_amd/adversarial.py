@@ -148,9 +148,18 @@ class Trainer:
         out = self.dnD.forward(samples, masks=masks, train=True)
         loss, dprob, _ = self.crit.forward_backward_device(self.ctx, out.reshape(-1), targets, want_confusion=False)
         df_do = self.dnD.backward(dprob.view(B, 1), param_grads=False, input_grad=True)   # MODEL_D.modules[1].gradInput
-        self.dnG.backward(df_do, param_grads=True, input_grad=False)
-        res = dict(loss=loss, outputs=out, samples=samples)
         pG, gG = self.dnG.params, self.dnG.grads
+        works = []
+        if self.world > 1 and self.overlap and not keep_grad:
+            # bucketed all-reduce overlapped with backward: G's gradients are produced output -> input; each finished
+            # ~1 M-parameter range of the flat vector goes onto RCCL's stream while the earlier layers still compute
+            for (s_from, s_to, lo, hi) in self._buckets_G():
+                self.dnG.backward_range(df_do if s_from == self._last_stage_G else None, s_from, s_to)
+                if hi > lo:
+                    works.append(self.dist.all_reduce(gG[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+        else:
+            self.dnG.backward(df_do, param_grads=True, input_grad=False)
+        res = dict(loss=loss, outputs=out, samples=samples)
         if keep_grad:
             g = gG.clone()
             o = self.opt
@@ -160,10 +169,20 @@ class Trainer:
                 g.clamp_(-o["G_clamp"], o["G_clamp"])
             res["grad"] = g
             res["f"] = loss.item() + self.penalty_f("G", pG)
-        self._allreduce(gG)
+        if works:
+            for w in works:
+                w.wait()
+        else:
+            self._allreduce(gG)
         self._update("G", pG, gG, loss)
         self.dnG.params_changed()
         return res
+
+    def _buckets_G(self):
+        if getattr(self, "_bk_G", None) is None:
+            self._bk_G = self.dnG.grad_buckets()
+            self._last_stage_G = self._bk_G[0][0]
+        return self._bk_G
 
     def iteration(self, real_nhwc, seed_noise=None, D_iterations=1, G_iterations=1):
         """One loop body of adversarial.lua:54-288 on device-resident inputs (used by bench.py)."""

@@ -67,6 +67,9 @@ struct fg_net {
     const float* const* masks = nullptr;
     std::vector<const float*> mask_ptrs;
     int last_train = 1;
+    // ranged backward state (fg_net_backward_range)
+    const float* bwd_gcur = nullptr;
+    int bwd_pp = 0, bwd_next = -1;
     // one-launch weight re-pack
     PackJob* jobs_dev = nullptr;
     int n_jobs = 0;
@@ -465,9 +468,35 @@ int fg_net_forward(fg_net* n, int B, const float* x, void* wsv, size_t ws_bytes,
     return FG_OK;
 }
 
+int fg_net_num_stages(const fg_net* n) { return n ? (int)n->st.size() : 0; }
+
+int fg_net_stage_params(const fg_net* n, int stage, long long* lo, long long* hi) {
+    if (!n || stage < 0 || stage >= (int)n->st.size()) return FG_ERR_INVALID;
+    const Stage& s = n->st[stage];
+    long long a = -1, b = -1;
+    auto take = [&](long long off, long long cnt) {
+        if (off < 0 || cnt <= 0) return;
+        if (a < 0 || off < a) a = off;
+        if (off + cnt > b) b = off + cnt;
+    };
+    take(s.w_off, s.w_n); take(s.b_off, s.b_n); take(s.gamma_off, s.ic); take(s.beta_off, s.ic); take(s.slope_off, 1);
+    if (a < 0) a = b = 0;
+    if (lo) *lo = a;
+    if (hi) *hi = b;
+    return FG_OK;
+}
+
 int fg_net_backward(fg_net* n, int B, const float* x, const float* gy, void* wsv, size_t ws_bytes, int flags, float* gx) {
-    if (!n || !x || !gy || !wsv) return fg_set_err(n ? n->ctx : nullptr, FG_ERR_INVALID, "fg_net_backward: null argument");
+    if (!n) return FG_ERR_INVALID;
+    return fg_net_backward_range(n, B, x, gy, wsv, ws_bytes, flags, gx, (int)n->st.size() - 1, 0);
+}
+
+int fg_net_backward_range(fg_net* n, int B, const float* x, const float* gy, void* wsv, size_t ws_bytes, int flags,
+                          float* gx, int stage_from, int stage_to) {
+    if (!n || !x || !wsv) return fg_set_err(n ? n->ctx : nullptr, FG_ERR_INVALID, "fg_net_backward: null argument");
     fg_ctx* ctx = n->ctx;
+    const int last = (int)n->st.size() - 1;
+    if (stage_from > last || stage_to < 0 || stage_from < stage_to) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward_range: bad range");
     if (n->plan_batch != B) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: batch %d != forward batch %d", B, n->plan_batch);
     if (!n->last_train) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: last forward was in evaluate mode");
     if ((size_t)n->total_floats * sizeof(float) > ws_bytes) return fg_set_err(ctx, FG_ERR_WORKSPACE, "fg_net_backward: workspace");
@@ -479,9 +508,16 @@ int fg_net_backward(fg_net* n, int B, const float* x, const float* gy, void* wsv
     float* tmp = ws + n->tmp_off;
     const float* P = n->params;
     float* Gp = n->grads;
-    const float* gcur = gy;
-    int pp = 0, rc = FG_OK;
-    for (int si = (int)n->st.size() - 1; si >= 0; --si) {
+    const float* gcur;
+    int pp, rc = FG_OK;
+    if (stage_from == last) {            // a new backward pass starts at the output
+        if (!gy) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: gy required");
+        gcur = gy; pp = 0;
+    } else {                             // continuation of a ranged pass
+        if (n->bwd_next != stage_from) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward_range: expected stage %d next", n->bwd_next);
+        gcur = n->bwd_gcur; pp = n->bwd_pp;
+    }
+    for (int si = stage_from; si >= stage_to; --si) {
         Stage& s = n->st[si];
         const float* xin = si == 0 ? x : ws + n->st[si - 1].out_off;
         const float* yout = ws + s.out_off;
@@ -577,6 +613,7 @@ int fg_net_backward(fg_net* n, int B, const float* x, const float* gy, void* wsv
         gcur = gxb;
         if (si > 0) pp ^= 1;
     }
+    n->bwd_gcur = gcur; n->bwd_pp = pp; n->bwd_next = stage_to - 1;
     return FG_OK;
 }
 

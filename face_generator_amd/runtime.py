@@ -226,6 +226,30 @@ class DeviceNet:
                                                 self.ws.numel() * 4, flags, gx.data_ptr() if gx is not None else None))
         return gx
 
+    def grad_buckets(self, target=900000):
+        """Split the plan's stages (output -> input order) into buckets of roughly `target` parameters for the bucketed
+        gradient all-reduce: [(stage_from, stage_to, param_lo, param_hi), ...] in execution order."""
+        ns = self.lib.fg_net_num_stages(self.h)
+        buckets, cur_from, lo_acc, hi_acc = [], ns - 1, None, None
+        for st in range(ns - 1, -1, -1):
+            lo, hi = ctypes.c_longlong(), ctypes.c_longlong()
+            self.ctx.check(self.lib.fg_net_stage_params(self.h, st, ctypes.byref(lo), ctypes.byref(hi)))
+            if hi.value > lo.value:
+                lo_acc = lo.value if lo_acc is None else min(lo_acc, lo.value)
+                hi_acc = hi.value if hi_acc is None else max(hi_acc, hi.value)
+            if (hi_acc is not None and hi_acc - lo_acc >= target and st > 0) or st == 0:
+                buckets.append((cur_from, st, lo_acc or 0, hi_acc or 0))
+                cur_from, lo_acc, hi_acc = st - 1, None, None
+        return buckets
+
+    def backward_range(self, gy, stage_from, stage_to, param_grads=True):
+        """Stages [stage_from .. stage_to] of the backward pass (see fg_net_backward_range)."""
+        flags = _lib.FG_BWD_PARAM_GRADS if param_grads else 0
+        gyp = gy.contiguous().data_ptr() if gy is not None else None
+        self._gy_keepalive = gy
+        self.ctx.check(self.lib.fg_net_backward_range(self.h, self._batch, self._x.data_ptr(), gyp, self.ws.data_ptr(),
+                                                      self.ws.numel() * 4, flags, None, stage_from, stage_to))
+
     def layer_output(self, layer_index):
         off, c, h, w = ctypes.c_longlong(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self.ctx.check(self.lib.fg_net_layer_output(self.h, layer_index, ctypes.byref(off), ctypes.byref(c),

@@ -112,6 +112,14 @@ enum { FG_BWD_PARAM_GRADS = 1, FG_BWD_INPUT_GRAD = 2 };
  * the flat gradient vector; FG_BWD_INPUT_GRAD writes gx (NHWC like x). */
 int fg_net_backward(fg_net* net, int batch, const float* x, const float* gy, void* ws, size_t ws_bytes, int flags,
                     float* gx);
+/* Bucketed backward for data parallelism: the plan's stages run output -> input; fg_net_backward_range executes stages
+ * [stage_from .. stage_to] (descending; the first call starts at fg_net_num_stages()-1 with gy, later calls continue
+ * where the previous one stopped and ignore gy), so the host can start the RCCL all-reduce of the gradient range
+ * fg_net_stage_params() reports for the finished stages while the remaining stages still compute. */
+int fg_net_num_stages(const fg_net* net);
+int fg_net_stage_params(const fg_net* net, int stage, long long* param_lo, long long* param_hi);
+int fg_net_backward_range(fg_net* net, int batch, const float* x, const float* gy, void* ws, size_t ws_bytes, int flags,
+                          float* gx, int stage_from, int stage_to);
 /* debugging / parity: activation after reference layer `layer_index` of the last forward (must end a stage) */
 int fg_net_layer_output(const fg_net* net, int layer_index, long long* ws_offset, int* c, int* h, int* w);
 

@@ -38,6 +38,11 @@ def test_trainer_with_rccl_world1_matches_plain_trainer():
             assert (tr._pending_D is not None) == use_dist
             tr.step_G(ctx.uniform((8, 100), -1.0, 1.0, seed=11))
             assert tr._pending_D is None
+            if use_dist:    # bucketed, backward-overlapped all-reduce of G: >= 2 buckets covering the whole flat vector
+                bk = tr._buckets_G()
+                assert len(bk) >= 2 and bk[0][0] == G.device_net.lib.fg_net_num_stages(G.device_net.h) - 1 and bk[-1][1] == 0
+                assert sorted((lo, hi) for (_, _, lo, hi) in bk)[0][0] == 0
+                assert sum(hi - lo for (_, _, lo, hi) in bk) == G.getParameters()[0].numel()
             outs.append((G.getParameters()[0].cpu().numpy().copy(), D.getParameters()[0].cpu().numpy().copy()))
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     finally:
