@@ -198,7 +198,8 @@ class DeviceNet:
         if train and self.n_masks:
             if masks is None:
                 masks = self.draw_masks(B)
-            assert len(masks) == self.n_masks
+            if len(masks) != self.n_masks:
+                raise FgError("forward: %d dropout masks given, the net has %d dropout layers" % (len(masks), self.n_masks))
             self._masks = [m.contiguous() for m in masks]
             mp = (ctypes.c_void_p * self.n_masks)(*[m.data_ptr() for m in self._masks])
         else:
