@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-iters", type=int, default=3)
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: all-reduce the BatchNorm sums (exact B_global statistics) instead of per-GPU statistics")
     ap.add_argument("--workload", choices=["cfg2", "c2f"], default="cfg2",
                     help="cfg2: 32x32 G32+D32b (BASELINE configs[1], the headline); c2f: 64x64 coarse-to-fine (configs[3])")
     args = ap.parse_args()
@@ -110,6 +112,7 @@ def main():
     S.OPT.update(batchSize=B, noiseDim=100)
     S.noise_seed = 1 + rank                             # each rank draws its own shard of the global batch
     G.device_net.mask_seed = D.device_net.mask_seed = 1000 + rank
+    S.OPT["sync_bn"] = bool(args.sync_bn)
     tr = adversarial.Trainer(ctx, G, D, S.OPT, dist=dist if world > 1 else None)
     real = ctx.uniform((B // 2, 32, 32, C), 0.0, 1.0, seed=77 + rank)
 
@@ -146,7 +149,8 @@ def main():
         "data": "synthetic (U[0,1) images, U(-1,1) noise, reference init N(0,.005^2)/N(0,.001^2))",
         "config": {"workload": "configs[1]: 32x32 color, noiseDim=100, batch 128 per GPU, Adam, D_it=G_it=1"
                                + ("" if world == 1 else "; configs[2]-style weak scaling, RCCL grad all-reduce"),
-                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world},
+                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
+                   "batchnorm": "sync (global-batch statistics)" if (args.sync_bn and world > 1) else "per-GPU statistics"},
         "reference_accounting_images_per_sec": value / 2,   # adversarial.lua:305 counts B/2 per iteration
     }
     flops = alg_flops_per_iter(B)

@@ -33,6 +33,7 @@ _CTYPES = [
     (r"^const char\*$", ctypes.c_char_p),
     (r"^char\*$", ctypes.c_char_p),
     (r"^long long\*$", ctypes.POINTER(ctypes.c_longlong)),
+    (r"^(const )?double\*$", ctypes.c_void_p),
     (r"^(const )?(fg_ctx|fg_net|void|float|int)\*$", ctypes.c_void_p),
     (r"^int$", ctypes.c_int),
     (r"^long long$", ctypes.c_longlong),

@@ -35,6 +35,9 @@ class Trainer:
         self.gscale = 1.0 / self.world   # BCE averages over the local batch: global mean = all-reduced sum / world
         self._targets = {}
         self._inputs = {}
+        if dist is not None and self.world > 1 and self.opt.get("sync_bn", False):
+            # exact B_global BatchNorm statistics: fp64 per-channel sums all-reduced at every BatchNorm
+            self.dnG.enable_sync_bn(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
         self._pending_D = None    # (async all-reduce handle, loss) of a D update deferred behind the next G forward
         self.overlap = True       # N > 1: hide D's gradient all-reduce under the G-step's generator forward
 

@@ -156,6 +156,11 @@ struct BnBwdArgs {
     float* scratch;
 };
 int fg_launch_bn_backward(fg_ctx*, const BnBwdArgs& a);
+// sync-BN halves: *_sync1 leaves fp64 per-channel sums [2C+1] in `sync` for the cross-rank all-reduce, *_sync2 finishes
+int fg_launch_bn_forward_sync1(fg_ctx*, const BnArgs& a, double* sync);
+int fg_launch_bn_forward_sync2(fg_ctx*, const BnArgs& a, const double* sync);
+int fg_launch_bn_backward_sync1(fg_ctx*, const BnBwdArgs& a, double* sync);
+int fg_launch_bn_backward_sync2(fg_ctx*, const BnBwdArgs& a, const double* sync);
 
 // PReLU [+ dropout mask (scaled)] elementwise over n elements; mask index = i (same shape) or nullptr
 int fg_launch_prelu_forward(fg_ctx*, const float* x, const float* slope, const float* mask, float mscale, float* y,

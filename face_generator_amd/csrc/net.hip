@@ -70,6 +70,17 @@ struct fg_net {
     // ranged backward state (fg_net_backward_range)
     const float* bwd_gcur = nullptr;
     int bwd_pp = 0, bwd_next = -1;
+    // sync-BN: forward / backward pause at every BatchNorm for a cross-rank all-reduce of its fp64 sums
+    bool sync_bn = false;
+    double* sync_buf = nullptr;
+    long long sync_cap = 0, sync_count = 0;
+    int run_stage = 0, run_phase = 0;          // where a paused pass resumes
+    int run_B = 0, run_train = 0, run_to = 0, run_flags = 0;
+    const float* run_x = nullptr;
+    const float* run_cur = nullptr;
+    float* run_ws = nullptr;
+    float* run_gx = nullptr;
+    int run_pp = 0;
     // one-launch weight re-pack
     PackJob* jobs_dev = nullptr;
     int n_jobs = 0;
@@ -117,6 +128,209 @@ static void make_plan(fg_net* n, int B) {
 }
 
 static int build_pack_jobs(fg_net* n);
+
+static int backward_run(fg_net* n) {
+    fg_ctx* ctx = n->ctx;
+    const int B = n->run_B, flags = n->run_flags, stage_to = n->run_to;
+    const float* x = n->run_x;
+    float* gx = n->run_gx;
+    const bool want_p = (flags & FG_BWD_PARAM_GRADS) != 0, want_x = (flags & FG_BWD_INPUT_GRAD) != 0;
+    float* ws = n->run_ws;
+    float* scratch = ws + n->scratch_off;
+    float* tmp = ws + n->tmp_off;
+    const float* P = n->params;
+    float* Gp = n->grads;
+    const float* gcur = n->bwd_gcur;
+    int pp = n->bwd_pp, rc = FG_OK;
+    for (int si = n->run_stage; si >= stage_to; --si) {
+        Stage& s = n->st[si];
+        const float* xin = si == 0 ? x : ws + n->st[si - 1].out_off;
+        const float* yout = ws + s.out_off;
+        const bool need_gx = si > 0 || want_x;
+        float* gxb = si == 0 ? gx : ws + n->grad_off[pp];
+        if (!need_gx) gxb = nullptr;
+        const float* mask = (s.mask_idx >= 0) ? n->mask_ptrs[s.mask_idx] : nullptr;
+        switch (s.kind) {
+            case ST_CONV: {
+                ConvGeom g = s.geom; g.B = B;
+                if (want_p) {
+                    rc = fg_conv_wgrad_run(ctx, g, xin, gcur, Gp + s.w_off, s.bias_packed ? nullptr : Gp + s.b_off, 0.f,
+                                           scratch, n->scratch_floats);
+                    if (!rc && s.bias_packed) {  // bias grad in NHWC feature order -> reference order
+                        float* tb = scratch + (long long)CR_ROWBLOCKS_MAX * g.Cout;
+                        rc = fg_launch_colsum(ctx, gcur, (long long)B, g.Cout, 0.f, tb, scratch);
+                        if (!rc) rc = fg_launch_nhwc_to_nchw(ctx, tb, Gp + s.b_off, 1, g.o_c, g.o_hw, 1);
+                    }
+                }
+                if (!rc && need_gx) rc = fg_conv_dgrad_run(ctx, g, gcur, s.wp_bwd, gxb, scratch, n->scratch_floats);
+                break;
+            }
+            case ST_GEMV:
+                rc = fg_launch_gemv_backward(ctx, xin, P + s.w_off, yout, gcur, gxb, want_p ? Gp + s.w_off : nullptr,
+                                             want_p ? Gp + s.b_off : nullptr, 0.f, B, s.ic, s.has_sigmoid);
+                break;
+            case ST_THIN_IN: {
+                const int k = s.geom.k;
+                if (want_p) {
+                    float* gw = scratch + (long long)FG_THIN_WGRAD_BLOCKS * k * k * s.ic * s.oc;
+                    rc = fg_launch_thin_wgrad(ctx, xin, gcur, gw, B, s.ih, s.iw, s.ic, s.oc, k, +1, scratch);
+                    if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 0, 0.f);
+                    if (!rc) rc = fg_launch_colsum(ctx, gcur, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
+                }
+                if (!rc && need_gx)
+                    rc = fg_launch_thin_out_conv(ctx, gcur, s.wp_fwd, nullptr, gxb, B, s.ih, s.iw, s.oc, s.ic, k, 1, 0);
+                break;
+            }
+            case ST_THIN_OUT: {
+                const int k = s.geom.k;
+                const float* gpre = gcur;
+                if (s.has_sigmoid) {
+                    rc = fg_launch_sigmoid_backward(ctx, yout, gcur, tmp, (long long)B * s.oc * s.oh * s.ow);
+                    gpre = tmp;
+                }
+                if (!rc && want_p) {
+                    float* gw = scratch + (long long)FG_THIN_WGRAD_BLOCKS * k * k * s.oc * s.ic;
+                    rc = fg_launch_thin_wgrad(ctx, gpre, xin, gw, B, s.ih, s.iw, s.oc, s.ic, k, -1, scratch);
+                    if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 1, 0.f);
+                    if (!rc) rc = fg_launch_colsum(ctx, gpre, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
+                }
+                if (!rc && need_gx)
+                    rc = fg_launch_thin_in_conv(ctx, gpre, s.wp_fwd, nullptr, gxb, B, s.ih, s.iw, s.oc, s.ic, k, 1);
+                break;
+            }
+            case ST_BNPRELU: {
+                BnBwdArgs a; memset(&a, 0, sizeof(a));
+                a.x = xin; a.gy = gcur; a.gx = gxb; a.M = (long long)B * s.ih * s.iw; a.C = s.ic;
+                a.gamma = P + s.gamma_off; a.beta = P + s.beta_off; a.slope = s.has_prelu ? P + s.slope_off : nullptr;
+                a.mean = ws + s.aux_off; a.invstd = ws + s.aux_off + s.ic;
+                a.ggamma = want_p ? Gp + s.gamma_off : nullptr; a.gbeta = want_p ? Gp + s.beta_off : nullptr;
+                a.gslope = (want_p && s.has_prelu) ? Gp + s.slope_off : nullptr; a.gbeta_acc = 0.f; a.scratch = scratch;
+                if (!n->sync_bn) { rc = fg_launch_bn_backward(ctx, a); break; }
+                if (n->run_phase == 0) {           // local fp64 sums -> pause for the cross-rank all-reduce
+                    if (2LL * s.ic + 1 > n->sync_cap) return fg_set_err(ctx, FG_ERR_WORKSPACE, "sync-BN buffer too small");
+                    if ((rc = fg_launch_bn_backward_sync1(ctx, a, n->sync_buf))) return rc;
+                    n->run_stage = si; n->run_phase = 2; n->bwd_gcur = gcur; n->bwd_pp = pp; n->sync_count = 2LL * s.ic + 1;
+                    return FG_PAUSED_SYNC;
+                }
+                n->run_phase = 0;
+                rc = fg_launch_bn_backward_sync2(ctx, a, n->sync_buf);
+                break;
+            }
+            case ST_PRELU: {
+                const long long cnt = (long long)B * s.ic * s.ih * s.iw;
+                const float sc = (s.mask_kind == 2) ? 1.f / (1.f - s.p) : 1.f;
+                rc = fg_launch_prelu_backward(ctx, xin, gcur, P + s.slope_off, mask, sc, gxb,
+                                              want_p ? Gp + s.slope_off : nullptr, 0.f, cnt, scratch);
+                break;
+            }
+            case ST_ACTPOOL:
+                rc = fg_launch_actpool_backward(ctx, xin, gcur, P + s.slope_off, mask, 1.f, gxb,
+                                                want_p ? Gp + s.slope_off : nullptr, 0.f, B, s.ih, s.iw, s.ic, scratch);
+                break;
+            case ST_SIGMOID:
+                if (need_gx) rc = fg_launch_sigmoid_backward(ctx, yout, gcur, gxb, (long long)B * s.ic * s.ih * s.iw);
+                break;
+            case ST_LEAKYRELU:
+                if (need_gx) rc = fg_launch_leakyrelu_backward(ctx, xin, gcur, s.negslope, gxb, (long long)B * s.ic * s.ih * s.iw);
+                break;
+            case ST_UPSAMPLE: if (need_gx) rc = fg_launch_upsample_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
+            case ST_AVGPOOL: if (need_gx) rc = fg_launch_avgpool_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
+            case ST_SDROPOUT: if (need_gx) rc = fg_launch_scale_mask_nc(ctx, gcur, mask, 1.f, gxb, B, s.ih * s.iw, s.ic); break;
+            case ST_MAXPOOL: if (need_gx) rc = fg_launch_maxpool_backward(ctx, xin, gcur, gxb, B, s.ih, s.iw, s.ic); break;
+            case ST_DROPOUT:
+                if (need_gx) rc = fg_launch_mul_mask(ctx, gcur, mask, 1.f / (1.f - s.p), gxb, (long long)B * s.ic * s.ih * s.iw);
+                break;
+            default: rc = fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: bad stage kind %d", s.kind);
+        }
+        if (rc) return rc;
+        gcur = gxb;
+        if (si > 0) pp ^= 1;
+    }
+    n->bwd_gcur = gcur; n->bwd_pp = pp; n->bwd_next = stage_to - 1; n->run_phase = 0;
+    return FG_OK;
+}
+
+static int forward_run(fg_net* n, long long* out_offset) {
+    fg_ctx* ctx = n->ctx;
+    const int B = n->run_B, train = n->run_train;
+    float* ws = n->run_ws;
+    float* scratch = ws + n->scratch_off;
+    const float* cur = n->run_cur;
+    const float* P = n->params;
+    int rc = FG_OK;
+    for (int si = n->run_stage; si < (int)n->st.size(); ++si) {
+        Stage& s = n->st[si];
+        float* y = ws + s.out_off;
+        const float* mask = (s.mask_idx >= 0) ? n->mask_ptrs[s.mask_idx] : nullptr;
+        switch (s.kind) {
+            case ST_CONV: {
+                ConvGeom g = s.geom; g.B = B;
+                rc = fg_conv_forward_run(ctx, g, cur, s.wp_fwd, s.bias_packed ? s.bias_packed : P + s.b_off, y, scratch,
+                                         n->scratch_floats);
+                break;
+            }
+            case ST_GEMV:
+                rc = fg_launch_gemv_forward(ctx, cur, P + s.w_off, P + s.b_off, y, B, s.ic, s.has_sigmoid);
+                break;
+            case ST_THIN_IN:
+                rc = fg_launch_thin_in_conv(ctx, cur, s.wp_fwd, P + s.b_off, y, B, s.ih, s.iw, s.ic, s.oc, s.geom.k, 0);
+                break;
+            case ST_THIN_OUT:
+                rc = fg_launch_thin_out_conv(ctx, cur, s.wp_fwd, P + s.b_off, y, B, s.ih, s.iw, s.ic, s.oc, s.geom.k, 0,
+                                             s.has_sigmoid);
+                break;
+            case ST_BNPRELU: {
+                const bool sync = n->sync_bn && train;
+                BnArgs a; memset(&a, 0, sizeof(a));
+                a.x = cur; a.y = y; a.M = (long long)B * s.ih * s.iw; a.C = s.ic;
+                a.gamma = P + s.gamma_off; a.beta = P + s.beta_off; a.slope = s.has_prelu ? P + s.slope_off : nullptr;
+                a.mean = ws + s.aux_off; a.invstd = ws + s.aux_off + s.ic;
+                a.running_mean = n->buffers + s.buf_off; a.running_var = n->buffers + s.buf_off + s.ic;
+                a.eps = s.eps; a.momentum = s.momentum; a.train = train; a.scratch = scratch;
+                if (!sync) { rc = fg_launch_bn_forward(ctx, a); break; }
+                if (n->run_phase == 0) {           // local fp64 sums -> pause for the cross-rank all-reduce
+                    if (2LL * s.ic + 1 > n->sync_cap) return fg_set_err(ctx, FG_ERR_WORKSPACE, "sync-BN buffer too small");
+                    if ((rc = fg_launch_bn_forward_sync1(ctx, a, n->sync_buf))) return rc;
+                    n->run_stage = si; n->run_phase = 1; n->run_cur = cur; n->sync_count = 2LL * s.ic + 1;
+                    return FG_PAUSED_SYNC;
+                }
+                n->run_phase = 0;
+                rc = fg_launch_bn_forward_sync2(ctx, a, n->sync_buf);
+                break;
+            }
+            case ST_PRELU: {
+                const long long cnt = (long long)B * s.ic * s.ih * s.iw;
+                const float sc = (s.mask_kind == 2 && train) ? 1.f / (1.f - s.p) : 1.f;
+                rc = fg_launch_prelu_forward(ctx, cur, P + s.slope_off, train ? mask : nullptr, sc, y, cnt);
+                break;
+            }
+            case ST_ACTPOOL: {
+                const float sc = train ? 1.f : (1.f - s.p);
+                rc = fg_launch_actpool_forward(ctx, cur, P + s.slope_off, train ? mask : nullptr, sc, y, B, s.ih, s.iw, s.ic);
+                break;
+            }
+            case ST_SIGMOID: rc = fg_launch_sigmoid_forward(ctx, cur, y, (long long)B * s.ic * s.ih * s.iw); break;
+            case ST_LEAKYRELU: rc = fg_launch_leakyrelu_forward(ctx, cur, s.negslope, y, (long long)B * s.ic * s.ih * s.iw); break;
+            case ST_UPSAMPLE: rc = fg_launch_upsample_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
+            case ST_AVGPOOL: rc = fg_launch_avgpool_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
+            case ST_SDROPOUT:
+                rc = fg_launch_scale_mask_nc(ctx, cur, train ? mask : nullptr, train ? 1.f : 1.f - s.p, y, B, s.ih * s.iw, s.ic);
+                break;
+            case ST_MAXPOOL: rc = fg_launch_maxpool_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
+            case ST_DROPOUT:
+                rc = fg_launch_mul_mask(ctx, cur, train ? mask : nullptr, train ? 1.f / (1.f - s.p) : 1.f, y,
+                                        (long long)B * s.ic * s.ih * s.iw);
+                break;
+            default: rc = fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: bad stage kind %d", s.kind);
+        }
+        if (rc) return rc;
+        cur = y;
+    }
+    n->run_phase = 0;
+    if (out_offset) *out_offset = n->st.back().out_off;
+    return FG_OK;
+}
+
 
 extern "C" {
 #pragma GCC visibility push(default)
@@ -404,68 +618,13 @@ int fg_net_forward(fg_net* n, int B, const float* x, void* wsv, size_t ws_bytes,
     n->mask_ptrs.assign(n->n_masks, nullptr);
     if (train) for (int i = 0; i < n->n_masks; ++i) n->mask_ptrs[i] = masks[i];
     n->last_train = train;
-    const float* cur = x;
-    const float* P = n->params;
-    for (auto& s : n->st) {
-        float* y = ws + s.out_off;
-        const float* mask = (s.mask_idx >= 0) ? n->mask_ptrs[s.mask_idx] : nullptr;
-        switch (s.kind) {
-            case ST_CONV: {
-                ConvGeom g = s.geom; g.B = B;
-                rc = fg_conv_forward_run(ctx, g, cur, s.wp_fwd, s.bias_packed ? s.bias_packed : P + s.b_off, y, scratch,
-                                         n->scratch_floats);
-                break;
-            }
-            case ST_GEMV:
-                rc = fg_launch_gemv_forward(ctx, cur, P + s.w_off, P + s.b_off, y, B, s.ic, s.has_sigmoid);
-                break;
-            case ST_THIN_IN:
-                rc = fg_launch_thin_in_conv(ctx, cur, s.wp_fwd, P + s.b_off, y, B, s.ih, s.iw, s.ic, s.oc, s.geom.k, 0);
-                break;
-            case ST_THIN_OUT:
-                rc = fg_launch_thin_out_conv(ctx, cur, s.wp_fwd, P + s.b_off, y, B, s.ih, s.iw, s.ic, s.oc, s.geom.k, 0,
-                                             s.has_sigmoid);
-                break;
-            case ST_BNPRELU: {
-                BnArgs a; memset(&a, 0, sizeof(a));
-                a.x = cur; a.y = y; a.M = (long long)B * s.ih * s.iw; a.C = s.ic;
-                a.gamma = P + s.gamma_off; a.beta = P + s.beta_off; a.slope = s.has_prelu ? P + s.slope_off : nullptr;
-                a.mean = ws + s.aux_off; a.invstd = ws + s.aux_off + s.ic;
-                a.running_mean = n->buffers + s.buf_off; a.running_var = n->buffers + s.buf_off + s.ic;
-                a.eps = s.eps; a.momentum = s.momentum; a.train = train; a.scratch = scratch;
-                rc = fg_launch_bn_forward(ctx, a);
-                break;
-            }
-            case ST_PRELU: {
-                const long long cnt = (long long)B * s.ic * s.ih * s.iw;
-                const float sc = (s.mask_kind == 2 && train) ? 1.f / (1.f - s.p) : 1.f;
-                rc = fg_launch_prelu_forward(ctx, cur, P + s.slope_off, train ? mask : nullptr, sc, y, cnt);
-                break;
-            }
-            case ST_ACTPOOL: {
-                const float sc = train ? 1.f : (1.f - s.p);
-                rc = fg_launch_actpool_forward(ctx, cur, P + s.slope_off, train ? mask : nullptr, sc, y, B, s.ih, s.iw, s.ic);
-                break;
-            }
-            case ST_SIGMOID: rc = fg_launch_sigmoid_forward(ctx, cur, y, (long long)B * s.ic * s.ih * s.iw); break;
-            case ST_LEAKYRELU: rc = fg_launch_leakyrelu_forward(ctx, cur, s.negslope, y, (long long)B * s.ic * s.ih * s.iw); break;
-            case ST_UPSAMPLE: rc = fg_launch_upsample_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
-            case ST_AVGPOOL: rc = fg_launch_avgpool_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
-            case ST_SDROPOUT:
-                rc = fg_launch_scale_mask_nc(ctx, cur, train ? mask : nullptr, train ? 1.f : 1.f - s.p, y, B, s.ih * s.iw, s.ic);
-                break;
-            case ST_MAXPOOL: rc = fg_launch_maxpool_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
-            case ST_DROPOUT:
-                rc = fg_launch_mul_mask(ctx, cur, train ? mask : nullptr, train ? 1.f / (1.f - s.p) : 1.f, y,
-                                        (long long)B * s.ic * s.ih * s.iw);
-                break;
-            default: rc = fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: bad stage kind %d", s.kind);
-        }
-        if (rc) return rc;
-        cur = y;
-    }
-    if (out_offset) *out_offset = n->st.back().out_off;
-    return FG_OK;
+    n->run_stage = 0; n->run_phase = 0; n->run_B = B; n->run_train = train; n->run_x = x; n->run_cur = x; n->run_ws = ws;
+    return forward_run(n, out_offset);
+}
+
+int fg_net_forward_resume(fg_net* n, long long* out_offset) {
+    if (!n || n->run_phase != 1) return fg_set_err(n ? n->ctx : nullptr, FG_ERR_INVALID, "fg_net_forward_resume: not paused");
+    return forward_run(n, out_offset);
 }
 
 int fg_net_num_stages(const fg_net* n) { return n ? (int)n->st.size() : 0; }
@@ -500,122 +659,31 @@ int fg_net_backward_range(fg_net* n, int B, const float* x, const float* gy, voi
     if (n->plan_batch != B) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: batch %d != forward batch %d", B, n->plan_batch);
     if (!n->last_train) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: last forward was in evaluate mode");
     if ((size_t)n->total_floats * sizeof(float) > ws_bytes) return fg_set_err(ctx, FG_ERR_WORKSPACE, "fg_net_backward: workspace");
-    const bool want_p = (flags & FG_BWD_PARAM_GRADS) != 0, want_x = (flags & FG_BWD_INPUT_GRAD) != 0;
-    if (want_p && !n->grads) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: gradient vector not bound");
-    if (want_x && !gx) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: gx required");
-    float* ws = (float*)wsv;
-    float* scratch = ws + n->scratch_off;
-    float* tmp = ws + n->tmp_off;
-    const float* P = n->params;
-    float* Gp = n->grads;
-    const float* gcur;
-    int pp, rc = FG_OK;
+    if ((flags & FG_BWD_PARAM_GRADS) && !n->grads) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: gradient vector not bound");
+    if ((flags & FG_BWD_INPUT_GRAD) && !gx) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: gx required");
     if (stage_from == last) {            // a new backward pass starts at the output
         if (!gy) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: gy required");
-        gcur = gy; pp = 0;
-    } else {                             // continuation of a ranged pass
-        if (n->bwd_next != stage_from) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward_range: expected stage %d next", n->bwd_next);
-        gcur = n->bwd_gcur; pp = n->bwd_pp;
+        n->bwd_gcur = gy; n->bwd_pp = 0;
+    } else if (n->bwd_next != stage_from) {
+        return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward_range: expected stage %d next", n->bwd_next);
     }
-    for (int si = stage_from; si >= stage_to; --si) {
-        Stage& s = n->st[si];
-        const float* xin = si == 0 ? x : ws + n->st[si - 1].out_off;
-        const float* yout = ws + s.out_off;
-        const bool need_gx = si > 0 || want_x;
-        float* gxb = si == 0 ? gx : ws + n->grad_off[pp];
-        if (!need_gx) gxb = nullptr;
-        const float* mask = (s.mask_idx >= 0) ? n->mask_ptrs[s.mask_idx] : nullptr;
-        switch (s.kind) {
-            case ST_CONV: {
-                ConvGeom g = s.geom; g.B = B;
-                if (want_p) {
-                    rc = fg_conv_wgrad_run(ctx, g, xin, gcur, Gp + s.w_off, s.bias_packed ? nullptr : Gp + s.b_off, 0.f,
-                                           scratch, n->scratch_floats);
-                    if (!rc && s.bias_packed) {  // bias grad in NHWC feature order -> reference order
-                        float* tb = scratch + (long long)CR_ROWBLOCKS_MAX * g.Cout;
-                        rc = fg_launch_colsum(ctx, gcur, (long long)B, g.Cout, 0.f, tb, scratch);
-                        if (!rc) rc = fg_launch_nhwc_to_nchw(ctx, tb, Gp + s.b_off, 1, g.o_c, g.o_hw, 1);
-                    }
-                }
-                if (!rc && need_gx) rc = fg_conv_dgrad_run(ctx, g, gcur, s.wp_bwd, gxb, scratch, n->scratch_floats);
-                break;
-            }
-            case ST_GEMV:
-                rc = fg_launch_gemv_backward(ctx, xin, P + s.w_off, yout, gcur, gxb, want_p ? Gp + s.w_off : nullptr,
-                                             want_p ? Gp + s.b_off : nullptr, 0.f, B, s.ic, s.has_sigmoid);
-                break;
-            case ST_THIN_IN: {
-                const int k = s.geom.k;
-                if (want_p) {
-                    float* gw = scratch + (long long)FG_THIN_WGRAD_BLOCKS * k * k * s.ic * s.oc;
-                    rc = fg_launch_thin_wgrad(ctx, xin, gcur, gw, B, s.ih, s.iw, s.ic, s.oc, k, +1, scratch);
-                    if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 0, 0.f);
-                    if (!rc) rc = fg_launch_colsum(ctx, gcur, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
-                }
-                if (!rc && need_gx)
-                    rc = fg_launch_thin_out_conv(ctx, gcur, s.wp_fwd, nullptr, gxb, B, s.ih, s.iw, s.oc, s.ic, k, 1, 0);
-                break;
-            }
-            case ST_THIN_OUT: {
-                const int k = s.geom.k;
-                const float* gpre = gcur;
-                if (s.has_sigmoid) {
-                    rc = fg_launch_sigmoid_backward(ctx, yout, gcur, tmp, (long long)B * s.oc * s.oh * s.ow);
-                    gpre = tmp;
-                }
-                if (!rc && want_p) {
-                    float* gw = scratch + (long long)FG_THIN_WGRAD_BLOCKS * k * k * s.oc * s.ic;
-                    rc = fg_launch_thin_wgrad(ctx, gpre, xin, gw, B, s.ih, s.iw, s.oc, s.ic, k, -1, scratch);
-                    if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 1, 0.f);
-                    if (!rc) rc = fg_launch_colsum(ctx, gpre, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
-                }
-                if (!rc && need_gx)
-                    rc = fg_launch_thin_in_conv(ctx, gpre, s.wp_fwd, nullptr, gxb, B, s.ih, s.iw, s.oc, s.ic, k, 1);
-                break;
-            }
-            case ST_BNPRELU: {
-                BnBwdArgs a; memset(&a, 0, sizeof(a));
-                a.x = xin; a.gy = gcur; a.gx = gxb; a.M = (long long)B * s.ih * s.iw; a.C = s.ic;
-                a.gamma = P + s.gamma_off; a.beta = P + s.beta_off; a.slope = s.has_prelu ? P + s.slope_off : nullptr;
-                a.mean = ws + s.aux_off; a.invstd = ws + s.aux_off + s.ic;
-                a.ggamma = want_p ? Gp + s.gamma_off : nullptr; a.gbeta = want_p ? Gp + s.beta_off : nullptr;
-                a.gslope = (want_p && s.has_prelu) ? Gp + s.slope_off : nullptr; a.gbeta_acc = 0.f; a.scratch = scratch;
-                rc = fg_launch_bn_backward(ctx, a);
-                break;
-            }
-            case ST_PRELU: {
-                const long long cnt = (long long)B * s.ic * s.ih * s.iw;
-                const float sc = (s.mask_kind == 2) ? 1.f / (1.f - s.p) : 1.f;
-                rc = fg_launch_prelu_backward(ctx, xin, gcur, P + s.slope_off, mask, sc, gxb,
-                                              want_p ? Gp + s.slope_off : nullptr, 0.f, cnt, scratch);
-                break;
-            }
-            case ST_ACTPOOL:
-                rc = fg_launch_actpool_backward(ctx, xin, gcur, P + s.slope_off, mask, 1.f, gxb,
-                                                want_p ? Gp + s.slope_off : nullptr, 0.f, B, s.ih, s.iw, s.ic, scratch);
-                break;
-            case ST_SIGMOID:
-                if (need_gx) rc = fg_launch_sigmoid_backward(ctx, yout, gcur, gxb, (long long)B * s.ic * s.ih * s.iw);
-                break;
-            case ST_LEAKYRELU:
-                if (need_gx) rc = fg_launch_leakyrelu_backward(ctx, xin, gcur, s.negslope, gxb, (long long)B * s.ic * s.ih * s.iw);
-                break;
-            case ST_UPSAMPLE: if (need_gx) rc = fg_launch_upsample_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
-            case ST_AVGPOOL: if (need_gx) rc = fg_launch_avgpool_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
-            case ST_SDROPOUT: if (need_gx) rc = fg_launch_scale_mask_nc(ctx, gcur, mask, 1.f, gxb, B, s.ih * s.iw, s.ic); break;
-            case ST_MAXPOOL: if (need_gx) rc = fg_launch_maxpool_backward(ctx, xin, gcur, gxb, B, s.ih, s.iw, s.ic); break;
-            case ST_DROPOUT:
-                if (need_gx) rc = fg_launch_mul_mask(ctx, gcur, mask, 1.f / (1.f - s.p), gxb, (long long)B * s.ic * s.ih * s.iw);
-                break;
-            default: rc = fg_set_err(ctx, FG_ERR_INVALID, "fg_net_backward: bad stage kind %d", s.kind);
-        }
-        if (rc) return rc;
-        gcur = gxb;
-        if (si > 0) pp ^= 1;
-    }
-    n->bwd_gcur = gcur; n->bwd_pp = pp; n->bwd_next = stage_to - 1;
+    n->run_stage = stage_from; n->run_phase = 0; n->run_to = stage_to; n->run_flags = flags; n->run_B = B;
+    n->run_x = x; n->run_ws = (float*)wsv; n->run_gx = gx;
+    return backward_run(n);
+}
+
+int fg_net_backward_resume(fg_net* n) {
+    if (!n || n->run_phase != 2) return fg_set_err(n ? n->ctx : nullptr, FG_ERR_INVALID, "fg_net_backward_resume: not paused");
+    return backward_run(n);
+}
+
+int fg_net_set_sync_bn(fg_net* n, int on, double* sync_buf, long long capacity_doubles) {
+    if (!n) return FG_ERR_INVALID;
+    if (on && (!sync_buf || capacity_doubles <= 0)) return fg_set_err(n->ctx, FG_ERR_INVALID, "fg_net_set_sync_bn: buffer required");
+    n->sync_bn = on != 0; n->sync_buf = sync_buf; n->sync_cap = capacity_doubles;
     return FG_OK;
 }
+long long fg_net_sync_count(const fg_net* n) { return n ? n->sync_count : 0; }
 
 int fg_net_layer_output(const fg_net* n, int li, long long* off, int* c, int* h, int* w) {
     if (!n || li < 0 || li >= (int)n->layers.size()) return FG_ERR_INVALID;

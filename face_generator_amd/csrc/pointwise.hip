@@ -320,6 +320,76 @@ int fg_launch_bn_forward(fg_ctx* ctx, const BnArgs& a) {
     return FG_OK;
 }
 
+// ---- sync-BN: per-channel sums leave the GPU as fp64 so that the cross-rank all-reduce + the global
+// mean / variance are exact to fp64 rounding.  sync = [sum x (C)] [sum x^2 (C)] [rows (1)]
+__global__ __launch_bounds__(1024) void bn_sync_local_kernel(const float* __restrict__ part, const float* __restrict__ x,
+                                                             int nrb, long long M, int C, double* __restrict__ sync) {
+    __shared__ double sh[2][16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int b = ty; b < nrb; b += 16) {
+            s1 += (double)part[(size_t)b * C + c];
+            s2 += (double)part[((size_t)nrb + b) * C + c];
+        }
+    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) sync[2 * C] = (double)M;
+    if (ty != 0 || c >= C) return;
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s1 += sh[0][i][tx]; s2 += sh[1][i][tx]; }
+    const double K = (double)x[c], n = (double)M;     // un-shift: sum x = S1 + nK ; sum x^2 = S2 + 2K S1 + n K^2
+    sync[c] = s1 + n * K;
+    sync[C + c] = s2 + 2.0 * K * s1 + n * K * K;
+}
+__global__ void bn_sync_global_kernel(const double* __restrict__ sync, int C, float eps, float momentum,
+                                      float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
+                                      float* __restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double n = sync[2 * C];
+    const double mu = sync[c] / n;
+    double var = sync[C + c] / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) {
+        const double unb = var * n / (n > 1.0 ? n - 1.0 : 1.0);
+        rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mu);
+        rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unb);
+    }
+}
+static int bn_launch_stats_partial(fg_ctx* ctx, const BnArgs& a, int nrb) {
+    if (cr4_ok(a.C))
+        hipLaunchKernelGGL(bn_stats4_partial_kernel, dim3(nrb), dim3(256), 0, ctx->stream, a.x, a.M, a.C, a.scratch);
+    else
+        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nrb, fg_cdiv(a.C, 64)), dim3(256), 0, ctx->stream, a.x, a.M,
+                           a.C, a.scratch);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_bn_forward_sync1(fg_ctx* ctx, const BnArgs& a, double* sync) {
+    const int nrb = cr_rowblocks(a.M);
+    int rc = bn_launch_stats_partial(ctx, a, nrb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_sync_local_kernel, dim3(fg_cdiv(a.C, 64)), dim3(1024), 0, ctx->stream, a.scratch, a.x, nrb, a.M,
+                       a.C, sync);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_bn_forward_sync2(fg_ctx* ctx, const BnArgs& a, const double* sync) {
+    hipLaunchKernelGGL(bn_sync_global_kernel, dim3(fg_cdiv(a.C, 256)), dim3(256), 0, ctx->stream, sync, a.C, a.eps,
+                       a.momentum, a.mean, a.invstd, a.running_mean, a.running_var);
+    FG_CHECK_LAUNCH(ctx);
+    const long long t4 = a.M * a.C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.y, t4, a.C,
+                       a.gamma, a.beta, a.slope, a.mean, a.invstd);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
 // backward: dz = PReLU'(z) * gy with z = gamma*xhat + beta; sums: S_dz, S_dz_xhat per channel, S_slope global
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                              long long M, int C, const float* __restrict__ gamma,
@@ -428,6 +498,73 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         ((float4*)gx)[i] = o;
     }
 }
+// sync-BN backward: local sums -> fp64 sync buffer [sum dz (C)] [sum dz*xhat (C)] [rows]; parameter gradients are written
+// from the LOCAL sums (the later gradient all-reduce makes them global); the coefficients use the reduced sums.
+__global__ __launch_bounds__(1024) void bn_bwd_sync_local_kernel(const float* __restrict__ part, int nrb, long long M, int C,
+                                                                 double* __restrict__ sync, float* __restrict__ ggamma,
+                                                                 float* __restrict__ gbeta, float acc) {
+    __shared__ double sh[2][16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int b = ty; b < nrb; b += 16) {
+            s1 += (double)part[(size_t)b * C + c];
+            s2 += (double)part[((size_t)nrb + b) * C + c];
+        }
+    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) sync[2 * C] = (double)M;
+    if (ty != 0 || c >= C) return;
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s1 += sh[0][i][tx]; s2 += sh[1][i][tx]; }
+    sync[c] = s1;
+    sync[C + c] = s2;
+    if (ggamma) ggamma[c] = (acc == 0.f ? 0.f : acc * ggamma[c]) + (float)s2;
+    if (gbeta) gbeta[c] = (acc == 0.f ? 0.f : acc * gbeta[c]) + (float)s1;
+}
+__global__ void bn_bwd_sync_global_kernel(const double* __restrict__ sync, int C, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double n = sync[2 * C];
+    coef[c] = (float)(sync[c] / n);
+    coef[C + c] = (float)(sync[C + c] / n);
+}
+int fg_launch_bn_backward_sync1(fg_ctx* ctx, const BnBwdArgs& a, double* sync) {
+    const int nrb = cr_rowblocks(a.M);
+    float* part = a.scratch;
+    if (cr4_ok(a.C))
+        hipLaunchKernelGGL(bn_bwd4_partial_kernel, dim3(nrb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
+                           a.beta, a.slope, a.mean, a.invstd, part);
+    else
+        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb, fg_cdiv(a.C, 64)), dim3(256), 0, ctx->stream, a.x, a.gy, a.M,
+                           a.C, a.gamma, a.beta, a.slope, a.mean, a.invstd, part);
+    FG_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(bn_bwd_sync_local_kernel, dim3(fg_cdiv(a.C, 64)), dim3(1024), 0, ctx->stream, part, nrb, a.M, a.C,
+                       sync, a.ggamma, a.gbeta, a.gbeta_acc);
+    FG_CHECK_LAUNCH(ctx);
+    if (a.slope && a.gslope) {
+        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, part + (size_t)2 * nrb * a.C,
+                           nrb * a.C, a.gslope, a.gbeta_acc);
+        FG_CHECK_LAUNCH(ctx);
+    }
+    return FG_OK;
+}
+int fg_launch_bn_backward_sync2(fg_ctx* ctx, const BnBwdArgs& a, const double* sync) {
+    const int nrb = cr_rowblocks(a.M);
+    float* coef = a.scratch + (size_t)3 * nrb * a.C;
+    hipLaunchKernelGGL(bn_bwd_sync_global_kernel, dim3(fg_cdiv(a.C, 256)), dim3(256), 0, ctx->stream, sync, a.C, coef);
+    FG_CHECK_LAUNCH(ctx);
+    if (a.gx) {
+        const long long t4 = a.M * a.C / 4;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.gy, a.gx,
+                           t4, a.C, a.gamma, a.beta, a.slope, a.mean, a.invstd, coef, 1);
+        FG_CHECK_LAUNCH(ctx);
+    }
+    return FG_OK;
+}
+
 int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
     if (a.C % 4) return fg_set_err(ctx, FG_ERR_INVALID, "bn: C %% 4");
     const int nrb = cr_rowblocks(a.M);

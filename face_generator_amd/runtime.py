@@ -35,7 +35,7 @@ class Context:
         self.check(self.lib.fg_ctx_set_stream(self.h, ctypes.c_void_p(s.cuda_stream)))
 
     def check(self, rc):
-        if rc != 0:
+        if rc < 0 or rc > 1:      # 1 == FG_PAUSED_SYNC (handled by the caller)
             raise FgError("libfacegen_hip error %d: %s" % (rc, self.lib.fg_last_error(self.h).decode()))
 
     def empty(self, *shape):
@@ -130,6 +130,7 @@ class DeviceNet:
         self.reserve(max_batch)
         ctx.check(self.lib.fg_net_bind(h, self.params.data_ptr(), self.grads.data_ptr(), self.buffers.data_ptr()))
         self.train = True
+        self.sync_buf, self._sync_reduce = None, None
         self.mask_seed, self.mask_offset = 1, 0
         self._masks = None
         self._batch = 0
@@ -189,8 +190,31 @@ class DeviceNet:
                 off += n
         return masks
 
-    def forward(self, x, masks=None, train=None):
-        """x: device NHWC [B,H,W,C] (or [B,F]).  Returns a VIEW into the workspace (NHWC)."""
+    # ---- sync-BN -------------------------------------------------------------------------------------------------
+    def enable_sync_bn(self, reduce_fn):
+        """Exact global-batch BatchNorm under data parallelism: `reduce_fn(t)` must sum the fp64 tensor `t` in place
+        across ranks (torch.distributed.all_reduce); forward/backward pause at every BatchNorm for it."""
+        cmax = max([l[1] for l in self.layers if l[0] == "BATCHNORM"] + [1])
+        self.sync_buf = torch.zeros(2 * cmax + 1, dtype=torch.float64, device=self.ctx.device)
+        self._sync_reduce = reduce_fn
+        self.ctx.check(self.lib.fg_net_set_sync_bn(self.h, 1, self.sync_buf.data_ptr(), self.sync_buf.numel()))
+
+    def disable_sync_bn(self):
+        self._sync_reduce = None
+        self.ctx.check(self.lib.fg_net_set_sync_bn(self.h, 0, None, 0))
+
+    def _sync_slice(self):
+        return self.sync_buf[: self.lib.fg_net_sync_count(self.h)]
+
+    def _drain(self, rc, resume):
+        """Run the pause / all-reduce / resume protocol until the pass completes."""
+        while rc == 1:
+            self._sync_reduce(self._sync_slice())
+            rc = resume()
+        self.ctx.check(rc)
+
+    # ---- forward / backward ---------------------------------------------------------------------------------------
+    def _forward_call(self, x, masks, train):
         train = self.train if train is None else train
         B = x.shape[0]
         self.reserve(B)
@@ -204,28 +228,60 @@ class DeviceNet:
             mp = (ctypes.c_void_p * self.n_masks)(*[m.data_ptr() for m in self._masks])
         else:
             self._masks, mp = None, None
-        off = ctypes.c_longlong()
-        self.ctx.check(self.lib.fg_net_forward(self.h, B, x.data_ptr(), self.ws.data_ptr(), self.ws.numel() * 4,
-                                               1 if train else 0, mp, self.n_masks if mp is not None else 0,
-                                               ctypes.byref(off)))
+        self._off = ctypes.c_longlong()
         self._batch, self._x = B, x
+        return self.lib.fg_net_forward(self.h, B, x.data_ptr(), self.ws.data_ptr(), self.ws.numel() * 4,
+                                       1 if train else 0, mp, self.n_masks if mp is not None else 0,
+                                       ctypes.byref(self._off))
+
+    def _forward_resume(self):
+        return self.lib.fg_net_forward_resume(self.h, ctypes.byref(self._off))
+
+    def _output_view(self):
+        B = self._batch
         n = B * self.out_c * self.out_h * self.out_w
-        out = self.ws[off.value: off.value + n]
+        out = self.ws[self._off.value: self._off.value + n]
         if self.out_h * self.out_w == 1:
             return out.view(B, self.out_c)
         return out.view(B, self.out_h, self.out_w, self.out_c)
 
+    def forward(self, x, masks=None, train=None):
+        """x: device NHWC [B,H,W,C] (or [B,F]).  Returns a VIEW into the workspace (NHWC)."""
+        self._drain(self._forward_call(x, masks, train), self._forward_resume)
+        return self._output_view()
+
+    def forward_steps(self, x, masks=None, train=None):
+        """Generator form of forward() for externally driven sync-BN: yields the fp64 sum buffer at every pause (the
+        driver reduces it in place across ranks, then advances the generator); the output view is self._output_view()."""
+        rc = self._forward_call(x, masks, train)
+        while rc == 1:
+            yield self._sync_slice()
+            rc = self._forward_resume()
+        self.ctx.check(rc)
+
     def backward(self, gy, param_grads=True, input_grad=False):
         """gy: device grad wrt the output (NHWC).  Returns gx (NHWC) if input_grad."""
-        B = self._batch
-        gy = gy.contiguous()
-        gx = None
-        if input_grad:
-            gx = self.ctx.empty(*self._x.shape)
-        flags = (_lib.FG_BWD_PARAM_GRADS if param_grads else 0) | (_lib.FG_BWD_INPUT_GRAD if input_grad else 0)
-        self.ctx.check(self.lib.fg_net_backward(self.h, B, self._x.data_ptr(), gy.data_ptr(), self.ws.data_ptr(),
-                                                self.ws.numel() * 4, flags, gx.data_ptr() if gx is not None else None))
+        gx = self.ctx.empty(*self._x.shape) if input_grad else None
+        self._drain(self._backward_call(gy, param_grads, gx), lambda: self.lib.fg_net_backward_resume(self.h))
         return gx
+
+    def _backward_call(self, gy, param_grads, gx, stage_from=None, stage_to=0):
+        flags = (_lib.FG_BWD_PARAM_GRADS if param_grads else 0) | (_lib.FG_BWD_INPUT_GRAD if gx is not None else 0)
+        gyp = gy.contiguous() if gy is not None else None
+        self._gy_keepalive = gyp
+        if stage_from is None:
+            stage_from = self.lib.fg_net_num_stages(self.h) - 1
+        return self.lib.fg_net_backward_range(self.h, self._batch, self._x.data_ptr(),
+                                              gyp.data_ptr() if gyp is not None else None, self.ws.data_ptr(),
+                                              self.ws.numel() * 4, flags, gx.data_ptr() if gx is not None else None,
+                                              stage_from, stage_to)
+
+    def backward_steps(self, gy, param_grads=True):
+        rc = self._backward_call(gy, param_grads, None)
+        while rc == 1:
+            yield self._sync_slice()
+            rc = self.lib.fg_net_backward_resume(self.h)
+        self.ctx.check(rc)
 
     def grad_buckets(self, target=900000):
         """Split the plan's stages (output -> input order) into buckets of roughly `target` parameters for the bucketed
@@ -245,11 +301,8 @@ class DeviceNet:
 
     def backward_range(self, gy, stage_from, stage_to, param_grads=True):
         """Stages [stage_from .. stage_to] of the backward pass (see fg_net_backward_range)."""
-        flags = _lib.FG_BWD_PARAM_GRADS if param_grads else 0
-        gyp = gy.contiguous().data_ptr() if gy is not None else None
-        self._gy_keepalive = gy
-        self.ctx.check(self.lib.fg_net_backward_range(self.h, self._batch, self._x.data_ptr(), gyp, self.ws.data_ptr(),
-                                                      self.ws.numel() * 4, flags, None, stage_from, stage_to))
+        self._drain(self._backward_call(gy, param_grads, None, stage_from, stage_to),
+                    lambda: self.lib.fg_net_backward_resume(self.h))
 
     def layer_output(self, layer_index):
         off, c, h, w = ctypes.c_longlong(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

@@ -120,6 +120,15 @@ int fg_net_num_stages(const fg_net* net);
 int fg_net_stage_params(const fg_net* net, int stage, long long* param_lo, long long* param_hi);
 int fg_net_backward_range(fg_net* net, int batch, const float* x, const float* gy, void* ws, size_t ws_bytes, int flags,
                           float* gx, int stage_from, int stage_to);
+/* sync-BN (data parallelism with exact global-batch BatchNorm statistics): with sync on, fg_net_forward /
+ * fg_net_backward[_range] return FG_PAUSED_SYNC (= 1) at every SpatialBatchNormalization after leaving
+ * fg_net_sync_count() fp64 values [sum x | sum x^2 | rows] (backward: [sum dz | sum dz*xhat | rows]) in `sync_buf`;
+ * the host sum-all-reduces that buffer across ranks and calls the matching *_resume, until FG_OK. */
+enum { FG_PAUSED_SYNC = 1 };
+int fg_net_set_sync_bn(fg_net* net, int on, double* sync_buf_dev, long long capacity_doubles);
+long long fg_net_sync_count(const fg_net* net);
+int fg_net_forward_resume(fg_net* net, long long* out_offset);
+int fg_net_backward_resume(fg_net* net);
 /* debugging / parity: activation after reference layer `layer_index` of the last forward (must end a stage) */
 int fg_net_layer_output(const fg_net* net, int layer_index, long long* ws_offset, int* c, int* h, int* w);
 

@@ -44,6 +44,14 @@ int fg_net_params_changed(fg_net* net);
 int fg_net_forward(fg_net* net, int batch, const float* x, void* ws, size_t ws_bytes, int train,
                    const float* const* masks, int n_masks, long long* out_offset);
 int fg_net_backward(fg_net* net, int batch, const float* x, const float* gy, void* ws, size_t ws_bytes, int flags, float* gx);
+int fg_net_num_stages(const fg_net* net);
+int fg_net_stage_params(const fg_net* net, int stage, long long* param_lo, long long* param_hi);
+int fg_net_backward_range(fg_net* net, int batch, const float* x, const float* gy, void* ws, size_t ws_bytes, int flags,
+                          float* gx, int stage_from, int stage_to);
+int fg_net_set_sync_bn(fg_net* net, int on, double* sync_buf_dev, long long capacity_doubles);
+long long fg_net_sync_count(const fg_net* net);
+int fg_net_forward_resume(fg_net* net, long long* out_offset);
+int fg_net_backward_resume(fg_net* net);
 int fg_bce_forward_backward(fg_ctx* ctx, const float* prob, const float* target, int n, float* loss_dev,
                             float* grad_dev, int* confusion_dev);
 int fg_adam_fused(fg_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float gscale, float l1_mul,
