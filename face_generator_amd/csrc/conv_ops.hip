@@ -3,6 +3,7 @@
 #include "fg_internal.h"
 #include "conv_ops.h"
 #include <string.h>
+#include <stdlib.h>
 
 static inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
@@ -56,6 +57,12 @@ static void choose_igemm(long long M, int Npad, int ksteps, int P, int* tile, in
     long long b1 = (long long)fg_cdiv(M, 128) * (Npad / 64) * P;
     long long b2 = (long long)fg_cdiv(M, 64) * (Npad / 64) * P;
     *splits = 1;
+    {   // large layers: wave-specialised 256x128 kernel when it fills the chip with whole rounds of 256 blocks
+        const long long bw = (Npad % 128 == 0) ? (long long)fg_cdiv(M, 256) * (Npad / 128) * P : 0;
+        static int use_ws = -1;
+        if (use_ws < 0) { const char* e = getenv("FG_IGEMM_WS"); use_ws = e ? atoi(e) : 1; }
+        if (use_ws && bw >= 256 && bw % 256 == 0 && M % 256 == 0) { *tile = 4; return; }
+    }
     if (b0 >= target) { *tile = 0; return; }
     if (b1 >= target) { *tile = 1; return; }
     *tile = 2;

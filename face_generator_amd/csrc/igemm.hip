@@ -37,6 +37,24 @@ __device__ __forceinline__ f32x4 fg_buffer_load4(__amdgpu_buffer_rsrc_t r, int v
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
 }
 
+// Epilogue store of one 32x32 accumulator tile: branch-free raw-buffer stores (masked rows / padded columns get an
+// out-of-range voffset, which the hardware drops).  The bias value is made available BEFORE the store sequence: with a
+// conditional bias load the compiler put `s_waitcnt vmcnt(0)` in front of every store, which on gfx9 also waits for
+// all earlier STORES -- the 64..128 stores of a wave ran one memory round trip at a time.
+__device__ __forceinline__ void fg_store_acc_tile(__amdgpu_buffer_rsrc_t orsrc, const int* rowoff, int row0, int col,
+                                                  bool colok, float bv, const f32x16& acc, int lane) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int4 ro = *(const int4*)(rowoff + row0 + 8 * r4 + 4 * (lane >> 5));
+        const int offs[4] = {ro.x, ro.y, ro.z, ro.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int voff = (offs[q] >= 0 && colok) ? (offs[q] + col) * 4 : FG_OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r4 * 4 + q] + bv), orsrc, voff, 0, 0);
+        }
+    }
+}
+
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     constexpr int LDK = BK + 4;                 // padded row: conflict-free ds_read_b128 fragment reads
@@ -193,20 +211,227 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 
     float* outp = a.Out + (size_t)split * a.split_stride;
     const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int col = tile_n * BN + wn * (BN / 2) + ni * 32 + (lane & 31);
-        const float bv = (add_bias && col < a.N) ? a.bias[col] : 0.f;
+        const bool colok = col < a.N;
+        float bv = add_bias ? a.bias[colok ? col : 0] : 0.f;
+        asm volatile("" : "+v"(bv));
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
+        for (int mi = 0; mi < MI; ++mi)
+            fg_store_acc_tile(orsrc, rowoff, wm * (BM / 2) + mi * 32, col, colok, bv, acc[mi][ni], lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant for the large layers: ONE 512-thread block per CU; waves 0-3 only multiply (one per SIMD,
+// 128x64 outputs each = 8 accumulator tiles, fragments double-buffered across the K-step barrier), waves 4-7 only move
+// data (gather address math, raw-buffer loads, ds_write) two K-steps ahead into a 4-stage LDS ring.  The MFMA waves
+// issue nothing but ds_read_b128 + v_mfma, so the matrix pipe never waits for a staging phase.
+// Block tile 256 x 128, BK = 16, rows padded to 20 floats (conflict-free b128 fragment reads).
+// ---------------------------------------------------------------------------------------------------------------
+#define WS_BM 256
+#define WS_BN 128
+#define WS_BK 16
+#define WS_LDK 20
+#define WS_NS 4
+#define WS_STAGE ((WS_BM + WS_BN) * WS_LDK)
+__global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* rowoff = (int*)(smem + WS_NS * WS_STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntn = a.Npad / WS_BN;
+    const int np = a.P;
+    const int per_m = ntn * np;
+    const int nmt = (a.M + WS_BM - 1) / WS_BM;
+    int lin = blockIdx.x;
+    if ((nmt & 7) == 0) {
+        const int xcd = lin & 7, loc = lin >> 3;
+        lin = (xcd * (nmt >> 3) + loc / per_m) * per_m + loc % per_m;
+    }
+    const int tile_m = lin / per_m;
+    const int rem = lin - tile_m * per_m;
+    const int tile_n = rem / np, p = rem - tile_n * np;
+    const int split = blockIdx.y;
+
+    if (tid < WS_BM) {
+        int m = tile_m * WS_BM + tid, off = -1;
+        if (m < a.M) {
+            int n, y, x;
+            fg_decode_m(m, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
+            off = ((n * a.Ho + y * a.osy + a.ooy[p]) * a.Wo + x * a.osx + a.oox[p]) * a.N;
+        }
+        rowoff[tid] = off;
+    }
+    const int kc = a.Kpad / WS_BK;
+    const int kt_all = a.G * kc;
+    const int kt_per = (kt_all + a.splits - 1) / a.splits;
+    const int kt0 = split * kt_per;
+    const int KT = max(0, min(kt_all, kt0 + kt_per) - kt0);
+
+    if (wid >= 4) {
+        // ------------------------------------------------------------------ loader waves (256 threads)
+        const int lt = tid - 256;
+        const int lrow = lt >> 2, lk = (lt & 3) * 4;           // 4 lanes per 16-float row, 64 rows per pass
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)a.a_bytes, 0x00020000);
+        int ry[4], rx[4], rn[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int off = rowoff[row];
-                if (off >= 0 && col < a.N) outp[(size_t)off + col] = acc[mi][ni][r] + bv;
+        for (int i = 0; i < 4; ++i) {
+            const int m = tile_m * WS_BM + lrow + 64 * i;
+            int n, y, x;
+            fg_decode_m(m < a.M ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
+            rn[i] = n * a.Ha * a.Wa;
+            ry[i] = m < a.M ? y * a.asy : -(1 << 20);
+            rx[i] = x * a.asx;
+        }
+        const bool ktail = a.Ca != a.Kpad;
+        int g = kt0 / kc;
+        int col0 = (kt0 - g * kc) * WS_BK;
+        int voff[4];
+#define WS_SET_GROUP()                                                                                   \
+        {                                                                                                \
+            const int go = a.goff[p][g < a.G ? g : 0];                                                   \
+            const int oy = (int)(short)(go & 0xffff), ox = go >> 16;                                     \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
+                const int ya = ry[i] + oy, xa = rx[i] + ox;                                              \
+                const bool ok = (unsigned)ya < (unsigned)a.Ha && (unsigned)xa < (unsigned)a.Wa;          \
+                voff[i] = ok ? ((rn[i] + ya * a.Wa + xa) * a.Ca + lk) * 4 : FG_OOB;                      \
+            }                                                                                            \
+        }
+        WS_SET_GROUP();
+        const float* bptr = a.Bp + ((size_t)(p * a.G + g) * a.Npad + tile_n * WS_BN + lrow) * a.Kpad + col0 + lk;
+        const size_t brow = (size_t)64 * a.Kpad;
+        const size_t bjump = (size_t)(a.Npad - 1) * a.Kpad;
+        f32x4 xa[4], xb[2], ya[4], yb[2];     // two tiles in flight: a load has two full K-steps to land
+#define WS_LOAD(ra, rb)                                                                                  \
+        {                                                                                                \
+            const int cb = col0 * 4;                                                                     \
+            const bool kin = !ktail || (col0 + lk < a.Ca);                                               \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+                ra[i] = fg_buffer_load4(arsrc, kin ? voff[i] + cb : FG_OOB);                             \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) rb[i] = *(const f32x4*)(bptr + i * brow);      \
+            col0 += WS_BK; bptr += WS_BK;                                                                \
+            if (col0 == a.Kpad) { col0 = 0; ++g; bptr += bjump; WS_SET_GROUP(); }                        \
+        }
+#define WS_STORE(st, ra, rb)                                                                             \
+        {                                                                                                \
+            float* As = smem + (st) * WS_STAGE;                                                          \
+            float* Bs = As + WS_BM * WS_LDK;                                                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+                *(f32x4*)(As + (lrow + 64 * i) * WS_LDK + lk) = ra[i];                                   \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+                *(f32x4*)(Bs + (lrow + 64 * i) * WS_LDK + lk) = rb[i];                                   \
+        }
+        // prologue: tiles 0 and 1 resident, tiles 2 and 3 in flight
+        if (KT > 0) { WS_LOAD(xa, xb); WS_STORE(0, xa, xb); }
+        if (KT > 1) { WS_LOAD(xa, xb); WS_STORE(1, xa, xb); }
+        if (KT > 2) { WS_LOAD(xa, xb); }
+        if (KT > 3) { WS_LOAD(ya, yb); }
+        __syncthreads();
+        for (int kt = 0; kt < KT; kt += 2) {
+            if (kt + 2 < KT) {
+                WS_STORE((kt + 2) & (WS_NS - 1), xa, xb);
+                if (kt + 4 < KT) { WS_LOAD(xa, xb); }
+            }
+            __syncthreads();
+            if (kt + 1 < KT) {
+                if (kt + 3 < KT) {
+                    WS_STORE((kt + 3) & (WS_NS - 1), ya, yb);
+                    if (kt + 5 < KT) { WS_LOAD(ya, yb); }
+                }
+                __syncthreads();
             }
         }
+#undef WS_SET_GROUP
+#undef WS_LOAD
+#undef WS_STORE
+        return;
     }
+
+    // ---------------------------------------------------------------------- MFMA waves (one per SIMD)
+    const int wm = wid >> 1, wn = wid & 1;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int a_lds = (wm * 128 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
+    const int b_lds = WS_BM * WS_LDK + (wn * 64 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
+    f32x4 af[2][4], bf[2][2];     // [chunk parity][tile]
+    __syncthreads();              // tiles 0 and 1 are in the ring
+    if (KT > 0) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[0][mi] = *(const f32x4*)(smem + a_lds + mi * 32 * WS_LDK);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bf[0][ni] = *(const f32x4*)(smem + b_lds + ni * 32 * WS_LDK);
+    }
+    for (int kt = 0; kt < KT; ++kt) {
+        const float* St = smem + (kt & (WS_NS - 1)) * WS_STAGE;
+        const float* Sn = smem + ((kt + 1) & (WS_NS - 1)) * WS_STAGE;
+        // chunk 1 fragments of this tile
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[1][mi] = *(const f32x4*)(St + a_lds + mi * 32 * WS_LDK + 8);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) bf[1][ni] = *(const f32x4*)(St + b_lds + ni * 32 * WS_LDK + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][mi][j], bf[0][ni][j], acc[mi][ni], 0, 0, 0);
+        // chunk 0 fragments of the NEXT tile (already in the ring: it was stored one K-step ago)
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) af[0][mi] = *(const f32x4*)(Sn + a_lds + mi * 32 * WS_LDK);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bf[0][ni] = *(const f32x4*)(Sn + b_lds + ni * 32 * WS_LDK);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][mi][j], bf[1][ni][j], acc[mi][ni], 0, 0, 0);
+        __syncthreads();
+    }
+
+    float* outp = a.Out + (size_t)split * a.split_stride;
+    const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = tile_n * WS_BN + wn * 64 + ni * 32 + (lane & 31);
+        const bool colok = col < a.N;
+        float bv = add_bias ? a.bias[colok ? col : 0] : 0.f;
+        asm volatile("" : "+v"(bv));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            fg_store_acc_tile(orsrc, rowoff, wm * 128 + mi * 32, col, colok, bv, acc[mi][ni], lane);
+    }
+}
+
+static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
+    const size_t lds = (size_t)(WS_NS * WS_STAGE + WS_BM) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / WS_BN) * P, a.splits, 1);
+    const double exec = 2.0 * (double)grid.x * WS_BM * WS_BN * (double)a.G * a.Kpad;
+    char label[96];
+    snprintf(label, sizeof(label), "igemm_ws_kernel/%s", a.tag ? a.tag : "?");
+    FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
+    hipLaunchKernelGGL(igemm_ws_kernel, grid, dim3(512), lds, ctx->stream, a);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
 }
 
 template <int BM, int BN, int BK>
@@ -233,12 +458,15 @@ int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
     IgemmArgs a = a_in;
     a.P = P;
     if (a.Ca % 4 != 0 || a.Kpad % 32 != 0) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: Ca %% 4 / Kpad %% 32");
+    if ((long long)a.Nb * a.Ho * a.Wo * a.N * 4 >= (long long)FG_OOB)
+        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "igemm: output tensor must be < 2 GiB per launch");
     if (a.a_bytes <= 0 || a.a_bytes >= (long long)FG_OOB) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "igemm: A operand of %lld bytes (must be < 2 GiB per launch)", a.a_bytes);
     if (a.G > FG_MAX_GROUPS || P > 4 || a.splits < 1) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: G/P/splits");
     switch (tile) {
         case 0: if (a.Npad % 128) break; return launch_igemm_t<128, 128, 32>(ctx, a, P);
         case 1: if (a.Npad % 64) break; return launch_igemm_t<128, 64, 32>(ctx, a, P);
         case 2: if (a.Npad % 64) break; return launch_igemm_t<64, 64, 32>(ctx, a, P);
+        case 4: if (a.Npad % 128) break; return launch_igemm_ws(ctx, a, P);
     }
     return fg_set_err(ctx, FG_ERR_INVALID, "igemm: bad tile %d for Npad %d", tile, a.Npad);
 }
