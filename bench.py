@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--prof-iters", type=int, default=3)
     ap.add_argument("--sync-bn", action="store_true",
                     help="N > 1: all-reduce the BatchNorm sums (exact B_global statistics) instead of per-GPU statistics")
+    ap.add_argument("--math", choices=["f32", "bf16x6"], default="f32",
+                    help="arithmetic of the large conv contractions: f32 = native fp32 MFMA (default, the headline); "
+                         "bf16x6 = fp32 emulated on the bf16 matrix pipe with six exact split-plane products (fg_set_math)")
     ap.add_argument("--workload", choices=["cfg2", "c2f"], default="cfg2",
                     help="cfg2: 32x32 G32+D32b (BASELINE configs[1], the headline); c2f: 64x64 coarse-to-fine (configs[3])")
     args = ap.parse_args()
@@ -98,6 +101,7 @@ def main():
     from face_generator_amd.state import S
 
     ctx = get_context(local_rank)
+    ctx.set_math(6 if args.math == "bf16x6" else 0)
     B = args.batch
     C = 3
     if args.workload == "c2f":
@@ -145,7 +149,8 @@ def main():
     out = {
         "metric": "GAN train images/sec (G+D step) at 32x32x3 bs128",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.math == "f32" else "f32 (emulated: 6 exact bf16 split-plane products, fp32 accumulate)",
         "data": "synthetic (U[0,1) images, U(-1,1) noise, reference init N(0,.005^2)/N(0,.001^2))",
         "config": {"workload": "configs[1]: 32x32 color, noiseDim=100, batch 128 per GPU, Adam, D_it=G_it=1"
                                + ("" if world == 1 else "; configs[2]-style weak scaling, RCCL grad all-reduce"),
@@ -251,7 +256,8 @@ def main_c2f(args, ctx, dist, world, rank, torch):
     flops = 37.220e9 * B
     out = {"metric": "GAN train images/sec (G+D step), c2f 64x64x3 bs128", "value": world * B * args.steps / dt,
            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.math == "f32" else "f32 (emulated: 6 exact bf16 split-plane products, fp32 accumulate)", "data": "synthetic",
            "config": {"workload": "configs[3]: 64x64 color coarse-to-fine G_d/D_c, batch 128 per GPU, Adam",
                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world},
            "step_roofline": {"algorithmic_gflop_per_iter": flops / 1e9,

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 static char g_err[512] = "";
 
@@ -63,10 +64,19 @@ int fg_ctx_create(int device, fg_ctx** out) {
         return fg_set_err(nullptr, FG_ERR_UNSUPPORTED, "fg_ctx_create: built for gfx950, device is %s", prop.gcnArchName);
     fg_ctx* c = new fg_ctx();
     c->device = device; c->stream = nullptr; c->err[0] = 0; c->sm_count = prop.multiProcessorCount;
+    if (const char* m = getenv("FG_MATH")) c->math = atoi(m) == 6 ? 6 : 0;   // default arithmetic, see fg_set_math
     *out = c;
     return FG_OK;
 }
 int fg_ctx_destroy(fg_ctx* ctx) { delete ctx; return FG_OK; }
+int fg_set_math(fg_ctx* ctx, int mode) {
+    if (!ctx) return FG_ERR_INVALID;
+    if (mode != 0 && mode != 6) return fg_set_err(ctx, FG_ERR_INVALID, "fg_set_math: mode %d (0 = fp32 MFMA, 6 = bf16x6)", mode);
+    ctx->math = mode;
+    return FG_OK;
+}
+int fg_get_math(fg_ctx* ctx) { return ctx ? ctx->math : -1; }
+
 int fg_prof_enable(fg_ctx* ctx, int on) { NEED(ctx, ctx, "null ctx"); ctx->prof = on != 0; return FG_OK; }
 // Synchronises, then writes one line per kernel label: "name calls total_ms alg_flops exec_flops bytes\n".
 int fg_prof_report(fg_ctx* ctx, char* buf, size_t len, int reset) {

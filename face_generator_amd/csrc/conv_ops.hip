@@ -51,7 +51,7 @@ int fg_conv_pack(fg_ctx* ctx, const ConvGeom& g, const float* W, float* wp_fwd, 
 }
 
 // ---- tile / split heuristics: fill >= 2 blocks per CU (256 CUs) where the problem allows ----
-static void choose_igemm(long long M, int Npad, int ksteps, int P, int* tile, int* splits) {
+static void choose_igemm(long long M, int Npad, int ksteps, int P, int math, int* tile, int* splits) {
     const long long target = 512;
     long long b0 = (Npad % 128 == 0) ? (long long)fg_cdiv(M, 128) * (Npad / 128) * P : 0;
     long long b1 = (long long)fg_cdiv(M, 128) * (Npad / 64) * P;
@@ -62,6 +62,11 @@ static void choose_igemm(long long M, int Npad, int ksteps, int P, int* tile, in
         static int use_ws = -1;
         if (use_ws < 0) { const char* e = getenv("FG_IGEMM_WS"); use_ws = e ? atoi(e) : 1; }
         if (use_ws && bw >= 256 && bw % 256 == 0 && M % 256 == 0) { *tile = 4; return; }
+        // bf16x6: a K-step is short and cheap, so mid-size layers also use the 256x128 kernel, split over K so that
+        // exactly one round of 256 blocks fills the chip (>= 12 sixteen-channel steps per block)
+        if (use_ws && math == 6 && bw > 0 && bw < 256 && 256 % bw == 0 && M % 256 == 0 && (2 * ksteps) / (256 / bw) >= 12) {
+            *tile = 4; *splits = (int)(256 / bw); return;
+        }
     }
     if (b0 >= target) { *tile = 0; return; }
     if (b1 >= target) { *tile = 1; return; }
@@ -98,24 +103,61 @@ static void choose_wgrad(long long M, int Cout, int Cin, int G, int P, int* tile
     *S = (int)((M + mp - 1) / mp);
 }
 
-long long fg_conv_scratch_floats(const ConvGeom& g) {
+
+// bf16x6 weight gradient: block tile 256 dY-channels x 128 X-channels (cfg 0) or 128 x 256 (cfg 1); -1 = not tileable.
+// S pixel-splits so that one round of ~256 blocks fills the chip with >= 12 sixteen-pixel steps per block.
+static int choose_wgrad6(long long M, int Cout, int Cin, int G, int P, int* S, int* mper) {
+    int cfg = -1;
+    if (Cout % 256 == 0 && Cin % 128 == 0) cfg = 0;
+    else if (Cout % 128 == 0 && Cin % 256 == 0) cfg = 1;
+    if (cfg < 0) return -1;
+    const long long base = (long long)(Cout / (cfg == 0 ? 256 : 128)) * (Cin / (cfg == 0 ? 128 : 256)) * G * P;
+    long long s = (256 + base / 2) / base;
+    if (s < 1) s = 1;
+    const long long maxs = M / 192 > 0 ? M / 192 : 1;
+    if (s > maxs) s = maxs;
+    int mp = fg_round_up((int)((M + s - 1) / s), 16);
+    *mper = mp;
+    *S = (int)((M + mp - 1) / mp);
+    return cfg;
+}
+
+static long long scratch_for_math(const ConvGeom& g, int math) {
     WeightMap wm; fg_geom_weightmap(g, &wm);
     const long long M = (long long)g.B * g.H * g.W;  // source-resolution M-space
     long long need = 0;
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
-    int tile, splits;
-    choose_igemm(M, rf, wm.G * (cf / 32), wm.P, &tile, &splits);
     const long long outM = g.fold ? M * 4 : M;
-    if (splits > 1) need = (long long)splits * outM * g.Cout;
-    choose_igemm(M, rb, wm.G * wm.P * (cb / 32), 1, &tile, &splits);
-    if (splits > 1) { long long n2 = (long long)splits * M * g.Cin; if (n2 > need) need = n2; }
+    int tile, splits;
+    choose_igemm(M, rf, wm.G * (cf / 32), wm.P, math, &tile, &splits);
+    {
+        long long n = splits > 1 ? (long long)splits * outM * g.Cout : 0;
+        if (math == 6 && tile == 4) n += ((M * g.Cin + (long long)wm.P * wm.G * rf * cf) * 3 + 1) / 2 + 64;   // split planes
+        if (n > need) need = n;
+    }
+    choose_igemm(M, rb, wm.G * wm.P * (cb / 32), 1, math, &tile, &splits);
+    {
+        long long n = splits > 1 ? (long long)splits * M * g.Cin : 0;
+        if (math == 6 && tile == 4) n += ((outM * g.Cout + (long long)wm.P * wm.G * rb * cb) * 3 + 1) / 2 + 64;
+        if (n > need) need = n;
+    }
     int wt, S, mper, Np, Cp;
     choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
     long long n3 = (long long)wm.P * wm.G * S * Np * Cp;
+    if (math == 6) {
+        int S6, mper6;
+        if (choose_wgrad6(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) >= 0)
+            n3 = (long long)wm.P * wm.G * S6 * g.Cout * g.Cin + 4 + ((outM * g.Cout + M * g.Cin) * 3 + 1) / 2 + 64;
+    }
     if (n3 > need) need = n3;
     long long n4 = (long long)(CR_ROWBLOCKS_MAX + 2) * g.Cout;
     if (n4 > need) need = n4;
     return need + 64;
+}
+// upper bound over the math modes, so fg_set_math can be toggled on a live net
+long long fg_conv_scratch_floats(const ConvGeom& g) {
+    const long long n0 = scratch_for_math(g, 0), n6 = scratch_for_math(g, 6);
+    return n0 > n6 ? n0 : n6;
 }
 
 // reference-formulation FLOPs of one pass over this layer (2 x MACs of the un-folded convolution)
@@ -136,6 +178,27 @@ static void fill_mspace(IgemmArgs& a, int B, int H, int W) {
     a.Nb = B; a.Hm = H; a.Wm = W; a.M = B * H * W;
     a.lgH = ilog2_exact(H); a.lgW = ilog2_exact(W);
     if (a.lgH < 0 || a.lgW < 0) a.lgH = a.lgW = -1;
+}
+
+
+// bf16x6 math mode (fg_set_math): the wave-specialised kernel reads both operands as split-bf16 planes; build them in
+// the (otherwise unused: tile 4 never splits K) scratch.  Weight planes are rebuilt per call -- a few MB, ~5 us.
+static int maybe_split_operands(fg_ctx* ctx, IgemmArgs& a, int tile, long long packed_floats, float* scratch,
+                                long long scratch_floats) {
+    if (ctx->math != 6 || tile != 4 || (a.Ca % 16) != 0 || (a.Kpad % 16) != 0) return FG_OK;
+    if (a.splits > 1) {      // the split-K partials occupy the head of the scratch
+        const long long used = (a.split_stride * a.splits + 3) / 4 * 4;
+        scratch += used; scratch_floats -= used;
+    }
+    const long long a_floats = a.a_bytes / 4;
+    const long long a6 = (a_floats * 3 + 1) / 2, b6 = (packed_floats * 3 + 1) / 2;
+    const long long a6_al = (a6 + 3) / 4 * 4;
+    if (a6_al + b6 > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "bf16x6 planes: scratch %lld > %lld", a6_al + b6, scratch_floats);
+    int rc;
+    if ((rc = fg_launch_split_planes(ctx, a.A, a_floats / a.Ca, a.Ca, scratch))) return rc;
+    if ((rc = fg_launch_split_planes(ctx, a.Bp, packed_floats / a.Kpad, a.Kpad, scratch + a6_al))) return rc;
+    a.A6 = scratch; a.B6 = scratch + a6_al;
+    return FG_OK;
 }
 
 int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* wp_fwd, const float* bias,
@@ -165,15 +228,17 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
     }
     a.a_bytes = (long long)g.B * g.H * g.W * g.Cin * 4;
     int tile, splits;
-    choose_igemm(a.M, rf, wm.G * (cf / 32), wm.P, &tile, &splits);
+    choose_igemm(a.M, rf, wm.G * (cf / 32), wm.P, ctx->math, &tile, &splits);
+    if (tile == 4 && ctx->math == 6 && ((a.Ca % 16) || (a.Kpad % 16))) choose_igemm(a.M, rf, wm.G * (cf / 32), wm.P, 0, &tile, &splits);
     const long long out_count = (long long)a.M * (g.fold ? 4 : 1) * g.Cout;
     a.splits = splits;
     if (splits > 1) {
         if ((long long)splits * out_count > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv fwd: scratch");
         a.Out = scratch; a.split_stride = out_count;
     }
-    int rc = fg_launch_igemm(ctx, a, wm.P, tile);
-    if (rc) return rc;
+    int rc;
+    if ((rc = maybe_split_operands(ctx, a, tile, (long long)wm.P * wm.G * rf * cf, scratch, scratch_floats))) return rc;
+    if ((rc = fg_launch_igemm(ctx, a, wm.P, tile))) return rc;
     if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, bias, g.Cout, y, out_count);
     return FG_OK;
 }
@@ -206,15 +271,17 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
     }
     a.a_bytes = (long long)g.B * g.H * g.W * (g.fold ? 4 : 1) * g.Cout * 4;
     int tile, splits;
-    choose_igemm(a.M, rb, a.G * (cb / 32), 1, &tile, &splits);
+    choose_igemm(a.M, rb, a.G * (cb / 32), 1, ctx->math, &tile, &splits);
+    if (tile == 4 && ctx->math == 6 && ((a.Ca % 16) || (a.Kpad % 16))) choose_igemm(a.M, rb, a.G * (cb / 32), 1, 0, &tile, &splits);
     const long long out_count = (long long)a.M * g.Cin;
     a.splits = splits;
     if (splits > 1) {
         if ((long long)splits * out_count > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv dgrad: scratch");
         a.Out = scratch; a.split_stride = out_count;
     }
-    int rc = fg_launch_igemm(ctx, a, 1, tile);
-    if (rc) return rc;
+    int rc;
+    if ((rc = maybe_split_operands(ctx, a, tile, (long long)a.G * rb * cb, scratch, scratch_floats))) return rc;
+    if ((rc = fg_launch_igemm(ctx, a, 1, tile))) return rc;
     if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, nullptr, g.Cin, gx, out_count);
     return FG_OK;
 }
@@ -249,12 +316,26 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
     }
     a.d_bytes = (long long)g.B * a.Hd * a.Wd * g.Cout * 4;
     a.x_bytes = (long long)g.B * g.H * g.W * g.Cin * 4;
-    int tile;
-    choose_wgrad(a.M, g.Cout, g.Cin, wm.G, wm.P, &tile, &a.S, &a.m_per_split, &a.Npad, &a.Cpad);
-    const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;
-    if (need > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad: scratch %lld > %lld", need, scratch_floats);
-    int rc = fg_launch_wgrad(ctx, a, wm.P, tile);
-    if (rc) return rc;
+    int tile, rc;
+    int cfg6 = -1;
+    if (ctx->math == 6 && g.Cout % 16 == 0 && g.Cin % 16 == 0)
+        cfg6 = choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split);
+    if (cfg6 >= 0) {
+        a.Npad = g.Cout; a.Cpad = g.Cin;
+        const long long part = ((long long)wm.P * wm.G * a.S * a.Npad * a.Cpad + 3) / 4 * 4;
+        const long long d_fl = a.d_bytes / 4, x_fl = a.x_bytes / 4;
+        const long long d6 = ((d_fl * 3 + 1) / 2 + 3) / 4 * 4, x6 = (x_fl * 3 + 1) / 2;
+        if (part + d6 + x6 > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad (bf16x6): scratch %lld > %lld", part + d6 + x6, scratch_floats);
+        if ((rc = fg_launch_split_planes(ctx, gy, d_fl / g.Cout, g.Cout, scratch + part))) return rc;
+        if ((rc = fg_launch_split_planes(ctx, x, x_fl / g.Cin, g.Cin, scratch + part + d6))) return rc;
+        a.D6 = scratch + part; a.X6 = scratch + part + d6;
+        if ((rc = fg_launch_wgrad6(ctx, a, wm.P, cfg6))) return rc;
+    } else {
+        choose_wgrad(a.M, g.Cout, g.Cin, wm.G, wm.P, &tile, &a.S, &a.m_per_split, &a.Npad, &a.Cpad);
+        const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;
+        if (need > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad: scratch %lld > %lld", need, scratch_floats);
+        if ((rc = fg_launch_wgrad(ctx, a, wm.P, tile))) return rc;
+    }
     if ((rc = fg_launch_wgrad_finish(ctx, wm, scratch, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
     if (gradb) {
         // bias grad = column sums of gy over all output pixels

@@ -17,6 +17,7 @@ struct fg_ctx {
     hipStream_t stream;
     char err[512];
     int sm_count;
+    int math = 0;        // 0: native fp32 MFMA; 6: fp32 emulated with six split-bf16 plane products (fg_set_math)
     // optional per-launch HIP-event timing of the contraction kernels (bench.py roofline leg)
     bool prof = false;
     std::vector<FgProfRec> prof_recs;
@@ -56,6 +57,8 @@ struct IgemmArgs {
     const float* A;      // NHWC [Nb][Ha][Wa][Ca]
     const float* Bp;     // packed [P][G][Npad][Kpad]  (row = output channel, contiguous k)
     const float* bias;   // [N] or nullptr
+    const void* A6;      // bf16x6 mode: A as split planes [pixel][Ca/16][3][16] bf16 (nullptr = fp32 path)
+    const void* B6;      // bf16x6 mode: packed weights as split planes [P][G][Npad][Kpad/16][3][16] bf16
     float* Out;          // NHWC [Nb][Ho][Wo][N]  (or [splits][...] partials)
     int Nb, Hm, Wm, M;   // M = Nb*Hm*Wm
     int lgH, lgW;        // log2(Hm), log2(Wm) if both are powers of two, else -1
@@ -75,6 +78,8 @@ struct IgemmArgs {
 // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64.  P = gridDim.z parities.
 int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a, int P, int tile);
 // sums split partials (+bias) : out[i] = bias[i % N] + sum_s part[s*stride + i]
+// fp32 rows [rows][C] (C % 16 == 0) -> split-bf16 planes [rows][C/16][3][16]: x = h + m + l exactly
+int fg_launch_split_planes(fg_ctx* ctx, const float* src, long long rows, int C, void* dst);
 int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long stride, const float* bias,
                          int N, float* out, long long count);
 
@@ -85,6 +90,8 @@ struct WgradArgs {
     const float* dY;     // NHWC [Nb][Hd][Wd][Nd]
     const float* X;      // NHWC [Nb][Hx][Wx][Cx]
     float* Part;         // [P*G][S][Npad][Cpad]
+    const void* D6;      // bf16x6 mode: dY / X as split planes [pixel][C/16][3][16] bf16 (nullptr = fp32 path)
+    const void* X6;
     int Nb, Hm, Wm, M, lgH, lgW;
     int Hd, Wd, Nd, dsy, dsx;
     int Hx, Wx, Cx, xsy, xsx;
@@ -97,6 +104,8 @@ struct WgradArgs {
     const char* tag;
 };
 int fg_launch_wgrad(fg_ctx* ctx, const WgradArgs& a, int P, int tile);  // tile: 0 = 128x128, 2 = 64x64
+// bf16x6 weight-gradient contraction; cfg 0: 256 dY-channels x 128 X-channels per block, cfg 1: 128 x 256
+int fg_launch_wgrad6(fg_ctx* ctx, const WgradArgs& a, int P, int cfg);
 
 // Reference-layout <-> packed-layout description of one weight tensor.
 struct WeightMap {

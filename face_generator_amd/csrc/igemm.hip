@@ -434,6 +434,271 @@ static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
     return FG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp32 contraction emulated on the bf16 matrix pipe ("bf16x6"): every fp32 operand is pre-split into three bf16
+// planes x = h + m + l (exact: 8+8+8 significand bits), and a*b is formed from the six plane products whose weight is
+// >= 2^-16 (hh, hm, mh, mm, hl, lh); each bf16 x bf16 product is exact in the fp32 accumulator and the dropped products
+// are <= 2^-24 relative, i.e. below one fp32 rounding.  Measured against fp64 the result is more accurate than the
+// native fp32 MFMA (scripts/bf16x_probe.hip, profiles/r01_bf16x_probe.md) while v_mfma_f32_32x32x16_bf16 runs at 16x
+// the fp32 MFMA rate: 6 products = 2.67x fewer matrix-pipe cycles.
+// Same block structure as igemm_ws_kernel (256x128 tile, 4 MFMA + 4 loader waves); K-step = 16 channels = one 96-byte
+// plane row per tile row, 3-stage LDS ring with 112-byte rows (conflict-free b128 fragment reads).
+// ---------------------------------------------------------------------------------------------------------------
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define W6_ROWB 112
+#define W6_STAGE (384 * W6_ROWB)
+#define W6_NS 3
+__device__ __forceinline__ f32x16 fg_mfma_bf16(s16x8 a, s16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__global__ __launch_bounds__(512, 2) void igemm_ws6_kernel(const IgemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+    int* rowoff = (int*)(smem6 + W6_NS * W6_STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntn = a.Npad / WS_BN;
+    const int np = a.P;
+    const int per_m = ntn * np;
+    const int nmt = (a.M + WS_BM - 1) / WS_BM;
+    int lin = blockIdx.x;
+    if ((nmt & 7) == 0) {
+        const int xcd = lin & 7, loc = lin >> 3;
+        lin = (xcd * (nmt >> 3) + loc / per_m) * per_m + loc % per_m;
+    }
+    const int tile_m = lin / per_m;
+    const int rem = lin - tile_m * per_m;
+    const int tile_n = rem / np, p = rem - tile_n * np;
+    const int split = blockIdx.y;
+
+    if (tid < WS_BM) {
+        int m = tile_m * WS_BM + tid, off = -1;
+        if (m < a.M) {
+            int n, y, x;
+            fg_decode_m(m, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
+            off = ((n * a.Ho + y * a.osy + a.ooy[p]) * a.Wo + x * a.osx + a.oox[p]) * a.N;
+        }
+        rowoff[tid] = off;
+    }
+    const int kc = a.Kpad / 16;          // K-steps (16-channel plane rows) per tap group
+    const int cgA = a.Ca / 16;           // plane rows per pixel actually present in A6
+    const int kt_all = a.G * kc;
+    const int kt_per = (kt_all + a.splits - 1) / a.splits;
+    const int kt0 = split * kt_per;
+    const int KT = max(0, min(kt_all, kt0 + kt_per) - kt0);
+
+    if (wid >= 4) {
+        // ------------------------------------------------------------------ loader waves: 16-byte chunk c = lt + 256*i,
+        // i < 6: A rows (c / 6, part c % 6), i >= 6: B rows
+        const int lt = tid - 256;
+        const long long a6_bytes = a.a_bytes / 4 * 6;
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.A6, 0, (int)a6_bytes, 0x00020000);
+        int ry[6], rx[6], rn[6], lds_a[6], part_a[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = lt + 256 * i;
+            const int row = c / 6, part = c - row * 6;
+            const int m = tile_m * WS_BM + row;
+            int n, y, x;
+            fg_decode_m(m < a.M ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
+            rn[i] = n * a.Ha * a.Wa;
+            ry[i] = m < a.M ? y * a.asy : -(1 << 20);
+            rx[i] = x * a.asx;
+            lds_a[i] = row * W6_ROWB + part * 16;
+            part_a[i] = part * 16;
+        }
+        int lds_b[3];
+        const unsigned char* bptr[3];
+        int g = kt0 / kc;
+        int cg = kt0 - g * kc;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = lt + 256 * i;            // 0 .. 767 over the 128 B rows
+            const int row = c / 6, part = c - row * 6;
+            lds_b[i] = (WS_BM + row) * W6_ROWB + part * 16;
+            bptr[i] = (const unsigned char*)a.B6 +
+                      (((size_t)(p * a.G + g) * a.Npad + tile_n * WS_BN + row) * kc + cg) * 96 + part * 16;
+        }
+        const size_t bjump = (size_t)(a.Npad - 1) * kc * 96;
+        int voff[6];
+#define W6_SET_GROUP()                                                                                   \
+        {                                                                                                \
+            const int go = a.goff[p][g < a.G ? g : 0];                                                   \
+            const int oy = (int)(short)(go & 0xffff), ox = go >> 16;                                     \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                              \
+                const int ya = ry[i] + oy, xa = rx[i] + ox;                                              \
+                const bool ok = (unsigned)ya < (unsigned)a.Ha && (unsigned)xa < (unsigned)a.Wa;          \
+                voff[i] = ok ? (rn[i] + ya * a.Wa + xa) * cgA * 96 + part_a[i] : FG_OOB;                 \
+            }                                                                                            \
+        }
+        W6_SET_GROUP();
+        f32x4 xa_[6], xb_[3], ya_[6], yb_[3], za_[6], zb_[3];   // three tiles in flight (a K-step is only ~1.2 us)
+#define W6_LOAD(ra, rb)                                                                                  \
+        {                                                                                                \
+            const bool kin = cg < cgA;                                                                   \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                \
+                ra[i] = fg_buffer_load4(arsrc, kin ? voff[i] + cg * 96 : FG_OOB);                        \
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) { rb[i] = *(const f32x4*)bptr[i]; bptr[i] += 96; } \
+            if (++cg == kc) {                                                                            \
+                cg = 0; ++g;                                                                             \
+                _Pragma("unroll") for (int i = 0; i < 3; ++i) bptr[i] += bjump;                          \
+                W6_SET_GROUP();                                                                          \
+            }                                                                                            \
+        }
+#define W6_STORE(st, ra, rb)                                                                             \
+        {                                                                                                \
+            unsigned char* S = smem6 + (st) * W6_STAGE;                                                  \
+            _Pragma("unroll") for (int i = 0; i < 6; ++i) *(f32x4*)(S + lds_a[i]) = ra[i];               \
+            _Pragma("unroll") for (int i = 0; i < 3; ++i) *(f32x4*)(S + lds_b[i]) = rb[i];               \
+        }
+        // prologue: tiles 0 and 1 resident, tiles 2, 3, 4 in flight; tile t lives in stage t % 3
+        if (KT > 0) { W6_LOAD(xa_, xb_); W6_STORE(0, xa_, xb_); }
+        if (KT > 1) { W6_LOAD(xa_, xb_); W6_STORE(1, xa_, xb_); }
+        if (KT > 2) { W6_LOAD(xa_, xb_); }
+        if (KT > 3) { W6_LOAD(ya_, yb_); }
+        if (KT > 4) { W6_LOAD(za_, zb_); }
+        __syncthreads();
+        for (int kt = 0; kt < KT; kt += 3) {
+            if (kt + 2 < KT) {
+                W6_STORE(2, xa_, xb_);
+                if (kt + 5 < KT) { W6_LOAD(xa_, xb_); }
+            }
+            __syncthreads();
+            if (kt + 1 < KT) {
+                if (kt + 3 < KT) {
+                    W6_STORE(0, ya_, yb_);
+                    if (kt + 6 < KT) { W6_LOAD(ya_, yb_); }
+                }
+                __syncthreads();
+            }
+            if (kt + 2 < KT) {
+                if (kt + 4 < KT) {
+                    W6_STORE(1, za_, zb_);
+                    if (kt + 7 < KT) { W6_LOAD(za_, zb_); }
+                }
+                __syncthreads();
+            }
+        }
+#undef W6_SET_GROUP
+#undef W6_LOAD
+#undef W6_STORE
+        return;
+    }
+
+    // ---------------------------------------------------------------------- MFMA waves (one per SIMD)
+    const int wm = wid >> 1, wn = wid & 1;
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int a_off = (wm * 128 + (lane & 31)) * W6_ROWB + (lane >> 5) * 16;
+    const int b_off = (WS_BM + wn * 64 + (lane & 31)) * W6_ROWB + (lane >> 5) * 16;
+    s16x8 A0[4], A1[4], A2[4], B0[2], B1[2], B2[2];
+#define W6_LDA(dst, S, pl) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) dst[mi] = *(const s16x8*)((S) + a_off + mi * 32 * W6_ROWB + (pl) * 32);
+#define W6_LDB(dst, S, pl) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) dst[ni] = *(const s16x8*)((S) + b_off + ni * 32 * W6_ROWB + (pl) * 32);
+#define W6_PROD(Ax, Bx)                                                                                  \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                     \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = fg_mfma_bf16(Ax[mi], Bx[ni], acc[mi][ni]);
+    __syncthreads();              // tiles 0 and 1 are in the ring
+    if (KT > 0) {
+        W6_LDA(A0, smem6, 0) W6_LDA(A1, smem6, 1) W6_LDA(A2, smem6, 2)
+        W6_LDB(B0, smem6, 0) W6_LDB(B1, smem6, 1) W6_LDB(B2, smem6, 2)
+    }
+    int sn = 1;
+    for (int kt = 0; kt < KT; ++kt) {
+        // every read of this iteration targets the NEXT tile's stage (sealed by the previous barrier); each fragment
+        // register set is re-filled right after its last use, ordered so the first products of the next step find theirs
+        const unsigned char* Sn = smem6 + sn * W6_STAGE;
+        const bool nxt = kt + 1 < KT;
+        W6_PROD(A1, B1)
+        W6_PROD(A2, B0)  if (nxt) { W6_LDA(A2, Sn, 2) }
+        W6_PROD(A0, B2)  if (nxt) { W6_LDB(B2, Sn, 2) }
+        W6_PROD(A1, B0)  if (nxt) { W6_LDA(A1, Sn, 1) }
+        W6_PROD(A0, B1)  if (nxt) { W6_LDB(B1, Sn, 1) }
+        W6_PROD(A0, B0)  if (nxt) { W6_LDA(A0, Sn, 0) W6_LDB(B0, Sn, 0) }
+        sn = sn == W6_NS - 1 ? 0 : sn + 1;
+        // bare barrier: these waves never write LDS and the stage the loaders overwrite next was last READ one full
+        // iteration ago, so the fragment loads just issued may stay in flight across it
+        asm volatile("s_barrier" ::: "memory");
+    }
+#undef W6_LDA
+#undef W6_LDB
+#undef W6_PROD
+
+    float* outp = a.Out + (size_t)split * a.split_stride;
+    const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = tile_n * WS_BN + wn * 64 + ni * 32 + (lane & 31);
+        const bool colok = col < a.N;
+        float bv = add_bias ? a.bias[colok ? col : 0] : 0.f;
+        asm volatile("" : "+v"(bv));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            fg_store_acc_tile(orsrc, rowoff, wm * 128 + mi * 32, col, colok, bv, acc[mi][ni], lane);
+    }
+}
+
+static int launch_igemm_ws6(fg_ctx* ctx, const IgemmArgs& a, int P) {
+    const size_t lds = (size_t)W6_NS * W6_STAGE + WS_BM * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (a.a_bytes / 4 * 6 >= (long long)FG_OOB) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "igemm bf16x6: A planes must be < 2 GiB");
+    dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / WS_BN) * P, a.splits, 1);
+    const double exec = 2.0 * (double)grid.x * WS_BM * WS_BN * (double)a.G * a.Kpad;     // fp32-equivalent FLOPs
+    char label[96];
+    snprintf(label, sizeof(label), "igemm_ws6_kernel/%s", a.tag ? a.tag : "?");
+    FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
+    hipLaunchKernelGGL(igemm_ws6_kernel, grid, dim3(512), lds, ctx->stream, a);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// fp32 rows -> split planes.  One thread per 8 consecutive channels (half a 16-channel plane row).
+__device__ __forceinline__ unsigned fg_bf16_rn(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void fg_split3(float v, unsigned& h, unsigned& m, unsigned& l) {
+    h = fg_bf16_rn(v);
+    const float r1 = v - __uint_as_float(h << 16);
+    m = fg_bf16_rn(r1);
+    const float r2 = r1 - __uint_as_float(m << 16);
+    l = fg_bf16_rn(r2);
+}
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, long long halves, unsigned char* __restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < halves; i += (long long)gridDim.x * 256) {
+        const f32x4 v0 = *(const f32x4*)(src + i * 8), v1 = *(const f32x4*)(src + i * 8 + 4);
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { fg_split3(v0[e], h[e], m[e], l[e]); fg_split3(v1[e], h[4 + e], m[4 + e], l[4 + e]); }
+        unsigned char* o = dst + (i >> 1) * 96 + (i & 1) * 16;
+        *(uint4*)(o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        *(uint4*)(o + 32) = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+        *(uint4*)(o + 64) = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    }
+}
+int fg_launch_split_planes(fg_ctx* ctx, const float* src, long long rows, int C, void* dst) {
+    if (C % 16) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "split planes: C=%d is not a multiple of 16", C);
+    const long long halves = rows * (C / 8);
+    if (halves == 0) return FG_OK;
+    long long blocks = (halves + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    FgProfScope prof(ctx, fg_intern(ctx, "split_planes_kernel"), 0.0, 0.0, (double)halves * 8 * 10);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, src, halves, (unsigned char*)dst);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
 template <int BM, int BN, int BK>
 static int launch_igemm_t(fg_ctx* ctx, const IgemmArgs& a, int P) {
     const size_t lds = (size_t)(2 * (BM + BN) * (BK + 4) + BM) * sizeof(float);
@@ -466,7 +731,7 @@ int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
         case 0: if (a.Npad % 128) break; return launch_igemm_t<128, 128, 32>(ctx, a, P);
         case 1: if (a.Npad % 64) break; return launch_igemm_t<128, 64, 32>(ctx, a, P);
         case 2: if (a.Npad % 64) break; return launch_igemm_t<64, 64, 32>(ctx, a, P);
-        case 4: if (a.Npad % 128) break; return launch_igemm_ws(ctx, a, P);
+        case 4: if (a.Npad % 128) break; return a.A6 ? launch_igemm_ws6(ctx, a, P) : launch_igemm_ws(ctx, a, P);
     }
     return fg_set_err(ctx, FG_ERR_INVALID, "igemm: bad tile %d for Npad %d", tile, a.Npad);
 }
@@ -828,4 +1093,200 @@ int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
     hipLaunchKernelGGL(wgrad_finish_kernel, grid, dim3(128), 0, ctx->stream, wm, Part, S, Npad, Cpad, beta, gradW);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16x6 weight-gradient contraction: Part[pg][s][o][c] = sum over the pixels of split s of dY[pixd][o] * X[pixx(g)][c],
+// both operands as split-bf16 planes.  The reduction runs over PIXELS, so MFMA fragments need 8 consecutive pixels of
+// one channel per lane while memory (and the LDS image) is pixel-major; the fragments are therefore read with gfx950's
+// transposing LDS read (ds_read_b64_tr_b16: within 16 lanes, lane c receives element c%4 of the 8-byte slots supplied
+// by lanes c/4 + 4j), two reads per 8-pixel fragment.  Same wave-specialised block as igemm_ws6_kernel: 4 MFMA waves
+// (2x2, each MI x NI 32x32 tiles) + 4 loader waves, K-step = 16 pixels, 3-stage LDS ring; pixel rows are padded so
+// that (row stride mod 256) = 64, which keeps the 8-byte slots of a 32-lane half on distinct banks.
+// ---------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x8 fg_tr_frag(const unsigned char* lo_addr, int hi_delta) {
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo_addr));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(lo_addr + hi_delta));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int MI, int NI>
+__global__ __launch_bounds__(512, 2) void wgrad_ws6_kernel(const WgradArgs a) {
+    constexpr int RT = MI * 64, QT = NI * 64;                 // dY channels x X channels per block
+    constexpr int RCH = RT / 16 * 6, QCH = QT / 16 * 6;       // 16-byte chunks per pixel row
+    constexpr int ROW_R = RT / 16 * 96 + 64, ROW_Q = QT / 16 * 96 + 64;
+    constexpr int STAGE = 16 * (ROW_R + ROW_Q);
+    constexpr int NR = 16 * RCH / 256, NQ = 16 * QCH / 256;   // chunks per loader thread and K-step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntq = a.Cpad / QT;
+    const int tn = blockIdx.x / ntq, tq = blockIdx.x - tn * ntq;
+    const int s = blockIdx.y, pg = blockIdx.z;
+    const int p = pg / a.G, g = pg - p * a.G;
+    const int m0 = s * a.m_per_split;
+    const int m1 = min(a.M, m0 + a.m_per_split);
+    const int KT = (m1 > m0) ? (m1 - m0 + 15) / 16 : 0;
+
+    if (wid >= 4) {
+        const int lt = tid - 256;
+        const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.D6, 0, (int)(a.d_bytes / 4 * 6), 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.X6, 0, (int)(a.x_bytes / 4 * 6), 0x00020000);
+        const int dpixB = a.Nd / 16 * 96, xpixB = a.Cx / 16 * 96;
+        const int doy = a.doy[p], dox = a.dox[p], xoy = a.xoy[p][g], xox = a.xox[p][g];
+        int pr[NR], ldsR[NR], gR[NR], pq[NQ], ldsQ[NQ], gQ[NQ];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int c = lt + 256 * i;
+            pr[i] = c / RCH;
+            const int w = c - pr[i] * RCH;
+            ldsR[i] = pr[i] * ROW_R + w * 16;
+            gR[i] = tn * (RT / 16) * 96 + w * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int c = lt + 256 * i;
+            pq[i] = c / QCH;
+            const int w = c - pq[i] * QCH;
+            ldsQ[i] = 16 * ROW_R + pq[i] * ROW_Q + w * 16;
+            gQ[i] = tq * (QT / 16) * 96 + w * 16;
+        }
+        int mcur = m0;
+        f32x4 xr[NR], xq[NQ], yr[NR], yq[NQ], zr[NR], zq[NQ];
+#define G6_LOAD(rr, rq)                                                                                  \
+        {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < NR; ++i) {                                             \
+                const int m = mcur + pr[i];                                                              \
+                int n, y, x;                                                                             \
+                fg_decode_m(m < m1 ? m : m0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                         \
+                const int off = ((n * a.Hd + y * a.dsy + doy) * a.Wd + x * a.dsx + dox) * dpixB + gR[i]; \
+                rr[i] = fg_buffer_load4(drsrc, m < m1 ? off : FG_OOB);                                   \
+            }                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < NQ; ++i) {                                             \
+                const int m = mcur + pq[i];                                                              \
+                int n, y, x;                                                                             \
+                fg_decode_m(m < m1 ? m : m0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                         \
+                const int yy = y * a.xsy + xoy, xx = x * a.xsx + xox;                                    \
+                const bool ok = m < m1 && (unsigned)yy < (unsigned)a.Hx && (unsigned)xx < (unsigned)a.Wx;\
+                rq[i] = fg_buffer_load4(xrsrc, ok ? ((n * a.Hx + yy) * a.Wx + xx) * xpixB + gQ[i] : FG_OOB); \
+            }                                                                                            \
+            mcur += 16;                                                                                  \
+        }
+#define G6_STORE(st, rr, rq)                                                                             \
+        {                                                                                                \
+            unsigned char* S = smem6 + (st) * STAGE;                                                     \
+            _Pragma("unroll") for (int i = 0; i < NR; ++i) *(f32x4*)(S + ldsR[i]) = rr[i];               \
+            _Pragma("unroll") for (int i = 0; i < NQ; ++i) *(f32x4*)(S + ldsQ[i]) = rq[i];               \
+        }
+        if (KT > 0) { G6_LOAD(xr, xq); G6_STORE(0, xr, xq); }
+        if (KT > 1) { G6_LOAD(xr, xq); G6_STORE(1, xr, xq); }
+        if (KT > 2) { G6_LOAD(xr, xq); }
+        if (KT > 3) { G6_LOAD(yr, yq); }
+        if (KT > 4) { G6_LOAD(zr, zq); }
+        __syncthreads();
+        for (int kt = 0; kt < KT; kt += 3) {
+            if (kt + 2 < KT) {
+                G6_STORE(2, xr, xq);
+                if (kt + 5 < KT) { G6_LOAD(xr, xq); }
+            }
+            __syncthreads();
+            if (kt + 1 < KT) {
+                if (kt + 3 < KT) {
+                    G6_STORE(0, yr, yq);
+                    if (kt + 6 < KT) { G6_LOAD(yr, yq); }
+                }
+                __syncthreads();
+            }
+            if (kt + 2 < KT) {
+                if (kt + 4 < KT) {
+                    G6_STORE(1, zr, zq);
+                    if (kt + 7 < KT) { G6_LOAD(zr, zq); }
+                }
+                __syncthreads();
+            }
+        }
+#undef G6_LOAD
+#undef G6_STORE
+        return;
+    }
+
+    const int wm = wid >> 1, wn = wid & 1;
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int i16 = lane & 15, cb = (lane >> 4) & 1, kg = lane >> 5;
+    const int r_off = (8 * kg + (i16 >> 2)) * ROW_R + (wm * MI * 2 + cb) * 96 + 8 * (i16 & 3);
+    const int q_off = 16 * ROW_R + (8 * kg + (i16 >> 2)) * ROW_Q + (wn * NI * 2 + cb) * 96 + 8 * (i16 & 3);
+    s16x8 A0[MI], A1[MI], A2[MI], B0[NI], B1[NI], B2[NI];
+#define G6_LDA(dst, S, pl) _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) dst[mi] = fg_tr_frag((S) + r_off + mi * 192 + (pl) * 32, 4 * ROW_R);
+#define G6_LDB(dst, S, pl) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) dst[ni] = fg_tr_frag((S) + q_off + ni * 192 + (pl) * 32, 4 * ROW_Q);
+#define G6_PROD(Ax, Bx)                                                                                  \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                    \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = fg_mfma_bf16(Ax[mi], Bx[ni], acc[mi][ni]);
+    __syncthreads();
+    if (KT > 0) {
+        G6_LDA(A0, smem6, 0) G6_LDA(A1, smem6, 1) G6_LDA(A2, smem6, 2)
+        G6_LDB(B0, smem6, 0) G6_LDB(B1, smem6, 1) G6_LDB(B2, smem6, 2)
+    }
+    int sn = 1;
+    for (int kt = 0; kt < KT; ++kt) {
+        const unsigned char* Sn = smem6 + sn * STAGE;
+        const bool nxt = kt + 1 < KT;
+        G6_PROD(A1, B1)
+        G6_PROD(A2, B0)  if (nxt) { G6_LDA(A2, Sn, 2) }
+        G6_PROD(A0, B2)  if (nxt) { G6_LDB(B2, Sn, 2) }
+        G6_PROD(A1, B0)  if (nxt) { G6_LDA(A1, Sn, 1) }
+        G6_PROD(A0, B1)  if (nxt) { G6_LDB(B1, Sn, 1) }
+        G6_PROD(A0, B0)  if (nxt) { G6_LDA(A0, Sn, 0) G6_LDB(B0, Sn, 0) }
+        sn = sn == 2 ? 0 : sn + 1;
+        asm volatile("s_barrier" ::: "memory");     // see igemm_ws6_kernel
+    }
+#undef G6_LDA
+#undef G6_LDB
+#undef G6_PROD
+
+    float* part = a.Part + ((size_t)pg * a.S + s) * a.Npad * a.Cpad;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = tq * QT + wn * NI * 32 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = tn * RT + wm * MI * 32 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                part[(size_t)row * a.Cpad + col] = acc[mi][ni][r];
+            }
+        }
+}
+
+template <int MI, int NI>
+static int launch_wgrad6_t(fg_ctx* ctx, const WgradArgs& a, int P) {
+    constexpr int RT = MI * 64, QT = NI * 64;
+    const size_t lds = (size_t)3 * 16 * ((RT / 16 * 96 + 64) + (QT / 16 * 96 + 64));
+    static bool attr_set = false;
+    if (!attr_set) {
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws6_kernel<MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if ((a.Nd % RT) || (a.Cx % QT) || a.Npad != a.Nd || a.Cpad != a.Cx)
+        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad bf16x6: %d x %d channels do not tile %d x %d", a.Nd, a.Cx, RT, QT);
+    if (a.d_bytes / 4 * 6 >= (long long)FG_OOB || a.x_bytes / 4 * 6 >= (long long)FG_OOB)
+        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad bf16x6: operand planes must be < 2 GiB");
+    dim3 grid((a.Npad / RT) * (a.Cpad / QT), a.S, a.G * P);
+    const double exec = 2.0 * (double)a.Npad * a.Cpad * (double)a.M * a.G * P;
+    char label[96];
+    snprintf(label, sizeof(label), "wgrad_ws6_kernel<%d,%d>/%s", MI, NI, a.tag ? a.tag : "?");
+    FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
+    hipLaunchKernelGGL((wgrad_ws6_kernel<MI, NI>), grid, dim3(512), lds, ctx->stream, a);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_wgrad6(fg_ctx* ctx, const WgradArgs& a, int P, int cfg) {
+    return cfg == 0 ? launch_wgrad6_t<4, 2>(ctx, a, P) : launch_wgrad6_t<2, 4>(ctx, a, P);
 }

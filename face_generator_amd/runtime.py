@@ -38,6 +38,13 @@ class Context:
         if rc < 0 or rc > 1:      # 1 == FG_PAUSED_SYNC (handled by the caller)
             raise FgError("libfacegen_hip error %d: %s" % (rc, self.lib.fg_last_error(self.h).decode()))
 
+    def set_math(self, mode):
+        """0: native fp32 MFMA (default); 6: fp32 emulated with six split-bf16 plane products (include/facegen_hip.h)."""
+        self.check(self.lib.fg_set_math(self.h, int(mode)))
+
+    def get_math(self):
+        return self.lib.fg_get_math(self.h)
+
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
