@@ -20,8 +20,15 @@ long long fg_geom_pack_floats(const ConvGeom& g, int bwd);
 long long fg_conv_scratch_floats(const ConvGeom& g);
 int fg_conv_pack(fg_ctx* ctx, const ConvGeom& g, const float* W, float* wp_fwd, float* wp_bwd);
 int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* wp_fwd, const float* bias,
-                        float* y, float* scratch, long long scratch_floats);
+                        float* y, float* scratch, long long scratch_floats, const void* wp6 = nullptr,
+                        void* x6_dst = nullptr, int* x6_written = nullptr);
+// x6_dst (forward): write the planes of x there instead of into the scratch (the caller keeps them for the weight
+// gradient); *x6_written tells whether the bf16x6 path ran.  gy6 (dgrad): planes of gy left by fg_conv_wgrad_run.
+// wp6: the packed weights as split-bf16 planes if the caller keeps them (bf16x6 mode), else they are built per call
 int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const float* wp_bwd, float* gx, float* scratch,
-                      long long scratch_floats);
+                      long long scratch_floats, const void* wp6 = nullptr, const void* gy6 = nullptr);
+// bf16x6 plane sharing (all optional): x6 = planes of x kept from the forward pass; *gy6_out = where this call left the
+// planes of gy (nullptr if it ran in fp32) and *used_out = scratch floats that must stay untouched while they are used
 int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* gy, float* gradW, float* gradb,
-                      float beta, float* scratch, long long scratch_floats);
+                      float beta, float* scratch, long long scratch_floats, const void* x6 = nullptr,
+                      const void** gy6_out = nullptr, long long* used_out = nullptr);

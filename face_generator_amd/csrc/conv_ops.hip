@@ -132,13 +132,17 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
     choose_igemm(M, rf, wm.G * (cf / 32), wm.P, math, &tile, &splits);
     {
         long long n = splits > 1 ? (long long)splits * outM * g.Cout : 0;
-        if (math == 6 && tile == 4) n += ((M * g.Cin + (long long)wm.P * wm.G * rf * cf) * 3 + 1) / 2 + 64;   // split planes
+        // bf16x6: a smaller run-time batch may pick split-K where the full batch does not; its partials are bounded by
+        // 256 blocks x one 256x128 tile each
+        if (math == 6 && rf % 128 == 0 && n < 256LL * 256 * 128 + 64) n = 256LL * 256 * 128 + 64;
+        if (math == 6 && rf % 128 == 0) n += ((M * g.Cin + (long long)wm.P * wm.G * rf * cf) * 3 + 1) / 2 + 64;   // split planes
         if (n > need) need = n;
     }
     choose_igemm(M, rb, wm.G * wm.P * (cb / 32), 1, math, &tile, &splits);
     {
         long long n = splits > 1 ? (long long)splits * M * g.Cin : 0;
-        if (math == 6 && tile == 4) n += ((outM * g.Cout + (long long)wm.P * wm.G * rb * cb) * 3 + 1) / 2 + 64;
+        if (math == 6 && rb % 128 == 0 && n < 256LL * 256 * 128 + 64) n = 256LL * 256 * 128 + 64;
+        if (math == 6 && rb % 128 == 0) n += ((outM * g.Cout + (long long)wm.P * wm.G * rb * cb) * 3 + 1) / 2 + 64;
         if (n > need) need = n;
     }
     int wt, S, mper, Np, Cp;
@@ -146,8 +150,10 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
     long long n3 = (long long)wm.P * wm.G * S * Np * Cp;
     if (math == 6) {
         int S6, mper6;
-        if (choose_wgrad6(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) >= 0)
-            n3 = (long long)wm.P * wm.G * S6 * g.Cout * g.Cin + 4 + ((outM * g.Cout + M * g.Cin) * 3 + 1) / 2 + 64;
+        if (M >= 1024 && choose_wgrad6(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) >= 0)
+            // Part + planes of gy and x, then (shared-plane backward) the data-gradient's split-K partials + weight planes
+            n3 = (long long)wm.P * wm.G * S6 * g.Cout * g.Cin + 4 + ((outM * g.Cout + M * g.Cin) * 3 + 1) / 2 + 64 +
+                 256LL * 256 * 128 + 64 + ((long long)wm.P * wm.G * rb * cb * 3 + 1) / 2 + 64;
     }
     if (n3 > need) need = n3;
     long long n4 = (long long)(CR_ROWBLOCKS_MAX + 2) * g.Cout;
@@ -184,25 +190,31 @@ static void fill_mspace(IgemmArgs& a, int B, int H, int W) {
 // bf16x6 math mode (fg_set_math): the wave-specialised kernel reads both operands as split-bf16 planes; build them in
 // the (otherwise unused: tile 4 never splits K) scratch.  Weight planes are rebuilt per call -- a few MB, ~5 us.
 static int maybe_split_operands(fg_ctx* ctx, IgemmArgs& a, int tile, long long packed_floats, float* scratch,
-                                long long scratch_floats) {
+                                long long scratch_floats, const void* wp6, const void* a6_have, void* a6_dst,
+                                int* a6_written) {
+    if (a6_written) *a6_written = 0;
     if (ctx->math != 6 || tile != 4 || (a.Ca % 16) != 0 || (a.Kpad % 16) != 0) return FG_OK;
     if (a.splits > 1) {      // the split-K partials occupy the head of the scratch
         const long long used = (a.split_stride * a.splits + 3) / 4 * 4;
         scratch += used; scratch_floats -= used;
     }
     const long long a_floats = a.a_bytes / 4;
-    const long long a6 = (a_floats * 3 + 1) / 2, b6 = (packed_floats * 3 + 1) / 2;
+    const long long a6 = (a6_have || a6_dst) ? 0 : (a_floats * 3 + 1) / 2;
+    const long long b6 = wp6 ? 0 : (packed_floats * 3 + 1) / 2;
     const long long a6_al = (a6 + 3) / 4 * 4;
     if (a6_al + b6 > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "bf16x6 planes: scratch %lld > %lld", a6_al + b6, scratch_floats);
     int rc;
-    if ((rc = fg_launch_split_planes(ctx, a.A, a_floats / a.Ca, a.Ca, scratch))) return rc;
-    if ((rc = fg_launch_split_planes(ctx, a.Bp, packed_floats / a.Kpad, a.Kpad, scratch + a6_al))) return rc;
-    a.A6 = scratch; a.B6 = scratch + a6_al;
+    void* adst = a6_dst ? a6_dst : (void*)scratch;
+    if (!a6_have && (rc = fg_launch_split_planes(ctx, a.A, a_floats / a.Ca, a.Ca, adst))) return rc;
+    if (!wp6 && (rc = fg_launch_split_planes(ctx, a.Bp, packed_floats / a.Kpad, a.Kpad, scratch + a6_al))) return rc;
+    a.A6 = a6_have ? a6_have : adst; a.B6 = wp6 ? wp6 : (const void*)(scratch + a6_al);
+    if (a6_written && a6_dst) *a6_written = 1;
     return FG_OK;
 }
 
 int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* wp_fwd, const float* bias,
-                        float* y, float* scratch, long long scratch_floats) {
+                        float* y, float* scratch, long long scratch_floats, const void* wp6, void* x6_dst, int* x6_written) {
+    if (x6_written) *x6_written = 0;
     if (g.B == 0) return FG_OK;
     WeightMap wm; fg_geom_weightmap(g, &wm);
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
@@ -237,14 +249,14 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
         a.Out = scratch; a.split_stride = out_count;
     }
     int rc;
-    if ((rc = maybe_split_operands(ctx, a, tile, (long long)wm.P * wm.G * rf * cf, scratch, scratch_floats))) return rc;
+    if ((rc = maybe_split_operands(ctx, a, tile, (long long)wm.P * wm.G * rf * cf, scratch, scratch_floats, wp6, nullptr, x6_dst, x6_written))) return rc;
     if ((rc = fg_launch_igemm(ctx, a, wm.P, tile))) return rc;
     if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, bias, g.Cout, y, out_count);
     return FG_OK;
 }
 
 int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const float* wp_bwd, float* gx, float* scratch,
-                      long long scratch_floats) {
+                      long long scratch_floats, const void* wp6, const void* gy6) {
     if (g.B == 0) return FG_OK;
     WeightMap wm; fg_geom_weightmap(g, &wm);
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
@@ -280,14 +292,17 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
         a.Out = scratch; a.split_stride = out_count;
     }
     int rc;
-    if ((rc = maybe_split_operands(ctx, a, tile, (long long)a.G * rb * cb, scratch, scratch_floats))) return rc;
+    if ((rc = maybe_split_operands(ctx, a, tile, (long long)a.G * rb * cb, scratch, scratch_floats, wp6, gy6, nullptr, nullptr))) return rc;
     if ((rc = fg_launch_igemm(ctx, a, 1, tile))) return rc;
     if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, nullptr, g.Cin, gx, out_count);
     return FG_OK;
 }
 
 int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* gy, float* gradW, float* gradb,
-                      float beta, float* scratch, long long scratch_floats) {
+                      float beta, float* scratch, long long scratch_floats, const void* x6, const void** gy6_out,
+                      long long* used_out) {
+    if (gy6_out) *gy6_out = nullptr;
+    if (used_out) *used_out = 0;
     if (g.B == 0) return FG_OK;
     WeightMap wm; fg_geom_weightmap(g, &wm);
     WgradArgs a; memset(&a, 0, sizeof(a));
@@ -318,18 +333,20 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
     a.x_bytes = (long long)g.B * g.H * g.W * g.Cin * 4;
     int tile, rc;
     int cfg6 = -1;
-    if (ctx->math == 6 && g.Cout % 16 == 0 && g.Cin % 16 == 0)
+    if (ctx->math == 6 && g.Cout % 16 == 0 && g.Cin % 16 == 0 && a.M >= 1024)   // Linear / tiny maps: too few pixels to reduce over
         cfg6 = choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split);
     if (cfg6 >= 0) {
         a.Npad = g.Cout; a.Cpad = g.Cin;
         const long long part = ((long long)wm.P * wm.G * a.S * a.Npad * a.Cpad + 3) / 4 * 4;
         const long long d_fl = a.d_bytes / 4, x_fl = a.x_bytes / 4;
-        const long long d6 = ((d_fl * 3 + 1) / 2 + 3) / 4 * 4, x6 = (x_fl * 3 + 1) / 2;
-        if (part + d6 + x6 > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad (bf16x6): scratch %lld > %lld", part + d6 + x6, scratch_floats);
+        const long long d6 = ((d_fl * 3 + 1) / 2 + 3) / 4 * 4, x6n = x6 ? 0 : (x_fl * 3 + 1) / 2;
+        if (part + d6 + x6n > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad (bf16x6): scratch %lld > %lld", part + d6 + x6n, scratch_floats);
         if ((rc = fg_launch_split_planes(ctx, gy, d_fl / g.Cout, g.Cout, scratch + part))) return rc;
-        if ((rc = fg_launch_split_planes(ctx, x, x_fl / g.Cin, g.Cin, scratch + part + d6))) return rc;
-        a.D6 = scratch + part; a.X6 = scratch + part + d6;
+        if (!x6 && (rc = fg_launch_split_planes(ctx, x, x_fl / g.Cin, g.Cin, scratch + part + d6))) return rc;
+        a.D6 = scratch + part; a.X6 = x6 ? x6 : (const void*)(scratch + part + d6);
         if ((rc = fg_launch_wgrad6(ctx, a, wm.P, cfg6))) return rc;
+        if (gy6_out) *gy6_out = a.D6;
+        if (used_out) *used_out = part + d6;
     } else {
         choose_wgrad(a.M, g.Cout, g.Cin, wm.G, wm.P, &tile, &a.S, &a.m_per_split, &a.Npad, &a.Cpad);
         const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;

@@ -37,12 +37,16 @@ struct Stage {
     ConvGeom geom{};
     float* wp_fwd = nullptr;
     float* wp_bwd = nullptr;
+    const void* wp_fwd6 = nullptr;   // the same packed weights as split-bf16 planes (bf16x6 math mode), views into fg_net::planes_all
+    const void* wp_bwd6 = nullptr;
     float* bias_packed = nullptr;  // Linear followed by View(C,H,W): bias in NHWC feature order
     int has_prelu = 0, has_sigmoid = 0;
     int mask_idx = -1, mask_kind = 0;  // 1 spatial [B][C], 2 elementwise
     float p = 0.f, eps = 1e-5f, momentum = 0.1f, negslope = 0.333f;
     // per-forward plan
     long long out_off = 0, aux_off = 0;
+    long long x6_off = -1;    // ST_CONV: split-bf16 planes of the stage input, kept from forward for the weight gradient
+    int x6_valid = 0;
 };
 
 struct LayerInfo {
@@ -83,6 +87,10 @@ struct fg_net {
     int run_pp = 0;
     // one-launch weight re-pack
     PackJob* jobs_dev = nullptr;
+    float* packed_all = nullptr;      // packed weights of every contraction stage, contiguous (one split launch)
+    unsigned char* planes_all = nullptr;
+    long long packed_total = 0;
+    bool planes_valid = false;
     int n_jobs = 0;
     long long jobs_total = 0;
 };
@@ -112,6 +120,7 @@ static void make_plan(fg_net* n, int B) {
         s.out_off = off; off += align64(osz);
         s.aux_off = off;
         if (s.kind == ST_BNPRELU) off += align64(2 * s.oc);
+        if (s.kind == ST_CONV && s.ic % 16 == 0) { s.x6_off = off; off += align64(((long long)B * s.ic * s.ih * s.iw * 3 + 1) / 2); }
         if (osz > maxact) maxact = osz;
         const long long isz = (long long)B * s.ic * s.ih * s.iw;
         if (isz > maxact) maxact = isz;
@@ -128,6 +137,7 @@ static void make_plan(fg_net* n, int B) {
 }
 
 static int build_pack_jobs(fg_net* n);
+static int ensure_packed(fg_net* n);
 
 static int backward_run(fg_net* n) {
     fg_ctx* ctx = n->ctx;
@@ -153,16 +163,20 @@ static int backward_run(fg_net* n) {
         switch (s.kind) {
             case ST_CONV: {
                 ConvGeom g = s.geom; g.B = B;
+                const void* gy6 = nullptr;       // bf16x6: planes of gcur shared by the weight- and data-gradient
+                long long gy6_used = 0;
                 if (want_p) {
                     rc = fg_conv_wgrad_run(ctx, g, xin, gcur, Gp + s.w_off, s.bias_packed ? nullptr : Gp + s.b_off, 0.f,
-                                           scratch, n->scratch_floats);
+                                           scratch, n->scratch_floats, s.x6_valid ? (const void*)(ws + s.x6_off) : nullptr,
+                                           &gy6, &gy6_used);
                     if (!rc && s.bias_packed) {  // bias grad in NHWC feature order -> reference order
                         float* tb = scratch + (long long)CR_ROWBLOCKS_MAX * g.Cout;
                         rc = fg_launch_colsum(ctx, gcur, (long long)B, g.Cout, 0.f, tb, scratch);
                         if (!rc) rc = fg_launch_nhwc_to_nchw(ctx, tb, Gp + s.b_off, 1, g.o_c, g.o_hw, 1);
                     }
                 }
-                if (!rc && need_gx) rc = fg_conv_dgrad_run(ctx, g, gcur, s.wp_bwd, gxb, scratch, n->scratch_floats);
+                if (!rc && need_gx) rc = fg_conv_dgrad_run(ctx, g, gcur, s.wp_bwd, gxb, scratch + gy6_used, n->scratch_floats - gy6_used,
+                                                         n->planes_valid ? s.wp_bwd6 : nullptr, gy6);
                 break;
             }
             case ST_GEMV:
@@ -265,8 +279,10 @@ static int forward_run(fg_net* n, long long* out_offset) {
         switch (s.kind) {
             case ST_CONV: {
                 ConvGeom g = s.geom; g.B = B;
+                s.x6_valid = 0;
                 rc = fg_conv_forward_run(ctx, g, cur, s.wp_fwd, s.bias_packed ? s.bias_packed : P + s.b_off, y, scratch,
-                                         n->scratch_floats);
+                                         n->scratch_floats, n->planes_valid ? s.wp_fwd6 : nullptr,
+                                         (train && s.x6_off >= 0) ? (void*)(ws + s.x6_off) : nullptr, &s.x6_valid);
                 break;
             }
             case ST_GEMV:
@@ -487,15 +503,29 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
     }
     if (rc == FG_OK && n->st.empty()) rc = fg_set_err(ctx, FG_ERR_INVALID, "fg_net_create: no compute stages");
     n->n_params = poff; n->n_buffers = boff;
-    // packed-weight storage (owned by the net; allocated here, never on the hot path)
+    // packed-weight storage (owned by the net; allocated here, never on the hot path).  The contraction stages share one
+    // allocation so that the bf16x6 planes of all of them are rebuilt by a single launch.
+    {
+        long long tot = 0;
+        for (auto& s : n->st)
+            if (s.kind == ST_CONV) {
+                ConvGeom g = s.geom; g.B = 1;
+                tot += fg_geom_pack_floats(g, 0) + fg_geom_pack_floats(g, 1);
+            }
+        n->packed_total = tot;
+        if (rc == FG_OK && tot > 0 &&
+            (hipMalloc((void**)&n->packed_all, tot * sizeof(float)) != hipSuccess ||
+             hipMalloc((void**)&n->planes_all, tot / 16 * 96) != hipSuccess))
+            rc = fg_set_err(ctx, FG_ERR_NOMEM, "fg_net_create: packed weights");
+    }
+    long long pk_off = 0;
     for (auto& s : n->st) {
         if (rc != FG_OK) break;
         if (s.kind == ST_CONV) {
             ConvGeom g = s.geom; g.B = 1;
             long long nf = fg_geom_pack_floats(g, 0), nb = fg_geom_pack_floats(g, 1);
-            if (hipMalloc((void**)&s.wp_fwd, nf * sizeof(float)) != hipSuccess ||
-                hipMalloc((void**)&s.wp_bwd, nb * sizeof(float)) != hipSuccess)
-                rc = fg_set_err(ctx, FG_ERR_NOMEM, "fg_net_create: packed weights");
+            s.wp_fwd = n->packed_all + pk_off; s.wp_fwd6 = n->planes_all + pk_off / 16 * 96; pk_off += nf;
+            s.wp_bwd = n->packed_all + pk_off; s.wp_bwd6 = n->planes_all + pk_off / 16 * 96; pk_off += nb;
             if (rc == FG_OK && g.o_hw > 1 && hipMalloc((void**)&s.bias_packed, s.b_n * sizeof(float)) != hipSuccess)
                 rc = fg_set_err(ctx, FG_ERR_NOMEM, "fg_net_create: packed bias");
         } else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT) {
@@ -512,10 +542,11 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
 int fg_net_destroy(fg_net* n) {
     if (!n) return FG_OK;
     for (auto& s : n->st) {
-        if (s.wp_fwd) (void)hipFree(s.wp_fwd);
-        if (s.wp_bwd) (void)hipFree(s.wp_bwd);
+        if (s.kind != ST_CONV && s.wp_fwd) (void)hipFree(s.wp_fwd);
         if (s.bias_packed) (void)hipFree(s.bias_packed);
     }
+    if (n->packed_all) (void)hipFree(n->packed_all);
+    if (n->planes_all) (void)hipFree(n->planes_all);
     if (n->jobs_dev) (void)hipFree(n->jobs_dev);
     delete n;
     return FG_OK;
@@ -594,6 +625,17 @@ static int pack_all(fg_net* n) {
     int rc = fg_launch_pack_jobs(n->ctx, n->jobs_dev, n->n_jobs, n->jobs_total, n->params);
     if (rc) return rc;
     n->dirty = false;
+    n->planes_valid = false;
+    return FG_OK;
+}
+// packed weights current (+ their bf16x6 planes when that math mode is on)
+static int ensure_packed(fg_net* n) {
+    int rc;
+    if (n->dirty && (rc = pack_all(n))) return rc;
+    if (n->ctx->math == 6 && !n->planes_valid && n->packed_total > 0) {
+        if ((rc = fg_launch_split_planes(n->ctx, n->packed_all, n->packed_total / 16, 16, n->planes_all))) return rc;
+        n->planes_valid = true;
+    }
     return FG_OK;
 }
 
@@ -612,7 +654,7 @@ int fg_net_forward(fg_net* n, int B, const float* x, void* wsv, size_t ws_bytes,
         return fg_set_err(ctx, FG_ERR_WORKSPACE, "fg_net_forward: workspace %zu < %lld bytes", ws_bytes,
                           n->total_floats * (long long)sizeof(float));
     int rc;
-    if (n->dirty && (rc = pack_all(n))) return rc;
+    if ((rc = ensure_packed(n))) return rc;
     float* ws = (float*)wsv;
     float* scratch = ws + n->scratch_off;
     n->mask_ptrs.assign(n->n_masks, nullptr);
@@ -669,6 +711,7 @@ int fg_net_backward_range(fg_net* n, int B, const float* x, const float* gy, voi
     }
     n->run_stage = stage_from; n->run_phase = 0; n->run_to = stage_to; n->run_flags = flags; n->run_B = B;
     n->run_x = x; n->run_ws = (float*)wsv; n->run_gx = gx;
+    { const int rc0 = ensure_packed(n); if (rc0) return rc0; }
     return backward_run(n);
 }
 

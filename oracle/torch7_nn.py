@@ -223,7 +223,11 @@ class PReLU(Module):
 
     def accGradParameters(self, x, gy, scale=1.0):
         # fp64 accumulate then round: the reduction order upstream is unspecified
-        s = np.sum(np.where(x > 0, 0.0, x.astype(np.float64) * gy.astype(np.float64)))
+        t = np.where(x > 0, 0.0, x.astype(np.float64) * gy.astype(np.float64))
+        s = np.sum(t)
+        # conditioning of this (heavily cancelling) scalar sum, for the parity tests: an eps-relative perturbation of x
+        # moves the sum by ~ eps * ||t||_2, whatever |s| is
+        self.gw_cond = float(np.sqrt(np.sum(t * t))) * abs(scale)
         self.gradWeight += self.gradWeight.dtype.type(scale * s)
 
 
