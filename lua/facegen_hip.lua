@@ -16,6 +16,8 @@ typedef struct fg_ctx fg_ctx;
 typedef struct fg_net fg_net;
 typedef struct fg_layer_spec { int type; int a, b, c, d; float p, q; } fg_layer_spec;
 int fg_ctx_create(int device, fg_ctx** out);
+int fg_set_math(fg_ctx* ctx, int mode);   /* 0 = fp32 MFMA, 6 = fp32 emulated with six split-bf16 plane products */
+int fg_get_math(fg_ctx* ctx);
 int fg_ctx_destroy(fg_ctx* ctx);
 const char* fg_last_error(const fg_ctx* ctx);
 int fg_stream_sync(fg_ctx* ctx);
