@@ -140,13 +140,21 @@ def load_state_dict(net, sd):
     return net
 
 
-def load_checkpoint(filename):
-    """train.lua:114-129 `--network`: -> {D, G, opt, epoch} (optimizer state is NOT restored, like the reference)."""
+def load_checkpoint(filename, image_dims=None):
+    """train.lua:114-129 `--network`: -> {D, G, opt, epoch} (optimizer state is NOT restored, like the reference).
+    Reads both this package's own file (state dicts) and a Torch7-serialised checkpoint written by the reference
+    (t7_checkpoint.py; detected by its leading table tag) -- the latter returns nets, not state dicts."""
+    with open(filename, "rb") as f:
+        head = f.read(4)
+    if head == b"\x03\x00\x00\x00":
+        from . import t7_checkpoint
+        return t7_checkpoint.load_checkpoint(filename, image_dims)
     return torch.load(filename, weights_only=False)
 
 
-def save_checkpoint(filename=None):
-    """adversarial.lua:319-329: rotate adversarial.net -> .old, save {D, G, opt, epoch}."""
+def save_checkpoint(filename=None, fmt="state_dict"):
+    """adversarial.lua:319-329: rotate adversarial.net -> .old, save {D, G, opt, epoch}.
+    fmt="torch7" writes Torch7's own serialisation (loadable by the reference's torch.load)."""
     filename = filename or os.path.join(S.OPT.get("save", "logs"), "adversarial.net")
     os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
     if os.path.isfile(filename):
@@ -154,4 +162,8 @@ def save_checkpoint(filename=None):
     print("<trainer> saving network to %s" % filename)
     prepareNetworkForSave(S.MODEL_D)
     prepareNetworkForSave(S.MODEL_G)
+    if fmt == "torch7":
+        from . import t7_checkpoint
+        t7_checkpoint.save_checkpoint(filename, S.MODEL_D, S.MODEL_G, dict(S.OPT), S.EPOCH)
+        return
     torch.save({"D": state_dict(S.MODEL_D), "G": state_dict(S.MODEL_G), "opt": dict(S.OPT), "epoch": S.EPOCH}, filename)
