@@ -30,10 +30,33 @@ def create_G_decoder_upsampling32(dimensions, noiseDim):
     return model
 
 
+def create_G_decoder_upsampling16(dimensions, noiseDim):
+    """models.lua:27-51: the same decoder started from a 4x4 map (no new kernel class)."""
+    model = nn.Sequential()
+    model.add(nn.Linear(noiseDim, 128 * 4 * 4))
+    model.add(nn.View(128, 4, 4))
+    model.add(nn.PReLU())
+
+    model.add(nn.SpatialUpSamplingNearest(2))
+    model.add(nn.SpatialConvolution(128, 256, 5, 5, 1, 1, (5 - 1) // 2, (5 - 1) // 2))
+    model.add(nn.SpatialBatchNormalization(256))
+    model.add(nn.PReLU())
+
+    model.add(nn.SpatialUpSamplingNearest(2))
+    model.add(nn.SpatialConvolution(256, 128, 5, 5, 1, 1, (5 - 1) // 2, (5 - 1) // 2))
+    model.add(nn.SpatialBatchNormalization(128))
+    model.add(nn.PReLU())
+
+    model.add(nn.SpatialConvolution(128, dimensions[0], 3, 3, 1, 1, (3 - 1) // 2, (3 - 1) // 2))
+    model.add(nn.Sigmoid())
+    model.input_dims = (noiseDim, 1, 1)
+    return model
+
+
 def create_G(dimensions, noiseDim):
-    """models.lua:87-93.  Only the 32-px path is on BASELINE's configs (16-px: SURVEY 8(f) rank 4)."""
+    """models.lua:87-93."""
     if dimensions[1] == 16:
-        raise NotImplementedError("16x16 generator (models.lua:27-51) is outside the hot-path scope (SURVEY 8(f))")
+        return create_G_decoder_upsampling16(dimensions, noiseDim)
     return create_G_decoder_upsampling32(dimensions, noiseDim)
 
 
@@ -63,5 +86,6 @@ def create_D32b(dimensions):
 def create_D(dimensions):
     """models.lua:98-104."""
     if dimensions[1] == 16:
-        raise NotImplementedError("16x16 discriminator (models.lua:279-316) is outside the hot-path scope (SURVEY 8(f))")
+        raise NotImplementedError("16x16 discriminator create_D16_d (models.lua:279-316: ConcatTable branches, stride-2 "
+                                  "convolutions) is not built -- SURVEY 8(f) rank 4")
     return create_D32b(dimensions)

@@ -689,6 +689,19 @@ def create_G32(dimensions, noise_dim, rng=None):
         SpatialConvolution(128, c, 3, 3, 1, 1, 1, 1, rng), Sigmoid())
 
 
+def create_G16(dimensions, noise_dim, rng=None):
+    """models.lua:27-51 create_G_decoder_upsampling16: the 32-px decoder started from a 4x4 map."""
+    rng = rng or np.random.default_rng(1)
+    c = dimensions[0]
+    return Sequential(
+        Linear(noise_dim, 128 * 4 * 4, rng), View(128, 4, 4), PReLU(),
+        SpatialUpSamplingNearest(2), SpatialConvolution(128, 256, 5, 5, 1, 1, 2, 2, rng),
+        SpatialBatchNormalization(256, rng=rng), PReLU(),
+        SpatialUpSamplingNearest(2), SpatialConvolution(256, 128, 5, 5, 1, 1, 2, 2, rng),
+        SpatialBatchNormalization(128, rng=rng), PReLU(),
+        SpatialConvolution(128, c, 3, 3, 1, 1, 1, 1, rng), Sigmoid())
+
+
 def create_D32b(dimensions, rng=None):
     """models.lua:382-416 create_D32b."""
     rng = rng or np.random.default_rng(2)

@@ -75,8 +75,11 @@ def test_models_mirror_reference_structure_and_parameter_order():
     assert sum(getattr(m, n).numel() for m, n in G3.parameter_list()) == 2470406
     assert nn_utils.getNumberOfParameters(D) == sum(
         m.weight.numel() for m in D.modules if getattr(m, "weight", None) is not None)  # biases excluded (nn_utils.lua:281)
+    G16 = models.create_G((3, 16, 16), 100)                 # models.lua:27-51, same chain from a 4x4 map
+    assert [type(m).__name__ for m in G16.modules] == [type(m).__name__ for m in O.create_G16((3, 16, 16), 100).modules]
+    assert tuple(G16.modules[0].weight.shape) == (128 * 4 * 4, 100)
     with pytest.raises(NotImplementedError):
-        models.create_G((3, 16, 16), 100)
+        models.create_D((3, 16, 16))                        # create_D16_d: ConcatTable + stride-2 convs, not built
 
 
 def test_initialize_weights_semantics():

@@ -189,3 +189,31 @@ def test_full_D_step_and_G_step(ctx, init):
     close(Gd.getParameters()[0].cpu().numpy(), st.pG, atol=2e-6, what="G params after Adam")
 
 
+
+
+def test_G16_forward_backward(ctx):
+    """models.lua:27-51 create_G_decoder_upsampling16: same kernels from a 4x4 map."""
+    from face_generator_amd import models
+    B, C = 6, 3
+    rng = np.random.default_rng(950)
+    G = O.create_G16((C, 16, 16), 100, rng)
+    for m in G.modules:
+        if isinstance(m, O.SpatialBatchNormalization):
+            m.bias[...] = rng.standard_normal(m.bias.shape).astype(np.float32) * 0.2
+            m.weight[...] = rng.uniform(0.5, 1.5, m.weight.shape).astype(np.float32)
+        if isinstance(m, O.PReLU):
+            m.weight[0] = np.float32(rng.uniform(0.1, 0.4))
+    pG, gG = G.getParameters()
+    Gd = models.create_G((C, 16, 16), 100).cuda(ctx, max_batch=B)
+    p, g = Gd.getParameters()
+    assert p.numel() == pG.size
+    p.copy_(torch.tensor(pG)); Gd.device_net.params_changed()
+    noise, img = draw_kink_safe(rng, lambda: rng.uniform(-1, 1, (B, 100)).astype(np.float32), G.forward, [G])
+    assert img.shape == (B, C, 16, 16)
+    gy = rng.standard_normal(img.shape).astype(np.float32)
+    gG[...] = 0
+    G.backward(noise, gy)
+    y = Gd.device_net.forward(dev(noise, ctx.device))
+    close(nchw(y), img, atol=1e-5, what="G16 images")
+    Gd.device_net.backward(nhwc(gy, ctx.device), param_grads=True)
+    check_flat_grads(g.cpu().numpy(), G, "G16")
