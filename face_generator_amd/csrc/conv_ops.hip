@@ -58,14 +58,18 @@ static void choose_igemm(long long M, int Npad, int ksteps, int P, int math, int
     long long b2 = (long long)fg_cdiv(M, 64) * (Npad / 64) * P;
     *splits = 1;
     {   // large layers: wave-specialised 256x128 kernel when it fills the chip with whole rounds of 256 blocks
-        const long long bw = (Npad % 128 == 0) ? (long long)fg_cdiv(M, 256) * (Npad / 128) * P : 0;
         static int use_ws = -1;
         if (use_ws < 0) { const char* e = getenv("FG_IGEMM_WS"); use_ws = e ? atoi(e) : 1; }
+        const long long bw = (Npad % 128 == 0) ? (long long)fg_cdiv(M, 256) * (Npad / 128) * P : 0;
         if (use_ws && bw >= 256 && bw % 256 == 0 && M % 256 == 0) { *tile = 4; return; }
-        // bf16x6: a K-step is short and cheap, so mid-size layers also use the 256x128 kernel, split over K so that
-        // exactly one round of 256 blocks fills the chip (>= 12 sixteen-channel steps per block)
-        if (use_ws && math == 6 && bw > 0 && bw < 256 && 256 % bw == 0 && M % 256 == 0 && (2 * ksteps) / (256 / bw) >= 12) {
-            *tile = 4; *splits = (int)(256 / bw); return;
+        // bf16x6: a K-step is short and cheap, so mid-size layers also use the wave-specialised kernel (256x64 tiles for
+        // layers with 64 output channels), split over K so that exactly one round of 256 blocks fills the chip
+        // (>= 12 sixteen-channel steps per block)
+        if (use_ws && math == 6 && Npad % 64 == 0 && M % 256 == 0) {
+            const int bn = (Npad % 128 == 0) ? 128 : 64;
+            const long long b6 = (long long)(M / 256) * (Npad / bn) * P;
+            if (b6 >= 256 && b6 % 256 == 0) { *tile = 4; return; }
+            if (b6 > 0 && b6 < 256 && 256 % b6 == 0 && (2 * ksteps) / (256 / b6) >= 12) { *tile = 4; *splits = (int)(256 / b6); return; }
         }
     }
     if (b0 >= target) { *tile = 0; return; }
@@ -104,14 +108,16 @@ static void choose_wgrad(long long M, int Cout, int Cin, int G, int P, int* tile
 }
 
 
-// bf16x6 weight gradient: block tile 256 dY-channels x 128 X-channels (cfg 0) or 128 x 256 (cfg 1); -1 = not tileable.
+// bf16x6 weight gradient: block tile (dY-channels x X-channels) 256x128 or 128x256; -1 = not tileable.
 // S pixel-splits so that one round of ~256 blocks fills the chip with >= 12 sixteen-pixel steps per block.
 static int choose_wgrad6(long long M, int Cout, int Cin, int G, int P, int* S, int* mper) {
+    // (128x64 / 64x64 tiles were measured slower than the fp32 kernel: too few MFMAs per transposing fragment read)
+    static const int RT[2] = {256, 128}, QT[2] = {128, 256};
     int cfg = -1;
-    if (Cout % 256 == 0 && Cin % 128 == 0) cfg = 0;
-    else if (Cout % 128 == 0 && Cin % 256 == 0) cfg = 1;
+    for (int c = 0; c < 2 && cfg < 0; ++c)
+        if (Cout % RT[c] == 0 && Cin % QT[c] == 0) cfg = c;
     if (cfg < 0) return -1;
-    const long long base = (long long)(Cout / (cfg == 0 ? 256 : 128)) * (Cin / (cfg == 0 ? 128 : 256)) * G * P;
+    const long long base = (long long)(Cout / RT[cfg]) * (Cin / QT[cfg]) * G * P;
     long long s = (256 + base / 2) / base;
     if (s < 1) s = 1;
     const long long maxs = M / 192 > 0 ? M / 192 : 1;
@@ -134,15 +140,15 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
         long long n = splits > 1 ? (long long)splits * outM * g.Cout : 0;
         // bf16x6: a smaller run-time batch may pick split-K where the full batch does not; its partials are bounded by
         // 256 blocks x one 256x128 tile each
-        if (math == 6 && rf % 128 == 0 && n < 256LL * 256 * 128 + 64) n = 256LL * 256 * 128 + 64;
-        if (math == 6 && rf % 128 == 0) n += ((M * g.Cin + (long long)wm.P * wm.G * rf * cf) * 3 + 1) / 2 + 64;   // split planes
+        if (math == 6 && rf % 64 == 0 && n < 256LL * 256 * 128 + 64) n = 256LL * 256 * 128 + 64;
+        if (math == 6 && rf % 64 == 0) n += ((M * g.Cin + (long long)wm.P * wm.G * rf * cf) * 3 + 1) / 2 + 64;   // split planes
         if (n > need) need = n;
     }
     choose_igemm(M, rb, wm.G * wm.P * (cb / 32), 1, math, &tile, &splits);
     {
         long long n = splits > 1 ? (long long)splits * M * g.Cin : 0;
-        if (math == 6 && rb % 128 == 0 && n < 256LL * 256 * 128 + 64) n = 256LL * 256 * 128 + 64;
-        if (math == 6 && rb % 128 == 0) n += ((outM * g.Cout + (long long)wm.P * wm.G * rb * cb) * 3 + 1) / 2 + 64;
+        if (math == 6 && rb % 64 == 0 && n < 256LL * 256 * 128 + 64) n = 256LL * 256 * 128 + 64;
+        if (math == 6 && rb % 64 == 0) n += ((outM * g.Cout + (long long)wm.P * wm.G * rb * cb) * 3 + 1) / 2 + 64;
         if (n > need) need = n;
     }
     int wt, S, mper, Np, Cp;

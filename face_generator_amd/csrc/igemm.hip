@@ -447,18 +447,25 @@ static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define W6_ROWB 112
-#define W6_STAGE (384 * W6_ROWB)
 #define W6_NS 3
 __device__ __forceinline__ f32x16 fg_mfma_bf16(s16x8 a, s16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// BN = 128: MFMA waves 2x2, each 128x64 (4x2 tiles); BN = 64 (layers with 64 output channels): waves 4x1, each 64x64
+template <int BN>
 __global__ __launch_bounds__(512, 2) void igemm_ws6_kernel(const IgemmArgs a) {
+    constexpr int WNW = BN / 64;                 // MFMA waves along N
+    constexpr int WMW = 4 / WNW;                 // ... along M
+    constexpr int MI = WS_BM / (WMW * 32);       // 32x32 tiles per wave along M (4 | 2)
+    constexpr int NI = 2;
+    constexpr int STAGE = (WS_BM + BN) * W6_ROWB;
+    constexpr int NBCH = (BN * 6 + 255) / 256;   // B chunks per loader thread (3 | 2, the last partly filled for BN = 64)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
-    int* rowoff = (int*)(smem6 + W6_NS * W6_STAGE);
+    int* rowoff = (int*)(smem6 + W6_NS * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntn = a.Npad / WS_BN;
+    const int ntn = a.Npad / BN;
     const int np = a.P;
     const int per_m = ntn * np;
     const int nmt = (a.M + WS_BM - 1) / WS_BM;
@@ -508,17 +515,19 @@ __global__ __launch_bounds__(512, 2) void igemm_ws6_kernel(const IgemmArgs a) {
             lds_a[i] = row * W6_ROWB + part * 16;
             part_a[i] = part * 16;
         }
-        int lds_b[3];
-        const unsigned char* bptr[3];
+        int lds_b[NBCH];
+        bool okb[NBCH];
+        const unsigned char* bptr[NBCH];
         int g = kt0 / kc;
         int cg = kt0 - g * kc;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int c = lt + 256 * i;            // 0 .. 767 over the 128 B rows
-            const int row = c / 6, part = c - row * 6;
+        for (int i = 0; i < NBCH; ++i) {
+            const int c = lt + 256 * i;            // 0 .. BN*6-1 over the B rows
+            okb[i] = c < BN * 6;
+            const int row = okb[i] ? c / 6 : 0, part = c - (c / 6) * 6;
             lds_b[i] = (WS_BM + row) * W6_ROWB + part * 16;
             bptr[i] = (const unsigned char*)a.B6 +
-                      (((size_t)(p * a.G + g) * a.Npad + tile_n * WS_BN + row) * kc + cg) * 96 + part * 16;
+                      (((size_t)(p * a.G + g) * a.Npad + tile_n * BN + row) * kc + cg) * 96 + part * 16;
         }
         const size_t bjump = (size_t)(a.Npad - 1) * kc * 96;
         int voff[6];
@@ -533,24 +542,24 @@ __global__ __launch_bounds__(512, 2) void igemm_ws6_kernel(const IgemmArgs a) {
             }                                                                                            \
         }
         W6_SET_GROUP();
-        f32x4 xa_[6], xb_[3], ya_[6], yb_[3], za_[6], zb_[3];   // three tiles in flight (a K-step is only ~1.2 us)
+        f32x4 xa_[6], xb_[NBCH], ya_[6], yb_[NBCH], za_[6], zb_[NBCH];   // three tiles in flight (a K-step is only ~1.2 us)
 #define W6_LOAD(ra, rb)                                                                                  \
         {                                                                                                \
             const bool kin = cg < cgA;                                                                   \
             _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                \
                 ra[i] = fg_buffer_load4(arsrc, kin ? voff[i] + cg * 96 : FG_OOB);                        \
-            _Pragma("unroll") for (int i = 0; i < 3; ++i) { rb[i] = *(const f32x4*)bptr[i]; bptr[i] += 96; } \
+            _Pragma("unroll") for (int i = 0; i < NBCH; ++i) { rb[i] = *(const f32x4*)bptr[i]; bptr[i] += 96; } \
             if (++cg == kc) {                                                                            \
                 cg = 0; ++g;                                                                             \
-                _Pragma("unroll") for (int i = 0; i < 3; ++i) bptr[i] += bjump;                          \
+                _Pragma("unroll") for (int i = 0; i < NBCH; ++i) bptr[i] += bjump;                       \
                 W6_SET_GROUP();                                                                          \
             }                                                                                            \
         }
 #define W6_STORE(st, ra, rb)                                                                             \
         {                                                                                                \
-            unsigned char* S = smem6 + (st) * W6_STAGE;                                                  \
+            unsigned char* S = smem6 + (st) * STAGE;                                                     \
             _Pragma("unroll") for (int i = 0; i < 6; ++i) *(f32x4*)(S + lds_a[i]) = ra[i];               \
-            _Pragma("unroll") for (int i = 0; i < 3; ++i) *(f32x4*)(S + lds_b[i]) = rb[i];               \
+            _Pragma("unroll") for (int i = 0; i < NBCH; ++i) if (okb[i]) *(f32x4*)(S + lds_b[i]) = rb[i]; \
         }
         // prologue: tiles 0 and 1 resident, tiles 2, 3, 4 in flight; tile t lives in stage t % 3
         if (KT > 0) { W6_LOAD(xa_, xb_); W6_STORE(0, xa_, xb_); }
@@ -587,22 +596,22 @@ __global__ __launch_bounds__(512, 2) void igemm_ws6_kernel(const IgemmArgs a) {
     }
 
     // ---------------------------------------------------------------------- MFMA waves (one per SIMD)
-    const int wm = wid >> 1, wn = wid & 1;
-    f32x16 acc[4][2];
+    const int wm = wid / WNW, wn = wid - wm * WNW;
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    const int a_off = (wm * 128 + (lane & 31)) * W6_ROWB + (lane >> 5) * 16;
+    const int a_off = (wm * MI * 32 + (lane & 31)) * W6_ROWB + (lane >> 5) * 16;
     const int b_off = (WS_BM + wn * 64 + (lane & 31)) * W6_ROWB + (lane >> 5) * 16;
-    s16x8 A0[4], A1[4], A2[4], B0[2], B1[2], B2[2];
-#define W6_LDA(dst, S, pl) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) dst[mi] = *(const s16x8*)((S) + a_off + mi * 32 * W6_ROWB + (pl) * 32);
-#define W6_LDB(dst, S, pl) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) dst[ni] = *(const s16x8*)((S) + b_off + ni * 32 * W6_ROWB + (pl) * 32);
+    s16x8 A0[MI], A1[MI], A2[MI], B0[NI], B1[NI], B2[NI];
+#define W6_LDA(dst, S, pl) _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) dst[mi] = *(const s16x8*)((S) + a_off + mi * 32 * W6_ROWB + (pl) * 32);
+#define W6_LDB(dst, S, pl) _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) dst[ni] = *(const s16x8*)((S) + b_off + ni * 32 * W6_ROWB + (pl) * 32);
 #define W6_PROD(Ax, Bx)                                                                                  \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                     \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = fg_mfma_bf16(Ax[mi], Bx[ni], acc[mi][ni]);
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                    \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = fg_mfma_bf16(Ax[mi], Bx[ni], acc[mi][ni]);
     __syncthreads();              // tiles 0 and 1 are in the ring
     if (KT > 0) {
         W6_LDA(A0, smem6, 0) W6_LDA(A1, smem6, 1) W6_LDA(A2, smem6, 2)
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws6_kernel(const IgemmArgs a) {
     for (int kt = 0; kt < KT; ++kt) {
         // every read of this iteration targets the NEXT tile's stage (sealed by the previous barrier); each fragment
         // register set is re-filled right after its last use, ordered so the first products of the next step find theirs
-        const unsigned char* Sn = smem6 + sn * W6_STAGE;
+        const unsigned char* Sn = smem6 + sn * STAGE;
         const bool nxt = kt + 1 < KT;
         W6_PROD(A1, B1)
         W6_PROD(A2, B0)  if (nxt) { W6_LDA(A2, Sn, 2) }
@@ -633,31 +642,32 @@ __global__ __launch_bounds__(512, 2) void igemm_ws6_kernel(const IgemmArgs a) {
     const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = tile_n * WS_BN + wn * 64 + ni * 32 + (lane & 31);
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = tile_n * BN + wn * 64 + ni * 32 + (lane & 31);
         const bool colok = col < a.N;
         float bv = add_bias ? a.bias[colok ? col : 0] : 0.f;
         asm volatile("" : "+v"(bv));
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-            fg_store_acc_tile(orsrc, rowoff, wm * 128 + mi * 32, col, colok, bv, acc[mi][ni], lane);
+        for (int mi = 0; mi < MI; ++mi)
+            fg_store_acc_tile(orsrc, rowoff, wm * MI * 32 + mi * 32, col, colok, bv, acc[mi][ni], lane);
     }
 }
 
+template <int BN>
 static int launch_igemm_ws6(fg_ctx* ctx, const IgemmArgs& a, int P) {
-    const size_t lds = (size_t)W6_NS * W6_STAGE + WS_BM * sizeof(int);
+    const size_t lds = (size_t)W6_NS * (WS_BM + BN) * W6_ROWB + WS_BM * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws6_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     if (a.a_bytes / 4 * 6 >= (long long)FG_OOB) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "igemm bf16x6: A planes must be < 2 GiB");
-    dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / WS_BN) * P, a.splits, 1);
-    const double exec = 2.0 * (double)grid.x * WS_BM * WS_BN * (double)a.G * a.Kpad;     // fp32-equivalent FLOPs
+    dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / BN) * P, a.splits, 1);
+    const double exec = 2.0 * (double)grid.x * WS_BM * BN * (double)a.G * a.Kpad;     // fp32-equivalent FLOPs
     char label[96];
-    snprintf(label, sizeof(label), "igemm_ws6_kernel/%s", a.tag ? a.tag : "?");
+    snprintf(label, sizeof(label), "igemm_ws6_kernel<%d>/%s", BN, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
-    hipLaunchKernelGGL(igemm_ws6_kernel, grid, dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL(igemm_ws6_kernel<BN>, grid, dim3(512), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
@@ -731,7 +741,10 @@ int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
         case 0: if (a.Npad % 128) break; return launch_igemm_t<128, 128, 32>(ctx, a, P);
         case 1: if (a.Npad % 64) break; return launch_igemm_t<128, 64, 32>(ctx, a, P);
         case 2: if (a.Npad % 64) break; return launch_igemm_t<64, 64, 32>(ctx, a, P);
-        case 4: if (a.Npad % 128) break; return a.A6 ? launch_igemm_ws6(ctx, a, P) : launch_igemm_ws(ctx, a, P);
+        case 4:
+            if (a.A6) { if (a.Npad % 64) break; return (a.Npad % 128 == 0) ? launch_igemm_ws6<128>(ctx, a, P) : launch_igemm_ws6<64>(ctx, a, P); }
+            if (a.Npad % 128) break;
+            return launch_igemm_ws(ctx, a, P);
     }
     return fg_set_err(ctx, FG_ERR_INVALID, "igemm: bad tile %d for Npad %d", tile, a.Npad);
 }
@@ -1117,7 +1130,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws6_kernel(const WgradArgs a) {
     constexpr int RCH = RT / 16 * 6, QCH = QT / 16 * 6;       // 16-byte chunks per pixel row
     constexpr int ROW_R = RT / 16 * 96 + 64, ROW_Q = QT / 16 * 96 + 64;
     constexpr int STAGE = 16 * (ROW_R + ROW_Q);
-    constexpr int NR = 16 * RCH / 256, NQ = 16 * QCH / 256;   // chunks per loader thread and K-step
+    constexpr int NR = (16 * RCH + 255) / 256, NQ = (16 * QCH + 255) / 256;   // chunks per loader thread and K-step (last may be partial)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem6[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1137,19 +1150,22 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws6_kernel(const WgradArgs a) {
         const int dpixB = a.Nd / 16 * 96, xpixB = a.Cx / 16 * 96;
         const int doy = a.doy[p], dox = a.dox[p], xoy = a.xoy[p][g], xox = a.xox[p][g];
         int pr[NR], ldsR[NR], gR[NR], pq[NQ], ldsQ[NQ], gQ[NQ];
+        bool okr[NR], okq[NQ];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int c = lt + 256 * i;
-            pr[i] = c / RCH;
-            const int w = c - pr[i] * RCH;
+            okr[i] = c < 16 * RCH;
+            pr[i] = okr[i] ? c / RCH : 0;
+            const int w = okr[i] ? c - pr[i] * RCH : 0;
             ldsR[i] = pr[i] * ROW_R + w * 16;
             gR[i] = tn * (RT / 16) * 96 + w * 16;
         }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int c = lt + 256 * i;
-            pq[i] = c / QCH;
-            const int w = c - pq[i] * QCH;
+            okq[i] = c < 16 * QCH;
+            pq[i] = okq[i] ? c / QCH : 0;
+            const int w = okq[i] ? c - pq[i] * QCH : 0;
             ldsQ[i] = 16 * ROW_R + pq[i] * ROW_Q + w * 16;
             gQ[i] = tq * (QT / 16) * 96 + w * 16;
         }
@@ -1177,8 +1193,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws6_kernel(const WgradArgs a) {
 #define G6_STORE(st, rr, rq)                                                                             \
         {                                                                                                \
             unsigned char* S = smem6 + (st) * STAGE;                                                     \
-            _Pragma("unroll") for (int i = 0; i < NR; ++i) *(f32x4*)(S + ldsR[i]) = rr[i];               \
-            _Pragma("unroll") for (int i = 0; i < NQ; ++i) *(f32x4*)(S + ldsQ[i]) = rq[i];               \
+            _Pragma("unroll") for (int i = 0; i < NR; ++i) if (okr[i]) *(f32x4*)(S + ldsR[i]) = rr[i];   \
+            _Pragma("unroll") for (int i = 0; i < NQ; ++i) if (okq[i]) *(f32x4*)(S + ldsQ[i]) = rq[i];   \
         }
         if (KT > 0) { G6_LOAD(xr, xq); G6_STORE(0, xr, xq); }
         if (KT > 1) { G6_LOAD(xr, xq); G6_STORE(1, xr, xq); }
@@ -1288,5 +1304,6 @@ static int launch_wgrad6_t(fg_ctx* ctx, const WgradArgs& a, int P) {
     return FG_OK;
 }
 int fg_launch_wgrad6(fg_ctx* ctx, const WgradArgs& a, int P, int cfg) {
-    return cfg == 0 ? launch_wgrad6_t<4, 2>(ctx, a, P) : launch_wgrad6_t<2, 4>(ctx, a, P);
+    return cfg == 0 ? launch_wgrad6_t<4, 2>(ctx, a, P)      // 256 dY-channels x 128 X-channels
+                    : launch_wgrad6_t<2, 4>(ctx, a, P);     // 128 x 256
 }

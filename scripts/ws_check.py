@@ -9,7 +9,7 @@ ctx = get_context(0); d = ctx.device
 g = torch.Generator(device='cpu').manual_seed(0)
 import torch.nn.functional as F
 torch.set_num_threads(64)
-SHAPES = [(128, 16, 16, 256, 128, 5, 1), (128, 8, 8, 128, 256, 5, 1), (128, 16, 16, 64, 128, 3, 0), (128, 8, 8, 128, 256, 3, 0),
+SHAPES = [(128, 16, 16, 64, 128, 3, 0), (128, 32, 32, 64, 64, 3, 0), (128, 16, 16, 256, 128, 5, 1), (128, 8, 8, 128, 256, 5, 1), (128, 16, 16, 64, 128, 3, 0), (128, 8, 8, 128, 256, 3, 0),
           (128, 4, 4, 256, 512, 3, 0)]
 if len(sys.argv) > 1: SHAPES = SHAPES[:int(sys.argv[1])]
 for (B, H, W, Cin, Cout, k, up) in SHAPES:
