@@ -152,24 +152,28 @@ def main():
     if args.math == "f32" and not args.no_alt_math:
         # supplementary, never the headline: the same K steps with the large contractions in bf16x6 (fp32 emulated with
         # six exact split-bf16 plane products, include/facegen_hip.h fg_set_math); every rank runs it (collectives)
-        ctx.set_math(6)
-        for _ in range(min(args.warmup, 4)):
-            iteration()
-        sync_all()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            iteration()
-        tr.finish_pending()
-        sync_all()
-        dt6 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dt6], dtype=torch.float64, device=ctx.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt6 = float(t.item())
-        ctx.set_math(0)
-        alt = {"math": "bf16x6 (fp32 emulated: 6 exact bf16 split-plane products, fp32 accumulate; fg_set_math(ctx, 6))",
-               "value": world * B * args.steps / dt6, "unit": "images/sec", "ms_per_step": 1000.0 * dt6 / args.steps,
-               "note": "opt-in mode, parity-tested at the same tolerances (FG_MATH=6 pytest -m gpu); not the headline value"}
+        try:
+            ctx.set_math(6)
+            for _ in range(min(args.warmup, 4)):
+                iteration()
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                iteration()
+            tr.finish_pending()
+            sync_all()
+            dt6 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dt6], dtype=torch.float64, device=ctx.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt6 = float(t.item())
+            alt = {"math": "bf16x6 (fp32 emulated: 6 exact bf16 split-plane products, fp32 accumulate; fg_set_math(ctx, 6))",
+                   "value": world * B * args.steps / dt6, "unit": "images/sec", "ms_per_step": 1000.0 * dt6 / args.steps,
+                   "note": "opt-in mode, parity-tested at the same tolerances (FG_MATH=6 pytest -m gpu); not the headline value"}
+        except Exception as e:      # supplementary only: never let it take the headline measurement down
+            alt = {"math": "bf16x6", "error": str(e)[:200]}
+        finally:
+            ctx.set_math(0)
 
     out = {
         "metric": "GAN train images/sec (G+D step) at 32x32x3 bs128",
