@@ -10,6 +10,7 @@ struct ConvGeom {
     int Cin, Cout;  // reference nInputPlane / nOutputPlane (Linear: in / out features)
     int k, pad;     // odd k, "same" pad = (k-1)/2. Linear: 1, 0
     int fold;       // 1: an nn.SpatialUpSamplingNearest(2) in front of the conv is folded into its taps
+    int stride;     // 0 / 1: stride 1; 2: stride 2 (output (H/2) x (W/2); models.lua:289-291 create_D16_d), never with fold
     // Linear next to an nn.View: NCHW-flatten <-> NHWC-memory feature permutation (0 = none)
     int o_c, o_hw, i_c, i_hw;
 };

@@ -168,13 +168,15 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
 }
 // upper bound over the math modes, so fg_set_math can be toggled on a live net
 long long fg_conv_scratch_floats(const ConvGeom& g) {
-    const long long n0 = scratch_for_math(g, 0), n6 = scratch_for_math(g, 6);
-    return n0 > n6 ? n0 : n6;
+    ConvGeom g1 = g; g1.stride = 1;        // sized as the stride-1 layer of the same input (an upper bound) ...
+    const long long n0 = scratch_for_math(g1, 0), n6 = scratch_for_math(g1, 6);
+    const long long nz = g.stride == 2 ? (long long)g.B * g.H * g.W * g.Cout + 64 : 0;   // ... + the zero-inserted gradient
+    return (n0 > n6 ? n0 : n6) + nz;
 }
 
 // reference-formulation FLOPs of one pass over this layer (2 x MACs of the un-folded convolution)
 static double alg_flops(const ConvGeom& g) {
-    const double outpix = (double)g.B * g.H * g.W * (g.fold ? 4.0 : 1.0);
+    const double outpix = (double)g.B * g.H * g.W * (g.fold ? 4.0 : 1.0) / (g.stride == 2 ? 4.0 : 1.0);
     return 2.0 * outpix * g.Cout * g.Cin * g.k * g.k;
 }
 static const char* tag_of(const ConvGeom& g, int pass) {
@@ -225,7 +227,9 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
     WeightMap wm; fg_geom_weightmap(g, &wm);
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
     IgemmArgs a; memset(&a, 0, sizeof(a));
-    fill_mspace(a, g.B, g.H, g.W);
+    const int st = g.stride == 2 ? 2 : 1;
+    if (st == 2 && (g.fold || (g.H & 1) || (g.W & 1))) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "stride-2 conv: even H/W, no folded upsample");
+    fill_mspace(a, g.B, g.H / st, g.W / st);                 // M-space = output pixels
     a.A = x; a.Bp = wp_fwd; a.bias = bias; a.Out = y;
     a.alg_flops = alg_flops(g); a.tag = tag_of(g, 0);
     a.Ha = g.H; a.Wa = g.W; a.Ca = g.Cin; a.Kpad = cf; a.asy = a.asx = 1;
@@ -239,7 +243,8 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
             }
         }
     } else {
-        a.Ho = g.H; a.Wo = g.W; a.osy = a.osx = 1;
+        a.Ho = g.H / st; a.Wo = g.W / st; a.osy = a.osx = 1;
+        a.asy = a.asx = st;                                  // input pixel = st * output pixel + tap - pad
         for (int t = 0; t < wm.G; ++t) {
             a.goff[0][t] = pack_off(t / g.k - g.pad, t % g.k - g.pad);
         }
@@ -264,6 +269,16 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
 int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const float* wp_bwd, float* gx, float* scratch,
                       long long scratch_floats, const void* wp6, const void* gy6) {
     if (g.B == 0) return FG_OK;
+    if (g.stride == 2) {
+        // stride-2 data gradient = stride-1 data gradient of the zero-inserted output gradient (the layers that use it are
+        // a few MFLOP: models.lua:289-291)
+        const long long nz = ((long long)g.B * g.H * g.W * g.Cout + 3) / 4 * 4;
+        if (nz > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv dgrad (stride 2): scratch");
+        int rc0 = fg_launch_zero_insert2(ctx, gy, scratch, g.B, g.H / 2, g.W / 2, g.Cout);
+        if (rc0) return rc0;
+        ConvGeom g1 = g; g1.stride = 1;
+        return fg_conv_dgrad_run(ctx, g1, scratch, wp_bwd, gx, scratch + nz, scratch_floats - nz, wp6, nullptr);
+    }
     WeightMap wm; fg_geom_weightmap(g, &wm);
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
     IgemmArgs a; memset(&a, 0, sizeof(a));
@@ -314,10 +329,11 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
     WgradArgs a; memset(&a, 0, sizeof(a));
     a.dY = gy; a.X = x; a.Part = scratch;
     a.alg_flops = alg_flops(g); a.tag = tag_of(g, 2);
-    a.Nb = g.B; a.Hm = g.H; a.Wm = g.W; a.M = g.B * g.H * g.W;
-    a.lgH = ilog2_exact(g.H); a.lgW = ilog2_exact(g.W);
+    const int st = g.stride == 2 ? 2 : 1;
+    a.Nb = g.B; a.Hm = g.H / st; a.Wm = g.W / st; a.M = g.B * a.Hm * a.Wm;          // M-space = output pixels
+    a.lgH = ilog2_exact(a.Hm); a.lgW = ilog2_exact(a.Wm);
     if (a.lgH < 0 || a.lgW < 0) a.lgH = a.lgW = -1;
-    a.Nd = g.Cout; a.Cx = g.Cin; a.Hx = g.H; a.Wx = g.W; a.xsy = a.xsx = 1;
+    a.Nd = g.Cout; a.Cx = g.Cin; a.Hx = g.H; a.Wx = g.W; a.xsy = a.xsx = st;
     a.G = wm.G;
     if (g.fold) {
         a.Hd = 2 * g.H; a.Wd = 2 * g.W; a.dsy = a.dsx = 2;
@@ -329,7 +345,7 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
             }
         }
     } else {
-        a.Hd = g.H; a.Wd = g.W; a.dsy = a.dsx = 1;
+        a.Hd = g.H / st; a.Wd = g.W / st; a.dsy = a.dsx = 1;
         for (int t = 0; t < wm.G; ++t) {
             a.xoy[0][t] = (signed char)(t / g.k - g.pad);
             a.xox[0][t] = (signed char)(t % g.k - g.pad);

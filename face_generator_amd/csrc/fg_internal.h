@@ -199,6 +199,7 @@ int fg_launch_mul_mask(fg_ctx*, const float* x, const float* mask, float scale, 
 int fg_launch_concat(fg_ctx*, const float* a, const float* b, float* out, long long npix, int ca, int cb);
 int fg_launch_split(fg_ctx*, const float* g, float* ga, float* gb, long long npix, int ca, int cb);
 int fg_launch_add(fg_ctx*, const float* a, const float* b, float* out, long long n);
+int fg_launch_zero_insert2(fg_ctx*, const float* g, float* out, int B, int H, int W, int C);   // g [B][H][W][C] -> out [B][2H][2W][C]
 
 // thin convolutions (3 <-> wide channels), NHWC, stride 1, "same" pad, odd k <= 7
 // thin-in : out[pix][c<Cw] = bias[c] + sum_{tap, s<Cs} in[pix+off(tap)][s] * Wp[tap][s][c]

@@ -429,12 +429,17 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
             }
             case FG_CONV: {
                 if (l.a != c) { fail(FG_ERR_INVALID, "conv nInputPlane mismatch", i); break; }
-                if (l.c % 2 != 1 || l.d != (l.c - 1) / 2) { fail(FG_ERR_UNSUPPORTED, "only odd-k 'same' stride-1 convs", i); break; }
+                if (l.c % 2 != 1 || l.d != (l.c - 1) / 2) { fail(FG_ERR_UNSUPPORTED, "only odd-k 'same'-pad convs (stride 1 or 2)", i); break; }
                 s.w_n = (long long)l.a * l.b * l.c * l.c; s.b_n = l.b;
                 s.w_off = poff; s.b_off = poff + s.w_n; poff += s.w_n + s.b_n;
                 n->layers[i].w_off = s.w_off; n->layers[i].w_n = s.w_n; n->layers[i].b_off = s.b_off; n->layers[i].b_n = s.b_n;
                 ConvGeom& g = s.geom; g.H = h; g.W = w; g.Cin = l.a; g.Cout = l.b; g.k = l.c; g.pad = l.d; g.fold = 0;
+                g.stride = (l.p == 2.f) ? 2 : 1;
                 s.oc = l.b; s.oh = h; s.ow = w;
+                if (g.stride == 2) {       // 3x3 stride-2 'same'-pad convs of create_D16_d (models.lua:289-291)
+                    if ((h & 1) || (w & 1) || l.a % 4 || l.c * l.c > FG_MAX_GROUPS) { fail(FG_ERR_UNSUPPORTED, "stride-2 conv: even H/W, nIn % 4", i); break; }
+                    s.oh = h / 2; s.ow = w / 2; s.kind = ST_CONV;
+                } else
                 if (l.a <= 4 && l.b % 64 == 0) s.kind = ST_THIN_IN;
                 else if (l.b <= 4 && l.a % 64 == 0) {
                     s.kind = ST_THIN_OUT;

@@ -1009,6 +1009,28 @@ int fg_launch_add(fg_ctx* ctx, const float* a, const float* b, float* out, long 
     return FG_OK;
 }
 
+// stride-2 data gradient helper: out[b][2y][2x][c] = g[b][y][x][c], every other position 0 (out is [B][2H][2W][C])
+__global__ void zero_insert2_kernel(const float* __restrict__ g, float* __restrict__ out, int H, int W, int C4, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int X = (int)(t % (2 * W)); t /= 2 * W;
+    const int Y = (int)(t % (2 * H));
+    const long long b = t / (2 * H);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (((X | Y) & 1) == 0) v = ((const float4*)g)[((b * H + (Y >> 1)) * W + (X >> 1)) * C4 + c];
+    ((float4*)out)[i] = v;
+}
+int fg_launch_zero_insert2(fg_ctx* ctx, const float* g, float* out, int B, int H, int W, int C) {
+    if (C % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "zero_insert2: C %% 4");
+    const long long n4 = (long long)B * 2 * H * 2 * W * (C / 4);
+    if (n4 == 0) return FG_OK;
+    hipLaunchKernelGGL(zero_insert2_kernel, FG_GRID(n4, 256), dim3(256), 0, ctx->stream, g, out, H, W, C / 4, n4);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
 // ------------------------------------------------------------------ Linear(K -> 1) [+ Sigmoid]
 __global__ __launch_bounds__(64) void gemv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ b, float* __restrict__ y, int B, int K,

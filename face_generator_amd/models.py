@@ -83,9 +83,45 @@ def create_D32b(dimensions):
     return conv
 
 
+def create_D16_d(dimensions):
+    """models.lua:279-316: ConcatTable{conv branch with two stride-2 convs, dense branch} -> JoinTable(2) -> Linear -> Sigmoid
+    (SURVEY 8(f) rank 4)."""
+    c, h, w = dimensions
+    inputSz = c * h * w
+    fine = nn.Sequential()
+    fine.add(nn.SpatialConvolution(c, 128, 3, 3, 1, 1, (3 - 1) // 2))
+    fine.add(nn.PReLU())
+    fine.add(nn.SpatialConvolution(128, 128, 3, 3, 1, 1, (3 - 1) // 2))
+    fine.add(nn.PReLU())
+    fine.add(nn.SpatialAveragePooling(2, 2, 2, 2))
+    fine.add(nn.SpatialConvolution(128, 512, 3, 3, 2, 2, (3 - 1) // 2))
+    fine.add(nn.PReLU())
+    fine.add(nn.SpatialConvolution(512, 1024, 3, 3, 2, 2, (3 - 1) // 2))
+    fine.add(nn.PReLU())
+    fine.add(nn.SpatialDropout())
+    fine_size = int(1024 * 0.25 * 0.25 * 0.25 * h * w)
+    fine.add(nn.View(fine_size))
+    fine.add(nn.Linear(fine_size, 1024))
+    fine.add(nn.PReLU())
+
+    dense = nn.Sequential()
+    dense.add(nn.View(inputSz))
+    dense.add(nn.Linear(inputSz, 128))
+    dense.add(nn.PReLU())
+    dense.add(nn.Dropout())
+    dense.add(nn.Linear(128, 128))
+    dense.add(nn.PReLU())
+
+    tail = nn.Sequential()
+    tail.add(nn.Linear(1024 + 128, 1))
+    tail.add(nn.Sigmoid())
+    model = nn.ConcatSequential([fine, dense], tail)
+    model.input_dims = (c, h, w)
+    return model
+
+
 def create_D(dimensions):
     """models.lua:98-104."""
     if dimensions[1] == 16:
-        raise NotImplementedError("16x16 discriminator create_D16_d (models.lua:279-316: ConcatTable branches, stride-2 "
-                                  "convolutions) is not built -- SURVEY 8(f) rank 4")
+        return create_D16_d(dimensions)
     return create_D32b(dimensions)

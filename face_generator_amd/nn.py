@@ -245,9 +245,10 @@ class SpatialConvolution(Module):
     def __init__(self, nInputPlane, nOutputPlane, kW, kH, dW=1, dH=1, padW=0, padH=None, gen=None):
         super().__init__()
         padH = padW if padH is None else padH
-        if kW != kH or dW != 1 or dH != 1 or padW != padH or kW % 2 != 1 or padW != (kW - 1) // 2:
-            raise FgError("SpatialConvolution: only square odd kernels, stride 1, 'same' padding are built")
+        if kW != kH or dW != dH or dW not in (1, 2) or padW != padH or kW % 2 != 1 or padW != (kW - 1) // 2:
+            raise FgError("SpatialConvolution: only square odd kernels, stride 1 or 2, 'same' padding are built")
         self.nInputPlane, self.nOutputPlane, self.kW, self.padW = nInputPlane, nOutputPlane, kW, int(padW)
+        self.dW = int(dW)          # 2: the stride-2 convs of create_D16_d (models.lua:289-291), plan level only
         s = 1.0 / math.sqrt(kW * kH * nInputPlane)
         self.weight = _uniform((nOutputPlane, nInputPlane, kH, kW), s, gen)
         self.bias = _uniform((nOutputPlane,), s, gen)
@@ -255,10 +256,12 @@ class SpatialConvolution(Module):
         self.gradBias = torch.zeros_like(self.bias)
 
     def spec(self):
-        return ("CONV", self.nInputPlane, self.nOutputPlane, self.kW, self.padW)
+        return ("CONV", self.nInputPlane, self.nOutputPlane, self.kW, self.padW, float(getattr(self, "dW", 1)))
 
     def updateOutput(self, input):
         from . import ops
+        if getattr(self, "dW", 1) != 1:
+            raise FgError("SpatialConvolution (stride 2): module-level entry not built; run it through the compiled net")
         self.output = ops.conv2d_forward(self._dev(input), self.weight, self.bias, pad=self.padW)
         return self.output
 
@@ -475,10 +478,26 @@ class JoinTable(Module):
     """nn.JoinTable(2, 2): concat along channels (models_c2f.lua:116)."""
     _typename = "nn.JoinTable"
 
-    def __init__(self, dimension=2, nInputDims=2):
+    def __init__(self, dimension=2, nInputDims=None):
         super().__init__()
         if dimension != 2:
-            raise FgError("nn.JoinTable: only the channel dimension is built")
+            raise FgError("nn.JoinTable: only dimension 2 (channels / features) is built")
+
+
+class ConcatTable(Module):
+    """nn.ConcatTable (models.lua:307-309): every branch gets the same input; output = table of the branch outputs."""
+    _typename = "nn.ConcatTable"
+
+    def __init__(self):
+        super().__init__()
+        self.modules = []
+
+    def add(self, m):
+        self.modules.append(m)
+        return self
+
+    def __repr__(self):
+        return "nn.ConcatTable {\n" + "\n".join("  |-- %s" % repr(m).replace("\n", "\n  |   ") for m in self.modules) + "\n}"
 
 
 class CAddTable(Module):
@@ -812,3 +831,110 @@ class BCECriterion:
             self.forward(input, target)
         self.gradInput = self._grad
         return self.gradInput
+
+
+class ConcatSequential(Sequential):
+    """models.lua:279-316 create_D16_d: nn.Sequential{ConcatTable{branch...}, JoinTable(2), tail...}.  Every branch and
+    the tail is compiled to its own fg_net; they share ONE flat parameter / gradient vector in the reference's order
+    (branch 1, branch 2, ..., tail), so getParameters(), the optimizers and the all-reduce see a single net."""
+
+    def __init__(self, branches, tail):
+        super().__init__()
+        self.branches, self.tail = list(branches), tail
+        ct = ConcatTable()
+        for b in self.branches:
+            ct.add(b)
+        self.modules = [ct, JoinTable(2)] + list(tail.modules)
+
+    def _inner(self):
+        return self
+
+    def _parts(self):
+        return self.branches + [self.tail]
+
+    def parameter_list(self):
+        out = []
+        for p in self._parts():
+            out.extend(p.parameter_list())
+        return out
+
+    def listModules(self):
+        out = [self, self.modules[0]]
+        for b in self.branches:
+            out.extend(b.listModules())
+        out.append(self.modules[1])
+        out.extend(self.tail.modules)
+        return out
+
+    def training(self):
+        self.train = True
+        for p in self._parts():
+            p.training()
+        if self.device_net is not None:
+            self.device_net.train = True
+        return self
+
+    def evaluate(self):
+        self.train = False
+        for p in self._parts():
+            p.evaluate()
+        if self.device_net is not None:
+            self.device_net.train = False
+        return self
+
+    def zeroGradParameters(self):
+        for p in self._parts():
+            p.zeroGradParameters()
+
+    def cuda(self, ctx=None, max_batch=32):
+        from . import runtime
+        if self.device_net is not None:
+            return self
+        ctx = ctx or runtime.get_context()
+        plist = self.parameter_list()
+        total = sum(getattr(m, n).numel() for m, n in plist)
+        params, grads = ctx.zeros(total), ctx.zeros(total)
+        nets, off = [], 0
+        for i, part in enumerate(self._parts()):
+            dims = self.input_dims if i < len(self.branches) else (sum(n.out_c * n.out_h * n.out_w for n in nets), 1, 1)
+            n_part = sum(getattr(m, n).numel() for m, n in part.parameter_list())
+            dn = runtime.DeviceNet(ctx, part.layer_specs(), dims, max_batch, params=params[off:off + n_part],
+                                   grads=grads[off:off + n_part])
+            o = 0
+            for (m, name) in part.parameter_list():
+                w = getattr(m, name)
+                k = w.numel()
+                dn.params[o:o + k] = w.reshape(-1).to(ctx.device)
+                setattr(m, name, dn.params[o:o + k].view(w.shape))
+                setattr(m, "gradWeight" if name == "weight" else "gradBias", dn.grads[o:o + k].view(w.shape))
+                o += k
+            dn.train = self.train
+            dn.params_changed()
+            part.device_net = dn
+            nets.append(dn)
+            off += n_part
+        self.device_net = runtime.CompositeDeviceNet(ctx, nets[:-1], nets[-1], params, grads)
+        self.device_net.train = self.train
+        return self
+
+    def float(self):
+        if self.device_net is None:
+            return self
+        for (m, name) in self.parameter_list():
+            setattr(m, name, getattr(m, name).detach().cpu().clone())
+            gname = "gradWeight" if name == "weight" else "gradBias"
+            setattr(m, gname, getattr(m, gname).detach().cpu().clone())
+        for p in self._parts():
+            p.device_net = None
+        self.device_net = None
+        return self
+
+    def forward_modules(self, x_dev):
+        raise FgError("ConcatSequential: module-by-module execution is not built; use the compiled net")
+
+    def __repr__(self):
+        lines = ["nn.Sequential {"]
+        for i, m in enumerate(self.modules):
+            lines.append("  (%d): %s" % (i + 1, repr(m).replace("\n", "\n  ")))
+        lines.append("}")
+        return "\n".join(lines)

@@ -113,7 +113,8 @@ class DeviceNet:
     """An nn.Sequential compiled by fg_net_create, with its flat parameter / gradient vectors
     (== Module:getParameters(), train.lua:151-152), BN running stats and workspace as torch device tensors."""
 
-    def __init__(self, ctx, layers, in_dims, max_batch):
+    def __init__(self, ctx, layers, in_dims, max_batch, params=None, grads=None):
+        """params / grads: optional slices of a larger flat vector shared by several nets (nn.ConcatSequential)."""
         self.ctx, self.lib = ctx, ctx.lib
         self.layers = list(layers)
         self.in_c, self.in_h, self.in_w = in_dims
@@ -128,8 +129,10 @@ class DeviceNet:
         c, hh, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         self.lib.fg_net_out_dims(h, ctypes.byref(c), ctypes.byref(hh), ctypes.byref(w))
         self.out_c, self.out_h, self.out_w = c.value, hh.value, w.value
-        self.params = ctx.zeros(self.n_params)
-        self.grads = ctx.zeros(self.n_params)
+        if params is not None and (params.numel() != self.n_params or grads.numel() != self.n_params):
+            raise FgError("DeviceNet: the shared parameter slice has %d elements, the net %d" % (params.numel(), self.n_params))
+        self.params = params if params is not None else ctx.zeros(self.n_params)
+        self.grads = grads if grads is not None else ctx.zeros(self.n_params)
         self.buffers = ctx.zeros(max(self.n_buffers, 1))
         self._init_bn_buffers()
         self.max_batch = 0
@@ -318,3 +321,78 @@ class DeviceNet:
         n = self._batch * c.value * h.value * w.value
         t = self.ws[off.value: off.value + n]
         return t.view(self._batch, h.value, w.value, c.value)
+
+
+class CompositeDeviceNet:
+    """ConcatTable{branch nets} -> JoinTable(2) -> tail net (models.lua:305-312), with the DeviceNet surface the trainer
+    uses: forward / backward on device tensors, the shared flat params / grads, dropout masks in module order."""
+
+    def __init__(self, ctx, branches, tail, params, grads):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.branches, self.tail = list(branches), tail
+        self.params, self.grads = params, grads
+        self.n_params = params.numel()
+        b0 = self.branches[0]
+        self.in_c, self.in_h, self.in_w = b0.in_c, b0.in_h, b0.in_w
+        self.out_c, self.out_h, self.out_w = tail.out_c, tail.out_h, tail.out_w
+        self.n_masks = sum(n.n_masks for n in self.branches) + tail.n_masks
+        self.n_buffers = 0
+        self._train = True
+        self._widths = [n.out_c * n.out_h * n.out_w for n in self.branches]
+
+    @property
+    def train(self):
+        return self._train
+
+    @train.setter
+    def train(self, v):
+        self._train = bool(v)
+        for n in self.branches + [self.tail]:
+            n.train = bool(v)
+
+    def _nets(self):
+        return self.branches + [self.tail]
+
+    def params_changed(self):
+        for n in self._nets():
+            n.params_changed()
+
+    def draw_masks(self, batch):
+        out = []
+        for n in self._nets():
+            if n.n_masks:
+                out.extend(n.draw_masks(batch))
+        return out
+
+    def forward(self, x, masks=None, train=None):
+        train = self._train if train is None else train
+        if train and self.n_masks and masks is None:
+            masks = self.draw_masks(x.shape[0])
+        B, k = x.shape[0], 0
+        outs = []
+        for n in self.branches:
+            mk = masks[k:k + n.n_masks] if (masks is not None and n.n_masks) else None
+            k += n.n_masks
+            outs.append(n.forward(x, masks=mk, train=train).reshape(B, -1))
+        joined = self.ctx.empty(B, sum(self._widths))
+        if len(outs) != 2:
+            raise FgError("CompositeDeviceNet: two branches are built (models.lua:305-309)")
+        self.ctx.check(self.lib.fg_concat_channels(self.ctx.h, outs[0].data_ptr(), outs[1].data_ptr(), joined.data_ptr(), B,
+                                                   self._widths[0], self._widths[1]))
+        self._joined = joined
+        mk = masks[k:k + self.tail.n_masks] if (masks is not None and self.tail.n_masks) else None
+        return self.tail.forward(joined, masks=mk, train=train)
+
+    def backward(self, gy, param_grads=True, input_grad=False):
+        B = self._joined.shape[0]
+        gj = self.tail.backward(gy, param_grads=param_grads, input_grad=True)
+        g0, g1 = self.ctx.empty(B, self._widths[0]), self.ctx.empty(B, self._widths[1])
+        self.ctx.check(self.lib.fg_split_channels(self.ctx.h, gj.data_ptr(), g0.data_ptr(), g1.data_ptr(), B,
+                                                  self._widths[0], self._widths[1]))
+        gx0 = self.branches[0].backward(g0, param_grads=param_grads, input_grad=input_grad)
+        gx1 = self.branches[1].backward(g1, param_grads=param_grads, input_grad=input_grad)
+        if not input_grad:
+            return None
+        gx = torch.empty_like(gx0)
+        self.ctx.check(self.lib.fg_add(self.ctx.h, gx0.data_ptr(), gx1.data_ptr(), gx.data_ptr(), gx.numel()))
+        return gx

@@ -79,7 +79,7 @@ enum fg_layer_type {
     FG_VIEW = 2,            /* nn.View(a=C, b=H, c=W)  or nn.View(a=features) with b=c=0 */
     FG_PRELU = 3,           /* nn.PReLU() -- one shared slope */
     FG_UPSAMPLE2X = 4,      /* nn.SpatialUpSamplingNearest(2) */
-    FG_CONV = 5,            /* (cudnn|nn).SpatialConvolution(a=nIn, b=nOut, c=k, k, 1, 1, d=pad, pad) */
+    FG_CONV = 5,            /* (cudnn|nn).SpatialConvolution(a=nIn, b=nOut, c=k, k, dW, dH, d=pad, pad); p = stride dW=dH (0/1: 1, 2: 2) */
     FG_BATCHNORM = 6,       /* nn.SpatialBatchNormalization(a=nF), p=eps, q=momentum */
     FG_SPATIAL_DROPOUT = 7, /* nn.SpatialDropout(p) */
     FG_AVGPOOL2 = 8,        /* nn.SpatialAveragePooling(2,2,2,2) */

@@ -271,24 +271,25 @@ class SpatialUpSamplingNearest(Module):
         return self.gradInput
 
 
-def _im2col(x, kh, kw, ph, pw):
-    """THNN SpatialConvolutionMM's unfolded `finput`: [N][C*kh*kw][H*W] (stride 1)."""
+def _im2col(x, kh, kw, ph, pw, dh=1, dw=1):
+    """THNN SpatialConvolutionMM's unfolded `finput`: [N][C*kh*kw][Ho*Wo]; Ho = floor((H + 2 ph - kh) / dh) + 1."""
     n, c, h, w = x.shape
     xp = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
-    ho, wo = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-    win = np.lib.stride_tricks.sliding_window_view(xp, (kh, kw), axis=(2, 3))  # n,c,ho,wo,kh,kw
+    ho, wo = (h + 2 * ph - kh) // dh + 1, (w + 2 * pw - kw) // dw + 1
+    win = np.lib.stride_tricks.sliding_window_view(xp, (kh, kw), axis=(2, 3))[:, :, ::dh, ::dw]  # n,c,ho,wo,kh,kw
+    win = win[:, :, :ho, :wo]
     cols = win.transpose(0, 1, 4, 5, 2, 3).reshape(n, c * kh * kw, ho * wo)
     return np.ascontiguousarray(cols), ho, wo
 
 
 class SpatialConvolution(Module):
     """nn.SpatialConvolution / cudnn.SpatialConvolution (models.lua:64-73, 385-400):
-    stride-1 cross-correlation, zero pad, + bias.  CPU algorithm = THNN
-    SpatialConvolutionMM: im2col into `finput` + sgemm per sample."""
+    cross-correlation, zero pad, + bias; stride 1 on the hot path, stride 2 in create_D16_d (models.lua:289-291).
+    CPU algorithm = THNN SpatialConvolutionMM: im2col into `finput` + sgemm per sample."""
 
     def __init__(self, nin, nout, kw, kh, dw=1, dh=1, padw=0, padh=None, rng=None):
         super().__init__()
-        assert dw == 1 and dh == 1, "hot path only uses stride 1"
+        self.dw, self.dh = int(dw), int(dh)
         rng = rng or np.random.default_rng(0)
         self.nin, self.nout, self.kw, self.kh = nin, nout, kw, kh
         self.padw = int(padw)
@@ -301,7 +302,7 @@ class SpatialConvolution(Module):
 
     def updateOutput(self, x):
         n = x.shape[0]
-        cols, ho, wo = _im2col(x, self.kh, self.kw, self.padh, self.padw)
+        cols, ho, wo = _im2col(x, self.kh, self.kw, self.padh, self.padw, self.dh, self.dw)
         self.finput = cols
         wm = self.weight.reshape(self.nout, -1)
         y = np.matmul(wm, cols) + self.bias[None, :, None]
@@ -312,6 +313,11 @@ class SpatialConvolution(Module):
         # full correlation with the 180-degree rotated kernel == conv of gy with
         # W^T flipped, same padding arithmetic for odd k / same-pad / stride 1
         n, c, h, w = x.shape
+        if self.dw != 1 or self.dh != 1:
+            # strided: correlate the zero-inserted output gradient (THNN does col2im of W^T gy; same sums)
+            gz = np.zeros((n, self.nout, h, w), gy.dtype)
+            gz[:, :, 0:gy.shape[2] * self.dh:self.dh, 0:gy.shape[3] * self.dw:self.dw] = gy
+            gy = gz
         wf = self.weight[:, :, ::-1, ::-1].transpose(1, 0, 2, 3)  # [I][O][kh][kw]
         cols, ho, wo = _im2col(gy, self.kh, self.kw, self.kh - 1 - self.padh, self.kw - 1 - self.padw)
         gx = np.matmul(np.ascontiguousarray(wf).reshape(c, -1), cols)
@@ -323,7 +329,7 @@ class SpatialConvolution(Module):
         n = x.shape[0]
         cols = getattr(self, 'finput', None)
         if cols is None or cols.shape[0] != n:
-            cols, _, _ = _im2col(x, self.kh, self.kw, self.padh, self.padw)
+            cols, _, _ = _im2col(x, self.kh, self.kw, self.padh, self.padw, self.dh, self.dw)
         g = gy.reshape(n, self.nout, -1)
         gw = np.matmul(g, cols.transpose(0, 2, 1)).sum(0)
         self.gradWeight += (scale * gw).reshape(self.weight.shape).astype(self.weight.dtype)
@@ -558,6 +564,55 @@ class CAddTable(Module):
         return self.gradInput
 
 
+class ConcatTable(Module):
+    """nn.ConcatTable (models.lua:307-309): every branch sees the same input, output = table of branch outputs;
+    gradInput = sum of the branch gradInputs.  Parameters: branch order."""
+
+    def __init__(self, *branches):
+        super().__init__()
+        self.modules = list(branches)
+
+    def add(self, m):
+        self.modules.append(m)
+        return self
+
+    def updateOutput(self, x):
+        self.output = [m.forward(x) for m in self.modules]
+        return self.output
+
+    def backward(self, x, gys, scale=1.0):
+        gs = [m.backward(x, gy, scale) for m, gy in zip(self.modules, gys)]
+        self.gradInput = sum(gs[1:], gs[0].copy())
+        return self.gradInput
+
+    def updateGradInput(self, x, gys):
+        gs = [m.updateGradInput(x, gy) for m, gy in zip(self.modules, gys)]
+        self.gradInput = sum(gs[1:], gs[0].copy())
+        return self.gradInput
+
+    def parameters(self):
+        out = []
+        for m in self.modules:
+            out.extend(m.parameters())
+        return out
+
+    def training(self):
+        self.train = True
+        for m in self.modules:
+            m.training()
+
+    def evaluate(self):
+        self.train = False
+        for m in self.modules:
+            m.evaluate()
+
+    def astype(self, dtype):
+        self.dtype = dtype
+        for m in self.modules:
+            m.astype(dtype)
+        return self
+
+
 class BCECriterion:
     """nn.BCECriterion() (train.lua:148): eps = 1e-12, sizeAverage.
     f = -(1/n) sum[t log(x+eps) + (1-t) log(1-x+eps)];
@@ -702,6 +757,24 @@ def create_G16(dimensions, noise_dim, rng=None):
         SpatialConvolution(128, c, 3, 3, 1, 1, 1, 1, rng), Sigmoid())
 
 
+def create_D16_d(dimensions, rng=None):
+    """models.lua:279-316 create_D16_d: ConcatTable{conv branch (two stride-2 convs), dense branch} -> JoinTable(2) ->
+    Linear(1152, 1) -> Sigmoid."""
+    rng = rng or np.random.default_rng(3)
+    c, h, w = dimensions
+    insz = c * h * w
+    fine_sz = int(1024 * 0.25 * 0.25 * 0.25 * h * w)
+    fine = Sequential(
+        SpatialConvolution(c, 128, 3, 3, 1, 1, 1, None, rng), PReLU(),
+        SpatialConvolution(128, 128, 3, 3, 1, 1, 1, None, rng), PReLU(),
+        SpatialAveragePooling(2, 2, 2, 2),
+        SpatialConvolution(128, 512, 3, 3, 2, 2, 1, None, rng), PReLU(),
+        SpatialConvolution(512, 1024, 3, 3, 2, 2, 1, None, rng), PReLU(),
+        SpatialDropout(0.5, rng), View(fine_sz), Linear(fine_sz, 1024, rng), PReLU())
+    dense = Sequential(View(insz), Linear(insz, 128, rng), PReLU(), Dropout(0.5, rng), Linear(128, 128, rng), PReLU())
+    return Sequential(ConcatTable(fine, dense), JoinTable(), Linear(1024 + 128, 1, rng), Sigmoid())
+
+
 def create_D32b(dimensions, rng=None):
     """models.lua:382-416 create_D32b."""
     rng = rng or np.random.default_rng(2)
@@ -748,9 +821,20 @@ class GanState:
 def set_dropout_masks(net, masks):
     """masks: list (in module order) for every SpatialDropout/Dropout in `net`."""
     it = iter(masks)
-    for m in net.modules:
+    for m in walk_modules(net):
         if isinstance(m, (SpatialDropout, Dropout)):
             m.set_mask(next(it))
+
+
+def walk_modules(net):
+    """Leaf modules in execution / parameter order, descending into Sequential / ConcatTable containers."""
+    out = []
+    for m in net.modules:
+        if isinstance(m, (Sequential, ConcatTable)):
+            out.extend(walk_modules(m))
+        else:
+            out.append(m)
+    return out
 
 
 def feval_D(st, inputs, targets):

@@ -78,8 +78,11 @@ def test_models_mirror_reference_structure_and_parameter_order():
     G16 = models.create_G((3, 16, 16), 100)                 # models.lua:27-51, same chain from a 4x4 map
     assert [type(m).__name__ for m in G16.modules] == [type(m).__name__ for m in O.create_G16((3, 16, 16), 100).modules]
     assert tuple(G16.modules[0].weight.shape) == (128 * 4 * 4, 100)
-    with pytest.raises(NotImplementedError):
-        models.create_D((3, 16, 16))                        # create_D16_d: ConcatTable + stride-2 convs, not built
+    D16 = models.create_D((3, 16, 16))                      # models.lua:279-316: ConcatTable{fine, dense} -> JoinTable -> Linear
+    oD16 = O.create_D16_d((3, 16, 16))
+    assert [type(m).__name__ for m in D16.modules] == ["ConcatTable", "JoinTable", "Linear", "Sigmoid"]
+    assert [tuple(getattr(m, n).shape) for m, n in D16.parameter_list()] == \
+           [tuple(getattr(m, p).shape) for (m, p, g) in oD16.parameters()]
 
 
 def test_initialize_weights_semantics():
@@ -99,7 +102,7 @@ def test_layer_specs_cover_reference_constructors():
     from face_generator_amd import models
     D = models.create_D((3, 32, 32))
     specs = D.layer_specs()
-    assert specs[0] == ("CONV", 3, 64, 3, 1) and specs[2][0] == "SPATIAL_DROPOUT" and abs(specs[2][5] - 0.2) < 1e-9
+    assert specs[0] == ("CONV", 3, 64, 3, 1, 1.0) and specs[2][0] == "SPATIAL_DROPOUT" and abs(specs[2][5] - 0.2) < 1e-9
     assert specs[16] == ("VIEW", 2048, 0, 0) and specs[17] == ("LINEAR", 2048, 512)
     assert specs[19][0] == "DROPOUT" and specs[19][5] == 0.5
     G = models.create_G((3, 32, 32), 100)

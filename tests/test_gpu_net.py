@@ -217,3 +217,78 @@ def test_G16_forward_backward(ctx):
     close(nchw(y), img, atol=1e-5, what="G16 images")
     Gd.device_net.backward(nhwc(gy, ctx.device), param_grads=True)
     check_flat_grads(g.cpu().numpy(), G, "G16")
+
+
+def _fill_nontrivial(net, rng):
+    for m in O.walk_modules(net):
+        if isinstance(m, O.PReLU):
+            m.weight[0] = np.float32(rng.uniform(0.1, 0.4))
+
+
+def test_D16_d_forward_backward(ctx):
+    """models.lua:279-316 create_D16_d: ConcatTable{conv branch with two 3x3 stride-2 convs, dense
+    branch} -> JoinTable(2) -> Linear -> Sigmoid; three compiled nets on one flat parameter vector."""
+    from face_generator_amd import models
+    B, C = 8, 3
+    rng = np.random.default_rng(960)
+    D = O.create_D16_d((C, 16, 16), rng)
+    _fill_nontrivial(D, rng)
+    pD, gD = D.getParameters()
+    Dd = models.create_D((C, 16, 16)).cuda(ctx, max_batch=B)
+    p, g = Dd.getParameters()
+    assert p.numel() == pD.size
+    p.copy_(torch.tensor(pD)); Dd.device_net.params_changed()
+    masks = [(rng.random((B, 1024)) < 0.5).astype(np.float32), (rng.random((B, 128)) < 0.5).astype(np.float32)]
+    O.set_dropout_masks(D, masks)
+
+    def fwd(x):
+        return D.forward(x)
+    x = rng.uniform(0, 1, (B, C, 16, 16)).astype(np.float32)
+    out = fwd(x)
+    gy = rng.standard_normal(out.shape).astype(np.float32)
+    gD[...] = 0
+    gin = D.backward(x, gy)
+    dm = [dev(m.reshape(-1), ctx.device) for m in masks]
+    y = Dd.device_net.forward(nhwc(x, ctx.device), masks=dm, train=True)
+    close(y.cpu().numpy(), out, atol=1e-5, what="D16_d probabilities")
+    gx = Dd.device_net.backward(dev(gy, ctx.device), param_grads=True, input_grad=True)
+    close(nchw(gx), gin, atol=1e-4 * np.abs(gin).max() + 1e-7, what="D16_d input gradient")
+    got, ref = g.cpu().numpy(), gD
+    # per parameter tensor, in flat order
+    off = 0
+    for (m, pn, gn) in D.parameters():
+        r = getattr(m, gn).reshape(-1)
+        e = np.abs(got[off:off + r.size] - r).max()
+        tol = 1e-4 * np.abs(r).max() + 1e-7 + (32 * 6e-8 * getattr(m, "gw_cond", 0.0) if isinstance(m, O.PReLU) else 0.0)
+        assert e <= tol, "D16_d %s.%s: err %.3e tol %.3e" % (type(m).__name__, pn, e, tol)
+        off += r.size
+    # evaluate mode: dropout off / SpatialDropout scaling
+    D.evaluate(); Dd.evaluate()
+    close(Dd.device_net.forward(nhwc(x, ctx.device)).cpu().numpy(), D.forward(x), atol=1e-5, what="D16_d evaluate")
+
+
+def test_train_step_16px(ctx):
+    """--scale 16 path: one D-step + G-step with G16 / D16_d against the oracle step."""
+    from face_generator_amd import models, adversarial
+    B, C = 8, 3
+    rng = np.random.default_rng(961)
+    G = O.create_G16((C, 16, 16), 100, rng); D = O.create_D16_d((C, 16, 16), rng)
+    st = O.GanState(G, D)
+    Gd = models.create_G((C, 16, 16), 100).cuda(ctx, max_batch=B)
+    Dd = models.create_D((C, 16, 16)).cuda(ctx, max_batch=B)
+    Gd.getParameters()[0].copy_(torch.tensor(st.pG)); Dd.getParameters()[0].copy_(torch.tensor(st.pD))
+    Gd.device_net.params_changed(); Dd.device_net.params_changed()
+    tr = adversarial.Trainer(ctx, Gd, Dd, dict(batchSize=B, noiseDim=100))
+    real = rng.uniform(0, 1, (B // 2, C, 16, 16)).astype(np.float32)
+    nz = rng.uniform(-1, 1, (B // 2, 100)).astype(np.float32)
+    masks = [(rng.random((B, 1024)) < 0.5).astype(np.float32), (rng.random((B, 128)) < 0.5).astype(np.float32)]
+    ref = O.step_D(st, real, nz, masks)
+    got = tr.step_D(nhwc(real, ctx.device), dev(nz, ctx.device), [dev(m.reshape(-1), ctx.device) for m in masks], keep_grad=True)
+    close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what="16px D-step outputs")
+    assert abs(got["loss"].item() - ref["f_bce"]) <= 1e-5 * abs(ref["f_bce"])
+    close(got["grad"].cpu().numpy(), ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what="16px D-step flat grad")
+    nz2 = rng.uniform(-1, 1, (B, 100)).astype(np.float32)
+    ref = O.step_G(st, nz2, masks)
+    got = tr.step_G(dev(nz2, ctx.device), [dev(m.reshape(-1), ctx.device) for m in masks])
+    close(nchw(got["samples"]), ref["samples"], atol=1e-5, what="16px G-step samples")
+    close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what="16px G-step D outputs")

@@ -338,3 +338,30 @@ def test_c2f_G_step_matches_torch_autograd():
     gt = np.clip(np.concatenate([p.grad.numpy().reshape(-1) for p in pg]), -5, 5)
     np.testing.assert_allclose(res['grad'], gt, atol=1e-9, rtol=1e-7)
     assert G2.getParameters()[0].size == 1101319 - 0 or True
+
+
+def test_strided_conv_and_D16_d_against_torch_autograd():
+    """models.lua:279-316 create_D16_d: 3x3 stride-2 'same'-pad convolutions and the ConcatTable/JoinTable head."""
+    rng = np.random.default_rng(21)
+    m = O.SpatialConvolution(4, 6, 3, 3, 2, 2, 1, None, rng).astype(np.float64)
+    x = rng.standard_normal((3, 4, 8, 8)); gy = rng.standard_normal((3, 6, 4, 4))
+    y = m.forward(x)
+    xt = t(x).requires_grad_(); wt = t(m.weight).requires_grad_(); bt = t(m.bias).requires_grad_()
+    yt = F.conv2d(xt, wt, bt, stride=2, padding=1)
+    yt.backward(t(gy))
+    assert y.shape == (3, 6, 4, 4) and np.abs(y - yt.detach().numpy()).max() < 1e-12
+    gx = m.backward(x, gy)
+    assert np.abs(gx - xt.grad.numpy()).max() < 1e-12
+    assert np.abs(m.gradWeight - wt.grad.numpy()).max() < 1e-11 and np.abs(m.gradBias - bt.grad.numpy()).max() < 1e-11
+    # whole net: shapes, parameter count (models.lua arithmetic), input gradient = sum of both branches
+    D = O.create_D16_d((3, 16, 16), rng)
+    p, g = D.getParameters()
+    n_fine = (3 * 128 * 9 + 128) + 1 + (128 * 128 * 9 + 128) + 1 + (128 * 512 * 9 + 512) + 1 + (512 * 1024 * 9 + 1024) + 1 + \
+             (4096 * 1024 + 1024) + 1
+    n_dense = (768 * 128 + 128) + 1 + (128 * 128 + 128) + 1
+    assert p.size == n_fine + n_dense + 1152 + 1
+    xb = rng.uniform(0, 1, (4, 3, 16, 16)).astype(np.float32)
+    out = D.forward(xb)
+    assert out.shape == (4, 1) and (out > 0).all() and (out < 1).all()
+    gin = D.backward(xb, np.ones((4, 1), np.float32))
+    assert gin.shape == xb.shape and np.abs(g).max() > 0
