@@ -51,6 +51,12 @@ def module_to_t7(m, cudnn_convs=False):
     """One host module descriptor -> the T7Object Torch7 would have serialised for it."""
     f = _base_fields(m)
     t = m._typename
+    if isinstance(m, nn.ConcatSequential):      # models.lua:305-312: Sequential{ConcatTable{branches}, JoinTable(2), tail...}
+        ct = _base_fields(m.modules[0])
+        ct["modules"] = [module_to_t7(b, cudnn_convs) for b in m.branches]
+        jt = module_to_t7(m.modules[1], cudnn_convs)
+        f["modules"] = [T7Object("nn.ConcatTable", ct), jt] + [module_to_t7(x, cudnn_convs) for x in m.tail.modules]
+        return T7Object("nn.Sequential", f)
     if isinstance(m, nn.TableSequential):
         f["modules"] = [module_to_t7(x, cudnn_convs) for x in (m.first, m.inner)]
         return T7Object("nn.Sequential", f)
@@ -124,7 +130,7 @@ def module_to_t7(m, cudnn_convs=False):
 def _conv_fields(f, m):
     f["nInputPlane"], f["nOutputPlane"] = int(m.nInputPlane), int(m.nOutputPlane)
     f["kW"] = f["kH"] = int(m.kW)
-    f["dW"] = f["dH"] = 1
+    f["dW"] = f["dH"] = int(getattr(m, "dW", 1))
     f["padW"] = f["padH"] = int(m.padW)
     _param_fields(f, m)
 
@@ -157,10 +163,17 @@ def module_from_t7(o):
             inner = [x for x in mods[1:] if not isinstance(x, nn.Copy)]
             if len(inner) == 1 and isinstance(inner[0], nn.Sequential):
                 return nn.TableSequential(mods[0], inner[0])
+        if mods and isinstance(mods[0], _LoadedConcat):                    # create_D16_d layout
+            tail = nn.Sequential()
+            for x in mods[2:]:
+                tail.add(x)
+            return nn.ConcatSequential(mods[0].branches, tail)
         s = nn.Sequential()
         for x in mods:
             s.add(x)
         return s
+    if t == "nn.ConcatTable":
+        return _LoadedConcat([module_from_t7(x) for x in lua_array(f["modules"])])
     if t == "nn.Linear":
         w = np.asarray(f["weight"])
         m = nn.Linear(w.shape[1], w.shape[0])
@@ -216,11 +229,18 @@ def module_from_t7(o):
     raise T7Error("module_from_t7: %s is not on the hot path (not mapped)" % t)
 
 
+class _LoadedConcat:
+    """nn.ConcatTable read from a file, before its parent Sequential turns it into an nn.ConcatSequential"""
+
+    def __init__(self, branches):
+        self.branches = branches
+
+
 def _set_input_dims(net):
     """MODELS.create_* record the per-sample input shape; recover it from the first compute module."""
     inner = net._inner() if hasattr(net, "_inner") else net
-    if getattr(inner, "input_dims", None) is not None:
-        return
+    if getattr(inner, "input_dims", None) is not None or isinstance(inner, nn.ConcatSequential):
+        return          # (a ConcatSequential takes images: the caller's image_dims)
     for m in inner.modules:
         if isinstance(m, nn.Linear):
             inner.input_dims = (m.weight.shape[1], 1, 1)

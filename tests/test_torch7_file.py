@@ -131,3 +131,20 @@ def test_c2f_checkpoint_round_trip(tmp_path):
         assert torch.equal(x, y)
     for x, y in zip(_params(D), _params(back["D"])):
         assert torch.equal(x, y)
+
+
+def test_16px_checkpoint_round_trip(tmp_path):
+    G, D = models.create_G((3, 16, 16), 100), models.create_D((3, 16, 16))      # models.lua:27-51, 279-316
+    path = str(tmp_path / "adv16.net")
+    C.save_checkpoint(path, D, G, dict(scale=16, grayscale=False), 2)
+    raw = T.load(path)
+    top = [o.typename for o in T.lua_array(raw["D"]["modules"])]
+    assert top == ["nn.ConcatTable", "nn.JoinTable", "nn.Linear", "nn.Sigmoid"]
+    fine = T.lua_array(T.lua_array(raw["D"]["modules"])[0]["modules"])[0]
+    strided = [o for o in T.lua_array(fine["modules"]) if o.typename == "nn.SpatialConvolution" and o["dW"] == 2.0]
+    assert len(strided) == 2                                                    # models.lua:289-291
+    back = C.load_checkpoint(path)
+    assert isinstance(back["D"], nn.ConcatSequential) and back["D"].input_dims == (3, 16, 16)
+    for x, y in zip(_params(D), _params(back["D"])):
+        assert torch.equal(x, y)
+    assert [m.spec() for m in back["D"].branches[0].modules] == [m.spec() for m in D.branches[0].modules]
