@@ -40,7 +40,9 @@ enum {
 /* Arithmetic of the large convolution contractions (forward / data-gradient of layers that fill the chip with 256x128
  * tiles).  mode 0 (default): native fp32 MFMA (v_mfma_f32_32x32x2_f32).  mode 6: fp32 emulated on the bf16 matrix pipe --
  * operands split exactly into three bf16 planes, six exact plane products accumulated in fp32 (dropped terms <= 2^-24
- * relative); measured more accurate than mode 0 against fp64 and ~2x faster.  Replaces nothing in the reference (its
+ * relative); measured more accurate than mode 0 against fp64 and ~1.7x faster.  Domain: finite operands below 2^127 in
+ * magnitude (an infinity, or a value that rounds to the bf16 infinity, splits into inf - inf = NaN where mode 0 would
+ * propagate inf); operands below 2^-110 lose their low plane to underflow (relative error up to 2^-16 on those).  Replaces nothing in the reference (its
  * cudnn backend picks algorithms internally, models.lua:1-2); exposed so parity can be run in both modes. */
 int fg_set_math(fg_ctx* ctx, int mode);
 int fg_get_math(fg_ctx* ctx);
