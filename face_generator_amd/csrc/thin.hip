@@ -3,6 +3,7 @@
 // N or K of the GEMM view is 3 (or 27), so MFMA tiles would be > 90 % padding: these are HBM/VALU-bound and
 // run on the vector ALU with coalesced NHWC accesses and weights held in registers.
 #include "fg_internal.h"
+typedef float tw_f32x16 __attribute__((ext_vector_type(16)));   // MFMA 32x32 accumulator
 
 __device__ __forceinline__ float wave_sum_x(float v) {
 #pragma unroll
@@ -245,6 +246,65 @@ __global__ __launch_bounds__(256) void thin_in_generic_kernel(const float* __res
     }
 }
 
+// 3x3 thin-input convolution (3 or 1 channels -> 64 / 128) on the fp32 matrix pipe: a 32-pixel x 32-channel tile is
+// ceil(9*CS / 2) v_mfma_f32_32x32x2_f32 with K = the (tap, channel) index; A = the shifted input values of the 32 pixels
+// (per-lane gather from the tiny input, zero outside the image), B = the packed weights held in registers for the whole
+// kernel, bias folded into the accumulator init.  Replaces the row-walking VALU kernel (26 us for a 33 MB output).
+template <int CS>
+__global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                           const float* __restrict__ bias, float* __restrict__ out,
+                                                           int npix, int H, int W, int flip, int Cw, int lgH, int lgW) {
+    constexpr int NA = 9 * CS;
+    constexpr int KS = (NA + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cb = blockIdx.y * 64;
+    const int h = lane >> 5, j = lane & 31;
+    float wb[KS][2];
+    int kdesc[KS];                       // (oy + 1) | (ox + 1) << 2 | s << 4 | valid << 8
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int k = 2 * ks + h;
+        const bool valid = k < NA;
+        const int tap = valid ? k / CS : 0, sc = valid ? k - tap * CS : 0;
+        const size_t widx = (size_t)((flip ? 8 - tap : tap) * CS + sc) * Cw + cb + j;
+        wb[ks][0] = valid ? Wp[widx] : 0.f;
+        wb[ks][1] = valid ? Wp[widx + 32] : 0.f;
+        kdesc[ks] = (tap / 3) | ((tap % 3) << 2) | (sc << 4) | ((valid ? 1 : 0) << 8);
+    }
+    const float b0 = bias ? bias[cb + j] : 0.f, b1 = bias ? bias[cb + 32 + j] : 0.f;
+    const bool p2 = lgW >= 0 && lgH >= 0;
+    const int ntiles = (npix + 31) / 32;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int pix = tile * 32 + j;
+        const bool ok = pix < npix;
+        int x, y, t;
+        if (p2) { x = pix & (W - 1); t = pix >> lgW; y = t & (H - 1); }
+        else { t = pix / W; x = pix - t * W; y = t % H; }
+        tw_f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int d = kdesc[ks];
+            const int yy = y + (d & 3) - 1, xx = x + ((d >> 2) & 3) - 1;
+            float a = 0.f;
+            if (ok && (d >> 8) && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                a = in[(size_t)((t - y + yy) * W + xx) * CS + ((d >> 4) & 15)];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[ks][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[ks][1], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (p < npix) {
+                float* o = out + (size_t)p * Cw + cb + j;
+                o[0] = acc0[r];
+                o[32] = acc1[r];
+            }
+        }
+    }
+}
+
 int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
                            int W, int Cs, int Cw, int k, int flip) {
     if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_in: Cw %% 64");
@@ -253,6 +313,17 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
     const int npix = B * H * W;
     if (npix == 0) return FG_OK;
     dim3 grid(fg_cdiv(npix, 128), Cw / cblk);
+    if (k == 3 && (Cs == 1 || Cs == 3)) {
+        int lgH = -1, lgW = -1;
+        for (int q = 0; q < 15; ++q) { if ((1 << q) == H) lgH = q; if ((1 << q) == W) lgW = q; }
+        int nb = fg_cdiv(fg_cdiv(npix, 32), 4);
+        if (nb > 2048) nb = 2048;
+        dim3 mgrid(nb, Cw / 64);
+        if (Cs == 3) hipLaunchKernelGGL((thin_in_mfma_kernel<3>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW);
+        else hipLaunchKernelGGL((thin_in_mfma_kernel<1>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW);
+        FG_CHECK_LAUNCH(ctx);
+        return FG_OK;
+    }
     if (k == 3 && (Cs == 1 || Cs == 3 || Cs == 4) && (Cw == 64 || Cw == 128)) {
         dim3 rgrid(fg_cdiv(B * H, 4), 1);
 #define TIR3(CC, JJ)                                                                                                 \
@@ -620,7 +691,6 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // used exactly once, so there is nothing to stage), B = the <= 27 shifted thin values of the pair (a per-lane gather from
 // the tiny thin tensor, zero outside the image), columns 27..31 idle.  The VALU kernel above needs one LDS read per FMA
 // and ran 10x over the HBM time of its 33 MB stream.
-typedef float tw_f32x16 __attribute__((ext_vector_type(16)));
 template <int CS>
 __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __restrict__ thin, const float* __restrict__ wide,
                                                               float* __restrict__ part, int B, int H, int W, int Cw, int sgn, int lgH, int lgW) {
