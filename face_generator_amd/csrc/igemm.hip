@@ -781,6 +781,21 @@ int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long s
 // ---------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------
+// XCD-aware block order for the pixel-split weight-gradient kernels: blocks of one pixel split (all tiles / taps /
+// parities) read the same dY / X rows, so they should share an XCD's L2.  Hardware deals blocks round-robin over the 8
+// XCDs in dispatch order; hand XCD k the k-th eighth of the split-major logical order instead.
+__device__ __forceinline__ void fg_wgrad_block(int& tile, int& s, int& pg) {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int n = gx * gy * gz;
+    int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if ((n & 7) == 0) lin = (lin & 7) * (n >> 3) + (lin >> 3);
+    const int per = gx * gz;
+    s = lin / per;
+    const int r = lin - s * per;
+    pg = r / gx;
+    tile = r - pg * gx;
+}
+
 template <int BT>  // square tile BT x BT (rows = dY channels, cols = X channels)
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     constexpr int BK = 32;
@@ -795,8 +810,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int ntc = a.Cpad / BT;
-    const int tn = blockIdx.x / ntc, tc = blockIdx.x - tn * ntc;
-    const int s = blockIdx.y, pg = blockIdx.z;
+    int bt_, s, pg;
+    fg_wgrad_block(bt_, s, pg);
+    const int tn = bt_ / ntc, tc = bt_ - tn * ntc;
     const int p = pg / a.G, g = pg - p * a.G;
     const int m0 = s * a.m_per_split;
     const int m1 = min(a.M, m0 + a.m_per_split);
@@ -1136,8 +1152,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws6_kernel(const WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntq = a.Cpad / QT;
-    const int tn = blockIdx.x / ntq, tq = blockIdx.x - tn * ntq;
-    const int s = blockIdx.y, pg = blockIdx.z;
+    int bt_, s, pg;
+    fg_wgrad_block(bt_, s, pg);
+    const int tn = bt_ / ntq, tq = bt_ - tn * ntq;
     const int p = pg / a.G, g = pg - p * a.G;
     const int m0 = s * a.m_per_split;
     const int m1 = min(a.M, m0 + a.m_per_split);
