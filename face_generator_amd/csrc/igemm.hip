@@ -788,7 +788,10 @@ __device__ __forceinline__ void fg_wgrad_block(int& tile, int& s, int& pg) {
     const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
     const int n = gx * gy * gz;
     int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
-    if ((n & 7) == 0) lin = (lin & 7) * (n >> 3) + (lin >> 3);
+    {   // XCD k owns the dispatch slots k, k+8, ...: n/8 of them, one more for k < n%8
+        const int k = lin & 7, q = n >> 3, rem = n & 7;
+        lin = k * q + (k < rem ? k : rem) + (lin >> 3);
+    }
     const int per = gx * gz;
     s = lin / per;
     const int r = lin - s * per;
