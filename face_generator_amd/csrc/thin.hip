@@ -691,67 +691,82 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // used exactly once, so there is nothing to stage), B = the <= 27 shifted thin values of the pair (a per-lane gather from
 // the tiny thin tensor, zero outside the image), columns 27..31 idle.  The VALU kernel above needs one LDS read per FMA
 // and ran 10x over the HBM time of its 33 MB stream.
-template <int CS>
+template <int K, int CS>
 __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __restrict__ thin, const float* __restrict__ wide,
                                                               float* __restrict__ part, int B, int H, int W, int Cw, int sgn, int lgH, int lgW) {
-    constexpr int NA = 9 * CS;
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int NA = K * K * CS;
+    constexpr int NCT = (NA + 31) / 32;          // 32-column tiles of the (tap, s) axis: 1 (3x3) ... 5 (7x7x3)
     __shared__ float red[4][2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cbase = blockIdx.y * 64;
     const long long npix = (long long)B * H * W, npairs = (npix + 1) / 2;
     const int j = lane & 31, k = lane >> 5;
-    const bool jok = j < NA;
-    const int tap = jok ? j / CS : 0, sch = jok ? j - tap * CS : 0;
-    const int oy = sgn * (tap / 3 - 1), ox = sgn * (tap % 3 - 1);
-    tw_f32x16 acc0, acc1;
+    int oy[NCT], ox[NCT], sch[NCT];
+    bool jok[NCT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int jj = ct * 32 + j;
+        jok[ct] = jj < NA;
+        const int tap = jok[ct] ? jj / CS : 0;
+        sch[ct] = jok[ct] ? jj - tap * CS : 0;
+        oy[ct] = sgn * (tap / K - PAD); ox[ct] = sgn * (tap % K - PAD);
+    }
+    tw_f32x16 acc[NCT][2];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[ct][0][r] = 0.f; acc[ct][1][r] = 0.f; }
     // 32-bit pixel indices (the launcher guarantees npix * Cw < 2^31); shifts instead of divisions for power-of-two maps
     const int npx = (int)npix, npr = (int)npairs;
     const int stride = gridDim.x * 4;
     const bool p2 = lgW >= 0 && lgH >= 0;
-#define TWM_STEP(PP, A0, A1, BV)                                                                 \
-    {                                                                                            \
-        const int pix = 2 * (PP) + k;                                                            \
-        A0 = 0.f; A1 = 0.f; BV = 0.f;                                                            \
-        if (pix < npx) {                                                                         \
-            const float* wp = wide + (size_t)pix * Cw + cbase + j;                               \
-            A0 = wp[0]; A1 = wp[32];                                                             \
-            int x, y, t;                                                                         \
-            if (p2) { x = pix & (W - 1); t = pix >> lgW; y = t & (H - 1); }                      \
-            else { t = pix / W; x = pix - t * W; y = t % H; }                                    \
-            const int yy = y + oy, xx = x + ox;                                                  \
-            if (jok && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)                 \
-                BV = thin[(size_t)((t - y + yy) * W + xx) * CS + sch];                           \
-        }                                                                                        \
-    }
-    int pp = blockIdx.x * 4 + wave;
-    for (; pp + stride < npr; pp += 2 * stride) {          // two independent steps in flight
-        float a0, a1, bv, c0, c1, dv;
-        TWM_STEP(pp, a0, a1, bv)
-        TWM_STEP(pp + stride, c0, c1, dv)
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, dv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, dv, acc1, 0, 0, 0);
-    }
-    if (pp < npr) {
-        float a0, a1, bv;
-        TWM_STEP(pp, a0, a1, bv)
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
-    }
-#undef TWM_STEP
-    // block reduce (fixed wave order) -> one slab [NA][Cw] per block, like thin_wgrad_kernel
+    constexpr int U = NCT <= 2 ? 2 : 1;           // independent pixel pairs in flight (register budget: NCT accumulators)
+    for (int pp0 = blockIdx.x * 4 + wave; pp0 < npr; pp0 += U * stride) {
+        float a0[U], a1[U], bv[U][NCT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { red[wave][0][r][lane] = acc0[r]; red[wave][1][r][lane] = acc1[r]; }
-    __syncthreads();
+        for (int u = 0; u < U; ++u) {
+            const int pp = pp0 + u * stride;
+            const int pix = 2 * pp + k;
+            a0[u] = 0.f; a1[u] = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bv[u][ct] = 0.f;
+            if (pp < npr && pix < npx) {
+                const float* wp = wide + (size_t)pix * Cw + cbase + j;
+                a0[u] = wp[0]; a1[u] = wp[32];
+                int x, y, t;
+                if (p2) { x = pix & (W - 1); t = pix >> lgW; y = t & (H - 1); }
+                else { t = pix / W; x = pix - t * W; y = t % H; }
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const int yy = y + oy[ct], xx = x + ox[ct];
+                    if (jok[ct] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                        bv[u][ct] = thin[(size_t)((t - y + yy) * W + xx) * CS + sch[ct]];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], bv[u][ct], acc[ct][0], 0, 0, 0);
+                acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], bv[u][ct], acc[ct][1], 0, 0, 0);
+            }
+    }
+    // block reduce (fixed wave order) -> one slab [NA][Cw] per block, like thin_wgrad_kernel
     float* dst = part + (size_t)blockIdx.x * NA * Cw;
-    for (int e = threadIdx.x; e < 2 * 16 * 64; e += 256) {
-        const int tile = e >> 10, r = (e >> 6) & 15, l = e & 63;
-        const int col = l & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        if (col < NA)
-            dst[(size_t)col * Cw + cbase + tile * 32 + row] = (red[0][tile][r][l] + red[1][tile][r][l]) + (red[2][tile][r][l] + red[3][tile][r][l]);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        if (ct) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { red[wave][0][r][lane] = acc[ct][0][r]; red[wave][1][r][lane] = acc[ct][1][r]; }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 2 * 16 * 64; e += 256) {
+            const int tile = e >> 10, r = (e >> 6) & 15, l = e & 63;
+            const int col = ct * 32 + (l & 31), row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+            if (col < NA)
+                dst[(size_t)col * Cw + cbase + tile * 32 + row] = (red[0][tile][r][l] + red[1][tile][r][l]) + (red[2][tile][r][l] + red[3][tile][r][l]);
+        }
     }
 }
 
@@ -760,18 +775,23 @@ int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float
 int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
                          int Cw, int k, int shift_thin, float* scratch) {
     if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_wgrad: Cw %% 64");
-    if (k == 3 && (Cs == 1 || Cs == 3)) {
+    {
         const long long npairs = ((long long)B * H * W + 1) / 2;
         int nb = (int)((npairs + 3) / 4 < TW_BLOCKS ? (npairs + 3) / 4 : TW_BLOCKS);
         if (nb < 1) nb = 1;
         dim3 grid(nb, Cw / 64);
         int lgH = -1, lgW = -1;
         for (int q = 0; q < 15; ++q) { if ((1 << q) == H) lgH = q; if ((1 << q) == W) lgW = q; }
-        if ((long long)B * H * W * Cw >= (1LL << 31)) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "thin_wgrad: tensor too large for 32-bit indexing");
-        if (Cs == 3) hipLaunchKernelGGL((thin_wgrad_mfma_kernel<3>), grid, dim3(256), 0, ctx->stream, thin, wide, scratch, B, H, W, Cw, shift_thin, lgH, lgW);
-        else hipLaunchKernelGGL((thin_wgrad_mfma_kernel<1>), grid, dim3(256), 0, ctx->stream, thin, wide, scratch, B, H, W, Cw, shift_thin, lgH, lgW);
-        FG_CHECK_LAUNCH(ctx);
-        return fg_launch_colsum_final(ctx, scratch, nb, 9 * Cs * Cw, 0.f, gw_tsc);
+        const bool fits = (long long)B * H * W * Cw < (1LL << 31);
+#define TWM(KK, CC)                                                                                                  \
+        if (fits && k == KK && Cs == CC) {                                                                           \
+            hipLaunchKernelGGL((thin_wgrad_mfma_kernel<KK, CC>), grid, dim3(256), 0, ctx->stream, thin, wide, scratch, B, H, \
+                               W, Cw, shift_thin, lgH, lgW);                                                         \
+            FG_CHECK_LAUNCH(ctx);                                                                                    \
+            return fg_launch_colsum_final(ctx, scratch, nb, KK * KK * CC * Cw, 0.f, gw_tsc);                         \
+        }
+        TWM(3, 1) TWM(3, 3) TWM(3, 4) TWM(5, 1) TWM(5, 3) TWM(7, 1) TWM(7, 3)
+#undef TWM
     }
     const int cblk = Cw >= 256 ? 256 : Cw;
     if (Cw % cblk || 256 % cblk) return fg_set_err(ctx, FG_ERR_INVALID, "thin_wgrad: Cw=%d unsupported", Cw);
