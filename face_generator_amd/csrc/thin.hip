@@ -305,6 +305,66 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
     }
 }
 
+// The same contraction for the larger thin layers (5x5 / 7x7 kernels, 4-channel input: the c2f nets): K = K*K*CS is up to
+// 147, too many weight fragments for registers, so the packed weights of the block's 64 output channels live in LDS
+// ([K*K*CS][64] floats, one conflict-free ds_read_b32 per MFMA).
+template <int K, int CS>
+__global__ __launch_bounds__(256) void thin_in_mfma_lds_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int npix, int H, int W, int flip, int Cw, int lgH, int lgW) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int NA = K * K * CS;
+    constexpr int KS = (NA + 1) / 2;
+    __shared__ float wsh[2 * KS][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cb = blockIdx.y * 64;
+    const int h = lane >> 5, j = lane & 31;
+    for (int e = threadIdx.x; e < 2 * KS * 64; e += 256) {
+        const int kk = e >> 6, c = e & 63;
+        float v = 0.f;
+        if (kk < NA) {
+            const int tap = kk / CS, sc = kk - tap * CS;
+            v = Wp[(size_t)((flip ? K * K - 1 - tap : tap) * CS + sc) * Cw + cb + c];
+        }
+        wsh[kk][c] = v;
+    }
+    __syncthreads();
+    const float b0 = bias ? bias[cb + j] : 0.f, b1 = bias ? bias[cb + 32 + j] : 0.f;
+    const bool p2 = lgW >= 0 && lgH >= 0;
+    const int ntiles = (npix + 31) / 32;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int pix = tile * 32 + j;
+        const bool ok = pix < npix;
+        int x, y, t;
+        if (p2) { x = pix & (W - 1); t = pix >> lgW; y = t & (H - 1); }
+        else { t = pix / W; x = pix - t * W; y = t % H; }
+        tw_f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
+#pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 2 * ks + h;
+            const int tap = k / CS, sc = k - tap * CS;
+            const int dy = tap / K, dx = tap - dy * K;
+            const int yy = y + dy - PAD, xx = x + dx - PAD;
+            float a = 0.f;
+            if (ok && k < NA && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                a = in[(size_t)((t - y + yy) * W + xx) * CS + sc];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wsh[k][j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wsh[k][32 + j], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (p < npix) {
+                float* o = out + (size_t)p * Cw + cb + j;
+                o[0] = acc0[r];
+                o[32] = acc1[r];
+            }
+        }
+    }
+}
+
 int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
                            int W, int Cs, int Cw, int k, int flip) {
     if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_in: Cw %% 64");
@@ -323,6 +383,22 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         else hipLaunchKernelGGL((thin_in_mfma_kernel<1>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW);
         FG_CHECK_LAUNCH(ctx);
         return FG_OK;
+    }
+    if ((k == 5 || k == 7 || (k == 3 && Cs == 4)) && (Cs == 1 || Cs == 3 || Cs == 4)) {
+        int lgH = -1, lgW = -1;
+        for (int q = 0; q < 15; ++q) { if ((1 << q) == H) lgH = q; if ((1 << q) == W) lgW = q; }
+        int nb = fg_cdiv(fg_cdiv(npix, 32), 4);
+        if (nb > 1024) nb = 1024;
+        dim3 mgrid(nb, Cw / 64);
+#define TIL(KK, CC)                                                                                                  \
+        if (k == KK && Cs == CC) {                                                                                   \
+            hipLaunchKernelGGL((thin_in_mfma_lds_kernel<KK, CC>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, \
+                               H, W, flip, Cw, lgH, lgW);                                                            \
+            FG_CHECK_LAUNCH(ctx);                                                                                    \
+            return FG_OK;                                                                                            \
+        }
+        TIL(3, 4) TIL(5, 1) TIL(5, 3) TIL(7, 1) TIL(7, 3)
+#undef TIL
     }
     if (k == 3 && (Cs == 1 || Cs == 3 || Cs == 4) && (Cw == 64 || Cw == 128)) {
         dim3 rgrid(fg_cdiv(B * H, 4), 1);
