@@ -286,3 +286,57 @@ def test_philox_rng(ctx):
     # offset continues the stream (4 values per counter)
     d = ctx.uniform((1024,), -1.0, 1.0, seed=1, offset=256).cpu().numpy()
     assert (d == a[1024:2048]).all()
+
+
+def _fuzz_cases():
+    """Seeded random conv shapes: odd / non power-of-two maps, every channel-count class (thin in / thin out / 64-wide / 128+),
+    all kernel sizes, folded upsample, and batch sizes on both sides of the thresholds that select the wave-specialised,
+    split-K and bf16x6 kernels."""
+    rng = np.random.default_rng(20260925)
+    cases = []
+    for _ in range(24):
+        k = int(rng.choice([3, 3, 3, 5, 7]))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:   cin, cout = int(rng.choice([1, 3, 4])), int(rng.choice([64, 128]))      # thin in
+        elif kind == 1: cin, cout = int(rng.choice([64, 128])), int(rng.choice([1, 3]))         # thin out
+        elif kind == 2: cin, cout = 64, int(rng.choice([64, 128]))
+        else:           cin, cout = int(rng.choice([128, 256])), int(rng.choice([128, 256]))
+        up = int(kind >= 2 and k != 7 and rng.random() < 0.4)
+        h, w = int(rng.integers(3, 20)), int(rng.integers(3, 20))
+        if rng.random() < 0.5: h, w = int(rng.choice([4, 8, 16])), int(rng.choice([4, 8, 16, 32]))
+        b = int(rng.choice([1, 2, 3, 5, 16, 33, 64]))
+        if b * h * w * max(cin, cout) * (4 if up else 1) > 6e6:     # keep the numpy reference to a second or two
+            b = max(1, int(6e6 // (h * w * max(cin, cout) * (4 if up else 1))))
+        cases.append((b, h, w, cin, cout, k, up))
+    return cases
+
+
+@pytest.mark.parametrize("math", [0, 6])
+@pytest.mark.parametrize("case", _fuzz_cases())
+def test_conv2d_random_shapes_both_math_modes(ctx, case, math):
+    from face_generator_amd import ops
+    B, H, W, Cin, Cout, k, up = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    pad = (k - 1) // 2
+    conv = O.SpatialConvolution(Cin, Cout, k, k, 1, 1, pad, pad, rng)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    ups = O.SpatialUpSamplingNearest(2)
+    xu = ups.forward(x) if up else x
+    y = conv.forward(xu)
+    gy = rng.standard_normal(y.shape).astype(np.float32)
+    gxu = conv.backward(xu, gy)
+    gx = ups.backward(x, gxu) if up else gxu
+    d = ctx.device
+    prev = ctx.get_math()
+    ctx.set_math(math)
+    try:
+        w_d, b_d = dev(conv.weight, d), dev(conv.bias, d)
+        y_d = ops.conv2d_forward(nhwc(x, d), w_d, b_d, upsample2x=bool(up))
+        close(nchw(y_d), y, atol=2e-5 * max(np.abs(y).max(), 1), what="conv fwd %s" % (case,))
+        gx_d = ops.conv2d_backward_data(nhwc(gy, d), w_d, (H, W), upsample2x=bool(up))
+        close(nchw(gx_d), gx, atol=2e-5 * max(np.abs(gx).max(), 1), what="conv dgrad %s" % (case,))
+        gw_d, gb_d = ops.conv2d_backward_weight(nhwc(x, d), nhwc(gy, d), k, upsample2x=bool(up))
+        close(gw_d.cpu().numpy(), conv.gradWeight, atol=3e-5 * max(np.abs(conv.gradWeight).max(), 1), what="conv wgrad %s" % (case,))
+        close(gb_d.cpu().numpy(), conv.gradBias, atol=3e-5 * max(np.abs(conv.gradBias).max(), 1), what="conv bgrad %s" % (case,))
+    finally:
+        ctx.set_math(prev)
