@@ -207,7 +207,7 @@ int fg_launch_thin_in_conv(fg_ctx*, const float* in, const float* Wp, const floa
                            int W, int Cs, int Cw, int k, int flip);
 // thin-out: out[pix][s<Cs] = act(bias[s] + sum_{tap, c<Cw} in[pix+off(tap)][c] * Wp[tap][s][c])
 int fg_launch_thin_out_conv(fg_ctx*, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
-                            int W, int Cw, int Cs, int k, int flip, int sigmoid);
+                            int W, int Cw, int Cs, int k, int flip, int sigmoid, float* rbuf = nullptr, long long rbuf_floats = 0)   /* rbuf: >= B*H*W*32 floats enables the two-pass 5x5/7x7 MFMA path */;
 // thin wgrad: gw[tap][s][c] (partials reduced) = sum_pix thin[pix + sgn*off(tap)][s] * wide[pix][c]
 int fg_launch_thin_wgrad(fg_ctx*, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
                          int Cw, int k, int shift_thin, float* scratch);

@@ -106,6 +106,8 @@ static long long stage_scratch(const Stage& s, int B) {
             const int cw = s.kind == ST_THIN_IN ? s.oc : s.ic, cs = s.kind == ST_THIN_IN ? s.ic : s.oc;
             const long long na = (long long)s.geom.k * s.geom.k * cs;
             need = (FG_THIN_WGRAD_BLOCKS + 1) * na * cw + (long long)CR_ROWBLOCKS_MAX * (s.oc > 64 ? s.oc : 64) + 64;
+            const long long nr = (long long)B * s.ih * s.iw * 32 + 64;      // R of the two-pass 5x5 / 7x7 thin-output forward
+            if (s.kind == ST_THIN_OUT && s.geom.k >= 5 && nr > need) need = nr;
             break;
         }
         default: break;
@@ -293,7 +295,7 @@ static int forward_run(fg_net* n, long long* out_offset) {
                 break;
             case ST_THIN_OUT:
                 rc = fg_launch_thin_out_conv(ctx, cur, s.wp_fwd, P + s.b_off, y, B, s.ih, s.iw, s.ic, s.oc, s.geom.k, 0,
-                                             s.has_sigmoid);
+                                             s.has_sigmoid, scratch, n->scratch_floats);
                 break;
             case ST_BNPRELU: {
                 const bool sync = n->sync_bn && train;

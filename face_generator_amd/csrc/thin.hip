@@ -631,11 +631,119 @@ __global__ __launch_bounds__(256) void thin_out_generic_kernel(const float* __re
     }
 }
 
+// 5x5 / 7x7 thin-OUTPUT convolution (e.g. 256 -> 3, 7x7: the c2f generator head, models_c2f.lua:131) in two passes:
+//   (1) R[pix][(dx, s)] = sum_{dy, c} in[y + dy - PAD][x][c] * W[dy][dx][c][s]   -- only the VERTICAL taps are folded into
+//       the contraction (K = K*Cw), so the N axis is the K*CS <= 21 (dx, s) columns of one 32-wide MFMA tile instead of 3;
+//       a block owns 4 output rows x 32 columns, stages the (4 + K - 1) input rows and the weights 32 channels at a time
+//       in LDS (conflict-free b128 / b32 fragment reads), one wave per output row;
+//   (2) out[y][x][s] = bias[s] + sum_dx R[y][x + dx - PAD][(dx, s)]   -- a K-tap horizontal gather of the small R.
+// The VALU kernel (thin_out_tiled_kernel) needs a scalar weight load and an LDS read per 4 FMAs and ran at 25 TFLOP/s.
+template <int K, int CS>
+__global__ __launch_bounds__(256) void thin_out_rows_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                                 float* __restrict__ R, int B, int H, int W, int Cw) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int NR = 4 + K - 1;                 // staged input rows
+    constexpr int LDC = 36;                       // floats per staged pixel (32 channels + 4 pad)
+    constexpr int NJ = K * CS;                    // live columns of the 32-wide tile
+    extern __shared__ __attribute__((aligned(16))) float tor_sm[];
+    float* xs = tor_sm;                            // [NR][32][LDC]
+    float* wsm = tor_sm + NR * 32 * LDC;           // [dy][c][j]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 3) / 4;
+    int bid = blockIdx.x;
+    const int txi = bid % tiles_x; bid /= tiles_x;
+    const int tyi = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int x0 = txi * 32, y0 = tyi * 4;
+    tw_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int c0 = 0; c0 < Cw; c0 += 32) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < NR * 32 * 8; e += 256) {          // input rows y0-PAD .. y0+3+PAD, 32 pixels, 32 channels
+            const int c4 = e & 7, pp = e >> 3;
+            const int px = pp & 31, py = pp >> 5;
+            const int xx = x0 + px, yy = y0 + py - PAD;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (xx < W && (unsigned)yy < (unsigned)H)
+                v = *(const float4*)(in + ((size_t)(b * H + yy) * W + xx) * Cw + c0 + c4 * 4);
+            *(float4*)(xs + pp * LDC + c4 * 4) = v;
+        }
+        for (int e = threadIdx.x; e < K * 32 * 32; e += 256) {          // weights of this channel chunk: [dy][c][j = dx*CS + s]
+            const int j = e & 31, c = (e >> 5) & 31, dy = e >> 10;
+            float v = 0.f;
+            if (j < NJ) v = Wp[(size_t)((dy * K + j / CS) * CS + j % CS) * Cw + c0 + c];
+            wsm[e] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int dy = 0; dy < K; ++dy) {
+            const float* xrow = xs + ((wave + dy) * 32 + i) * LDC + 4 * h;
+            const float* wrow = wsm + dy * 1024 + i;                    // + c * 32
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 xv = *(const float4*)(xrow + 8 * q);       // channels 8q + 4h + {0..3}
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.x, wrow[(8 * q + 4 * h + 0) * 32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.y, wrow[(8 * q + 4 * h + 1) * 32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.z, wrow[(8 * q + 4 * h + 2) * 32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.w, wrow[(8 * q + 4 * h + 3) * 32], acc, 0, 0, 0);
+            }
+        }
+    }
+    const int y = y0 + wave;
+    if (y < H) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (x < W) R[((size_t)(b * H + y) * W + x) * 32 + i] = acc[r];
+        }
+    }
+}
+template <int K, int CS>
+__global__ __launch_bounds__(256) void thin_out_rows_gather_kernel(const float* __restrict__ R, const float* __restrict__ bias,
+                                                                   float* __restrict__ out, int npix, int W, int sigmoid) {
+    constexpr int PAD = (K - 1) / 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npix * CS) return;
+    const int pix = idx / CS, s = idx - pix * CS;
+    const int x = pix % W;
+    float r = bias ? bias[s] : 0.f;
+#pragma unroll
+    for (int dx = 0; dx < K; ++dx) {
+        const int xx = x + dx - PAD;
+        if ((unsigned)xx < (unsigned)W) r += R[(size_t)(pix + dx - PAD) * 32 + dx * CS + s];
+    }
+    if (sigmoid) r = 1.f / (1.f + expf(-r));
+    out[idx] = r;
+}
+
 int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
-                            int W, int Cw, int Cs, int k, int flip, int sigmoid) {
+                            int W, int Cw, int Cs, int k, int flip, int sigmoid, float* rbuf, long long rbuf_floats) {
     if (Cs > 4) return fg_set_err(ctx, FG_ERR_INVALID, "thin_out: Cs > 4");
     const int npix = B * H * W;
     if (npix == 0) return FG_OK;
+    if (rbuf && !flip && (k == 5 || k == 7) && (Cs == 1 || Cs == 3) && Cw % 32 == 0 && (long long)npix * 32 <= rbuf_floats) {
+        dim3 grid(B * ((H + 3) / 4) * ((W + 31) / 32));
+#define TOR(KK, CC)                                                                                                  \
+        if (k == KK && Cs == CC) {                                                                                   \
+            const size_t lds = (size_t)((4 + KK - 1) * 32 * 36 + KK * 1024) * sizeof(float);                         \
+            static bool attr = false;                                                                                \
+            if (!attr) {                                                                                             \
+                FG_HIP(ctx, hipFuncSetAttribute((const void*)thin_out_rows_mfma_kernel<KK, CC>,                      \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+                attr = true;                                                                                         \
+            }                                                                                                        \
+            hipLaunchKernelGGL((thin_out_rows_mfma_kernel<KK, CC>), grid, dim3(256), lds, ctx->stream, in, Wp, rbuf, B, H, W, Cw); \
+            FG_CHECK_LAUNCH(ctx);                                                                                    \
+            hipLaunchKernelGGL((thin_out_rows_gather_kernel<KK, CC>), dim3(fg_cdiv(npix * CC, 256)), dim3(256), 0,    \
+                               ctx->stream, rbuf, bias, out, npix, W, sigmoid);                                      \
+            FG_CHECK_LAUNCH(ctx);                                                                                    \
+            return FG_OK;                                                                                            \
+        }
+        TOR(5, 1) TOR(5, 3) TOR(7, 1) TOR(7, 3)
+#undef TOR
+    }
     dim3 grid(fg_cdiv(npix, 64));
     const long long in_bytes = (long long)npix * Cw * 4;
     if (in_bytes < (long long)FG_OOB_T) {
