@@ -60,7 +60,7 @@ static void choose_igemm(long long M, int Npad, int ksteps, int P, int math, int
     {   // large layers: wave-specialised 256x128 kernel when it fills the chip with whole rounds of 256 blocks
         static int use_ws = -1;
         if (use_ws < 0) { const char* e = getenv("FG_IGEMM_WS"); use_ws = e ? atoi(e) : 1; }
-        const long long bw = (Npad % 128 == 0) ? (long long)fg_cdiv(M, 256) * (Npad / 128) * P : 0;
+        const long long bw = (Npad % 64 == 0) ? (long long)fg_cdiv(M, 256) * (Npad / ((Npad % 128 == 0) ? 128 : 64)) * P : 0;
         if (use_ws && bw >= 256 && bw % 256 == 0 && M % 256 == 0) { *tile = 4; return; }
         // bf16x6: a K-step is short and cheap, so mid-size layers also use the wave-specialised kernel (256x64 tiles for
         // layers with 64 output channels), split over K so that exactly one round of 256 blocks fills the chip

@@ -237,13 +237,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 #define WS_LDK 20
 #define WS_NS 4
 #define WS_STAGE ((WS_BM + WS_BN) * WS_LDK)
+// BN = 128: MFMA waves 2x2, each 128x64; BN = 64 (layers with 64 output channels): waves 4x1, each 64x64
+template <int BN>
 __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
+    constexpr int WNW = BN / 64, MI = WS_BM / ((4 / WNW) * 32), NI = 2, NB = BN / 64;
+    constexpr int STAGE = (WS_BM + BN) * WS_LDK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* rowoff = (int*)(smem + WS_NS * WS_STAGE);
+    int* rowoff = (int*)(smem + WS_NS * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntn = a.Npad / WS_BN;
+    const int ntn = a.Npad / BN;
     const int np = a.P;
     const int per_m = ntn * np;
     const int nmt = (a.M + WS_BM - 1) / WS_BM;
@@ -302,27 +306,27 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
             }                                                                                            \
         }
         WS_SET_GROUP();
-        const float* bptr = a.Bp + ((size_t)(p * a.G + g) * a.Npad + tile_n * WS_BN + lrow) * a.Kpad + col0 + lk;
+        const float* bptr = a.Bp + ((size_t)(p * a.G + g) * a.Npad + tile_n * BN + lrow) * a.Kpad + col0 + lk;
         const size_t brow = (size_t)64 * a.Kpad;
         const size_t bjump = (size_t)(a.Npad - 1) * a.Kpad;
-        f32x4 xa[4], xb[2], ya[4], yb[2];     // two tiles in flight: a load has two full K-steps to land
+        f32x4 xa[4], xb[NB], ya[4], yb[NB];     // two tiles in flight: a load has two full K-steps to land
 #define WS_LOAD(ra, rb)                                                                                  \
         {                                                                                                \
             const int cb = col0 * 4;                                                                     \
             const bool kin = !ktail || (col0 + lk < a.Ca);                                               \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
                 ra[i] = fg_buffer_load4(arsrc, kin ? voff[i] + cb : FG_OOB);                             \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) rb[i] = *(const f32x4*)(bptr + i * brow);      \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = *(const f32x4*)(bptr + i * brow);      \
             col0 += WS_BK; bptr += WS_BK;                                                                \
             if (col0 == a.Kpad) { col0 = 0; ++g; bptr += bjump; WS_SET_GROUP(); }                        \
         }
 #define WS_STORE(st, ra, rb)                                                                             \
         {                                                                                                \
-            float* As = smem + (st) * WS_STAGE;                                                          \
+            float* As = smem + (st) * STAGE;                                                          \
             float* Bs = As + WS_BM * WS_LDK;                                                             \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
                 *(f32x4*)(As + (lrow + 64 * i) * WS_LDK + lk) = ra[i];                                   \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i)                                               \
                 *(f32x4*)(Bs + (lrow + 64 * i) * WS_LDK + lk) = rb[i];                                   \
         }
         // prologue: tiles 0 and 1 resident, tiles 2 and 3 in flight
@@ -352,52 +356,52 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
     }
 
     // ---------------------------------------------------------------------- MFMA waves (one per SIMD)
-    const int wm = wid >> 1, wn = wid & 1;
-    f32x16 acc[4][2];
+    const int wm = wid / WNW, wn = wid - wm * WNW;
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    const int a_lds = (wm * 128 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
+    const int a_lds = (wm * MI * 32 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
     const int b_lds = WS_BM * WS_LDK + (wn * 64 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
-    f32x4 af[2][4], bf[2][2];     // [chunk parity][tile]
+    f32x4 af[2][MI], bf[2][NI];     // [chunk parity][tile]
     __syncthreads();              // tiles 0 and 1 are in the ring
     if (KT > 0) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) af[0][mi] = *(const f32x4*)(smem + a_lds + mi * 32 * WS_LDK);
+        for (int mi = 0; mi < MI; ++mi) af[0][mi] = *(const f32x4*)(smem + a_lds + mi * 32 * WS_LDK);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bf[0][ni] = *(const f32x4*)(smem + b_lds + ni * 32 * WS_LDK);
+        for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *(const f32x4*)(smem + b_lds + ni * 32 * WS_LDK);
     }
     for (int kt = 0; kt < KT; ++kt) {
-        const float* St = smem + (kt & (WS_NS - 1)) * WS_STAGE;
-        const float* Sn = smem + ((kt + 1) & (WS_NS - 1)) * WS_STAGE;
+        const float* St = smem + (kt & (WS_NS - 1)) * STAGE;
+        const float* Sn = smem + ((kt + 1) & (WS_NS - 1)) * STAGE;
         // chunk 1 fragments of this tile
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) af[1][mi] = *(const f32x4*)(St + a_lds + mi * 32 * WS_LDK + 8);
+        for (int mi = 0; mi < MI; ++mi) af[1][mi] = *(const f32x4*)(St + a_lds + mi * 32 * WS_LDK + 8);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) bf[1][ni] = *(const f32x4*)(St + b_lds + ni * 32 * WS_LDK + 8);
+        for (int ni = 0; ni < NI; ++ni) bf[1][ni] = *(const f32x4*)(St + b_lds + ni * 32 * WS_LDK + 8);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][mi][j], bf[0][ni][j], acc[mi][ni], 0, 0, 0);
         // chunk 0 fragments of the NEXT tile (already in the ring: it was stored one K-step ago)
         if (kt + 1 < KT) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) af[0][mi] = *(const f32x4*)(Sn + a_lds + mi * 32 * WS_LDK);
+            for (int mi = 0; mi < MI; ++mi) af[0][mi] = *(const f32x4*)(Sn + a_lds + mi * 32 * WS_LDK);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bf[0][ni] = *(const f32x4*)(Sn + b_lds + ni * 32 * WS_LDK);
+            for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *(const f32x4*)(Sn + b_lds + ni * 32 * WS_LDK);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][mi][j], bf[1][ni][j], acc[mi][ni], 0, 0, 0);
         __syncthreads();
     }
@@ -406,30 +410,31 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
     const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = tile_n * WS_BN + wn * 64 + ni * 32 + (lane & 31);
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = tile_n * BN + wn * 64 + ni * 32 + (lane & 31);
         const bool colok = col < a.N;
         float bv = add_bias ? a.bias[colok ? col : 0] : 0.f;
         asm volatile("" : "+v"(bv));
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-            fg_store_acc_tile(orsrc, rowoff, wm * 128 + mi * 32, col, colok, bv, acc[mi][ni], lane);
+        for (int mi = 0; mi < MI; ++mi)
+            fg_store_acc_tile(orsrc, rowoff, wm * MI * 32 + mi * 32, col, colok, bv, acc[mi][ni], lane);
     }
 }
 
+template <int BN>
 static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
-    const size_t lds = (size_t)(WS_NS * WS_STAGE + WS_BM) * sizeof(float);
+    const size_t lds = (size_t)(WS_NS * (WS_BM + BN) * WS_LDK + WS_BM) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / WS_BN) * P, a.splits, 1);
-    const double exec = 2.0 * (double)grid.x * WS_BM * WS_BN * (double)a.G * a.Kpad;
+    dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / BN) * P, a.splits, 1);
+    const double exec = 2.0 * (double)grid.x * WS_BM * BN * (double)a.G * a.Kpad;
     char label[96];
-    snprintf(label, sizeof(label), "igemm_ws_kernel/%s", a.tag ? a.tag : "?");
+    snprintf(label, sizeof(label), BN == 128 ? "igemm_ws_kernel/%s" : "igemm_ws_kernel<64>/%s", a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
-    hipLaunchKernelGGL(igemm_ws_kernel, grid, dim3(512), lds, ctx->stream, a);
+    hipLaunchKernelGGL(igemm_ws_kernel<BN>, grid, dim3(512), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
@@ -743,8 +748,8 @@ int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
         case 2: if (a.Npad % 64) break; return launch_igemm_t<64, 64, 32>(ctx, a, P);
         case 4:
             if (a.A6) { if (a.Npad % 64) break; return (a.Npad % 128 == 0) ? launch_igemm_ws6<128>(ctx, a, P) : launch_igemm_ws6<64>(ctx, a, P); }
-            if (a.Npad % 128) break;
-            return launch_igemm_ws(ctx, a, P);
+            if (a.Npad % 64) break;
+            return (a.Npad % 128 == 0) ? launch_igemm_ws<128>(ctx, a, P) : launch_igemm_ws<64>(ctx, a, P);
     }
     return fg_set_err(ctx, FG_ERR_INVALID, "igemm: bad tile %d for Npad %d", tile, a.Npad);
 }
