@@ -432,7 +432,7 @@ static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
     dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / BN) * P, a.splits, 1);
     const double exec = 2.0 * (double)grid.x * WS_BM * BN * (double)a.G * a.Kpad;
     char label[96];
-    snprintf(label, sizeof(label), BN == 128 ? "igemm_ws_kernel/%s" : "igemm_ws_kernel<64>/%s", a.tag ? a.tag : "?");
+    snprintf(label, sizeof(label), "igemm_ws_kernel<%d>/%s", BN, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
     hipLaunchKernelGGL(igemm_ws_kernel<BN>, grid, dim3(512), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
