@@ -1,0 +1,39 @@
+"""End-to-end data parallelism with TWO real processes (both on the single GPU of the test box, collectives over gloo --
+RCCL refuses two ranks on one device): one D-step + one G-step of `adversarial.Trainer` with the batch sharded over the
+ranks (deferred D all-reduce, bucketed backward-overlapped G all-reduce, 1/world in the fused Adam, sync-BN) must give the
+parameters of a single process run on the global batch, and the replicas must agree bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist2_worker.py")
+
+
+def test_two_process_sharded_step_equals_global_batch(tmp_path):
+    from gpu_util import close_after_first_adam_step
+    B = 16
+    prefix = str(tmp_path / "dp")
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, WORKER, "0", "1", str(B), prefix], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    procs = [subprocess.Popen([sys.executable, WORKER, str(k), "2", str(B), prefix, "29577"], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for k in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    one = np.load(prefix + "_0_of_1.npz")
+    r0, r1 = np.load(prefix + "_0_of_2.npz"), np.load(prefix + "_1_of_2.npz")
+    for k in ("pG", "pD", "gG", "gD"):
+        assert np.array_equal(r0[k], r1[k]), "replicas diverged in %s" % k
+    # all-reduced SUM of the shard gradients (each a mean over B/2 rows) = 2 x the global-batch mean gradient
+    # (G's gradient is taken through the D that was just updated by Adam -- whose step is sign-like, so near-zero D
+    #  gradients may legitimately move a D parameter differently in the two runs -- hence the wider bar for G)
+    for net, rel in (("D", 1e-4), ("G", 1e-3)):
+        g_one, g_two = one["g" + net], 0.5 * r0["g" + net]
+        assert np.abs(g_two - g_one).max() <= rel * np.abs(g_one).max() + 1e-7, net
+        close_after_first_adam_step(r0["p" + net], one["p" + net], g_two, g_one, "%s parameters, 2 ranks vs global batch" % net)
