@@ -31,12 +31,12 @@ def data(B):
     return real, nz1, nz2, masks1, masks2
 
 
-def run(ctx, dist, rank, world, B, out_prefix):
+def run(ctx, dist, rank, world, B, out_prefix, sync_bn=True):
     from face_generator_amd import adversarial
     d = ctx.device
     G, D = build(ctx, B // world)
     opt = dict(batchSize=B // world, noiseDim=100, D_L1=0.0, D_L2=0.0, G_L1=0.0, G_L2=0.0, D_clamp=0.0, G_clamp=0.0,
-               sync_bn=world > 1)
+               sync_bn=(world > 1 and sync_bn))
     tr = adversarial.Trainer(ctx, G, D, opt, dist=dist if world > 1 else None)
     real, nz1, nz2, masks1, masks2 = data(B)
     h = B // 2
@@ -57,6 +57,7 @@ def run(ctx, dist, rank, world, B, out_prefix):
 
 def main():
     rank, world, B, out_prefix = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    sync_bn = (sys.argv[6] != "0") if len(sys.argv) > 6 else True
     from face_generator_amd.runtime import get_context
     import torch.distributed as dist
     ctx = get_context(0)
@@ -64,7 +65,7 @@ def main():
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[5], RANK=str(rank), WORLD_SIZE=str(world))
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        run(ctx, dist, rank, world, B, out_prefix)
+        run(ctx, dist, rank, world, B, out_prefix, sync_bn)
     finally:
         if world > 1:
             dist.destroy_process_group()

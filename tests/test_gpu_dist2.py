@@ -37,3 +37,17 @@ def test_two_process_sharded_step_equals_global_batch(tmp_path):
         g_one, g_two = one["g" + net], 0.5 * r0["g" + net]
         assert np.abs(g_two - g_one).max() <= rel * np.abs(g_one).max() + 1e-7, net
         close_after_first_adam_step(r0["p" + net], one["p" + net], g_two, g_one, "%s parameters, 2 ranks vs global batch" % net)
+
+
+def test_two_process_default_per_gpu_batchnorm_keeps_replicas_identical(tmp_path):
+    """The default (throughput) mode: per-GPU BatchNorm statistics, deferred D all-reduce, bucketed G all-reduce."""
+    prefix = str(tmp_path / "dp_local_bn")
+    env = dict(os.environ)
+    procs = [subprocess.Popen([sys.executable, WORKER, str(k), "2", "16", prefix, "29579", "0"], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for k in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    r0, r1 = np.load(prefix + "_0_of_2.npz"), np.load(prefix + "_1_of_2.npz")
+    for k in ("pG", "pD", "gG", "gD"):
+        assert np.isfinite(r0[k]).all() and np.array_equal(r0[k], r1[k]), "replicas diverged in %s" % k
