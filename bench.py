@@ -93,10 +93,18 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (one process per GPU)" % args.gpus)
+    # test hook (tests/test_gpu_dist2.py): FG_BENCH_TEST_GLOO=1 runs every rank on device 0 with gloo collectives, so the
+    # multi-rank control flow of this file can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
+    test_gloo = os.environ.get("FG_BENCH_TEST_GLOO") == "1"
+    if test_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if test_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from face_generator_amd import models, nn_utils, adversarial
     from face_generator_amd.runtime import get_context

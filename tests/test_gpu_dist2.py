@@ -51,3 +51,20 @@ def test_two_process_default_per_gpu_batchnorm_keeps_replicas_identical(tmp_path
     r0, r1 = np.load(prefix + "_0_of_2.npz"), np.load(prefix + "_1_of_2.npz")
     for k in ("pG", "pD", "gG", "gD"):
         assert np.isfinite(r0[k]).all() and np.array_equal(r0[k], r1[k]), "replicas diverged in %s" % k
+
+
+def test_bench_multi_rank_control_flow_on_one_gpu():
+    """bench.py under torch.distributed.run with TWO ranks (test hook: both on device 0, gloo): barriers, MAX-over-ranks
+    timing, the supplementary bf16x6 leg and the profiled iterations all contain collectives and must not dead-lock."""
+    import json
+    env = dict(os.environ, FG_BENCH_TEST_GLOO="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29583", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32 and j["value"] > 0 and j["scaling"] == "weak"
+    assert "alt_math" in j and "error" not in j["alt_math"] and "roofline" in j and "cpu_baseline" not in j
