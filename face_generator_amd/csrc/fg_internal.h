@@ -127,7 +127,9 @@ int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
 // One launch re-packs every layer of a net after an optimizer step.
 struct PackJob {
     WeightMap wm;
-    int mode;             // 0 forward pack, 1 data-grad pack, 2 thin pack [tap][I][O], 3 thin pack [tap][O][I], 4 bias NCHW->NHWC perm
+    int mode;             // 0 forward pack, 1 data-grad pack (one thread per packed element: Linear + View permutations),
+                          // 5 / 6 the same for conv layers (one thread per channel pair), 2 thin pack [tap][I][O],
+                          // 3 thin pack [tap][O][I], 4 bias NCHW->NHWC perm
     long long src_off;    // offset into the flat parameter vector
     float* dst;
     int rows, cols;       // padded tile dims (modes 0/1)

@@ -1077,6 +1077,22 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
             v = packed_weight_value(wm, W, p, g, o, i);
         }
         jb.dst[loc] = v;
+    } else if (jb.mode == 5 || jb.mode == 6) {
+        // conv layers, one thread per (out, in) channel pair, all parities / taps in a loop: the pair's k*k reference
+        // weights are one contiguous run, re-read from L1 for every folded tap, and the lanes of a wave write consecutive
+        // packed elements (forward layout: in-channel fastest; data-grad layout: out-channel fastest)
+        const bool fwd = jb.mode == 5;
+        const long long tile = (long long)jb.rows * jb.cols;
+        const int part = (int)(loc / tile);                  // (parity, third of the taps): keeps the per-thread chain short
+        const long long e = loc - (long long)part * tile;
+        const int p = part / 3, third = part - p * 3;
+        const int fast = (int)(e % jb.cols), slow = (int)(e / jb.cols);         // (col, row) of the packed tile
+        const int po = fwd ? slow : fast, pi = fwd ? fast : slow;
+        const bool live = po < wm.O && pi < wm.I;
+        float* d = jb.dst + (long long)slow * jb.cols + fast;
+        const int g0 = third * wm.G / 3, g1 = (third + 1) * wm.G / 3;
+        for (int g = g0; g < g1; ++g)
+            d[(long long)(p * wm.G + g) * tile] = live ? packed_weight_value(wm, W, p, g, po, pi) : 0.f;
     } else if (jb.mode <= 3) {   // thin layouts [tap][s][c]
         const int kk = wm.k * wm.k;
         const int Cs = jb.mode == 2 ? wm.I : wm.O, Cw = jb.mode == 2 ? wm.O : wm.I;

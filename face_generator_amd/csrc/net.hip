@@ -610,8 +610,13 @@ static int build_pack_jobs(fg_net* n) {
             ConvGeom g = s.geom; g.B = 1;
             WeightMap wm; fg_geom_weightmap(g, &wm);
             int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
-            add(wm, 0, s.w_off, s.wp_fwd, rf, cf, (long long)wm.P * wm.G * rf * cf);
-            add(wm, 1, s.w_off, s.wp_bwd, rb, cb, (long long)wm.P * wm.G * rb * cb);
+            if (wm.k > 1 && wm.o_hw <= 1 && wm.i_hw <= 1) {      // convolutions: threads = channel pairs x parities x 3 tap thirds
+                add(wm, 5, s.w_off, s.wp_fwd, rf, cf, (long long)rf * cf * wm.P * 3);
+                add(wm, 6, s.w_off, s.wp_bwd, rb, cb, (long long)rb * cb * wm.P * 3);
+            } else {
+                add(wm, 0, s.w_off, s.wp_fwd, rf, cf, (long long)wm.P * wm.G * rf * cf);
+                add(wm, 1, s.w_off, s.wp_bwd, rb, cb, (long long)wm.P * wm.G * rb * cb);
+            }
             if (s.bias_packed) add(wm, 4, s.b_off, s.bias_packed, 0, 0, s.b_n);
         } else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT) {
             WeightMap wm; memset(&wm, 0, sizeof(wm));
