@@ -123,12 +123,16 @@ __device__ __forceinline__ void colreduce_body(long long M, int C, float* __rest
 
 // float4 variant: thread = 4 consecutive channels x one row lane; needs C % 4 == 0 and 256 % (C/4) == 0 (C <= 1024).
 // 16 B per lane per load (1 KiB per wave instruction), rows of a block reduced through LDS.
+// Blocks of CR4_NT = 1024 threads: the number of partial rows (and with it the cost of the final pass) stays at
+// CR_ROWBLOCKS while four times as many loads are in flight per CU (256-thread blocks left one wave per SIMD and ran at
+// ~2 TB/s).
+#define CR4_NT 1024
 static inline bool cr4_ok(int C) { return C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0; }
 template <int K, class F>
 __device__ __forceinline__ void colreduce4_body(long long M, int C, float* __restrict__ part, F f) {
-    __shared__ float4 sh4[K][256];
+    __shared__ float4 sh4[K][CR4_NT];
     const int c4n = C >> 2;
-    const int cx = threadIdx.x % c4n, ry = threadIdx.x / c4n, RY = 256 / c4n;
+    const int cx = threadIdx.x % c4n, ry = threadIdx.x / c4n, RY = CR4_NT / c4n;
     const int nrb = gridDim.x;
     const long long rows_per = (M + nrb - 1) / nrb;
     const long long r0 = blockIdx.x * rows_per;
@@ -153,7 +157,7 @@ __device__ __forceinline__ void colreduce4_body(long long M, int C, float* __res
     }
 }
 
-__global__ __launch_bounds__(256) void colsum4_partial_kernel(const float* __restrict__ x, long long M, int C,
+__global__ __launch_bounds__(CR4_NT) void colsum4_partial_kernel(const float* __restrict__ x, long long M, int C,
                                                               float* __restrict__ part) {
     colreduce4_body<1>(M, C, part, [&](long long r, int cx, float4* acc) {
         const float4 v = *((const float4*)(x + r * C) + cx);
@@ -190,7 +194,7 @@ int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float
 int fg_launch_colsum(fg_ctx* ctx, const float* x, long long M, int N, float beta, float* out, float* scratch) {
     const int nrb = cr_rowblocks(M);
     if (cr4_ok(N))
-        hipLaunchKernelGGL(colsum4_partial_kernel, dim3(nrb), dim3(256), 0, ctx->stream, x, M, N, scratch);
+        hipLaunchKernelGGL(colsum4_partial_kernel, dim3(nrb), dim3(CR4_NT), 0, ctx->stream, x, M, N, scratch);
     else
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nrb, fg_cdiv(N, 64)), dim3(256), 0, ctx->stream, x, M, N, scratch);
     FG_CHECK_LAUNCH(ctx);
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
         acc[1] = fmaf(d, d, acc[1]);
     });
 }
-__global__ __launch_bounds__(256) void bn_stats4_partial_kernel(const float* __restrict__ x, long long M, int C,
+__global__ __launch_bounds__(CR4_NT) void bn_stats4_partial_kernel(const float* __restrict__ x, long long M, int C,
                                                                 float* __restrict__ part) {
     const float4 piv = *((const float4*)x + threadIdx.x % (C >> 2));
     colreduce4_body<2>(M, C, part, [&](long long r, int cx, float4* acc) {
@@ -300,7 +304,7 @@ int fg_launch_bn_forward(fg_ctx* ctx, const BnArgs& a) {
     if (a.train) {
         const int nrb = cr_rowblocks(a.M);
         if (cr4_ok(a.C))
-            hipLaunchKernelGGL(bn_stats4_partial_kernel, dim3(nrb), dim3(256), 0, ctx->stream, a.x, a.M, a.C, a.scratch);
+            hipLaunchKernelGGL(bn_stats4_partial_kernel, dim3(nrb), dim3(CR4_NT), 0, ctx->stream, a.x, a.M, a.C, a.scratch);
         else
             hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nrb, fg_cdiv(a.C, 64)), dim3(256), 0, ctx->stream, a.x, a.M,
                                a.C, a.scratch);
@@ -363,7 +367,7 @@ __global__ void bn_sync_global_kernel(const double* __restrict__ sync, int C, fl
 }
 static int bn_launch_stats_partial(fg_ctx* ctx, const BnArgs& a, int nrb) {
     if (cr4_ok(a.C))
-        hipLaunchKernelGGL(bn_stats4_partial_kernel, dim3(nrb), dim3(256), 0, ctx->stream, a.x, a.M, a.C, a.scratch);
+        hipLaunchKernelGGL(bn_stats4_partial_kernel, dim3(nrb), dim3(CR4_NT), 0, ctx->stream, a.x, a.M, a.C, a.scratch);
     else
         hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nrb, fg_cdiv(a.C, 64)), dim3(256), 0, ctx->stream, a.x, a.M,
                            a.C, a.scratch);
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         if (!(z > 0.f)) acc[2] = fmaf(z, g, acc[2]);
     });
 }
-__global__ __launch_bounds__(256) void bn_bwd4_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+__global__ __launch_bounds__(CR4_NT) void bn_bwd4_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               long long M, int C, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
                                                               const float* __restrict__ slope,
@@ -535,7 +539,7 @@ int fg_launch_bn_backward_sync1(fg_ctx* ctx, const BnBwdArgs& a, double* sync) {
     const int nrb = cr_rowblocks(a.M);
     float* part = a.scratch;
     if (cr4_ok(a.C))
-        hipLaunchKernelGGL(bn_bwd4_partial_kernel, dim3(nrb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
+        hipLaunchKernelGGL(bn_bwd4_partial_kernel, dim3(nrb), dim3(CR4_NT), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
                            a.beta, a.slope, a.mean, a.invstd, part);
     else
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb, fg_cdiv(a.C, 64)), dim3(256), 0, ctx->stream, a.x, a.gy, a.M,
@@ -572,7 +576,7 @@ int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
     float* part = a.scratch;
     float* coef = a.scratch + (size_t)3 * nrb * a.C;
     if (cr4_ok(a.C))
-        hipLaunchKernelGGL(bn_bwd4_partial_kernel, dim3(nrb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
+        hipLaunchKernelGGL(bn_bwd4_partial_kernel, dim3(nrb), dim3(CR4_NT), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
                            a.beta, a.slope, a.mean, a.invstd, part);
     else
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb, ncb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
