@@ -191,8 +191,39 @@ int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
+// N <= 4 columns (bias gradients of the 3- / 1-channel convolutions): lanes over ROWS, the N sums in registers
+template <int N>
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ x, long long M, float* __restrict__ part) {
+    __shared__ float sh[N][256];
+    float acc[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) acc[c] = 0.f;
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < M; r += (long long)gridDim.x * 256) {
+#pragma unroll
+        for (int c = 0; c < N; ++c) acc[c] += x[r * N + c];
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) sh[c][threadIdx.x] = acc[c];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {          // fixed-shape tree: deterministic
+        if ((int)threadIdx.x < o) {
+#pragma unroll
+            for (int c = 0; c < N; ++c) sh[c][threadIdx.x] += sh[c][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < N) part[(size_t)blockIdx.x * N + threadIdx.x] = sh[threadIdx.x][0];
+}
 int fg_launch_colsum(fg_ctx* ctx, const float* x, long long M, int N, float beta, float* out, float* scratch) {
     const int nrb = cr_rowblocks(M);
+    if (N <= 4 && N >= 1) {
+        switch (N) {
+            case 1: hipLaunchKernelGGL(colsum_small_kernel<1>, dim3(nrb), dim3(256), 0, ctx->stream, x, M, scratch); break;
+            case 2: hipLaunchKernelGGL(colsum_small_kernel<2>, dim3(nrb), dim3(256), 0, ctx->stream, x, M, scratch); break;
+            case 3: hipLaunchKernelGGL(colsum_small_kernel<3>, dim3(nrb), dim3(256), 0, ctx->stream, x, M, scratch); break;
+            default: hipLaunchKernelGGL(colsum_small_kernel<4>, dim3(nrb), dim3(256), 0, ctx->stream, x, M, scratch); break;
+        }
+    } else
     if (cr4_ok(N))
         hipLaunchKernelGGL(colsum4_partial_kernel, dim3(nrb), dim3(CR4_NT), 0, ctx->stream, x, M, N, scratch);
     else
