@@ -631,6 +631,77 @@ __global__ __launch_bounds__(256) void thin_out_generic_kernel(const float* __re
     }
 }
 
+// 3x3 thin-output convolution, sliding window: one wave computes NP = 4 horizontally adjacent output pixels from the
+// (NP + 2) x 3 input pixels they share -- 18 coalesced 256-byte channel-row loads instead of 36 (thin_out_kernel loads all
+// nine taps of every pixel separately and is bound by the vector-memory pipe).  Needs W % 4 == 0.
+template <int CJ, int CS>
+__global__ __launch_bounds__(256) void thin_out_win_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                           int H, int W, int flip, int sigmoid, int in_bytes) {
+    constexpr int NP = 4;
+    constexpr int Cw = CJ * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    float w[9][CS][CJ];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int s = 0; s < CS; ++s)
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) w[t][s][j] = Wp[((size_t)(flip ? 8 - t : t) * CS + s) * Cw + lane + 64 * j];
+    const int ngrp = B * H * (W / NP);
+    const int nwaves = gridDim.x * 4;
+    for (int grp = blockIdx.x * 4 + wave; grp < ngrp; grp += nwaves) {
+        const int xg = grp % (W / NP);
+        const int t = grp / (W / NP);              // b * H + y
+        const int y = t % H;
+        const int x0 = xg * NP;
+        float acc[NP][CS];
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int s = 0; s < CS; ++s) acc[q][s] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            const bool rok = (unsigned)yy < (unsigned)H;
+            float v[NP + 2][CJ];
+#pragma unroll
+            for (int c = 0; c < NP + 2; ++c) {
+                const int xx = x0 + c - 1;
+                const bool ok = rok && (unsigned)xx < (unsigned)W;
+                const int base = ok ? (((t - y + yy) * W + xx) * Cw + lane) * 4 : FG_OOB_T;
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) v[c][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, base + 256 * j, 0, 0));
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j)
+#pragma unroll
+                        for (int s = 0; s < CS; ++s) acc[q][s] = fmaf(v[q + dx][j], w[dy * 3 + dx][s][j], acc[q][s]);
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int s = 0; s < CS; ++s) acc[q][s] = wave_sum_x(acc[q][s]);
+        if (lane < NP * CS) {
+            float r = 0.f;
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int s = 0; s < CS; ++s) r = (lane == q * CS + s) ? acc[q][s] : r;
+            const int s = lane % CS;
+            r += bias ? bias[s] : 0.f;
+            if (sigmoid) r = 1.f / (1.f + expf(-r));
+            out[((size_t)t * W + x0) * CS + lane] = r;       // NP*CS consecutive floats per group
+        }
+    }
+}
+
 // 5x5 / 7x7 thin-OUTPUT convolution (e.g. 256 -> 3, 7x7: the c2f generator head, models_c2f.lua:131) in two passes:
 //   (1) R[pix][(dx, s)] = sum_{dy, c} in[y + dy - PAD][x][c] * W[dy][dx][c][s]   -- only the VERTICAL taps are folded into
 //       the contraction (K = K*Cw), so the N axis is the K*CS <= 21 (dx, s) columns of one 32-wide MFMA tile instead of 3;
@@ -746,6 +817,19 @@ int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const
     }
     dim3 grid(fg_cdiv(npix, 64));
     const long long in_bytes = (long long)npix * Cw * 4;
+    if (in_bytes < (long long)FG_OOB_T && k == 3 && W % 4 == 0) {
+        int nblk = fg_cdiv(fg_cdiv(npix, 4), 4);
+        if (nblk > 4096) nblk = 4096;
+#define TOW(JJ, CC)                                                                                                  \
+        if (Cw == JJ * 64 && Cs == CC) {                                                                             \
+            hipLaunchKernelGGL((thin_out_win_kernel<JJ, CC>), dim3(nblk), dim3(256), 0, ctx->stream, in, Wp, bias, out, B, H, \
+                               W, flip, sigmoid, (int)in_bytes);                                                     \
+            FG_CHECK_LAUNCH(ctx);                                                                                    \
+            return FG_OK;                                                                                            \
+        }
+        TOW(1, 1) TOW(1, 3) TOW(2, 1) TOW(2, 3)
+#undef TOW
+    }
     if (in_bytes < (long long)FG_OOB_T) {
         int nblk = fg_cdiv(fg_cdiv(npix, 4), 4);
         if (nblk > 4096) nblk = 4096;
