@@ -12,7 +12,18 @@
 #include <vector>
 #include <string>
 struct FgProfRec { const char* name; hipEvent_t e0, e1; double alg_flops, exec_flops, bytes; };
+// Deferred final reductions (fg_net backward): the second stage of the bias-gradient / PReLU-slope reductions of a whole
+// backward pass is collected here and run by ONE launch (fg_defer_flush) instead of one ~6 us launch per layer.
+#define FG_DEFER_MAX 48
+struct FgFinalJob { const float* part; float* out; int nrb, C; float beta; int blk0; };
+struct FgDefer {
+    float* arena = nullptr;          // partial sums must outlive the shared scratch: dedicated workspace region
+    long long cap = 0, used = 0;
+    FgFinalJob jobs[FG_DEFER_MAX];
+    int n = 0, blocks = 0;
+};
 struct fg_ctx {
+    FgDefer* defer = nullptr;        // non-null only inside fg_net backward
     int device;
     hipStream_t stream;
     char err[512];
@@ -201,6 +212,11 @@ int fg_launch_mul_mask(fg_ctx*, const float* x, const float* mask, float scale, 
 int fg_launch_concat(fg_ctx*, const float* a, const float* b, float* out, long long npix, int ca, int cb);
 int fg_launch_split(fg_ctx*, const float* g, float* ga, float* gb, long long npix, int ca, int cb);
 int fg_launch_add(fg_ctx*, const float* a, const float* b, float* out, long long n);
+// deferred finals: partial buffer of `floats` floats (nullptr = not deferring / arena full -> caller uses its scratch and an
+// immediate final); registration of one final job; flush = run all registered jobs in one launch
+float* fg_defer_alloc(fg_ctx* ctx, long long floats);
+void fg_defer_push(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);
+int fg_defer_flush(fg_ctx* ctx);
 int fg_launch_zero_insert2(fg_ctx*, const float* g, float* out, int B, int H, int W, int C);   // g [B][H][W][C] -> out [B][2H][2W][C]
 
 // thin convolutions (3 <-> wide channels), NHWC, stride 1, "same" pad, odd k <= 7

@@ -87,6 +87,8 @@ struct fg_net {
     int run_pp = 0;
     // one-launch weight re-pack
     PackJob* jobs_dev = nullptr;
+    FgDefer defer;                    // deferred final reductions of a backward pass (arena inside the workspace)
+    long long defer_off = 0, defer_floats = 0;
     float* packed_all = nullptr;      // packed weights of every contraction stage, contiguous (one split launch)
     unsigned char* planes_all = nullptr;
     long long packed_total = 0;
@@ -129,6 +131,14 @@ static void make_plan(fg_net* n, int B) {
         const long long sc = stage_scratch(s, B);
         if (sc > maxscr) maxscr = sc;
     }
+    {   // arena for the deferred finals: [row blocks][C] partials of every bias-gradient / slope-gradient reduction
+        long long dn = 0;
+        for (auto& s : n->st) {
+            if (s.kind == ST_CONV || s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT || s.kind == ST_GEMV) dn += (long long)CR_ROWBLOCKS_MAX * s.oc + 64;
+            if (s.has_prelu || s.kind == ST_PRELU || s.kind == ST_ACTPOOL) dn += 1024 + 64;
+        }
+        n->defer_off = off; n->defer_floats = dn; off += align64(dn);
+    }
     n->grad_off[0] = off; off += align64(maxact);
     n->grad_off[1] = off; off += align64(maxact);
     n->tmp_off = off; off += align64(maxact);
@@ -141,7 +151,7 @@ static void make_plan(fg_net* n, int B) {
 static int build_pack_jobs(fg_net* n);
 static int ensure_packed(fg_net* n);
 
-static int backward_run(fg_net* n) {
+static int backward_run_stages(fg_net* n) {
     fg_ctx* ctx = n->ctx;
     const int B = n->run_B, flags = n->run_flags, stage_to = n->run_to;
     const float* x = n->run_x;
@@ -173,7 +183,9 @@ static int backward_run(fg_net* n) {
                                            &gy6, &gy6_used);
                     if (!rc && s.bias_packed) {  // bias grad in NHWC feature order -> reference order
                         float* tb = scratch + (long long)CR_ROWBLOCKS_MAX * g.Cout;
+                        FgDefer* dsv = ctx->defer; ctx->defer = nullptr;      // `tb` is consumed right away: no deferral
                         rc = fg_launch_colsum(ctx, gcur, (long long)B, g.Cout, 0.f, tb, scratch);
+                        ctx->defer = dsv;
                         if (!rc) rc = fg_launch_nhwc_to_nchw(ctx, tb, Gp + s.b_off, 1, g.o_c, g.o_hw, 1);
                     }
                 }
@@ -594,6 +606,19 @@ int fg_net_params_changed(fg_net* n) {
     if (!n) return FG_ERR_INVALID;
     n->dirty = true;
     return FG_OK;
+}
+
+// backward with the per-layer final reductions batched into one launch per call (also on a sync-BN pause or an error:
+// nothing deferred may survive the return to the caller)
+static int backward_run(fg_net* n) {
+    fg_ctx* ctx = n->ctx;
+    n->defer.arena = n->run_ws + n->defer_off; n->defer.cap = n->defer_floats;
+    n->defer.used = 0; n->defer.n = 0; n->defer.blocks = 0;
+    ctx->defer = &n->defer;
+    const int rc = backward_run_stages(n);
+    const int rf = fg_defer_flush(ctx);
+    ctx->defer = nullptr;
+    return rc ? rc : rf;
 }
 
 static int build_pack_jobs(fg_net* n) {

@@ -4,6 +4,7 @@
 // BCECriterion, fused penalty+clamp+Adam, norms, Philox RNG.
 // Reference semantics: SURVEY.md Appendix A (Torch7 nn modules; call sites models.lua:57-81, 382-416,
 // train.lua:148, interruptable_optimizers.lua:49-94, adversarial.lua:103-123).
+#include <string.h>
 #include "fg_internal.h"
 
 #define FG_GRID(n, bs) dim3((unsigned)((((n) + (bs)-1) / (bs)) < 4096 ? (((n) + (bs)-1) / (bs)) : 4096))
@@ -186,6 +187,53 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
         out[c] = (beta == 0.f) ? (float)t : beta * out[c] + (float)t;
     }
 }
+// ---- deferred finals (see FgDefer): all jobs of a backward pass in one launch; block -> job by a scan over <= 48 entries
+struct FgFinalBatch { FgFinalJob jobs[FG_DEFER_MAX]; int n; };
+__global__ __launch_bounds__(1024) void multi_final_kernel(const FgFinalBatch b) {
+    __shared__ double sh[16][64];
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.jobs[j + 1].blk0) ++j;
+    const FgFinalJob jb = b.jobs[j];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = ((int)blockIdx.x - jb.blk0) * 64 + tx;
+    double s = 0.0;
+    if (c < jb.C)
+        for (int r = ty; r < jb.nrb; r += 16) s += (double)jb.part[(size_t)r * jb.C + c];
+    sh[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < jb.C) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sh[i][tx];
+        jb.out[c] = (jb.beta == 0.f) ? (float)t : jb.beta * jb.out[c] + (float)t;
+    }
+}
+float* fg_defer_alloc(fg_ctx* ctx, long long floats) {
+    FgDefer* d = ctx->defer;
+    if (!d || d->n >= FG_DEFER_MAX) return nullptr;
+    const long long need = (floats + 3) / 4 * 4;
+    if (d->used + need > d->cap) return nullptr;
+    float* p = d->arena + d->used;
+    d->used += need;
+    return p;
+}
+void fg_defer_push(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out) {
+    FgDefer* d = ctx->defer;
+    FgFinalJob& j = d->jobs[d->n++];
+    j.part = part; j.out = out; j.nrb = nrb; j.C = C; j.beta = beta; j.blk0 = d->blocks;
+    d->blocks += fg_cdiv(C, 64);
+}
+int fg_defer_flush(fg_ctx* ctx) {
+    FgDefer* d = ctx->defer;
+    if (!d || d->n == 0) { if (d) { d->used = 0; d->blocks = 0; } return FG_OK; }
+    FgFinalBatch b;
+    memcpy(b.jobs, d->jobs, sizeof(FgFinalJob) * d->n);
+    b.n = d->n;
+    hipLaunchKernelGGL(multi_final_kernel, dim3(d->blocks), dim3(1024), 0, ctx->stream, b);
+    d->n = 0; d->used = 0; d->blocks = 0;
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
 int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out) {
     hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(C, 64)), dim3(1024), 0, ctx->stream, part, nrb, C, beta, out);
     FG_CHECK_LAUNCH(ctx);
@@ -216,6 +264,8 @@ __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restri
 }
 int fg_launch_colsum(fg_ctx* ctx, const float* x, long long M, int N, float beta, float* out, float* scratch) {
     const int nrb = cr_rowblocks(M);
+    float* dpart = fg_defer_alloc(ctx, (long long)nrb * N);        // inside fg_net backward: final batched at the end
+    if (dpart) scratch = dpart;
     if (N <= 4 && N >= 1) {
         switch (N) {
             case 1: hipLaunchKernelGGL(colsum_small_kernel<1>, dim3(nrb), dim3(256), 0, ctx->stream, x, M, scratch); break;
@@ -229,6 +279,7 @@ int fg_launch_colsum(fg_ctx* ctx, const float* x, long long M, int N, float beta
     else
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nrb, fg_cdiv(N, 64)), dim3(256), 0, ctx->stream, x, M, N, scratch);
     FG_CHECK_LAUNCH(ctx);
+    if (dpart) { fg_defer_push(ctx, dpart, nrb, N, beta, out); return FG_OK; }
     hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(N, 64)), dim3(1024), 0, ctx->stream, scratch, nrb, N, beta, out);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
@@ -671,8 +722,11 @@ int fg_launch_prelu_backward(fg_ctx* ctx, const float* x, const float* gy, const
     if (n == 0) return FG_OK;
     dim3 grid = FG_GRID(n, 256);
     if (grid.x > 1024) grid.x = 1024;
+    float* dpart = gslope ? fg_defer_alloc(ctx, grid.x) : nullptr;
+    if (dpart) scratch = dpart;
     hipLaunchKernelGGL(prelu_bwd_kernel, grid, dim3(256), 0, ctx->stream, x, gy, slope, mask, mscale, gx, scratch, n);
     FG_CHECK_LAUNCH(ctx);
+    if (dpart) { fg_defer_push(ctx, dpart, (int)grid.x, 1, acc, gslope); return FG_OK; }
     if (gslope) {
         hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, scratch, (int)grid.x, gslope, acc);
         FG_CHECK_LAUNCH(ctx);
@@ -767,9 +821,12 @@ int fg_launch_actpool_backward(fg_ctx* ctx, const float* x, const float* gy, con
     if (n == 0) return FG_OK;
     dim3 grid = FG_GRID(n, 256);
     if (grid.x > 1024) grid.x = 1024;
+    float* dpart = (slope && gslope) ? fg_defer_alloc(ctx, grid.x) : nullptr;
+    if (dpart) scratch = dpart;
     hipLaunchKernelGGL(actpool_bwd_kernel, grid, dim3(256), 0, ctx->stream, x, gy, slope, mask, mscale, gx, scratch, B,
                        H, W, C);
     FG_CHECK_LAUNCH(ctx);
+    if (dpart) { fg_defer_push(ctx, dpart, (int)grid.x, 1, acc, gslope); return FG_OK; }
     if (slope && gslope) {
         hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, scratch, (int)grid.x, gslope, acc);
         FG_CHECK_LAUNCH(ctx);
