@@ -11,8 +11,14 @@ Philox inside the step, dropout masks drawn on device), reference init N(0,0.005
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  N > 1: weak scaling (B=128 per GPU), RCCL all-reduce (sum) of the flat D / G
-gradient vectors each update, replicas stay identical.
+Prints ONE JSON line on rank 0.  N > 1: weak scaling (B=128 per GPU; --strong: B=128 globally), RCCL all-reduce (sum)
+of the flat D / G gradient vectors each update through the library's own communicator (fg_comm_*), replicas identical.
+
+Roofline keys (dominant kernel, HIP events on the launch stream, live in this run):
+  roofline.achieved / frac      EXECUTED MFMA TFLOP/s of that kernel and its fraction of the fp32 MFMA peak (<= 1)
+  roofline.algorithmic_*        the same time priced with the reference-formulation FLOPs of SURVEY 8(d) (un-folded 5x5
+                                taps; nearest-x2 tap folding executes 9/25 of them, so this can exceed the peak)
+  step_roofline.*               the whole iteration: algorithmic and executed FLOPs over the measured step time
 """
 import argparse
 import json
@@ -27,6 +33,7 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 # algorithmic FLOPs per image for cfg2/3: 7.962 GFLOP/img, 1019.19 GFLOP per B=128 iteration
 MG, MD, G1, D1 = 1052934144, 59703808, 819200, 1769472
+C2F_FLOP_PER_IMAGE = 37.220e9    # configs[3]: 4764.19 GFLOP per B=128 iteration
 
 
 def alg_flops_per_iter(B, d_it=1, g_it=1):
@@ -44,25 +51,173 @@ def parse_prof(text):
     return rows
 
 
-def cpu_baseline(sample_batch=None):
-    """The oracle (numpy restatement of the Torch7 nn CPU path: im2col + sgemm per layer) timed on this host's
-    cores: ONE iteration at batch `sample_batch` of the same nets / inputs / optimizer."""
+def cpu_baselines(workload, batch):
+    """The iteration restated on the host cores, two ways: primary = PyTorch-CPU fp32 (ATen / oneDNN, all
+    cores), secondary = the numpy oracle (im2col + sgemm per layer, the THNN SpatialConvolutionMM algorithm).  The
+    reference's own Lua/Torch `nn` path cannot run here (no Lua) -- both are restatements ("port")."""
     import numpy as np
-    from oracle import torch7_nn as O
-    rng = np.random.default_rng(1)
-    G = O.create_G32((3, 32, 32), 100, rng)
-    D = O.create_D32b((3, 32, 32), rng)
-    O.initialize_weights(G, rng=rng)
-    O.initialize_weights(D, rng=rng)
-    st = O.GanState(G, D)
-    B = sample_batch or (128 if (os.cpu_count() or 1) >= 64 else 32)   # ~10-30 s of CPU work
-    real = rng.uniform(0, 1, (B // 2, 3, 32, 32)).astype(np.float32)
-    t0 = time.time()
-    O.step_D(st, real, rng.uniform(-1, 1, (B // 2, 100)).astype(np.float32))
-    O.step_G(st, rng.uniform(-1, 1, (B, 100)).astype(np.float32))
-    dt = time.time() - t0
-    return dict(value=B / dt, unit="images/sec", cores=os.cpu_count(), kind="port",
-                sample="1 iteration (D-step + G-step) at batch %d, numpy/OpenBLAS oracle, %.1f s" % (B, dt))
+    from oracle import torch_cpu as TC
+    out = {}
+    cores = os.cpu_count() or 1
+    try:
+        Bc = batch if workload == "cfg2" else min(batch, 32)
+        r = TC.time_iterations(workload, Bc, min_seconds=10.0)
+        out["cpu_baseline"] = dict(value=r["images_per_sec"], unit="images/sec", cores=r["threads"], kind="port",
+                                   sample="%d iterations (D-step + G-step) at batch %d in %.1f s after 1 warm-up, PyTorch-CPU fp32 "
+                                          "(oracle/torch_cpu.py: ATen/oneDNN, torch.set_num_threads(%d)); restated CPU baseline -- the "
+                                          "reference's Lua/Torch nn path is not executable in this environment"
+                                          % (r["iters"], Bc, r["seconds"], r["threads"]))
+    except Exception as e:
+        out["cpu_baseline"] = dict(value=None, unit="images/sec", cores=cores, kind="port", sample="failed: %s" % str(e)[:200])
+    if workload == "cfg2":
+        from oracle import torch7_nn as O
+        rng = np.random.default_rng(1)
+        G = O.create_G32((3, 32, 32), 100, rng)
+        D = O.create_D32b((3, 32, 32), rng)
+        O.initialize_weights(G, rng=rng)
+        O.initialize_weights(D, rng=rng)
+        st = O.GanState(G, D)
+        B = 128 if cores >= 64 else 32
+        real = rng.uniform(0, 1, (B // 2, 3, 32, 32)).astype(np.float32)
+        t0 = time.time()
+        O.step_D(st, real, rng.uniform(-1, 1, (B // 2, 100)).astype(np.float32))
+        O.step_G(st, rng.uniform(-1, 1, (B, 100)).astype(np.float32))
+        dt = time.time() - t0
+        out["cpu_baseline_port"] = dict(value=B / dt, unit="images/sec", cores=cores, kind="port",
+                                        sample="1 iteration at batch %d, numpy/OpenBLAS oracle (oracle/torch7_nn.py), %.1f s" % (B, dt))
+    return out
+
+
+def load_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot
+    be collected in-process); newest round first."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        if tj.get("kernel") == kernel:
+            return tj
+    return None
+
+
+def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_iter, out):
+    """Timed region + roofline leg shared by both workloads.  Fills `out` in place."""
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(v):
+        if world > 1:
+            t = torch.tensor([v], dtype=torch.float64, device=ctx.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return v
+
+    for _ in range(args.warmup):
+        iteration()
+    tr.finish_pending()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        iteration()
+    tr.finish_pending()          # N > 1: the last D update is deferred behind the next G forward -- complete it in-region
+    t_enq = time.perf_counter() - t0
+    sync_all()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    ms = 1000.0 * dt / args.steps
+    out.update(value=world * B * args.steps / dt, ms_per_step=ms)
+    # host cost of a step: wall time until the loop has ENQUEUED all K steps (no sync inside).  When the host runs ahead
+    # of the GPU this is the pure enqueue cost; when the launch queue back-pressures it approaches ms_per_step.
+    out["host_enqueue_ms_per_step"] = 1000.0 * max_over_ranks(t_enq) / args.steps
+    out["step_roofline"] = {"algorithmic_gflop_per_iter": flops_per_iter / 1e9,
+                            "algorithmic_tflops_per_gpu": flops_per_iter / (ms * 1e-3) / 1e12,
+                            "algorithmic_frac_of_f32_mfma_peak": flops_per_iter / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+
+    alt = None
+    if args.math == "f32" and not args.no_alt_math:
+        # supplementary, never the headline: the same K steps with the large contractions in bf16x6 (fp32 emulated with
+        # six exact split-bf16 plane products, include/facegen_hip.h fg_set_math); every rank runs it (collectives)
+        try:
+            ctx.set_math(6)
+            for _ in range(min(args.warmup, 4)):
+                iteration()
+            tr.finish_pending()
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                iteration()
+            tr.finish_pending()
+            sync_all()
+            dt6 = max_over_ranks(time.perf_counter() - t1)
+            alt = {"math": "bf16x6 (fp32 emulated: 6 exact bf16 split-plane products, fp32 accumulate; fg_set_math(ctx, 6))",
+                   "value": world * B * args.steps / dt6, "unit": "images/sec", "ms_per_step": 1000.0 * dt6 / args.steps,
+                   "note": "opt-in mode, parity-tested at the same tolerances (FG_MATH=6 pytest -m gpu); not the headline value"}
+        except Exception as e:      # supplementary only: never let it take the headline measurement down
+            alt = {"math": "bf16x6", "error": str(e)[:200]}
+        finally:
+            ctx.set_math(0)
+
+    if not args.no_roofline:
+        # every rank runs the extra iterations (they contain collectives); only rank 0 records HIP events
+        import ctypes
+        if rank == 0:
+            ctx.check(ctx.lib.fg_prof_enable(ctx.h, 1))
+        for _ in range(args.prof_iters):
+            iteration()
+        tr.finish_pending()
+        sync_all()
+    if rank == 0 and not args.no_roofline:
+        buf = ctypes.create_string_buffer(1 << 16)
+        ctx.check(ctx.lib.fg_prof_report(ctx.h, buf, len(buf), 1))
+        ctx.check(ctx.lib.fg_prof_enable(ctx.h, 0))
+        rows = parse_prof(buf.value.decode())
+        sym = {}                                   # aggregate by kernel symbol (what rocprofv3 --stats reports)
+        for name, r in rows.items():
+            k = name.split("/")[0]
+            a = sym.setdefault(k, dict(calls=0, ms=0.0, alg=0.0, exe=0.0))
+            for f in ("calls", "ms", "alg", "exe"):
+                a[f] += r[f]
+        if sym:
+            exe_iter = sum(v["exe"] for v in sym.values()) / args.prof_iters
+            mfma_ms_iter = sum(v["ms"] for v in sym.values() if v["exe"] > 0) / args.prof_iters
+            out["step_roofline"].update({
+                "executed_gflop_per_iter": exe_iter / 1e9,
+                "executed_tflops_per_gpu": exe_iter / (ms * 1e-3) / 1e12,
+                "executed_frac": exe_iter / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "contraction_kernel_ms_per_iter": mfma_ms_iter,
+                "note": "executed = MFMA FLOPs the contraction kernels issue (igemm / wgrad launches; the 3-channel thin "
+                        "convolutions and the 512->1 head, < 1 % of the FLOPs, are not counted)"})
+            dom = max(sym, key=lambda k: sym[k]["ms"])
+            a = sym[dom]
+            alg = a["alg"] / (a["ms"] * 1e-3) / 1e12
+            exe = a["exe"] / (a["ms"] * 1e-3) / 1e12
+            tj = load_traffic(dom) if args.workload == "cfg2" else None
+            out["roofline"] = {"bound": "mfma", "achieved": exe, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": exe / PEAK_F32_MFMA_TFLOPS,
+                               "traffic": tj["hbm_bytes_per_launch"] if tj else None,
+                               "algorithmic_bytes": tj.get("algorithmic_bytes_per_launch") if tj else None,
+                               "traffic_over_algorithmic": (tj["hbm_bytes_per_launch"] / tj["algorithmic_bytes_per_launch"])
+                               if tj and tj.get("algorithmic_bytes_per_launch") else None,
+                               "traffic_note": (tj["launch"] + "; " + tj["source"]) if tj else None,
+                               "kernel": dom, "avg_launch_ms": a["ms"] / a["calls"],
+                               "launches_per_iter": a["calls"] / args.prof_iters,
+                               "algorithmic_tflops": alg, "algorithmic_frac": alg / PEAK_F32_MFMA_TFLOPS,
+                               "note": "achieved / frac = MFMA FLOPs this kernel executes / its HIP-event time (all its launches "
+                                       "of the iteration); algorithmic_* prices the same time with the reference-formulation "
+                                       "(un-folded 5x5) FLOPs of SURVEY 8(d)"}
+            if "ws6" in dom:      # bf16x6 kernels issue 6 bf16 MFMA flops per fp32-equivalent flop: price against the bf16 pipe too
+                out["roofline"].update({"bf16_issued_tflops": 6.0 * exe, "bf16_dense_peak": PEAK_BF16_MFMA_TFLOPS,
+                                        "bf16_issued_frac": 6.0 * exe / PEAK_BF16_MFMA_TFLOPS})
+            out["kernels"] = {k: {"calls_per_iter": v["calls"] / args.prof_iters, "ms_per_iter": v["ms"] / args.prof_iters,
+                                  "executed_tflops": v["exe"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0}
+                              for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])}
+    if alt is not None:
+        out["alt_math"] = alt
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out.update(cpu_baselines(args.workload, B))
 
 
 def main():
@@ -70,7 +225,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (OPT.batchSize)")
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (OPT.batchSize); with --strong the GLOBAL batch")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --batch is the global batch, split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prof-iters", type=int, default=3)
@@ -80,6 +236,9 @@ def main():
                     help="arithmetic of the large conv contractions: f32 = native fp32 MFMA (default, the headline); "
                          "bf16x6 = fp32 emulated on the bf16 matrix pipe with six exact split-plane products (fg_set_math)")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the supplementary bf16x6 timing")
+    ap.add_argument("--collective", choices=["auto", "fg_comm", "torch"], default="auto",
+                    help="N > 1: gradient all-reduce through the library's own RCCL communicator (fg_comm_*, default) or "
+                         "torch.distributed; auto = fg_comm, falling back (and saying so) if its self-test fails")
     ap.add_argument("--workload", choices=["cfg2", "c2f"], default="cfg2",
                     help="cfg2: 32x32 G32+D32b (BASELINE configs[1], the headline); c2f: 64x64 coarse-to-fine (configs[3])")
     args = ap.parse_args()
@@ -106,207 +265,87 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from face_generator_amd import models, nn_utils, adversarial
+    from face_generator_amd import models, nn_utils, adversarial, distributed
     from face_generator_amd.runtime import get_context
     from face_generator_amd.state import S
 
     ctx = get_context(local_rank)
     ctx.set_math(6 if args.math == "bf16x6" else 0)
-    B = args.batch
+    if args.strong:
+        if args.batch % (2 * world):
+            raise SystemExit("--strong: the global batch %d must split into even per-GPU batches over %d ranks" % (args.batch, world))
+        B = args.batch // world
+    else:
+        B = args.batch
+    coll = None
+    if world > 1:
+        coll = distributed.make_collective(ctx, dist, prefer="torch" if (test_gloo or args.collective == "torch") else "fg_comm",
+                                           strict=args.collective == "fg_comm")
+    out = {
+        "metric": "GAN train images/sec (G+D step) at 32x32x3 bs128" if args.workload == "cfg2"
+                  else "GAN train images/sec (G+D step), c2f 64x64x3 bs128",
+        "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+        "dtype": "f32" if args.math == "f32" else "f32 (emulated: 6 exact bf16 split-plane products, fp32 accumulate)",
+    }
+    if world > 1:
+        out["collective"] = coll.describe()
     C = 3
     if args.workload == "c2f":
-        return main_c2f(args, ctx, dist, world, rank, torch)
-    gen = torch.Generator().manual_seed(1)              # identical initial replicas on every rank
-    G = models.create_G((C, 32, 32), 100)
-    D = models.create_D((C, 32, 32))
-    nn_utils.initializeWeights(D, gen=gen)
-    nn_utils.initializeWeights(G, gen=gen)
-    G.cuda(ctx, max_batch=B)
-    D.cuda(ctx, max_batch=B)
-    S.OPT.update(batchSize=B, noiseDim=100)
-    S.noise_seed = 1 + rank                             # each rank draws its own shard of the global batch
-    G.device_net.mask_seed = D.device_net.mask_seed = 1000 + rank
-    S.OPT["sync_bn"] = bool(args.sync_bn)
-    tr = adversarial.Trainer(ctx, G, D, S.OPT, dist=dist if world > 1 else None)
-    real = ctx.uniform((B // 2, 32, 32, C), 0.0, 1.0, seed=77 + rank)
+        from face_generator_amd import models_c2f, adversarial_c2f
+        Sz = 64
+        gen = torch.Generator().manual_seed(1)
+        G = models_c2f.create_G((3, Sz, Sz), gen=gen).cuda(ctx, max_batch=B)
+        D = models_c2f.create_D((3, Sz, Sz), gen=gen).cuda(ctx, max_batch=B)
+        S.noise_seed = 1 + rank
+        G.inner.device_net.mask_seed = D.inner.device_net.mask_seed = 1000 + rank
+        tr = adversarial_c2f.TrainerC2F(ctx, G, D, dict(batchSize=B), dist=coll)
+        fine = ctx.uniform((B, Sz, Sz, 3), 0.0, 1.0, seed=70 + rank)
+        coarse = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(fine.permute(0, 3, 1, 2), 2), scale_factor=2)
+        coarse = coarse.permute(0, 2, 3, 1).contiguous()          # synthetic-input preparation (dataset_c2f.lua:49-61)
+        diff = (fine - coarse).contiguous()
+        h = B // 2
+        diff_r, coarse_r, coarse_f = diff[:h].contiguous(), coarse[:h].contiguous(), coarse[h:].contiguous()
 
-    def iteration():
-        tr.step_D(real, S.next_noise(ctx, B // 2, 100))
-        tr.step_G(S.next_noise(ctx, B, 100))
+        def iteration():
+            tr.step_D(diff_r, coarse_r, S.next_noise(ctx, h, Sz * Sz).view(h, Sz, Sz, 1), coarse_f)
+            tr.step_G(S.next_noise(ctx, B, Sz * Sz).view(B, Sz, Sz, 1), coarse)
+        out["data"] = "synthetic (U[0,1) fine images, coarse = 2x box down / nearest up, diff = fine - coarse, U(-1,1) noise planes)"
+        out["config"] = {"workload": "configs[3]: 64x64 color coarse-to-fine G_d/D_c, batch 128 per GPU, Adam, D_it=G_it=1",
+                         "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world}
+        flops = C2F_FLOP_PER_IMAGE * B
+    else:
+        gen = torch.Generator().manual_seed(1)              # identical initial replicas on every rank
+        G = models.create_G((C, 32, 32), 100)
+        D = models.create_D((C, 32, 32))
+        nn_utils.initializeWeights(D, gen=gen)
+        nn_utils.initializeWeights(G, gen=gen)
+        G.cuda(ctx, max_batch=B)
+        D.cuda(ctx, max_batch=B)
+        S.OPT.update(batchSize=B, noiseDim=100)
+        S.noise_seed = 1 + rank                             # each rank draws its own shard of the global batch
+        G.device_net.mask_seed = D.device_net.mask_seed = 1000 + rank
+        S.OPT["sync_bn"] = bool(args.sync_bn)
+        tr = adversarial.Trainer(ctx, G, D, S.OPT, dist=coll)
+        real = ctx.uniform((B // 2, 32, 32, C), 0.0, 1.0, seed=77 + rank)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        def iteration():
+            tr.step_D(real, S.next_noise(ctx, B // 2, 100))
+            tr.step_G(S.next_noise(ctx, B, 100))
+        out["data"] = "synthetic (U[0,1) images, U(-1,1) noise, reference init N(0,.005^2)/N(0,.001^2))"
+        out["config"] = {"workload": "configs[1]: 32x32 color, noiseDim=100, batch 128 per GPU, Adam, D_it=G_it=1"
+                                     + ("" if world == 1 else "; configs[2]-style %s scaling, RCCL grad all-reduce"
+                                        % ("strong" if args.strong else "weak")),
+                         "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
+                         "batchnorm": "sync (global-batch statistics)" if (args.sync_bn and world > 1) else "per-GPU statistics"}
+        flops = alg_flops_per_iter(B)
 
-    for _ in range(args.warmup):
-        iteration()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        iteration()
-    tr.finish_pending()          # N > 1: the last D update is deferred behind the next G forward -- complete it in-region
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms = 1000.0 * dt / args.steps
-    value = world * B * args.steps / dt
-
-    alt = None
-    if args.math == "f32" and not args.no_alt_math:
-        # supplementary, never the headline: the same K steps with the large contractions in bf16x6 (fp32 emulated with
-        # six exact split-bf16 plane products, include/facegen_hip.h fg_set_math); every rank runs it (collectives)
-        try:
-            ctx.set_math(6)
-            for _ in range(min(args.warmup, 4)):
-                iteration()
-            sync_all()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                iteration()
-            tr.finish_pending()
-            sync_all()
-            dt6 = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([dt6], dtype=torch.float64, device=ctx.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt6 = float(t.item())
-            alt = {"math": "bf16x6 (fp32 emulated: 6 exact bf16 split-plane products, fp32 accumulate; fg_set_math(ctx, 6))",
-                   "value": world * B * args.steps / dt6, "unit": "images/sec", "ms_per_step": 1000.0 * dt6 / args.steps,
-                   "note": "opt-in mode, parity-tested at the same tolerances (FG_MATH=6 pytest -m gpu); not the headline value"}
-        except Exception as e:      # supplementary only: never let it take the headline measurement down
-            alt = {"math": "bf16x6", "error": str(e)[:200]}
-        finally:
-            ctx.set_math(0)
-
-    out = {
-        "metric": "GAN train images/sec (G+D step) at 32x32x3 bs128",
-        "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.math == "f32" else "f32 (emulated: 6 exact bf16 split-plane products, fp32 accumulate)",
-        "data": "synthetic (U[0,1) images, U(-1,1) noise, reference init N(0,.005^2)/N(0,.001^2))",
-        "config": {"workload": "configs[1]: 32x32 color, noiseDim=100, batch 128 per GPU, Adam, D_it=G_it=1"
-                               + ("" if world == 1 else "; configs[2]-style weak scaling, RCCL grad all-reduce"),
-                   "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
-                   "batchnorm": "sync (global-batch statistics)" if (args.sync_bn and world > 1) else "per-GPU statistics"},
-        "reference_accounting_images_per_sec": value / 2,   # adversarial.lua:305 counts B/2 per iteration
-    }
-    flops = alg_flops_per_iter(B)
-    out["step_roofline"] = {"algorithmic_gflop_per_iter": flops / 1e9, "achieved_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
-                            "frac_of_f32_mfma_peak": flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
-
-    if not args.no_roofline:
-        # every rank runs the extra iterations (they contain collectives); only rank 0 records HIP events
-        import ctypes
-        if rank == 0:
-            ctx.check(ctx.lib.fg_prof_enable(ctx.h, 1))
-        for _ in range(args.prof_iters):
-            iteration()
-        tr.finish_pending()
-        sync_all()
-    if rank == 0 and not args.no_roofline:
-        buf = ctypes.create_string_buffer(1 << 16)
-        ctx.check(ctx.lib.fg_prof_report(ctx.h, buf, len(buf), 1))
-        ctx.check(ctx.lib.fg_prof_enable(ctx.h, 0))
-        rows = parse_prof(buf.value.decode())
-        # aggregate by kernel symbol (what rocprofv3 --stats reports)
-        sym = {}
-        for name, r in rows.items():
-            k = name.split("/")[0]
-            a = sym.setdefault(k, dict(calls=0, ms=0.0, alg=0.0, exe=0.0))
-            for f in ("calls", "ms", "alg", "exe"):
-                a[f] += r[f]
-        if sym:
-            dom = max(sym, key=lambda k: sym[k]["ms"])
-            a = sym[dom]
-            ach = a["alg"] / (a["ms"] * 1e-3) / 1e12
-            exe = a["exe"] / (a["ms"] * 1e-3) / 1e12
-            traffic, tnote = None, None
-            try:   # HBM bytes per launch from the committed rocprofv3 PMC passes (cannot be collected in-process)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-                if tj["kernel"] == dom:
-                    traffic, tnote = tj["hbm_bytes_per_launch"], tj["launch"] + "; " + tj["source"]
-            except Exception:
-                pass
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": tnote, "kernel": dom,
-                               "avg_launch_ms": a["ms"] / a["calls"], "launches_per_iter": a["calls"] / args.prof_iters,
-                               "executed_tflops": exe, "executed_frac": exe / PEAK_F32_MFMA_TFLOPS,
-                               "note": "achieved = reference-formulation (un-folded 5x5) conv FLOPs / kernel time; "
-                                       "executed = MFMA FLOPs actually issued (nearest-x2 tap folding: 9/25 of the taps)"}
-            if "ws6" in dom:      # bf16x6 kernels issue 6 bf16 MFMA flops per fp32-equivalent flop: price against the bf16 pipe too
-                out["roofline"].update({"bf16_issued_tflops": 6.0 * exe, "bf16_dense_peak": PEAK_BF16_MFMA_TFLOPS,
-                                        "bf16_issued_frac": 6.0 * exe / PEAK_BF16_MFMA_TFLOPS})
-            out["kernels"] = {k: {"calls_per_iter": v["calls"] / args.prof_iters, "ms_per_iter": v["ms"] / args.prof_iters,
-                                  "executed_tflops": v["exe"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0}
-                              for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])}
-    if alt is not None:
-        out["alt_math"] = alt
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+    measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops, out)
+    out["reference_accounting_images_per_sec"] = out["value"] / 2   # adversarial.lua:305 counts B/2 per iteration
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
-
-
-def main_c2f(args, ctx, dist, world, rank, torch):
-    """BASELINE configs[3]: 64x64 colour coarse-to-fine (models_c2f.lua G_d / D_c, adversarial_c2f.lua), B=128/GPU.
-    Algorithmic FLOPs: 37.220 GFLOP/img, 4764.19 GFLOP per B=128 iteration (D_it = G_it = 1)."""
-    from face_generator_amd import models_c2f, adversarial_c2f
-    from face_generator_amd.state import S
-    B, Sz = args.batch, 64
-    gen = torch.Generator().manual_seed(1)
-    G = models_c2f.create_G((3, Sz, Sz), gen=gen).cuda(ctx, max_batch=B)
-    D = models_c2f.create_D((3, Sz, Sz), gen=gen).cuda(ctx, max_batch=B)
-    S.noise_seed = 1 + rank
-    G.inner.device_net.mask_seed = D.inner.device_net.mask_seed = 1000 + rank
-    tr = adversarial_c2f.TrainerC2F(ctx, G, D, dict(batchSize=B), dist=dist if world > 1 else None)
-    fine = ctx.uniform((B, Sz, Sz, 3), 0.0, 1.0, seed=70 + rank)
-    coarse = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(fine.permute(0, 3, 1, 2), 2), scale_factor=2)
-    coarse = coarse.permute(0, 2, 3, 1).contiguous()          # synthetic-input preparation (dataset_c2f.lua:49-61)
-    diff = (fine - coarse).contiguous()
-    h = B // 2
-
-    def iteration():
-        tr.step_D(diff[:h], coarse[:h], S.next_noise(ctx, h, Sz * Sz).view(h, Sz, Sz, 1), coarse[h:])
-        tr.step_G(S.next_noise(ctx, B, Sz * Sz).view(B, Sz, Sz, 1), coarse)
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        iteration()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        iteration()
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms = 1000.0 * dt / args.steps
-    flops = 37.220e9 * B
-    out = {"metric": "GAN train images/sec (G+D step), c2f 64x64x3 bs128", "value": world * B * args.steps / dt,
-           "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.math == "f32" else "f32 (emulated: 6 exact bf16 split-plane products, fp32 accumulate)", "data": "synthetic",
-           "config": {"workload": "configs[3]: 64x64 color coarse-to-fine G_d/D_c, batch 128 per GPU, Adam",
-                      "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world},
-           "step_roofline": {"algorithmic_gflop_per_iter": flops / 1e9,
-                             "achieved_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
-                             "frac_of_f32_mfma_peak": flops / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
-    if world > 1:
-        dist.barrier()
+        if coll is not None:
+            coll.close()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))

@@ -29,12 +29,12 @@ class LayerSpec(ctypes.Structure):
 _CTYPES = [
     (r"^const fg_layer_spec\*$", ctypes.POINTER(LayerSpec)),
     (r"^const float\* const\*$", ctypes.POINTER(ctypes.c_void_p)),
-    (r"^(fg_ctx|fg_net|void)\*\*$", ctypes.POINTER(ctypes.c_void_p)),
+    (r"^(fg_ctx|fg_net|fg_comm|fg_gan|void)\*\*$", ctypes.POINTER(ctypes.c_void_p)),
     (r"^const char\*$", ctypes.c_char_p),
     (r"^char\*$", ctypes.c_char_p),
     (r"^long long\*$", ctypes.POINTER(ctypes.c_longlong)),
     (r"^(const )?double\*$", ctypes.c_void_p),
-    (r"^(const )?(fg_ctx|fg_net|void|float|int)\*$", ctypes.c_void_p),
+    (r"^(const )?(fg_ctx|fg_net|fg_comm|fg_gan|void|float|int)\*$", ctypes.c_void_p),
     (r"^int$", ctypes.c_int),
     (r"^long long$", ctypes.c_longlong),
     (r"^size_t$", ctypes.c_size_t),

@@ -29,16 +29,27 @@ class Trainer:
                         G_optmethod="adam")
         self.opt.update(opt)
         self.crit = BCECriterion()
-        self.optstate = dict(adam=dict(D={}, G={}), sgd=dict(D={}, G={}), adagrad=dict(D={}, G={}))
-        self.dist = dist          # torch.distributed module (initialised) or None
-        self.world = dist.get_world_size() if dist is not None else 1
+        # OPTSTATE of train.lua:180-191: SGD takes its learning rate / momentum from --{D,G}_SGD_lr / _SGD_momentum
+        # (defaults 0.02 / 0, train.lua:21-24), Adam an explicit learning rate only when --{D,G}_adam_lr ~= -1
+        o = self.opt
+        self.optstate = dict(adagrad=dict(D={}, G={}), adam=dict(D={}, G={}), rmsprop=dict(D={}, G={}),
+                             sgd=dict(D=dict(learningRate=o.get("D_SGD_lr", 0.02), momentum=o.get("D_SGD_momentum", 0)),
+                                      G=dict(learningRate=o.get("G_SGD_lr", 0.02), momentum=o.get("G_SGD_momentum", 0))))
+        for w in ("D", "G"):
+            if o.get(w + "_adam_lr", -1) != -1:
+                self.optstate["adam"][w]["learningRate"] = o[w + "_adam_lr"]
+        # the exchange carrier: None, a distributed.Collective (fg_comm_* of the library, or torch.distributed), or the
+        # initialised torch.distributed module itself (wrapped)
+        from .distributed import as_collective
+        self.dist = self.coll = as_collective(dist)
+        self.world = self.coll.get_world_size() if self.coll is not None else 1
         self.gscale = 1.0 / self.world   # BCE averages over the local batch: global mean = all-reduced sum / world
         self._targets = {}
         self._inputs = {}
-        if dist is not None and self.world > 1 and self.opt.get("sync_bn", False):
+        if self.coll is not None and self.world > 1 and self.opt.get("sync_bn", False):
             # exact B_global BatchNorm statistics: fp64 per-channel sums all-reduced at every BatchNorm
-            self.dnG.enable_sync_bn(lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
-        self._pending_D = None    # (async all-reduce handle, loss) of a D update deferred behind the next G forward
+            self.dnG.enable_sync_bn(self.coll.allreduce_sum_)
+        self._pending_D = None    # loss of a D update deferred behind the next G forward (its all-reduce is in flight)
         self.overlap = True       # N > 1: hide D's gradient all-reduce under the G-step's generator forward
 
     # -- helpers -----------------------------------------------------------------------------
@@ -61,8 +72,7 @@ class Trainer:
 
     def _allreduce(self, grads):
         if self.world > 1:
-            from .distributed import allreduce_sum_
-            allreduce_sum_(grads)
+            self.coll.allreduce_sum_(grads)
 
     def _update(self, which, params, grads, f):
         o = self.opt
@@ -117,6 +127,10 @@ class Trainer:
             res["f"] = loss.item() + self.penalty_f("D", pD)
         do_train = True
         if gate is not None:
+            if self.world > 1:
+                # every rank must take the same branch (a skipped update skips its all-reduce too): the gate is decided
+                # on the GLOBAL batch's confusion counts, so all replicas keep one identical `accs` history
+                conf = self.coll.allreduce_sum_(conf.clone())
             c = conf.tolist()
             acc = (c[0] + c[3]) / max(1, sum(c))     # [pred0,t0] + [pred1,t1]
             do_train = gate(acc)
@@ -124,8 +138,8 @@ class Trainer:
             if self.world > 1 and self.overlap:
                 # xGMI all-reduce of the 11.45 MB D gradient runs on RCCL's stream while the G-step's generator
                 # forward (no dependency on D's parameters) computes; the update lands before D is next used.
-                work = self.dist.all_reduce(gD, op=self.dist.ReduceOp.SUM, async_op=True)
-                self._pending_D = (work, loss)
+                self.coll.allreduce_sum_async_(gD)
+                self._pending_D = (loss,)
             else:
                 self._allreduce(gD)
                 self._update("D", pD, gD, loss)
@@ -136,9 +150,9 @@ class Trainer:
     def finish_pending(self):
         """Complete a deferred D update (wait for its all-reduce, fused Adam, re-pack)."""
         if self._pending_D is not None:
-            work, loss = self._pending_D
+            (loss,) = self._pending_D
             self._pending_D = None
-            work.wait()
+            self.coll.wait()
             self._update("D", self.dnD.params, self.dnD.grads, loss)
             self.dnD.params_changed()
 
@@ -152,14 +166,15 @@ class Trainer:
         loss, dprob, _ = self.crit.forward_backward_device(self.ctx, out.reshape(-1), targets, want_confusion=False)
         df_do = self.dnD.backward(dprob.view(B, 1), param_grads=False, input_grad=True)   # MODEL_D.modules[1].gradInput
         pG, gG = self.dnG.params, self.dnG.grads
-        works = []
+        bucketed = False
         if self.world > 1 and self.overlap and not keep_grad:
             # bucketed all-reduce overlapped with backward: G's gradients are produced output -> input; each finished
             # ~1 M-parameter range of the flat vector goes onto RCCL's stream while the earlier layers still compute
             for (s_from, s_to, lo, hi) in self._buckets_G():
                 self.dnG.backward_range(df_do if s_from == self._last_stage_G else None, s_from, s_to)
                 if hi > lo:
-                    works.append(self.dist.all_reduce(gG[lo:hi], op=self.dist.ReduceOp.SUM, async_op=True))
+                    self.coll.allreduce_sum_async_(gG[lo:hi])
+            bucketed = True
         else:
             self.dnG.backward(df_do, param_grads=True, input_grad=False)
         res = dict(loss=loss, outputs=out, samples=samples)
@@ -172,9 +187,8 @@ class Trainer:
                 g.clamp_(-o["G_clamp"], o["G_clamp"])
             res["grad"] = g
             res["f"] = loss.item() + self.penalty_f("G", pG)
-        if works:
-            for w in works:
-                w.wait()
+        if bucketed:
+            self.coll.wait()
         else:
             self._allreduce(gG)
         self._update("G", pG, gG, loss)
@@ -238,6 +252,8 @@ def train(dataset, maxAccuracyD=1.01, accsInterval=20):
         if thisBatchSize < 4:
             print("[INFO] skipping batch at t=%d, because its size is less than 4" % t)
             break
+        # odd thisBatchSize (odd N_epoch): Lua's `for i = 1, thisBatchSize / 2` fills floor(thisBatchSize / 2) real + as many
+        # fake rows and leaves the last row of inputs / targets uninitialised; that garbage row is dropped here (C9)
         thisBatchSize -= thisBatchSize % 2
         half = thisBatchSize // 2
         for _ in range(OPT.get("D_iterations", 1)):
@@ -255,7 +271,14 @@ def train(dataset, maxAccuracyD=1.01, accsInterval=20):
             nz = S.next_noise(ctx, thisBatchSize, OPT["noiseDim"])
             tr.step_G(nz)
     for c in pending:                      # deferred: one host read at the end of the epoch
-        conf_total += c.cpu().to(torch.int64)
+        ch = c.cpu().to(torch.int64)
+        conf_total += ch
+        if not use_gate:                   # adversarial.accs (:156-159) is kept even when the gate can never fire
+            cl = ch.tolist()
+            accs.append((cl[0] + cl[3]) / max(1, sum(cl)))
+            if len(accs) > accsInterval:
+                accs.pop(0)
+    tr.finish_pending()
     dt = time.time() - t0
     print("<trainer> time required for this epoch = %d s" % dt)
     print("<trainer> time to learn 1 sample = %f ms" % (1000 * dt / N_epoch))

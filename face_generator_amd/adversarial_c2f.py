@@ -120,6 +120,12 @@ def train(trainData):
     cl = conf_total.tolist()
     tV = (cl[0] + cl[3]) / max(1, sum(cl))
     print("Confusion of D: [pred][target] = %s  totalValid = %.4f" % (cl, tV))
+    S.CONFUSION = cl
+    if S.EPOCH % OPT.get("saveFreq", 30) == 0:          # adversarial_c2f.lua:206-217
+        from . import nn_utils
+        import os
+        nn_utils.save_checkpoint(os.path.join(OPT.get("save", "logs"), "adversarial_c2f_%d_to_%d.net"
+                                              % (OPT.get("coarseSize", h // 2), OPT.get("fineSize", h))))
     S.EPOCH += 1
     return tV
 
@@ -136,17 +142,18 @@ def approxParzen(ds, nsamples, nneighbors):
     from .runtime import get_context
     ctx = get_context()
     c, h, w = S.IMG_DIMENSIONS
-    distances = torch.empty(nsamples)
+    dist_dev, min_dev = ctx.empty(nneighbors), ctx.empty(nsamples)
     G = S.MODEL_G
     for n in range(nsamples):
         example = ds[S.rng.randrange(ds.size())]
         cond = ctx.to_device_nhwc(torch.as_tensor(example.coarse, dtype=torch.float32).unsqueeze(0).repeat(nneighbors, 1, 1, 1))
         noise = S.next_noise(ctx, nneighbors, h * w).view(nneighbors, h, w, 1)
         neighbors = G.inner.device_net.forward(G.combine_device(ctx, noise, cond), train=G.inner.train)
-        full = ctx.to_nchw(neighbors).add_(ctx.to_nchw(cond))                 # neighbors:add(condInputs)
-        fine = torch.as_tensor(example.fine, dtype=torch.float32).to(ctx.device)
-        d = (full - fine.unsqueeze(0)).flatten(1).norm(dim=1)                   # torch.dist(neighbors[i], fine)
-        distances[n] = float(d.min())
+        fine = ctx.to_device_nhwc(torch.as_tensor(example.fine, dtype=torch.float32).unsqueeze(0))
+        # neighbors:add(condInputs); min_i torch.dist(neighbors[i], fine)  (:322-329) -- one reduction kernel, NHWC throughout
+        ctx.check(ctx.lib.fg_parzen_min_dist(ctx.h, neighbors.data_ptr(), cond.data_ptr(), fine.data_ptr(), nneighbors,
+                                             c * h * w, dist_dev.data_ptr(), min_dev[n:].data_ptr()))
+    distances = min_dev.cpu()
     mean = float(distances.mean())
     print("average || x_%s - G(x_%s) || = %f" % (S.OPT.get("fineSize", h), S.OPT.get("coarseSize", h // 2), mean))
     if mean < best_dist:

@@ -1,8 +1,16 @@
-"""Data-parallel exchange step of the GAN update: one process per GPU, the flat gradient vector
-of the net being updated is all-reduced (sum) with torch.distributed -- backend "nccl" is RCCL over xGMI on the
-GPU box, "gloo" in the CPU tests -- and averaged by the 1/world factor folded into the fused optimizer pass.
-The reference has no multi-GPU path (single process, cutorch.setDevice, train.lua:79); this is new functionality
-required by BASELINE configs 3 and 5."""
+"""Data-parallel exchange step of the GAN update: one process per GPU, the flat gradient vector of the
+net being updated is sum-all-reduced over xGMI and averaged by the 1/world factor folded into the fused optimizer pass.
+The reference has no multi-GPU path (single process, cutorch.setDevice, train.lua:79); this is new functionality required
+by BASELINE configs 3 and 5.
+
+Two carriers behind one small interface (`Collective`):
+  * FgCollective   -- the library's own RCCL communicator behind the C ABI (fg_comm_create / fg_allreduce_sum[_async] /
+                      fg_comm_wait, include/facegen_hip.h).  This is the path a Lua host uses too; only the 128-byte
+                      bootstrap id travels through the host's own channel (here: a torch.distributed broadcast).
+  * TorchCollective -- torch.distributed ("nccl" == RCCL on the GPU box, "gloo" in the CPU tests and in the two-process
+                      one-GPU tests, where RCCL refuses two ranks on one device).
+"""
+import ctypes
 import os
 
 import torch
@@ -24,8 +32,169 @@ def init(backend=None):
     return dist.get_rank(), dist.get_world_size()
 
 
+class Collective:
+    """What the trainers need from a carrier.  All calls are in place and ordered on the context's stream."""
+    name = "none"
+    world, rank = 1, 0
+
+    def get_world_size(self):
+        return self.world
+
+    def get_rank(self):
+        return self.rank
+
+    def allreduce_sum_(self, t):
+        """Blocking (stream-ordered) sum of `t` (fp32 / fp64 / int32) across ranks."""
+        return t
+
+    def allreduce_sum_async_(self, t):
+        """Start the sum of fp32 `t` off the critical path; `wait()` orders every later launch after it."""
+        return self.allreduce_sum_(t)
+
+    def wait(self):
+        pass
+
+    def broadcast_(self, t, src=0):
+        return t
+
+    def describe(self):
+        return self.name
+
+    def close(self):
+        pass
+
+
+class TorchCollective(Collective):
+    def __init__(self, d=dist):
+        self.d = d
+        self.world, self.rank = d.get_world_size(), d.get_rank()
+        self.name = "torch.distributed (%s)" % d.get_backend()
+        self._works = []
+
+    def allreduce_sum_(self, t):
+        if self.world > 1:
+            self.d.all_reduce(t, op=self.d.ReduceOp.SUM)
+        return t
+
+    def allreduce_sum_async_(self, t):
+        if self.world > 1:
+            self._works.append(self.d.all_reduce(t, op=self.d.ReduceOp.SUM, async_op=True))
+        return t
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def broadcast_(self, t, src=0):
+        if self.world > 1:
+            self.d.broadcast(t, src)
+        return t
+
+
+class FgCollective(Collective):
+    """fg_comm_* of libfacegen_hip.so: RCCL bound by the library itself, exchange on the communicator's own stream."""
+
+    def __init__(self, ctx, rank, world, id_bytes):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.world, self.rank = world, rank
+        h = ctypes.c_void_p()
+        ctx.check(self.lib.fg_comm_create(ctx.h, id_bytes, len(id_bytes), rank, world, ctypes.byref(h)))
+        self.h = h
+        self.name = "fg_comm (RCCL via the C ABI: %s)" % self.lib.fg_comm_library().decode()
+
+    @staticmethod
+    def unique_id(ctx):
+        buf = ctypes.create_string_buffer(128)
+        ctx.check(ctx.lib.fg_comm_unique_id(ctx.h, buf, 128))
+        return buf.raw
+
+    def allreduce_sum_(self, t):
+        fn = {torch.float32: self.lib.fg_allreduce_sum, torch.float64: self.lib.fg_allreduce_sum_f64,
+              torch.int32: self.lib.fg_allreduce_sum_i32}[t.dtype]
+        assert t.is_contiguous()
+        self.ctx.check(fn(self.h, t.data_ptr(), t.numel()))
+        return t
+
+    def allreduce_sum_async_(self, t):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self.ctx.check(self.lib.fg_allreduce_sum_async(self.h, t.data_ptr(), t.numel()))
+        return t
+
+    def wait(self):
+        self.ctx.check(self.lib.fg_comm_wait(self.h))
+
+    def broadcast_(self, t, src=0):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self.ctx.check(self.lib.fg_broadcast(self.h, t.data_ptr(), t.numel(), src))
+        return t
+
+    def close(self):
+        if self.h is not None:
+            self.lib.fg_comm_destroy(self.h)
+            self.h = None
+
+
+def as_collective(d):
+    """Trainer argument -> Collective: None (single process), a Collective, or the torch.distributed module."""
+    if d is None:
+        return None
+    if isinstance(d, Collective):
+        return d
+    return TorchCollective(d)
+
+
+def make_collective(ctx, d=dist, prefer="fg_comm", strict=False):
+    """The carrier for an initialised torch.distributed job: the library's own communicator unless `prefer` says torch.
+    The 128-byte RCCL id is broadcast from rank 0 over `d`; a one-element self-test (sum of ones == world) runs on every
+    rank, and unless `strict` a failure falls back to torch.distributed on ALL ranks (the decision is itself reduced)."""
+    if prefer != "fg_comm":
+        return TorchCollective(d)
+    rank, world = d.get_rank(), d.get_world_size()
+    err, coll = "", None
+    # (1) local, non-collective: can this rank bind librccl at all?  Decided jointly BEFORE the collective create, so a
+    #     rank without RCCL cannot leave the others waiting inside ncclCommInitRank.
+    try:
+        my_id = FgCollective.unique_id(ctx)
+    except Exception as e:        # noqa: BLE001
+        my_id, err = None, str(e)
+    bad = torch.tensor([1.0 if err else 0.0], device=ctx.device)
+    d.all_reduce(bad, op=d.ReduceOp.SUM)
+    if float(bad.item()) != 0.0:
+        if strict:
+            raise RuntimeError("fg_comm unavailable on %d rank(s): %s" % (int(bad.item()), err or "(another rank)"))
+        t = TorchCollective(d)
+        t.name += " [fg_comm fell back: %s]" % (err or "another rank cannot bind librccl")[:160]
+        return t
+    try:
+        idt = torch.zeros(128, dtype=torch.uint8, device=ctx.device)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+        d.broadcast(idt, 0)
+        coll = FgCollective(ctx, rank, world, bytes(idt.cpu().numpy().tobytes()))
+        probe = torch.ones(4, dtype=torch.float32, device=ctx.device)
+        coll.allreduce_sum_(probe)
+        torch.cuda.synchronize()
+        if probe.tolist() != [float(world)] * 4:
+            raise RuntimeError("self-test: sum of ones = %s, expected %d" % (probe.tolist(), world))
+    except Exception as e:        # noqa: BLE001 -- reported, and decided collectively below
+        err = str(e)
+    bad = torch.tensor([1.0 if err else 0.0], device=ctx.device)
+    d.all_reduce(bad, op=d.ReduceOp.SUM)
+    if float(bad.item()) == 0.0:
+        return coll
+    if strict:
+        raise RuntimeError("fg_comm unavailable on %d rank(s): %s" % (int(bad.item()), err or "(another rank)"))
+    if coll is not None:
+        coll.close()
+    t = TorchCollective(d)
+    t.name += " [fg_comm fell back: %s]" % (err or "another rank failed")[:160]
+    return t
+
+
+# ---- helpers kept for the host loops -----------------------------------------------------------------------------
 def allreduce_sum_(flat):
-    """In-place SUM all-reduce of a flat gradient vector (no-op for a single process)."""
+    """In-place SUM all-reduce of a flat gradient vector over torch.distributed (no-op for a single process)."""
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat

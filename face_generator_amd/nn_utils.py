@@ -112,14 +112,23 @@ def prepareNetworkForSave(net):
         m.gradInput = None
 
 
+def _bn_modules(inner):
+    """Every SpatialBatchNormalization of the net in module order, descending into nested containers (the branches of
+    models.lua:279-316 create_D16_d are Sequentials inside a ConcatTable)."""
+    return [m for m in inner.listModules() if isinstance(m, nn.SpatialBatchNormalization)]
+
+
 def state_dict(net):
     inner = net._inner()
-    sd = {"layers": inner.layer_specs(), "input_dims": inner.input_dims, "params": [], "bn": []}
+    if isinstance(inner, nn.ConcatSequential):     # per-part layer specs: ConcatTable / JoinTable have no fg_layer_spec
+        layers = {"branches": [b.layer_specs() for b in inner.branches], "tail": inner.tail.layer_specs()}
+    else:
+        layers = inner.layer_specs()
+    sd = {"layers": layers, "input_dims": inner.input_dims, "params": [], "bn": []}
     for (m, name) in inner.parameter_list():
         sd["params"].append(getattr(m, name).detach().cpu().clone())
-    for m in inner.modules:
-        if isinstance(m, nn.SpatialBatchNormalization):
-            sd["bn"].append((m.running_mean.detach().cpu().clone(), m.running_var.detach().cpu().clone()))
+    for m in _bn_modules(inner):
+        sd["bn"].append((m.running_mean.detach().cpu().clone(), m.running_var.detach().cpu().clone()))
     return sd
 
 
@@ -131,8 +140,7 @@ def load_state_dict(net, sd):
     with torch.no_grad():
         for (m, name), w in zip(plist, sd["params"]):
             getattr(m, name).copy_(w.reshape(getattr(m, name).shape))
-        bns = [m for m in inner.modules if isinstance(m, nn.SpatialBatchNormalization)]
-        for m, (rm, rv) in zip(bns, sd["bn"]):
+        for m, (rm, rv) in zip(_bn_modules(inner), sd["bn"]):
             m.running_mean.copy_(rm)
             m.running_var.copy_(rv)
     if inner.device_net is not None:
@@ -154,16 +162,24 @@ def load_checkpoint(filename, image_dims=None):
 
 def save_checkpoint(filename=None, fmt="state_dict"):
     """adversarial.lua:319-329: rotate adversarial.net -> .old, save {D, G, opt, epoch}.
-    fmt="torch7" writes Torch7's own serialisation (loadable by the reference's torch.load)."""
+    fmt="torch7" writes Torch7's own serialisation (loadable by the reference's torch.load).
+    The new file is written next to the target first and renamed into place only after a successful save, so a failed
+    save never costs the previous checkpoint.  Data parallelism: replicas are identical, only rank 0 writes."""
     filename = filename or os.path.join(S.OPT.get("save", "logs"), "adversarial.net")
+    if S._trainer is not None:
+        S._trainer.finish_pending()            # a deferred D update (N > 1) belongs to the saved weights
+    if S.dist is not None and S.dist.get_rank() != 0:
+        return
     os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
-    if os.path.isfile(filename):
-        os.replace(filename, filename + ".old")
     print("<trainer> saving network to %s" % filename)
     prepareNetworkForSave(S.MODEL_D)
     prepareNetworkForSave(S.MODEL_G)
+    tmp = filename + ".tmp"
     if fmt == "torch7":
         from . import t7_checkpoint
-        t7_checkpoint.save_checkpoint(filename, S.MODEL_D, S.MODEL_G, dict(S.OPT), S.EPOCH)
-        return
-    torch.save({"D": state_dict(S.MODEL_D), "G": state_dict(S.MODEL_G), "opt": dict(S.OPT), "epoch": S.EPOCH}, filename)
+        t7_checkpoint.save_checkpoint(tmp, S.MODEL_D, S.MODEL_G, dict(S.OPT), S.EPOCH)
+    else:
+        torch.save({"D": state_dict(S.MODEL_D), "G": state_dict(S.MODEL_G), "opt": dict(S.OPT), "epoch": S.EPOCH}, tmp)
+    if os.path.isfile(filename):
+        os.replace(filename, filename + ".old")
+    os.replace(tmp, filename)

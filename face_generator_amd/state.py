@@ -22,6 +22,7 @@ class _State:
         self.noise_seed, self.noise_offset = 1, 0   # torch.manualSeed(seed): noise stream (nn_utils.lua:37)
         self._trainer = None
         self.dist = None
+        self.OPTSTATE = None                 # train.lua:180-191, created with the trainer
 
     def next_noise(self, ctx, n, dim):
         """NN_UTILS.createNoiseInputs on the device: U(-1,1), Philox stream keyed by (seed, running offset)."""
@@ -34,7 +35,23 @@ class _State:
             from .adversarial import Trainer
             from .runtime import get_context
             self._trainer = Trainer(get_context(), self.MODEL_G, self.MODEL_D, self.OPT, dist=self.dist)
+            self.OPTSTATE = self._trainer.optstate
         return self._trainer
+
+    def set_dist(self, dist):
+        """Data parallelism (one process per GPU): every rank draws ITS shard of the global batch -- the three RNG
+        streams of train.lua:64-65, 80 (real-image picks, noise, dropout masks) are offset by the rank -- and only rank
+        0 writes checkpoints (nn_utils.save_checkpoint)."""
+        self.dist = dist
+        rank = dist.get_rank() if dist is not None else 0
+        seed = self.OPT.get("seed", 1)
+        self.rng = random.Random(seed + rank)
+        self.noise_seed = seed + rank
+        for net in (self.MODEL_G, self.MODEL_D):
+            dn = getattr(net._inner(), "device_net", None) if net is not None else None
+            if dn is not None:
+                for d in ([dn] if not hasattr(dn, "_nets") else dn._nets()):
+                    d.mask_seed = 1000 * (seed + rank) + 1
 
 
 S = _State()

@@ -27,6 +27,7 @@ extern "C" {
 
 typedef struct fg_ctx fg_ctx;
 typedef struct fg_net fg_net;
+typedef struct fg_comm fg_comm;
 
 enum {
     FG_OK = 0,
@@ -160,6 +161,35 @@ int fg_adagrad_fused(fg_ctx* ctx, float* p, const float* g, float* variance, lon
                      float l2, float clamp, double clr);
 /* out2[0] = ||p||_1, out2[1] = ||p||_2^2 (torch.norm of adversarial.lua:105-106); scratch >= 1024 floats */
 int fg_norms(fg_ctx* ctx, const float* p, long long n, float* out2_dev, float* scratch);
+
+/* ---- data parallelism: one process (rank) per GPU, RCCL over xGMI (SURVEY.md 8(b) `fg_allreduce_sum(fg_comm*, ...)`, 8(e)).
+ *      The reference has no multi-GPU path (train.lua:79 selects one device); BASELINE configs 3 and 5 shard the batch
+ *      and sum-all-reduce the flat gradient vector of the net being updated.  librccl is bound at run time (dlopen; an
+ *      instance already loaded by the host process is shared; FG_RCCL_LIB overrides the search).
+ *      Bootstrap: rank 0 calls fg_comm_unique_id and hands the FG_COMM_ID_BYTES bytes to every rank through any host
+ *      channel (file, environment, socket, torch.distributed store); every rank then calls fg_comm_create, which is
+ *      collective.  fg_allreduce_sum* / fg_broadcast are in-place and stream-ordered on the context's stream;
+ *      fg_allreduce_sum_async runs the exchange on the communicator's own stream after everything enqueued so far and
+ *      returns at once -- fg_comm_wait makes the context's stream wait for every exchange issued that way. ---- */
+enum { FG_COMM_ID_BYTES = 128 };
+int fg_comm_unique_id(fg_ctx* ctx, char* id_out, size_t len);
+int fg_comm_create(fg_ctx* ctx, const char* id, size_t len, int rank, int world, fg_comm** out);
+int fg_comm_destroy(fg_comm* comm);
+int fg_comm_rank(const fg_comm* comm);
+int fg_comm_world(const fg_comm* comm);
+const char* fg_comm_library(void);   /* which librccl was bound ("" before the first fg_comm_* call) */
+int fg_allreduce_sum(fg_comm* comm, float* buf, size_t n);
+int fg_allreduce_sum_async(fg_comm* comm, float* buf, size_t n);
+int fg_comm_wait(fg_comm* comm);
+int fg_allreduce_sum_f64(fg_comm* comm, double* buf, size_t n);   /* sync-BN sums */
+int fg_allreduce_sum_i32(fg_comm* comm, int* buf, size_t n);      /* confusion counts of the global batch */
+int fg_broadcast(fg_comm* comm, float* buf, size_t n, int root);  /* identical initial replicas */
+
+/* ---- adversarial.approxParzen (adversarial_c2f.lua:305-344): dist[i] = || (gen[i] + cond) - fine ||_2 for the n
+ *      generations of one example (torch.dist: squares accumulated in double), min_out[0] = min(1e10, min_i dist[i]).
+ *      gen [n][elems]; cond, fine [elems]; all three in the same element order. ---- */
+int fg_parzen_min_dist(fg_ctx* ctx, const float* gen, const float* cond, const float* fine, int n, long long elems,
+                       float* dist, float* min_out);
 
 /* ---- module-level ops (nn.Module protocol: updateOutput / updateGradInput / accGradParameters), NHWC ----
  * conv / linear take REFERENCE-layout weights and pack them into `ws` on the fly. */

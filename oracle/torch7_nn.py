@@ -885,9 +885,10 @@ def feval_G_on_D(st, noise, targets):
     return f, st.gG, samples, out
 
 
-def step_D(st, real, noise_half, masks=None):
+def step_D(st, real, noise_half, masks=None, gate=None):
     """adversarial.lua:240-268: B/2 real (target 1) || B/2 fake from G in TRAIN mode
-    (target 0) -> fevalD -> Adam on D."""
+    (target 0) -> fevalD -> Adam on D.  gate(tV) -> bool is the maxAccuracyD interrupt of adversarial.lua:124-178:
+    when it says no, fevalD returns false,false and interruptableAdam skips the update (no `t` increment)."""
     fake = st.G.forward(noise_half).copy()
     inputs = np.concatenate([real, fake], 0)
     targets = np.concatenate([np.ones(real.shape[0]), np.zeros(fake.shape[0])]).astype(real.dtype)
@@ -897,10 +898,35 @@ def step_D(st, real, noise_half, masks=None):
 
     def op(x):
         f, g, out, conf = feval_D(st, inputs, targets)
-        res.update(f=f, f_bce=st.last_f_bce, out=out.copy(), conf=conf, grad=g.copy(), inputs=inputs)
+        res.update(f=f, f_bce=st.last_f_bce, out=out.copy(), conf=conf, grad=g.copy(), inputs=inputs, trained=True)
+        if gate is not None:
+            tV = float(conf[0, 0] + conf[1, 1]) / float(conf.sum())     # confusionBatchD.totalValid (:125-126)
+            if not gate(tV):
+                res['trained'] = False
+                return False, False
         return f, g
-    interruptable_adam(op, st.pD, st.adamD)
+    optimizer_for(st, 'D')(op, st.pD, optstate_for(st, 'D'))
     return res
+
+
+def optimizer_for(st, which):
+    """adversarial.lua:259-267 / 279-287: --{D,G}_optmethod selects the interruptable optimizer."""
+    return dict(adam=interruptable_adam, sgd=interruptable_sgd, adagrad=interruptable_adagrad)[
+        st.opt.get(which + '_optmethod', 'adam')]
+
+
+def optstate_for(st, which):
+    m = st.opt.get(which + '_optmethod', 'adam')
+    if m == 'adam':
+        return st.adamD if which == 'D' else st.adamG
+    if not hasattr(st, 'optstate'):
+        st.optstate = {}
+    o = st.opt
+    if m == 'sgd':       # train.lua:184-187
+        init = dict(learningRate=o.get(which + '_SGD_lr', 0.02), momentum=o.get(which + '_SGD_momentum', 0))
+    else:
+        init = {}
+    return st.optstate.setdefault((m, which), init)
 
 
 def step_G(st, noise, masks=None):
@@ -914,8 +940,72 @@ def step_G(st, noise, masks=None):
         f, g, samples, out = feval_G_on_D(st, noise, targets)
         res.update(f=f, f_bce=st.last_f_bce, out=out.copy(), grad=g.copy(), samples=samples.copy())
         return f, g
-    interruptable_adam(op, st.pG, st.adamG)
+    optimizer_for(st, 'G')(op, st.pG, optstate_for(st, 'G'))
     return res
+
+
+def lua_mean(t):
+    """adversarial.mean (adversarial.lua:15-27)."""
+    return sum(t) / len(t)
+
+
+def train_epoch(st, dataset, opt, max_accuracy_d, accs_interval, accs, pick, draw_noise, draw_masks, before_step=None):
+    """adversarial.train(dataset, maxAccuracyD, accsInterval) -- adversarial.lua:30-335, one epoch.
+
+    opt: batchSize, N_epoch, D_iterations, G_iterations, noiseDim.  `accs` is the module-level adversarial.accs list
+    (:13) and persists across epochs.  The three RNG streams of the reference are callbacks so that a test can feed
+    both this loop and the device loop the same draws: pick(n) = math.random(n) - 1 (:245), draw_noise(n) =
+    NN_UTILS.createNoiseInputs(n) (nn_utils.lua:35-39), draw_masks(B) = the dropout masks of one D forward.
+    before_step(kind, k) is a test hook called right before step number k ('D' or 'G').
+
+    Odd thisBatchSize (N_epoch odd): Lua's `for i = 1, thisBatchSize / 2` fills floor(thisBatchSize / 2) real and as
+    many fake rows and leaves the last row of `inputs` / `targets` uninitialised (torch.Tensor(n) does not clear);
+    that garbage row is not restated -- the even part is used."""
+    n_epoch = opt['N_epoch'] if opt['N_epoch'] > 0 else len(dataset)
+    B = opt['batchSize']
+    data_bs = B // 2
+    log = dict(iters=[], trained=0, not_trained=0, conf=np.zeros((2, 2), np.int64), skipped_at=None)
+
+    def gate(tV):
+        accs.append(tV)                                   # :156-159
+        if len(accs) > accs_interval:
+            accs.pop(0)
+        do_train = lua_mean(accs) < max_accuracy_d        # :162-167
+        if do_train:
+            log['trained'] += 1
+        else:
+            log['not_trained'] += 1
+        return do_train
+    k = 0
+    for t in range(1, n_epoch + 1, data_bs):
+        this = min(B, n_epoch - t + 1)
+        if this < 4:                                      # :73-76
+            log['skipped_at'] = t
+            break
+        half = this // 2
+        this = 2 * half
+        it = dict(t=t, batch=this, D=[], G=[])
+        for _ in range(opt.get('D_iterations', 1)):
+            idx = [pick(len(dataset)) for _ in range(half)]
+            real = np.stack([np.asarray(dataset[i], F32) for i in idx])
+            nz = draw_noise(half)
+            if before_step:
+                before_step('D', k)
+            r = step_D(st, real, nz, draw_masks(this), gate=gate)
+            log['conf'] += r['conf']                      # CONFUSION:add (:115) happens whether or not D trains
+            r['idx'] = idx
+            it['D'].append(r)
+            k += 1
+        for _ in range(opt.get('G_iterations', 1)):
+            nz = draw_noise(this)
+            if before_step:
+                before_step('G', k)
+            it['G'].append(step_G(st, nz, draw_masks(this)))
+            k += 1
+        log['iters'].append(it)
+    c = log['conf']
+    log['totalValid'] = float(c[0, 0] + c[1, 1]) / max(1.0, float(c.sum()))
+    return log
 
 
 # ----------------------------------------------------------------------------------
@@ -1035,3 +1125,66 @@ def step_G_c2f(st, noise, cond, masks=None):
         return f, st.gG
     interruptable_adam(op, st.pG, st.adamG)
     return res
+
+
+def train_epoch_c2f(st, train_data, opt, pick, draw_noise, draw_masks, before_step=None):
+    """adversarial.train(trainData) of the coarse-to-fine trainer -- adversarial_c2f.lua:10-223, one epoch.
+    train_data[i] = dict(diff=, coarse=, fine=) (CHW).  Pick order per D-iteration: B/2 real examples (diff + coarse of the
+    SAME example, :125-133), then B/2 fresh examples whose coarse conditions the fake half (:137-142, quirk C13);
+    per G-iteration: B fresh conditions (:170-174).  optim.adam == interruptableAdam without the gate."""
+    n_epoch = opt['N_epoch'] if opt['N_epoch'] > 0 else len(train_data)
+    B = opt['batchSize']
+    log = dict(iters=[], conf=np.zeros((2, 2), np.int64), skipped_at=None)
+    k = 0
+    for t in range(1, n_epoch + 1, B // 2):
+        this = min(B, n_epoch - t + 1)
+        if this < 4:
+            log['skipped_at'] = t
+            break
+        half = this // 2
+        this = 2 * half
+        it = dict(t=t, batch=this, D=[], G=[])
+        for _ in range(opt.get('D_iterations', 1)):
+            idx = [pick(len(train_data)) for _ in range(half)]
+            diff = np.stack([np.asarray(train_data[i]['diff'], F32) for i in idx])
+            cond_r = np.stack([np.asarray(train_data[i]['coarse'], F32) for i in idx])
+            idx_f = [pick(len(train_data)) for _ in range(half)]
+            cond_f = np.stack([np.asarray(train_data[i]['coarse'], F32) for i in idx_f])
+            nz = draw_noise(half)
+            if before_step:
+                before_step('D', k)
+            r = step_D_c2f(st, diff, cond_r, nz, cond_f, draw_masks(this))
+            log['conf'] += r['conf']
+            it['D'].append(r)
+            k += 1
+        for _ in range(opt.get('G_iterations', 1)):
+            idx = [pick(len(train_data)) for _ in range(this)]
+            cond = np.stack([np.asarray(train_data[i]['coarse'], F32) for i in idx])
+            nz = draw_noise(this)
+            if before_step:
+                before_step('G', k)
+            it['G'].append(step_G_c2f(st, nz, cond, draw_masks(this)))
+            k += 1
+        log['iters'].append(it)
+    c = log['conf']
+    log['totalValid'] = float(c[0, 0] + c[1, 1]) / max(1.0, float(c.sum()))
+    return log
+
+
+def approx_parzen(G, ds, nsamples, nneighbors, pick, draw_noise):
+    """adversarial.approxParzen (adversarial_c2f.lua:305-344) without the checkpoint side effect: for each of `nsamples`
+    random examples, the L2 distance (torch.dist: accumulate in double, THTensor_(dist) with accreal) from the ground-truth
+    fine image to the nearest of `nneighbors` generations G({noise, coarse}) + coarse.  G runs in its current mode."""
+    distances = np.zeros(nsamples, F32)
+    for n in range(nsamples):
+        ex = ds[pick(len(ds))]
+        cond = np.repeat(np.asarray(ex['coarse'], F32)[None], nneighbors, 0)
+        noise = draw_noise(nneighbors)
+        neighbors = G.forward([noise, cond]) + cond
+        fine = np.asarray(ex['fine'], F32)
+        d = 1e10
+        for i in range(nneighbors):
+            diff = neighbors[i].astype(np.float64) - fine.astype(np.float64)
+            d = min(float(np.sqrt((diff * diff).sum())), d)
+        distances[n] = d
+    return distances

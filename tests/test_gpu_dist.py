@@ -24,18 +24,21 @@ def test_trainer_with_rccl_world1_matches_plain_trainer():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         outs = []
-        for use_dist in (False, True):
+        from face_generator_amd import distributed
+        fgc = distributed.make_collective(ctx, dist, prefer="fg_comm", strict=True)     # the library's own RCCL communicator
+        assert fgc.describe().startswith("fg_comm") and fgc.get_world_size() == 1
+        for use_dist in (False, True, fgc):
             gen = torch.Generator().manual_seed(3)
             G = models.create_G((3, 32, 32), 100); D = models.create_D((3, 32, 32))
             nn_utils.initializeWeights(D, 0.05, 0.01, gen=gen); nn_utils.initializeWeights(G, 0.05, 0.01, gen=gen)
             G.cuda(ctx, max_batch=8); D.cuda(ctx, max_batch=8)
             D.device_net.mask_seed = 5
-            tr = adversarial.Trainer(ctx, G, D, dict(batchSize=8), dist=dist if use_dist else None)
+            tr = adversarial.Trainer(ctx, G, D, dict(batchSize=8), dist=(dist if use_dist is True else use_dist) or None)
             real = ctx.uniform((4, 32, 32, 3), 0.0, 1.0, seed=9)
             if use_dist:             # force the N > 1 code path (async all-reduce + deferred D update) on one rank:
                 tr.world, tr.gscale = 2, 1.0     # a 1-rank sum all-reduce is the identity, so keep the scale at 1
             tr.step_D(real, ctx.uniform((4, 100), -1.0, 1.0, seed=10))
-            assert (tr._pending_D is not None) == use_dist
+            assert (tr._pending_D is not None) == bool(use_dist)
             tr.step_G(ctx.uniform((8, 100), -1.0, 1.0, seed=11))
             assert tr._pending_D is None
             if use_dist:    # bucketed, backward-overlapped all-reduce of G: >= 2 buckets covering the whole flat vector
@@ -45,6 +48,8 @@ def test_trainer_with_rccl_world1_matches_plain_trainer():
                 assert sum(hi - lo for (_, _, lo, hi) in bk) == G.getParameters()[0].numel()
             outs.append((G.getParameters()[0].cpu().numpy().copy(), D.getParameters()[0].cpu().numpy().copy()))
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        assert np.array_equal(outs[0][0], outs[2][0]) and np.array_equal(outs[0][1], outs[2][1])     # fg_comm carrier
+        fgc.close()
     finally:
         dist.destroy_process_group()
 
@@ -58,3 +63,35 @@ def test_bench_runs_under_torchrun_single_rank():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["unit"] == "images/sec" and "roofline" in j
+
+
+def test_fg_comm_c_abi_world1():
+    """fg_comm_* (include/facegen_hip.h): RCCL bound by the library at run time; a one-rank communicator must be the
+    identity for sum / broadcast in fp32, fp64 and int32, blocking and overlapped (side stream + fg_comm_wait)."""
+    import ctypes
+    from face_generator_amd.runtime import get_context
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ctx = get_context(0)
+    lib = ctx.lib
+    buf = ctypes.create_string_buffer(128)
+    ctx.check(lib.fg_comm_unique_id(ctx.h, buf, 128))
+    assert lib.fg_comm_unique_id(ctx.h, buf, 64) < 0                       # short buffer -> FG_ERR_INVALID, not a crash
+    h = ctypes.c_void_p()
+    ctx.check(lib.fg_comm_create(ctx.h, buf.raw, 128, 0, 1, ctypes.byref(h)))
+    assert lib.fg_comm_rank(h) == 0 and lib.fg_comm_world(h) == 1 and b"rccl" in lib.fg_comm_library()
+    x = ctx.uniform((1 << 20,), -1.0, 1.0, seed=3)
+    ref = x.clone()
+    ctx.check(lib.fg_allreduce_sum(h, x.data_ptr(), x.numel()))
+    ctx.check(lib.fg_allreduce_sum_async(h, x.data_ptr(), x.numel()))
+    ctx.check(lib.fg_allreduce_sum_async(h, x[:1000].data_ptr(), 1000))
+    ctx.check(lib.fg_comm_wait(h))
+    ctx.check(lib.fg_broadcast(h, x.data_ptr(), x.numel(), 0))
+    d64 = torch.arange(7, dtype=torch.float64, device=ctx.device)
+    i32 = torch.arange(4, dtype=torch.int32, device=ctx.device)
+    ctx.check(lib.fg_allreduce_sum_f64(h, d64.data_ptr(), 7))
+    ctx.check(lib.fg_allreduce_sum_i32(h, i32.data_ptr(), 4))
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref) and d64.tolist() == list(range(7)) and i32.tolist() == [0, 1, 2, 3]
+    assert lib.fg_broadcast(h, x.data_ptr(), 4, 3) < 0                     # root outside the communicator
+    assert lib.fg_comm_create(ctx.h, buf.raw, 128, 2, 1, ctypes.byref(ctypes.c_void_p())) < 0
+    ctx.check(lib.fg_comm_destroy(h))

@@ -365,3 +365,42 @@ def test_strided_conv_and_D16_d_against_torch_autograd():
     assert out.shape == (4, 1) and (out > 0).all() and (out < 1).all()
     gin = D.backward(xb, np.ones((4, 1), np.float32))
     assert gin.shape == xb.shape and np.abs(g).max() > 0
+
+
+def test_torch_cpu_baseline_matches_the_numpy_oracle():
+    """oracle/torch_cpu.py (bench.py's PyTorch-CPU baseline) runs the SAME iteration as the numpy oracle:
+    identical parameters, inputs and dropout masks -> same outputs, loss, clamped flat gradients and post-Adam parameters."""
+    from oracle import torch_cpu as TC
+    rng = np.random.default_rng(77)
+    B = 4
+    G = O.create_G32((3, 32, 32), 100, rng); D = O.create_D32b((3, 32, 32), rng)
+    st = O.GanState(G, D)
+    gan = TC.GanCPU(G, D)
+    real = rng.uniform(0, 1, (B // 2, 3, 32, 32)).astype(np.float32)
+    nz = rng.uniform(-1, 1, (B // 2, 100)).astype(np.float32)
+    masks = [(rng.random((B, c)) < 0.8).astype(np.float32) for c in (64, 128, 256, 512)] + \
+            [(rng.random((B, 512)) < 0.5).astype(np.float32) for _ in range(2)]
+    ref = O.step_D(st, real, nz, masks)
+    got = gan.step_D(torch.tensor(real), torch.tensor(nz), masks=masks)
+    assert np.abs(got["out"].numpy().reshape(-1) - ref["out"].reshape(-1)).max() < 1e-5
+    assert abs(got["f_bce"] - ref["f_bce"]) < 1e-5 * abs(ref["f_bce"])
+    assert np.abs(got["grad"].numpy() - ref["grad"]).max() < 1e-4 * np.abs(ref["grad"]).max() + 1e-7
+    nz2 = rng.uniform(-1, 1, (B, 100)).astype(np.float32)
+    gan.D.set_flat(torch.tensor(st.pD))
+    ref = O.step_G(st, nz2, masks)
+    got = gan.step_G(torch.tensor(nz2), masks=masks)
+    assert np.abs(got["samples"].numpy() - ref["samples"]).max() < 1e-5
+    assert np.abs(got["grad"].numpy() - ref["grad"]).max() < 1e-4 * np.abs(ref["grad"]).max() + 1e-7
+    # c2f nets (table inputs, max-pool, 4-D dropout)
+    S = 16
+    G = O.create_G_d((3, S, S), rng); D = O.create_D_c((3, S, S), rng)
+    st = O.GanState(G, D, O.C2F_OPT)
+    gan = TC.GanCPU(G, D, O.C2F_OPT)
+    diff = rng.uniform(-1, 1, (B // 2, 3, S, S)).astype(np.float32)
+    cr = rng.uniform(0, 1, (B // 2, 3, S, S)).astype(np.float32); cf = rng.uniform(0, 1, (B // 2, 3, S, S)).astype(np.float32)
+    nz = rng.uniform(-1, 1, (B // 2, 1, S, S)).astype(np.float32)
+    masks = [(rng.random((B, 256, S // 4, S // 4)) < 0.5).astype(np.float32), (rng.random((B, 512)) < 0.5).astype(np.float32)]
+    ref = O.step_D_c2f(st, diff, cr, nz, cf, masks)
+    got = gan.step_D(torch.tensor(diff), [torch.tensor(nz), torch.tensor(cf)], cond=torch.tensor(np.concatenate([cr, cf])), masks=masks)
+    assert np.abs(got["out"].numpy().reshape(-1) - ref["out"].reshape(-1)).max() < 1e-5
+    assert np.abs(got["grad"].numpy() - ref["grad"]).max() < 1e-4 * np.abs(ref["grad"]).max() + 1e-7
