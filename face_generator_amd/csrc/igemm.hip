@@ -839,15 +839,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     // row's offsets are  (wave-uniform base of this K-step) + (per-thread constant), so the per-step address math is
     // scalar except one add and one bounds compare per row.
     const bool fast = a.lgW >= 0 && ((a.Hm * a.Wm) & 31) == 0;
-    int cD[R], cX[R], cy[R];
-    bool xin[R];
+    int cD[R], cX[R], cy[R], cxx[R];
     if (fast) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
             const int j = lpix + PSTEP * i;
             const int x = j & (a.Wm - 1), yr = j >> a.lgW;          // pixel inside the K-step (Wm < 32: several rows)
             const int xx = x * a.xsx + xox;
-            xin[i] = okX && (unsigned)xx < (unsigned)a.Wx;
+            cxx[i] = xx;
             cy[i] = yr * a.xsy + xoy;
             cD[i] = (((yr * a.dsy + doy) * a.Wd + x * a.dsx + dox) * a.Nd + chD) * 4;
             cX[i] = (((yr * a.xsy + xoy) * a.Wx + xx) * a.Cx + chX) * 4;
@@ -860,12 +859,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         if (fast) {                                                                                         \
             const int rowi = mcur >> a.lgW;                 /* wave-uniform */                              \
             const int yb = rowi & (a.Hm - 1), nb = rowi >> a.lgH;                                           \
-            const int bD = nb * sDn + yb * sDy, bX = nb * sXn + yb * sXy, ybx = yb * a.xsy;                 \
+            const int x0 = mcur & (a.Wm - 1);               /* Wm > 32: the K-step starts inside a row */  \
+            const int x0x = x0 * a.xsx;                                                                     \
+            const int bD = nb * sDn + yb * sDy + x0 * a.dsx * a.Nd * 4;                                     \
+            const int bX = nb * sXn + yb * sXy + x0x * a.Cx * 4, ybx = yb * a.xsy;                          \
             _Pragma("unroll") for (int i = 0; i < R; ++i) {                                                 \
                 const bool ok = mcur + lpix + PSTEP * i < m1;                                               \
                 const bool iny = (unsigned)(ybx + cy[i]) < (unsigned)a.Hx;                                  \
+                const bool inx = okX && (unsigned)(cxx[i] + x0x) < (unsigned)a.Wx;                          \
                 rd[i] = fg_buffer_load4(drsrc, (ok && okD) ? bD + cD[i] : FG_OOB);                          \
-                rx[i] = fg_buffer_load4(xrsrc, (ok && xin[i] && iny) ? bX + cX[i] : FG_OOB);                \
+                rx[i] = fg_buffer_load4(xrsrc, (ok && inx && iny) ? bX + cX[i] : FG_OOB);                   \
             }                                                                                               \
         } else {                                                                                            \
             _Pragma("unroll") for (int i = 0; i < R; ++i) {                                                 \

@@ -213,17 +213,28 @@ class PReLU(Module):
         self.weight = np.full((1,), 0.25, F32)
         self.gradWeight = np.zeros((1,), F32)
 
+    # Test hook: `pos_override` (bool array shaped like the input, or None) replaces the branch decision x > 0.  PReLU is not
+    # differentiable at 0; a unit whose pre-activation is within fp32 rounding of 0 may legitimately take either branch
+    # depending on the summation order of the producing GEMM.  The GPU parity tests at the BASELINE sizes (10^7 units per
+    # step) copy the device's decisions in here so that the gradients are compared on IDENTICAL branches.
+    pos_override = None
+
+    def _pos(self, x):
+        if self.pos_override is not None:
+            return self.pos_override.reshape(x.shape)
+        return x > 0
+
     def updateOutput(self, x):
-        self.output = np.where(x > 0, x, self.weight[0] * x).astype(x.dtype)
+        self.output = np.where(self._pos(x), x, self.weight[0] * x).astype(x.dtype)
         return self.output
 
     def updateGradInput(self, x, gy):
-        self.gradInput = np.where(x > 0, gy, self.weight[0] * gy).astype(x.dtype)
+        self.gradInput = np.where(self._pos(x), gy, self.weight[0] * gy).astype(x.dtype)
         return self.gradInput
 
     def accGradParameters(self, x, gy, scale=1.0):
         # fp64 accumulate then round: the reduction order upstream is unspecified
-        t = np.where(x > 0, 0.0, x.astype(np.float64) * gy.astype(np.float64))
+        t = np.where(self._pos(x), 0.0, x.astype(np.float64) * gy.astype(np.float64))
         s = np.sum(t)
         # conditioning of this (heavily cancelling) scalar sum, for the parity tests: an eps-relative perturbation of x
         # moves the sum by ~ eps * ||t||_2, whatever |s| is
@@ -451,7 +462,8 @@ class SpatialMaxPooling(Module):
     def updateOutput(self, x):
         n, c, h, w = x.shape
         blk = x.reshape(n, c, h // 2, 2, w // 2, 2).transpose(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
-        self.indices = blk.argmax(axis=-1)
+        # test hook (see PReLU.pos_override): the argmax of a near-tie block decided elsewhere
+        self.indices = blk.argmax(axis=-1) if getattr(self, 'indices_override', None) is None else self.indices_override
         self.output = np.take_along_axis(blk, self.indices[..., None], -1)[..., 0]
         return self.output
 

@@ -158,12 +158,20 @@ class GanCPU:
         return dict(out=out.detach(), f_bce=float(loss.detach()), grad=g, samples=samples.detach())
 
 
+def usable_cores():
+    import os
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 def time_iterations(workload, batch, min_seconds=10.0, max_iters=50, threads=None):
     """One iteration = D-step + G-step at `batch` (cfg2: 32x32x3 G32 / D32b; c2f: 64x64 G_d / D_c), reference init,
     synthetic inputs.  -> dict(images_per_sec, iters, seconds, threads).  First iteration is warm-up."""
     import os
     import time
-    threads = threads or os.cpu_count() or 1
+    threads = threads or usable_cores()
     torch.set_num_threads(threads)
     rng = np.random.default_rng(1)
     if workload == "c2f":

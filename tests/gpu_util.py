@@ -47,3 +47,68 @@ def close_after_first_adam_step(p_dev, p_ref, g_dev, g_ref, what, lr=1e-3, beta2
         i = int(np.argmax(err - tol))
         raise AssertionError("%s: %d/%d parameters differ beyond the Adam-sensitivity bound; worst at %d: |err| %.3g tol %.3g "
                              "(g_dev %.3e g_ref %.3e)" % (what, bad.sum(), bad.size, i, err[i], tol[i], g_dev[i], g_ref[i]))
+
+
+def adopt_device_branches(ctx, dn, onet, clear=False, params=None, also=()):
+    """Copy the DEVICE's branch decisions of its last forward into the oracle net: PReLU (pre-activation > 0) and the 2x2
+    max-pool argmax (PReLU.pos_override / SpatialMaxPooling.indices_override in oracle/torch7_nn.py).  PReLU is not
+    differentiable at 0 and a max-pool not at a tie: with 10^7 units per step at the BASELINE sizes a few always sit within
+    fp32 rounding of the kink, where the oracle's GEMM and the device's legitimately land on different sides; copying the
+    decisions compares the gradients on identical branches at the plain SURVEY 8(c) bars, with no flip allowance.
+
+    The pre-activation is read from the device plan: the stage output in front of the PReLU (conv / Linear[+View] / fused
+    PReLU in front of a max-pool); for the fused BatchNorm+PReLU stage z = gamma * xhat + beta is recomputed by the SAME
+    kernels through the module-level entry (fg_batchnorm_forward with slope = NULL evaluates the identical expression).
+    `params`: the device's flat parameter vector as it was DURING that forward (the optimizer step that follows a backward
+    moves gamma / beta); `also`: further oracle nets (e.g. the float64 twin) that receive the same decisions."""
+    import torch
+    from oracle import torch7_nn as O
+    mods = getattr(onet, "inner", onet).modules
+    twins = [getattr(o, "inner", o).modules for o in also]
+    lib = ctx.lib
+    P = dn.params if params is None else params
+    for i, m in enumerate(mods):
+        if isinstance(m, O.PReLU):
+            if clear:
+                for mm in [m] + [t[i] for t in twins]:
+                    mm.pos_override = None
+                continue
+            prev = mods[i - 1]
+            if isinstance(prev, O.SpatialBatchNormalization):
+                x = dn.layer_output(i - 2).contiguous()
+                B, H, W, C = x.shape
+                wo, wn, bo, bn = dn.param_offsets(i - 1)
+                z = torch.empty_like(x)
+                aux = ctx.empty(4 * C)
+                scr = ctx.empty(int(lib.fg_bn_scratch_floats(C)))
+                ctx.check(lib.fg_batchnorm_forward(ctx.h, x.data_ptr(), z.data_ptr(), B * H * W, C,
+                                                   P[wo:wo + wn].data_ptr(), P[bo:bo + bn].data_ptr(), None,
+                                                   aux[:C].data_ptr(), aux[C:2 * C].data_ptr(), aux[2 * C:3 * C].data_ptr(),
+                                                   aux[3 * C:].data_ptr(), prev.eps, prev.momentum, 1, scr.data_ptr()))
+            else:
+                z = dn.layer_output(i - 1)
+            pos = nchw(z) > 0
+            for mm in [m] + [t[i] for t in twins]:
+                mm.pos_override = pos
+        elif isinstance(m, O.SpatialMaxPooling):
+            if clear:
+                for mm in [m] + [t[i] for t in twins]:
+                    mm.indices_override = None
+                continue
+            x = nchw(dn.layer_output(i - 1))
+            n, c, h, w = x.shape
+            blk = x.reshape(n, c, h // 2, 2, w // 2, 2).transpose(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+            idx = blk.argmax(axis=-1)                           # first max in scan order, like the kernel
+            for mm in [m] + [t[i] for t in twins]:
+                mm.indices_override = idx
+
+
+def count_branch_flips(onet):
+    """After an oracle forward with adopted branches: how many PReLU units would the oracle itself have decided otherwise."""
+    from oracle import torch7_nn as O
+    net = getattr(onet, "inner", onet)
+    k = 0
+    for m, x in zip(net.modules, net._inputs):
+        if isinstance(m, O.PReLU) and m.pos_override is not None:
+            k += int(((x > 0) != m.pos_override.reshape(x.shape)).sum())
+    return k
