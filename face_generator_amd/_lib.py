@@ -29,7 +29,7 @@ class LayerSpec(ctypes.Structure):
 _CTYPES = [
     (r"^const fg_layer_spec\*$", ctypes.POINTER(LayerSpec)),
     (r"^const float\* const\*$", ctypes.POINTER(ctypes.c_void_p)),
-    (r"^(fg_ctx|fg_net|fg_comm|fg_gan|void)\*\*$", ctypes.POINTER(ctypes.c_void_p)),
+    (r"^(fg_ctx|fg_net|fg_comm|fg_gan|void|float)\*\*$", ctypes.POINTER(ctypes.c_void_p)),
     (r"^const char\*$", ctypes.c_char_p),
     (r"^char\*$", ctypes.c_char_p),
     (r"^long long\*$", ctypes.POINTER(ctypes.c_longlong)),

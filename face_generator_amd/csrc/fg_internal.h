@@ -264,6 +264,10 @@ int fg_launch_adagrad(fg_ctx*, float* p, const float* g, float* var, long long n
 int fg_launch_norms(fg_ctx*, const float* p, long long n, float* out2, float* scratch);
 
 // Philox4x32-10 counter RNG
+#define FG_RNG_MAX_SEGS 12
+struct RngSeg { float* out; long long n; uint64_t seed, offset; float lo, hi; int mode; long long q0; };   // mode 0 uniform(lo,hi), 1 bernoulli(keep = lo)
+struct RngMulti { RngSeg seg[FG_RNG_MAX_SEGS]; int n; long long total_quads; };
+int fg_launch_rng_multi(fg_ctx*, RngMulti& m);   // fills q0 / total_quads; segment i == fg_launch_rng_*(seed_i, offset_i, ...)
 int fg_launch_rng_uniform(fg_ctx*, uint64_t seed, uint64_t offset, float* out, long long n, float lo, float hi);
 int fg_launch_rng_bernoulli(fg_ctx*, uint64_t seed, uint64_t offset, float* out, long long n, float keep_prob);
 int fg_launch_rng_normal(fg_ctx*, uint64_t seed, uint64_t offset, float* out, long long n, float mean, float std);

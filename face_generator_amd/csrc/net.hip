@@ -93,6 +93,7 @@ struct fg_net {
     unsigned char* planes_all = nullptr;
     long long packed_total = 0;
     bool planes_valid = false;
+    float* out_override = nullptr;    // fg_net_forward_to: the last stage writes here instead of into the workspace
     int n_jobs = 0;
     long long jobs_total = 0;
 };
@@ -167,7 +168,7 @@ static int backward_run_stages(fg_net* n) {
     for (int si = n->run_stage; si >= stage_to; --si) {
         Stage& s = n->st[si];
         const float* xin = si == 0 ? x : ws + n->st[si - 1].out_off;
-        const float* yout = ws + s.out_off;
+        const float* yout = (si + 1 == (int)n->st.size() && n->out_override) ? n->out_override : ws + s.out_off;
         const bool need_gx = si > 0 || want_x;
         float* gxb = si == 0 ? gx : ws + n->grad_off[pp];
         if (!need_gx) gxb = nullptr;
@@ -288,7 +289,7 @@ static int forward_run(fg_net* n, long long* out_offset) {
     int rc = FG_OK;
     for (int si = n->run_stage; si < (int)n->st.size(); ++si) {
         Stage& s = n->st[si];
-        float* y = ws + s.out_off;
+        float* y = (si + 1 == (int)n->st.size() && n->out_override) ? n->out_override : ws + s.out_off;
         const float* mask = (s.mask_idx >= 0) ? n->mask_ptrs[s.mask_idx] : nullptr;
         switch (s.kind) {
             case ST_CONV: {
@@ -572,6 +573,21 @@ int fg_net_destroy(fg_net* n) {
 }
 
 long long fg_net_num_params(const fg_net* n) { return n ? n->n_params : 0; }
+int fg_net_in_dims(const fg_net* n, int* c, int* h, int* w) {
+    if (!n) return FG_ERR_INVALID;
+    if (c) *c = n->in_c; if (h) *h = n->in_h; if (w) *w = n->in_w;
+    return FG_OK;
+}
+int fg_net_vectors(const fg_net* n, float** params, float** grads, float** buffers) {
+    if (!n) return FG_ERR_INVALID;
+    if (params) *params = n->params; if (grads) *grads = n->grads; if (buffers) *buffers = n->buffers;
+    return FG_OK;
+}
+int fg_net_max_bn_channels(const fg_net* n) {
+    int c = 0;
+    if (n) for (auto& s : n->st) if (s.kind == ST_BNPRELU && s.ic > c) c = s.ic;
+    return c;
+}
 long long fg_net_num_buffers(const fg_net* n) { return n ? n->n_buffers : 0; }
 int fg_net_num_masks(const fg_net* n) { return n ? n->n_masks : 0; }
 long long fg_net_mask_elems(const fg_net* n, int mi, int batch) {
@@ -678,7 +694,14 @@ static int ensure_packed(fg_net* n) {
 
 int fg_net_forward(fg_net* n, int B, const float* x, void* wsv, size_t ws_bytes, int train, const float* const* masks,
                    int n_masks, long long* out_offset) {
+    return fg_net_forward_to(n, B, x, wsv, ws_bytes, train, masks, n_masks, out_offset, nullptr);
+}
+
+int fg_net_forward_to(fg_net* n, int B, const float* x, void* wsv, size_t ws_bytes, int train, const float* const* masks,
+                      int n_masks, long long* out_offset, float* out_override) {
     if (!n || !x || !wsv) return fg_set_err(n ? n->ctx : nullptr, FG_ERR_INVALID, "fg_net_forward: null argument");
+    if (out_override && ((uintptr_t)out_override & 15)) return fg_set_err(n->ctx, FG_ERR_INVALID, "fg_net_forward_to: 16-byte alignment");
+    n->out_override = out_override;
     fg_ctx* ctx = n->ctx;
     if (!n->params) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: fg_net_bind first");
     if (B <= 0) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_forward: batch %d", B);
@@ -770,6 +793,8 @@ int fg_net_layer_output(const fg_net* n, int li, long long* off, int* c, int* h,
     const LayerInfo& l = n->layers[li];
     if (l.stage < 0 || !l.ends_stage) return fg_set_err(n->ctx, FG_ERR_INVALID, "layer %d is fused inside a stage", li);
     const Stage& s = n->st[l.stage];
+    if (l.stage + 1 == (int)n->st.size() && n->out_override)
+        return fg_set_err(n->ctx, FG_ERR_INVALID, "layer %d: the net's output was redirected by fg_net_forward_to", li);
     if (off) *off = s.out_off;
     if (c) *c = s.oc; if (h) *h = s.oh; if (w) *w = s.ow;
     return FG_OK;

@@ -1366,6 +1366,39 @@ __global__ void rng_kernel(uint64_t seed, uint64_t offset, float* __restrict__ o
             if (q * 4 + j < n) out[q * 4 + j] = v[j];
     }
 }
+// several independent draws (the noise batch and every dropout mask of a training step) in ONE launch: segment k owns the
+// quads [q0_k, q0_{k+1}) of the launch and is bit-identical to rng_kernel(seed_k, offset_k, out_k, n_k, ...)
+__global__ __launch_bounds__(256) void rng_multi_kernel(const RngMulti m) {
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < m.total_quads; q += (long long)gridDim.x * blockDim.x) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < FG_RNG_MAX_SEGS; ++j) k += (j < m.n && q >= m.seg[j].q0) ? 1 : 0;
+        const RngSeg sg = m.seg[k];
+        const long long ql = q - sg.q0;
+        const uint64_t ctr = sg.offset + (uint64_t)ql;
+        uint32_t r[4];
+        philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)sg.seed, (uint32_t)(sg.seed >> 32), r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float u = (r[j] >> 8) * (1.f / 16777216.f);
+            const float v = sg.mode == 0 ? sg.lo + u * (sg.hi - sg.lo) : (u < sg.lo ? 1.f : 0.f);
+            if (ql * 4 + j < sg.n) sg.out[ql * 4 + j] = v;
+        }
+    }
+}
+int fg_launch_rng_multi(fg_ctx* ctx, RngMulti& m) {
+    long long q = 0;
+    for (int i = 0; i < m.n; ++i) {
+        if (m.seg[i].mode != 0 && m.seg[i].mode != 1) return fg_set_err(ctx, FG_ERR_INVALID, "rng_multi: uniform / bernoulli only");
+        m.seg[i].q0 = q;
+        q += (m.seg[i].n + 3) / 4;
+    }
+    m.total_quads = q;
+    if (q == 0) return FG_OK;
+    hipLaunchKernelGGL(rng_multi_kernel, FG_GRID(q, 256), dim3(256), 0, ctx->stream, m);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
 static int launch_rng(fg_ctx* ctx, uint64_t seed, uint64_t offset, float* out, long long n, float lo, float hi,
                       int mode) {
     if (n == 0) return FG_OK;

@@ -117,6 +117,13 @@ int fg_net_params_changed(fg_net* net); /* call after the optimizer touched `par
  * (NHWC [batch][out_h][out_w][out_c]) inside ws. */
 int fg_net_forward(fg_net* net, int batch, const float* x, void* ws, size_t ws_bytes, int train,
                    const float* const* masks, int n_masks, long long* out_offset);
+/* fg_net_forward whose LAST stage writes its output to `out` (device, NHWC, 16-byte aligned) instead of into the workspace:
+ * a producer net hands its result straight to the consumer's input buffer (G -> D's batch, adversarial.lua:252-256). */
+int fg_net_forward_to(fg_net* net, int batch, const float* x, void* ws, size_t ws_bytes, int train,
+                      const float* const* masks, int n_masks, long long* out_offset, float* out);
+int fg_net_in_dims(const fg_net* net, int* c, int* h, int* w);
+int fg_net_vectors(const fg_net* net, float** params, float** grads, float** buffers);   /* what fg_net_bind attached */
+int fg_net_max_bn_channels(const fg_net* net);
 enum { FG_BWD_PARAM_GRADS = 1, FG_BWD_INPUT_GRAD = 2 };
 /* Module:backward after a train-mode forward with the same (batch, x, ws).  gy: grad wrt the output.
  * FG_BWD_PARAM_GRADS writes (overwrites: the reference zeroes before every feval, adversarial.lua:92, 193)
