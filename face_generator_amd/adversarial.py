@@ -51,6 +51,60 @@ class Trainer:
             self.dnG.enable_sync_bn(self.coll.allreduce_sum_)
         self._pending_D = None    # loss of a D update deferred behind the next G forward (its all-reduce is in flight)
         self.overlap = True       # N > 1: hide D's gradient all-reduce under the G-step's generator forward
+        self.gan = None           # runtime.FusedGan: one C call per closure (fg_step_D / fg_step_G)
+        self._make_fused()
+
+    table_inputs = 0              # 1: the {noise, cond} / {x, cond} table nets of adversarial_c2f.lua
+
+    def _make_fused(self):
+        """The step-level C entries (fg_step_D / fg_step_G) carry the closure whenever both nets are single compiled plans
+        and the exchange carrier is the library's own communicator (or there is none).  The module-by-module host path
+        below stays for ConcatTable nets (create_D16_d) and for torch.distributed carriers (gloo in the CPU / one-GPU tests)."""
+        from .runtime import DeviceNet, FusedGan
+        from .distributed import FgCollective
+        if not (isinstance(self.dnG, DeviceNet) and isinstance(self.dnD, DeviceNet)):
+            return
+        if self.coll is not None and not isinstance(self.coll, FgCollective):
+            return
+        if self.dnG.n_masks:
+            return
+        B = max(int(self.opt.get("batchSize", 0) or 0), self.dnG.max_batch, self.dnD.max_batch)
+        self.gan = FusedGan(self.ctx, self.dnG, self.dnD, self.table_inputs, B)
+        o = self.opt
+        self.gan.set_penalty(0, o["D_L1"], o["D_L2"], o["D_clamp"])
+        self.gan.set_penalty(1, o["G_L1"], o["G_L2"], o["G_clamp"])
+        from .state import S
+        self.gan.set_seeds(S.noise_seed, S.noise_offset, self.dnD.mask_seed, self.dnD.mask_offset)
+        if self.coll is not None:
+            self.gan.set_comm(self.coll, sync_bn=bool(o.get("sync_bn", False)), overlap=1)
+
+    def _sync_fused_config(self, which):
+        """OPT / OPTSTATE are plain Lua tables the caller may edit between steps (train.lua:180-191): push them down."""
+        w = 0 if which == "D" else 1
+        o = self.opt
+        self.gan.set_penalty(w, o[which + "_L1"], o[which + "_L2"], o[which + "_clamp"])
+        method = o[which + "_optmethod"]
+        self.gan.set_optimizer(w, method, self.optstate[method][which])
+
+    def _publish_optstate(self, which):
+        """Mirror the optimizer state held by the step object into OPTSTATE.<method>.<net> (t / m / v ...)."""
+        w = 0 if which == "D" else 1
+        method = self.opt[which + "_optmethod"]
+        st = self.optstate[method][which]
+        n = (self.dnD if w == 0 else self.dnG).n_params
+        buf = self.gan.view("OPT_STATE_D" if w == 0 else "OPT_STATE_G")
+        steps = self.gan.steps(w)
+        if method == "adam":
+            if steps > 0:
+                st.update(t=steps, m=buf[:n], v=buf[n:2 * n])
+        elif method == "sgd":
+            st["evalCounter"] = steps
+            if st.get("momentum", 0) != 0 and steps > 0:
+                st["dfdx"] = buf[:n]
+        else:
+            st["evalCounter"] = steps
+            if steps > 0:
+                st["paramVariance"] = buf[:n]
 
     # -- helpers -----------------------------------------------------------------------------
     def _targets_for(self, B, kind):
@@ -102,7 +156,10 @@ class Trainer:
     # -- the two closures ----------------------------------------------------------------------
     def step_D(self, real_nhwc, noise_half, masks=None, keep_grad=False, gate=None):
         """adversarial.lua:240-268 + fevalD (:83-179).  real_nhwc: device [B/2,H,W,C]; noise_half: [B/2,noiseDim].
-        gate(accuracy)->bool reproduces the maxAccuracyD interrupt (host sync only when a gate is given)."""
+        gate(accuracy)->bool reproduces the maxAccuracyD interrupt (host sync only when a gate is given).
+        noise_half = None: the library draws the noise (and the dropout masks, when masks is None) in one launch."""
+        if self.gan is not None:
+            return self._step_D_fused(real_nhwc, noise_half, masks, keep_grad, gate)
         self.finish_pending()
         half = real_nhwc.shape[0]
         B = 2 * half
@@ -147,8 +204,70 @@ class Trainer:
         res["trained"] = do_train
         return res
 
+    def _grad_view(self, which, p, g):
+        """feval's return value: the penalised + clamped gradient (adversarial.lua:103-123 / 218-228) -- parity / debug."""
+        o = self.opt
+        g = g.clone()
+        if o[which + "_L1"] != 0 or o[which + "_L2"] != 0:
+            g += torch.sign(p) * (o["D_L1"] if which == "D" else o["G_L2"]) + p * o[which + "_L2"]     # quirk C4 for G
+        if o[which + "_clamp"] != 0:
+            g.clamp_(-o[which + "_clamp"], o[which + "_clamp"])
+        return g
+
+    def _step_D_fused(self, real_nhwc, noise_half, masks, keep_grad, gate, cond_real=None, cond_fake=None):
+        gan = self.gan
+        half = real_nhwc.shape[0]
+        B = 2 * half
+        self._sync_fused_config("D")
+        hold = keep_grad or gate is not None
+        gan.step_D(B, real_nhwc, cond_real, cond_fake, noise_half, masks, gan.NO_UPDATE if hold else 0)
+        conf = gan.view("CONFUSION").view(torch.int32)
+        res = dict(loss=gan.view("LOSS")[0:1], outputs=gan.view("D_OUTPUT", B).view(B, 1), confusion=conf[:4],
+                   inputs=gan.view("D_INPUT", B * real_nhwc[0].numel()).view((B,) + tuple(real_nhwc.shape[1:])))
+        if noise_half is None:
+            res["noise"] = gan.view("NOISE", half * (self.dnG.in_c if not self.table_inputs else self.dnG.in_h * self.dnG.in_w))
+        if masks is None and gan.n_masks:
+            res["masks"] = [gan.mask_view(i, B) for i in range(gan.n_masks)]
+        pD, gD = self.dnD.params, self.dnD.grads
+        if keep_grad:
+            res["grad"] = self._grad_view("D", pD, gD)
+            res["f"] = res["loss"].item() + self.penalty_f("D", pD)
+        do_train = True
+        if gate is not None:
+            c = conf[4:8].tolist()                    # counts of the GLOBAL batch: every rank takes the same branch
+            do_train = gate((c[0] + c[3]) / max(1, sum(c)))
+        if hold and do_train:
+            gan.update(0)
+        res["trained"] = do_train
+        self._publish_optstate("D")
+        return res
+
+    def _step_G_fused(self, noise, masks, keep_grad, cond=None, B=None):
+        gan = self.gan
+        B = noise.shape[0] if B is None else B
+        self._sync_fused_config("G")
+        gan.step_G(B, cond, noise, masks, gan.NO_UPDATE if keep_grad else 0)
+        dn = self.dnD
+        res = dict(loss=gan.view("LOSS")[1:2], outputs=gan.view("D_OUTPUT", B).view(B, 1),
+                   samples=gan.view("D_INPUT", B * dn.in_c * dn.in_h * dn.in_w).view(B, dn.in_h, dn.in_w, dn.in_c))
+        if noise is None:
+            res["noise"] = gan.view("NOISE", B * (self.dnG.in_c if not self.table_inputs else self.dnG.in_h * self.dnG.in_w))
+        if masks is None and gan.n_masks:
+            res["masks"] = [gan.mask_view(i, B) for i in range(gan.n_masks)]
+        if keep_grad:
+            pG, gG = self.dnG.params, self.dnG.grads
+            res["grad"] = self._grad_view("G", pG, gG)
+            res["f"] = res["loss"].item() + self.penalty_f("G", pG)
+            gan.update(1)
+        self._publish_optstate("G")
+        self._publish_optstate("D")        # a deferred D update lands inside the G-step
+        return res
+
     def finish_pending(self):
         """Complete a deferred D update (wait for its all-reduce, fused Adam, re-pack)."""
+        if self.gan is not None:
+            self.gan.finish_pending()
+            return
         if self._pending_D is not None:
             (loss,) = self._pending_D
             self._pending_D = None
@@ -157,7 +276,11 @@ class Trainer:
             self.dnD.params_changed()
 
     def step_G(self, noise, masks=None, keep_grad=False):
-        """adversarial.lua:275-288 + fevalG_on_D (:187-231)."""
+        """adversarial.lua:275-288 + fevalG_on_D (:187-231).  `noise` may be an int B: the library draws the noise."""
+        if self.gan is not None:
+            if isinstance(noise, int):
+                return self._step_G_fused(None, masks, keep_grad, B=noise)
+            return self._step_G_fused(noise, masks, keep_grad)
         B = noise.shape[0]
         samples = self.dnG.forward(noise, train=True)
         self.finish_pending()                                     # D's update must land before D is evaluated
@@ -206,11 +329,9 @@ class Trainer:
         B = 2 * real_nhwc.shape[0]
         nd = self.dnG.in_c
         for _ in range(D_iterations):
-            nz = S.next_noise(self.ctx, B // 2, nd)
-            self.step_D(real_nhwc, nz)
+            self.step_D(real_nhwc, None if self.gan is not None else S.next_noise(self.ctx, B // 2, nd))
         for _ in range(G_iterations):
-            nz = S.next_noise(self.ctx, B, nd)
-            self.step_G(nz)
+            self.step_G(B if self.gan is not None else S.next_noise(self.ctx, B, nd))
 
 
 def mean(t):
@@ -260,16 +381,15 @@ def train(dataset, maxAccuracyD=1.01, accsInterval=20):
             idx = [S.rng.randrange(dataset.size()) for _ in range(half)]            # math.random picks (:245)
             real = torch.stack([torch.as_tensor(dataset[i], dtype=torch.float32) for i in idx])
             real_d = ctx.to_device_nhwc(real)
-            nz = S.next_noise(ctx, half, OPT["noiseDim"])
+            nz = None if tr.gan is not None else S.next_noise(ctx, half, OPT["noiseDim"])   # fused: drawn inside the step
             r = tr.step_D(real_d, nz, gate=gate if use_gate else None)
-            pending.append(r["confusion"])
+            pending.append(r["confusion"].clone())
             if r["trained"]:
                 countTrainedD += 1
             else:
                 countNotTrainedD += 1
         for _ in range(OPT.get("G_iterations", 1)):
-            nz = S.next_noise(ctx, thisBatchSize, OPT["noiseDim"])
-            tr.step_G(nz)
+            tr.step_G(thisBatchSize if tr.gan is not None else S.next_noise(ctx, thisBatchSize, OPT["noiseDim"]))
     for c in pending:                      # deferred: one host read at the end of the epoch
         ch = c.cpu().to(torch.int64)
         conf_total += ch

@@ -10,6 +10,8 @@ from .state import S
 
 
 class TrainerC2F(Trainer):
+    table_inputs = 1
+
     def __init__(self, ctx, model_G, model_D, opt, dist=None):
         o = dict(D_L1=1e-7, D_L2=0.0, G_L1=0.0, G_L2=0.0, D_clamp=1.0, G_clamp=5.0)   # train_c2f.lua:27-34
         o.update(opt)
@@ -17,6 +19,8 @@ class TrainerC2F(Trainer):
 
     def step_D(self, diff_real, cond_real, noise_half, cond_fake, masks=None, keep_grad=False):
         """adversarial_c2f.lua:123-160 + fevalD (:40-80).  All inputs device NHWC; *_real/*_fake have B/2 rows."""
+        if self.gan is not None:
+            return self._step_D_fused(diff_real, noise_half, masks, keep_grad, None, cond_real=cond_real, cond_fake=cond_fake)
         self.finish_pending()
         half = diff_real.shape[0]
         B = 2 * half
@@ -48,6 +52,8 @@ class TrainerC2F(Trainer):
 
     def step_G(self, noise, cond, masks=None, keep_grad=False):
         """adversarial_c2f.lua:166-187 + fevalG_on_D (:83-119)."""
+        if self.gan is not None:
+            return self._step_G_fused(noise, masks, keep_grad, cond=cond, B=cond.shape[0])
         B = noise.shape[0]
         ctx = self.ctx
         samples = self.dnG.forward(self.G.combine_device(ctx, noise, cond), train=True)
@@ -106,7 +112,7 @@ def train(trainData):
             cond_r = ctx.to_device_nhwc(torch.stack([torch.as_tensor(trainData[i].coarse, dtype=torch.float32) for i in idx]))
             _, cond_f = pick(half, "coarse")                                  # new random conds for the fake half (C13)
             nz = S.next_noise(ctx, half, h * w).view(half, h, w, 1)
-            pending.append(tr.step_D(diff, cond_r, nz, cond_f)["confusion"])
+            pending.append(tr.step_D(diff, cond_r, nz, cond_f)["confusion"].clone())
         for _ in range(OPT.get("G_iterations", 1)):
             _, cond = pick(thisBatchSize, "coarse")
             nz = S.next_noise(ctx, thisBatchSize, h * w).view(thisBatchSize, h, w, 1)

@@ -595,6 +595,10 @@ long long fg_net_mask_elems(const fg_net* n, int mi, int batch) {
     const Stage& s = n->st[n->mask_stage[mi]];
     return s.mask_kind == 1 ? (long long)batch * s.ic : (long long)batch * s.ic * s.ih * s.iw;
 }
+float fg_net_mask_keep(const fg_net* n, int mi) {
+    if (!n || mi < 0 || mi >= n->n_masks) return -1.f;
+    return 1.f - n->st[n->mask_stage[mi]].p;
+}
 int fg_net_out_dims(const fg_net* n, int* c, int* h, int* w) {
     if (!n) return FG_ERR_INVALID;
     const Stage& s = n->st.back();

@@ -396,3 +396,118 @@ class CompositeDeviceNet:
         gx = torch.empty_like(gx0)
         self.ctx.check(self.lib.fg_add(self.ctx.h, gx0.data_ptr(), gx1.data_ptr(), gx.data_ptr(), gx.numel()))
         return gx
+
+
+class FusedGan:
+    """fg_gan (include/facegen_hip.h, step level): one C call per closure of adversarial.lua / adversarial_c2f.lua.  The step
+    workspace is a torch tensor owned here; results are views into it (valid until the next closure of the same kind)."""
+    BUF = dict(D_INPUT=0, NOISE=1, D_GRAD_INPUT=2, LOSS=3, CONFUSION=4, OPT_STATE_D=5, OPT_STATE_G=6, D_OUTPUT=7, D_MASKS=8)
+    NO_UPDATE = 1
+
+    def __init__(self, ctx, dnG, dnD, table_inputs, max_batch):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.dnG, self.dnD = dnG, dnD
+        self.table = 1 if table_inputs else 0
+        self.max_batch = int(max_batch)
+        dnG.reserve(self.max_batch)
+        dnD.reserve(self.max_batch)
+        nbytes = self.lib.fg_gan_workspace_bytes(dnG.h, dnD.h, self.table, self.max_batch)
+        self.ws = torch.empty((nbytes + 3) // 4 + 64, dtype=torch.float32, device=ctx.device)
+        base = self.ws.data_ptr()
+        self._skip = ((-base) % 256) // 4                       # 256-byte aligned start inside the tensor
+        h = ctypes.c_void_p()
+        ctx.check(self.lib.fg_gan_create(ctx.h, dnG.h, dnD.h, self.table, self.max_batch, base + 4 * self._skip,
+                                         nbytes, ctypes.byref(h)))
+        self.h = h
+        self._bound = None
+        self.n_masks = dnD.n_masks
+
+    def __del__(self):
+        try:
+            self.lib.fg_gan_destroy(self.h)
+        except Exception:
+            pass
+
+    def _bind(self):
+        key = (self.dnG.ws.data_ptr(), self.dnG.ws.numel(), self.dnD.ws.data_ptr(), self.dnD.ws.numel())
+        if key != self._bound:
+            self.ctx.check(self.lib.fg_gan_bind_workspaces(self.h, key[0], key[1] * 4, key[2], key[3] * 4))
+            self._bound = key
+
+    def view(self, what, n=None):
+        off, cnt = ctypes.c_longlong(), ctypes.c_longlong()
+        self.ctx.check(self.lib.fg_gan_buffer(self.h, self.BUF[what], ctypes.byref(off), ctypes.byref(cnt)))
+        n = cnt.value if n is None else n
+        if what == "D_OUTPUT":                                   # lives in D's own workspace
+            return self.dnD.ws[off.value: off.value + n]
+        o = self._skip + off.value
+        return self.ws[o: o + n]
+
+    def mask_view(self, i, batch):
+        off = self.lib.fg_gan_mask_offset(self.h, i)
+        n = self.lib.fg_net_mask_elems(self.dnD.h, i, batch)
+        return self.ws[self._skip + off: self._skip + off + n]
+
+    def set_comm(self, coll, sync_bn=False, overlap=1):
+        self.ctx.check(self.lib.fg_gan_set_comm(self.h, coll.h if coll is not None else None, 1 if sync_bn else 0, int(overlap)))
+
+    def set_seeds(self, noise_seed, noise_offset, mask_seed, mask_offset):
+        self.ctx.check(self.lib.fg_gan_set_seeds(self.h, noise_seed, noise_offset, mask_seed, mask_offset))
+
+    def set_penalty(self, which, l1, l2, clamp):
+        self.ctx.check(self.lib.fg_gan_set_penalty(self.h, which, l1, l2, clamp))
+
+    def set_optimizer(self, which, method, cfg):
+        m = dict(adam=0, sgd=1, adagrad=2)[method]
+        mom = cfg.get("momentum", 0)
+        self.ctx.check(self.lib.fg_gan_set_optimizer(
+            self.h, which, m, cfg.get("learningRate", -1.0), cfg.get("beta1", 0.9), cfg.get("beta2", 0.999),
+            cfg.get("epsilon", 1e-8), mom, cfg.get("dampening", -1.0), cfg.get("weightDecay", 0.0),
+            cfg.get("learningRateDecay", 0.0), 1 if cfg.get("nesterov", False) else 0))
+
+    def steps(self, which):
+        return self.lib.fg_gan_optimizer_steps(self.h, which)
+
+    def pending(self):
+        return bool(self.lib.fg_gan_pending(self.h))
+
+    def finish_pending(self):
+        self.ctx.check(self.lib.fg_gan_finish_pending(self.h))
+
+    def update(self, which):
+        self.ctx.check(self.lib.fg_gan_update(self.h, which))
+
+    def _mask_array(self, masks):
+        if masks is None:
+            return None, None
+        if len(masks) != self.n_masks:
+            raise FgError("step: %d dropout masks given, D has %d dropout layers" % (len(masks), self.n_masks))
+        keep = [m.contiguous() for m in masks]
+        return (ctypes.c_void_p * self.n_masks)(*[m.data_ptr() for m in keep]), keep
+
+    @staticmethod
+    def _p(t):
+        return t.data_ptr() if t is not None else None
+
+    def step_D(self, B, real, cond_real=None, cond_fake=None, noise=None, masks=None, flags=0):
+        if B > self.max_batch:
+            raise FgError("step_D: batch %d exceeds the %d the step object was built for" % (B, self.max_batch))
+        self._bind()
+        mp, keep = self._mask_array(masks)
+        args = [t.contiguous() if t is not None else None for t in (real, cond_real, cond_fake, noise)]
+        self.ctx.check(self.lib.fg_step_D(self.h, B, self._p(args[0]), self._p(args[1]), self._p(args[2]), self._p(args[3]),
+                                          mp, flags))
+        self._after(B, B // 2)
+
+    def step_G(self, B, cond=None, noise=None, masks=None, flags=0):
+        if B > self.max_batch:
+            raise FgError("step_G: batch %d exceeds the %d the step object was built for" % (B, self.max_batch))
+        self._bind()
+        mp, keep = self._mask_array(masks)
+        args = [t.contiguous() if t is not None else None for t in (cond, noise)]
+        self.ctx.check(self.lib.fg_step_G(self.h, B, self._p(args[0]), self._p(args[1]), mp, flags))
+        self._after(B, B)
+
+    def _after(self, B, Bg):
+        # keep the DeviceNets' own bookkeeping in step (layer_output / a later stand-alone backward read it)
+        self.dnD._batch, self.dnG._batch = B, Bg

@@ -28,6 +28,7 @@ extern "C" {
 typedef struct fg_ctx fg_ctx;
 typedef struct fg_net fg_net;
 typedef struct fg_comm fg_comm;
+typedef struct fg_gan fg_gan;
 
 enum {
     FG_OK = 0,
@@ -103,6 +104,7 @@ long long fg_net_num_params(const fg_net* net);   /* length of the flat paramete
 long long fg_net_num_buffers(const fg_net* net);  /* BN running_mean||running_var per BN layer, module order */
 int fg_net_num_masks(const fg_net* net);          /* dropout layers, module order */
 long long fg_net_mask_elems(const fg_net* net, int mask_index, int batch);
+float fg_net_mask_keep(const fg_net* net, int mask_index);   /* Bernoulli keep probability 1 - p of that dropout layer */
 int fg_net_out_dims(const fg_net* net, int* c, int* h, int* w);
 size_t fg_net_workspace_bytes(const fg_net* net, int max_batch);
 /* offsets (in floats) of layer `layer_index`'s weight / bias inside the flat vector; -1 if it has none */
@@ -191,6 +193,62 @@ int fg_comm_wait(fg_comm* comm);
 int fg_allreduce_sum_f64(fg_comm* comm, double* buf, size_t n);   /* sync-BN sums */
 int fg_allreduce_sum_i32(fg_comm* comm, int* buf, size_t n);      /* confusion counts of the global batch */
 int fg_broadcast(fg_comm* comm, float* buf, size_t n, int root);  /* identical initial replicas */
+
+/* ---- step level (SURVEY.md 8(b) level (ii)): the two closures of the training loop as device-resident entries.
+ *      fg_step_D = adversarial.lua:240-268 (batch assembly: B/2 real || B/2 fakes from G in TRAIN mode) + fevalD (:83-179:
+ *                  D forward, BCECriterion, D backward, confusion counts) + penalty / clamp (:103-123) + the optimizer
+ *                  (interruptable_optimizers.lua) on D's flat vectors;
+ *      fg_step_G = adversarial.lua:275-288 + fevalG_on_D (:187-231): G forward on B noises, D forward, BCE against all
+ *                  ones, D backward to its input only (MODEL_D.modules[1].gradInput, :210), G backward, optimizer on G.
+ *      table_inputs = 1: adversarial_c2f.lua:40-187 -- G{noise[B,S,S,1], cond[B,S,S,C]} (JoinTable) -> diff image,
+ *                  D{x, cond} (CAddTable); cond_* are device NHWC.
+ *      The nets are fg_net objects bound to their flat vectors (fg_net_bind); their workspaces are the caller's
+ *      (fg_gan_bind_workspaces: fg_net_workspace_bytes(net, max_batch) each) plus one workspace of the step object itself.
+ *      noise / masks == NULL: drawn by the library, all of a closure in one Philox launch (fg_gan_set_seeds); otherwise
+ *      noise = device [rows][noiseDim] (table mode [rows][S][S][1]), masks = fg_net_num_masks(D) device pointers.
+ *      FG_STEP_NO_UPDATE: stop before the optimizer (gradients stay in the bound gradient vector, un-reduced);
+ *      fg_gan_update applies it later -- the maxAccuracyD gate of adversarial.lua:124-178 reads the confusion counts in
+ *      between (FG_GAN_CONFUSION: int[0..3] this rank, int[4..7] the global batch, both [pred*2 + target]); never calling
+ *      fg_gan_update IS interruptableAdam's false,false path.
+ *      fg_gan_set_comm: data parallelism -- gradients are sum-all-reduced over the communicator, scaled by 1/world inside
+ *      the optimizer pass, clamp after the reduce; D's exchange overlaps the next generator forward (its update is deferred
+ *      until D is next evaluated or fg_gan_finish_pending), G's is bucketed under its own backward; sync_bn = exact
+ *      global-batch BatchNorm statistics (fp64 sums reduced at every BatchNorm).  overlap: 0 = blocking exchange, 1 =
+ *      overlapped, 2 = overlapped even on a one-rank communicator (exercises the N > 1 path on one GPU). ---- */
+enum { FG_STEP_NO_UPDATE = 1 };
+enum fg_gan_buffer_id {
+    FG_GAN_D_INPUT = 0,       /* D's batch, NHWC [B][H][W][C]: real || fake (D-step), G's samples (G-step)            */
+    FG_GAN_NOISE = 1,         /* the noise the last closure used when the library drew it                              */
+    FG_GAN_D_GRAD_INPUT = 2,  /* G-step: d loss / d samples                                                           */
+    FG_GAN_LOSS = 3,          /* float[2]: BCE of the last D-step, of the last G-step                                  */
+    FG_GAN_CONFUSION = 4,     /* int[8] (same storage as floats): local counts, global counts                         */
+    FG_GAN_OPT_STATE_D = 5,   /* 2 * nparams(D): Adam m | v   (SGD: momentum buffer; Adagrad: variance)                */
+    FG_GAN_OPT_STATE_G = 6,
+    FG_GAN_D_OUTPUT = 7,      /* D's probabilities [B] of the last closure; offset relative to D's OWN workspace       */
+    FG_GAN_D_MASKS = 8        /* dropout masks the library drew (fg_gan_mask_offset per mask)                          */
+};
+size_t fg_gan_workspace_bytes(const fg_net* G, const fg_net* D, int table_inputs, int max_batch);
+int fg_gan_create(fg_ctx* ctx, fg_net* G, fg_net* D, int table_inputs, int max_batch, void* ws, size_t ws_bytes,
+                  fg_gan** out);
+int fg_gan_destroy(fg_gan* gan);
+int fg_gan_bind_workspaces(fg_gan* gan, void* wsG, size_t wsG_bytes, void* wsD, size_t wsD_bytes);
+int fg_gan_set_comm(fg_gan* gan, fg_comm* comm, int sync_bn, int overlap);
+int fg_gan_set_seeds(fg_gan* gan, uint64_t noise_seed, uint64_t noise_offset, uint64_t mask_seed, uint64_t mask_offset);
+int fg_gan_set_penalty(fg_gan* gan, int which, float l1, float l2, float clamp);             /* which: 0 = D, 1 = G */
+/* method 0 adam / 1 sgd / 2 adagrad (OPT.*_optmethod); lr < 0: the rule's default (1e-3); dampening < 0: = momentum */
+int fg_gan_set_optimizer(fg_gan* gan, int which, int method, double lr, double beta1, double beta2, double eps,
+                         double momentum, double dampening, double weight_decay, double lr_decay, int nesterov);
+int fg_gan_optimizer_steps(const fg_gan* gan, int which);          /* Adam's t / optim.sgd's evalCounter */
+int fg_gan_set_optimizer_steps(fg_gan* gan, int which, int steps);
+/* offset (in floats, relative to the step workspace unless noted) and length of a result / state buffer */
+int fg_gan_buffer(const fg_gan* gan, int what, long long* offset_floats, long long* count);
+long long fg_gan_mask_offset(const fg_gan* gan, int mask_index);
+int fg_step_D(fg_gan* gan, int batch, const float* real, const float* cond_real, const float* cond_fake,
+              const float* noise, const float* const* masks, int flags);
+int fg_step_G(fg_gan* gan, int batch, const float* cond, const float* noise, const float* const* masks, int flags);
+int fg_gan_update(fg_gan* gan, int which);
+int fg_gan_finish_pending(fg_gan* gan);
+int fg_gan_pending(const fg_gan* gan);   /* 1 while D's update is deferred behind its gradient all-reduce */
 
 /* ---- adversarial.approxParzen (adversarial_c2f.lua:305-344): dist[i] = || (gen[i] + cond) - fine ||_2 for the n
  *      generations of one example (torch.dist: squares accumulated in double), min_out[0] = min(1e10, min_i dist[i]).

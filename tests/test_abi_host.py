@@ -23,7 +23,7 @@ def lib():
 def test_header_symbols_all_exported(lib):
     from face_generator_amd import _lib
     decls = _lib.parse_header()
-    names = set(re.findall(r"\b(fg_[a-z0-9_]+)\s*\(", open(_lib.HEADER).read()))
+    names = set(re.findall(r"\b(fg_[A-Za-z0-9_]+)\s*\(", open(_lib.HEADER).read()))
     names -= {"fg_layer_spec", "fg_layer_type"}
     assert names == set(decls), names ^ set(decls)       # the ctypes binding covers the whole header
     assert len(decls) >= 60

@@ -35,13 +35,21 @@ def test_trainer_with_rccl_world1_matches_plain_trainer():
             D.device_net.mask_seed = 5
             tr = adversarial.Trainer(ctx, G, D, dict(batchSize=8), dist=(dist if use_dist is True else use_dist) or None)
             real = ctx.uniform((4, 32, 32, 3), 0.0, 1.0, seed=9)
-            if use_dist:             # force the N > 1 code path (async all-reduce + deferred D update) on one rank:
+            if use_dist is True:     # force the N > 1 code path (async all-reduce + deferred D update) on one rank:
+                assert tr.gan is None            # torch.distributed carrier -> host-driven closures
                 tr.world, tr.gscale = 2, 1.0     # a 1-rank sum all-reduce is the identity, so keep the scale at 1
-            tr.step_D(real, ctx.uniform((4, 100), -1.0, 1.0, seed=10))
-            assert (tr._pending_D is not None) == bool(use_dist)
-            tr.step_G(ctx.uniform((8, 100), -1.0, 1.0, seed=11))
-            assert tr._pending_D is None
-            if use_dist:    # bucketed, backward-overlapped all-reduce of G: >= 2 buckets covering the whole flat vector
+            elif use_dist is fgc:    # the same inside fg_step_D / fg_step_G: overlap = 2 takes the exchange path on one rank
+                assert tr.gan is not None
+                tr.gan.set_comm(fgc, overlap=2)
+            pending = (lambda: tr.gan.pending()) if tr.gan is not None else (lambda: tr._pending_D is not None)
+            # explicit masks: the fused closure and the host-driven one draw their own masks from different Philox layouts
+            mk = lambda s0: [ctx.bernoulli((8 * c,), 0.8, s0, i * 100000) for i, c in enumerate((64, 128, 256, 512))] + \
+                            [ctx.bernoulli((8 * 512,), 0.5, s0 + 1, i * 100000) for i in range(2)]
+            tr.step_D(real, ctx.uniform((4, 100), -1.0, 1.0, seed=10), mk(20))
+            assert pending() == bool(use_dist)
+            tr.step_G(ctx.uniform((8, 100), -1.0, 1.0, seed=11), mk(30))
+            assert not pending()
+            if use_dist is True:    # bucketed, backward-overlapped all-reduce of G: >= 2 buckets covering the whole flat vector
                 bk = tr._buckets_G()
                 assert len(bk) >= 2 and bk[0][0] == G.device_net.lib.fg_net_num_stages(G.device_net.h) - 1 and bk[-1][1] == 0
                 assert sorted((lo, hi) for (_, _, lo, hi) in bk)[0][0] == 0

@@ -73,24 +73,34 @@ class Recorder:
                                  v=a["v"].cpu().numpy().copy() if "v" in a else None)
         return st
 
+    @staticmethod
+    def _np(a):
+        return a.cpu().numpy().copy() if torch.is_tensor(a) else a
+
+    def _finish(self, rec, r, n0):
+        """noise / masks of the step: explicit arguments, or what the library drew inside the fused closure."""
+        if r.get("masks") is not None:
+            rec["masks"] = [m.cpu().numpy().copy() for m in r["masks"]]
+        else:
+            rec["masks"] = [m.cpu().numpy() for m in self._mask_log[n0]] if len(self._mask_log) > n0 else None
+        rec["noise"] = r["noise"].cpu().numpy().copy() if r.get("noise") is not None else None
+        rec.update(out=r["outputs"].cpu().numpy().reshape(-1).copy(), loss=float(r["loss"].item()))
+        self.steps.append(rec)
+
     def step_D(self, *args, **kw):
-        rec = dict(kind="D", state=self._state(), args=[a.cpu().numpy().copy() for a in args])
+        rec = dict(kind="D", state=self._state(), args=[self._np(a) for a in args])
         n0 = len(self._mask_log)
         r = self._sd(*args, **kw)
-        rec["masks"] = [m.cpu().numpy() for m in self._mask_log[n0]] if len(self._mask_log) > n0 else None
-        rec.update(out=r["outputs"].cpu().numpy().reshape(-1).copy(), loss=float(r["loss"].item()),
-                   conf=r["confusion"].cpu().numpy().reshape(2, 2).copy(), trained=r["trained"])
-        self.steps.append(rec)
+        rec.update(conf=r["confusion"].cpu().numpy().reshape(2, 2).copy(), trained=r["trained"])
+        self._finish(rec, r, n0)
         return r
 
     def step_G(self, *args, **kw):
-        rec = dict(kind="G", state=self._state(), args=[a.cpu().numpy().copy() for a in args])
+        rec = dict(kind="G", state=self._state(), args=[self._np(a) for a in args])
         n0 = len(self._mask_log)
         r = self._sg(*args, **kw)
-        rec["masks"] = [m.cpu().numpy() for m in self._mask_log[n0]] if len(self._mask_log) > n0 else None
-        rec.update(out=r["outputs"].cpu().numpy().reshape(-1).copy(), loss=float(r["loss"].item()),
-                   samples=nchw(r["samples"]).copy())
-        self.steps.append(rec)
+        rec["samples"] = nchw(r["samples"]).copy()
+        self._finish(rec, r, n0)
         return r
 
 
@@ -155,7 +165,8 @@ def test_adversarial_train_epoch_config1_gray_batch16(ctx, tmp_path):
             cursor["k"] = k
 
         # noise / masks in consumption order
-        noise_q = [s["args"][1] if s["kind"] == "D" else s["args"][0] for s in steps]
+        noise_q = [(s["noise"] if s["noise"] is not None else (s["args"][1] if s["kind"] == "D" else s["args"][0])).reshape(-1, 100)
+                   for s in steps]
         mask_q = [s["masks"] for s in steps]
         real_q = [s["args"][0] for s in steps if s["kind"] == "D"]
         qi = dict(n=0, m=0)
