@@ -222,8 +222,7 @@ class Trainer:
         hold = keep_grad or gate is not None
         gan.step_D(B, real_nhwc, cond_real, cond_fake, noise_half, masks, gan.NO_UPDATE if hold else 0)
         conf = gan.view("CONFUSION").view(torch.int32)
-        res = dict(loss=gan.view("LOSS")[0:1], outputs=gan.view("D_OUTPUT", B).view(B, 1), confusion=conf[:4],
-                   inputs=gan.view("D_INPUT", B * real_nhwc[0].numel()).view((B,) + tuple(real_nhwc.shape[1:])))
+        res = dict(loss=gan.view("LOSS")[0:1], outputs=gan.view("D_OUTPUT", B).view(B, 1), confusion=conf[:4])
         if noise_half is None:
             res["noise"] = gan.view("NOISE", half * (self.dnG.in_c if not self.table_inputs else self.dnG.in_h * self.dnG.in_w))
         if masks is None and gan.n_masks:

@@ -153,7 +153,7 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
     }
     int wt, S, mper, Np, Cp;
     choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
-    long long n3 = (long long)wm.P * wm.G * S * Np * Cp;
+    long long n3 = (long long)wm.P * wm.G * S * Np * Cp + (long long)wm.P * S * g.Cout;   // partials + bias-gradient partials
     if (math == 6) {
         int S6, mper6;
         if (M >= 1024 && choose_wgrad6(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) >= 0)
@@ -373,9 +373,23 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         choose_wgrad(a.M, g.Cout, g.Cin, wm.G, wm.P, &tile, &a.S, &a.m_per_split, &a.Npad, &a.Cpad);
         const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;
         if (need > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad: scratch %lld > %lld", need, scratch_floats);
+        // bias gradient = column sums of gy over all output pixels: the contraction kernel leaves them per (parity, split)
+        const int nrb = wm.P * a.S;
+        const long long nb = (long long)nrb * g.Cout;
+        bool deferred = false;
+        if (gradb) {
+            float* dp = fg_defer_alloc(ctx, nb);          // inside fg_net backward: final batched at the end
+            if (dp) { a.bias_part = dp; deferred = true; }
+            else if (need + nb <= scratch_floats) a.bias_part = scratch + need;
+        }
         if ((rc = fg_launch_wgrad(ctx, a, wm.P, tile))) return rc;
+        if ((rc = fg_launch_wgrad_finish(ctx, wm, scratch, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
+        if (gradb && a.bias_part) {
+            if (deferred) { fg_defer_push(ctx, a.bias_part, nrb, g.Cout, beta, gradb); return FG_OK; }
+            return fg_launch_colsum_final(ctx, a.bias_part, nrb, g.Cout, beta, gradb);
+        }
     }
-    if ((rc = fg_launch_wgrad_finish(ctx, wm, scratch, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
+    if (cfg6 >= 0 && (rc = fg_launch_wgrad_finish(ctx, wm, scratch, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
     if (gradb) {
         // bias grad = column sums of gy over all output pixels
         const long long rows = (long long)a.M * (g.fold ? 4 : 1);

@@ -101,6 +101,7 @@ struct WgradArgs {
     const float* dY;     // NHWC [Nb][Hd][Wd][Nd]
     const float* X;      // NHWC [Nb][Hx][Wx][Cx]
     float* Part;         // [P*G][S][Npad][Cpad]
+    float* bias_part;    // optional [P][S][Nd]: per-channel sums of dY over each (parity, split) -- the bias gradient's partials
     const void* D6;      // bf16x6 mode: dY / X as split planes [pixel][C/16][3][16] bf16 (nullptr = fp32 path)
     const void* X6;
     int Nb, Hm, Wm, M, lgH, lgW;
@@ -212,8 +213,11 @@ int fg_launch_mul_mask(fg_ctx*, const float* x, const float* mask, float scale, 
 int fg_launch_concat(fg_ctx*, const float* a, const float* b, float* out, long long npix, int ca, int cb);
 int fg_launch_split(fg_ctx*, const float* g, float* ga, float* gb, long long npix, int ca, int cb);
 int fg_launch_add(fg_ctx*, const float* a, const float* b, float* out, long long n);
+int fg_launch_copy(fg_ctx*, const float* src, float* dst, long long n);
+int fg_launch_add_halves(fg_ctx*, const float* a0, const float* b0, const float* a1, const float* b1, float* out, long long nh);
 // deferred finals: partial buffer of `floats` floats (nullptr = not deferring / arena full -> caller uses its scratch and an
 // immediate final); registration of one final job; flush = run all registered jobs in one launch
+int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);   // out[c] = beta*out[c] + sum_r part[r][c]
 float* fg_defer_alloc(fg_ctx* ctx, long long floats);
 void fg_defer_push(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);
 int fg_defer_flush(fg_ctx* ctx);

@@ -804,6 +804,8 @@ __device__ __forceinline__ void fg_wgrad_block(int& tile, int& s, int& pg) {
     tile = r - pg * gx;
 }
 
+// Bias gradient: the blocks with tc == 0, g == 0 see every dY pixel of their split exactly once and also leave its
+// per-channel sums in `bias_part` [P][S][Nd] (no separate column-sum pass over dY).
 template <int BT>  // square tile BT x BT (rows = dY channels, cols = X channels)
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     constexpr int BK = 32;
@@ -833,6 +835,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const bool okD = chD < a.Nd, okX = chX < a.Cx;
     const int doy = a.doy[p], dox = a.dox[p], xoy = a.xoy[p][g], xox = a.xox[p][g];
 
+    const bool want_bias = a.bias_part != nullptr && tc == 0 && g == 0;   // block-uniform
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     f32x4 rd[R], rx[R];
     int mcur = m0;
     // Fast path (all hot-path shapes): Hm, Wm powers of two and a 32-pixel K-step never straddles two samples.  Then a
@@ -890,6 +894,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #define FG_WSTORE(buf)                                                                                      \
     {                                                                                                       \
         _Pragma("unroll") for (int i = 0; i < R; ++i) {                                                     \
+            if (want_bias) bsum += rd[i];                                                                   \
             *(f32x4*)(Ds + (buf) * BK * BT + (lpix + PSTEP * i) * BT + lc) = rd[i];                         \
             *(f32x4*)(Xs + (buf) * BK * BT + (lpix + PSTEP * i) * BT + lc) = rx[i];                         \
         }                                                                                                   \
@@ -957,6 +962,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                 part[(size_t)row * a.Cpad + col] = acc[mi][ni][r];
             }
         }
+    if (want_bias) {                                         // per-channel sums of this split's dY pixels
+        float* sh = smem;                                    // [PSTEP pixel rows][BT channels] (the K loop is finished)
+        *(f32x4*)(sh + lpix * BT + lc) = bsum;
+        __syncthreads();
+        if (tid < BT && tn * BT + tid < a.Nd) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < PSTEP; ++q) t += sh[q * BT + tid];             // fixed order: deterministic
+            a.bias_part[((size_t)p * a.S + s) * a.Nd + tn * BT + tid] = t;
+        }
+    }
 }
 
 template <int BT>

@@ -1100,6 +1100,36 @@ int fg_launch_add(fg_ctx* ctx, const float* a, const float* b, float* out, long 
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
+// plain device copy (hipMemcpyAsync's blit kernel took ~0.4 ms for a 3 MB batch half on this stack: a 7 % tax on the c2f step)
+__global__ __launch_bounds__(256) void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    const long long n4 = n >> 2;
+    const bool al = (((size_t)src | (size_t)dst) & 15) == 0;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    if (al) {
+        for (long long i = i0; i < n4; i += step) ((float4*)dst)[i] = ((const float4*)src)[i];
+        for (long long i = (n4 << 2) + i0; i < n; i += step) dst[i] = src[i];
+    } else
+        for (long long i = i0; i < n; i += step) dst[i] = src[i];
+}
+int fg_launch_copy(fg_ctx* ctx, const float* src, float* dst, long long n) {
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(copy_kernel, FG_GRID((n + 3) / 4, 256), dim3(256), 0, ctx->stream, src, dst, n);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+// out = [a0 + b0 | a1 + b1]: nn.CAddTable over a batch assembled from two halves (adversarial_c2f.lua:125-150)
+__global__ __launch_bounds__(256) void add_halves_kernel(const float* __restrict__ a0, const float* __restrict__ b0,
+                                                         const float* __restrict__ a1, const float* __restrict__ b1,
+                                                         float* __restrict__ out, long long nh) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * nh; i += (long long)gridDim.x * blockDim.x)
+        out[i] = i < nh ? a0[i] + b0[i] : a1[i - nh] + b1[i - nh];
+}
+int fg_launch_add_halves(fg_ctx* ctx, const float* a0, const float* b0, const float* a1, const float* b1, float* out, long long nh) {
+    if (nh == 0) return FG_OK;
+    hipLaunchKernelGGL(add_halves_kernel, FG_GRID(2 * nh, 256), dim3(256), 0, ctx->stream, a0, b0, a1, b1, out, nh);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
 
 // stride-2 data gradient helper: out[b][2y][2x][c] = g[b][y][x][c], every other position 0 (out is [B][2H][2W][C])
 __global__ void zero_insert2_kernel(const float* __restrict__ g, float* __restrict__ out, int H, int W, int C4, long long n4) {

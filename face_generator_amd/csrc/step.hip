@@ -239,7 +239,7 @@ struct fg_gan {
     size_t wsG_bytes = 0, wsD_bytes = 0, ws_bytes = 0;
     int gc = 0, gh = 0, gw = 0, ic = 0, ih = 0, iw = 0;
     long long img = 0, gin = 0, nz_elems = 0, nP[2] = {0, 0};      // per-sample sizes; parameter counts [D, G]
-    long long o_dinput = 0, o_ginput = 0, o_noise = 0, o_dcond = 0, o_dsum = 0, o_gx = 0, o_targets = 0, o_dprob = 0,
+    long long o_dinput = 0, o_ginput = 0, o_noise = 0, o_dsum = 0, o_gx = 0, o_targets = 0, o_dprob = 0,
               o_loss = 0, o_conf = 0, o_opt[2] = {0, 0}, o_sync = 0, total = 0;
     std::vector<long long> o_mask[2];  // [D, G] dropout masks
     float l1[2] = {0.f, 0.f}, l2[2] = {1e-4f, 0.f}, clamp[2] = {1.f, 5.f};    // train.lua:29-37
@@ -264,7 +264,6 @@ static void gan_layout(fg_gan* g) {
     g->o_dinput = take(B * g->img);
     g->o_ginput = take(B * g->gin);
     g->o_noise = take(B * g->nz_elems);
-    g->o_dcond = g->table ? take(B * g->img) : 0;
     g->o_dsum = g->table ? take(B * g->img) : 0;
     g->o_gx = take(B * g->img);
     for (int w = 0; w < 2; ++w) {
@@ -575,15 +574,12 @@ int fg_step_D(fg_gan* g, int B, const float* real, const float* cond_real, const
     // C5: the fakes come from G in TRAIN mode (BatchNorm batch statistics over B/2; running statistics move)
     rc = fg_net_forward_to(g->G, h, gin, g->wsG, g->wsG_bytes, 1, nullptr, 0, &off, dinput + (long long)h * g->img);
     if ((rc = gan_drain(g, g->G, rc, true))) return rc;
-    FG_HIP(ctx, hipMemcpyAsync(dinput, real, (size_t)h * g->img * 4, hipMemcpyDeviceToDevice, ctx->stream));
     const float* din = dinput;
-    if (g->table) {                      // nn.CAddTable{x, cond} (models_c2f.lua:240)
-        float* dc = g->ws + g->o_dcond;
-        FG_HIP(ctx, hipMemcpyAsync(dc, cond_real, (size_t)h * g->img * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        FG_HIP(ctx, hipMemcpyAsync(dc + (long long)h * g->img, cond_fake, (size_t)h * g->img * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        if ((rc = fg_launch_add(ctx, dinput, dc, g->ws + g->o_dsum, (long long)B * g->img))) return rc;
+    if (g->table) {                      // nn.CAddTable{x, cond} (models_c2f.lua:240) over [real | fake] x [cond_real | cond_fake]
+        if ((rc = fg_launch_add_halves(ctx, real, cond_real, dinput + (long long)h * g->img, cond_fake, g->ws + g->o_dsum,
+                                       (long long)h * g->img))) return rc;
         din = g->ws + g->o_dsum;
-    }
+    } else if ((rc = fg_launch_copy(ctx, real, dinput, (long long)h * g->img))) return rc;
     if ((rc = gan_targets(g, 0, B))) return rc;
     rc = fg_net_forward(g->D, B, din, g->wsD, g->wsD_bytes, 1, dm.empty() ? nullptr : dm.data(), (int)dm.size(), &off);
     if ((rc = gan_drain(g, g->D, rc, true))) return rc;
@@ -595,7 +591,7 @@ int fg_step_D(fg_gan* g, int B, const float* real, const float* cond_real, const
     if (flags & FG_STEP_NO_UPDATE) {
         // the maxAccuracyD gate (adversarial.lua:124-178) is decided on the host from the confusion counts; with N > 1 it
         // must be the same decision on every rank: conf[4..7] = counts of the GLOBAL batch
-        FG_HIP(ctx, hipMemcpyAsync(conf + 4, conf, 16, hipMemcpyDeviceToDevice, ctx->stream));
+        if ((rc = fg_launch_copy(ctx, (const float*)conf, (float*)(conf + 4), 4))) return rc;
         if (gan_exchange(g) && (rc = fg_allreduce_sum_i32(g->comm, conf + 4, 4))) return rc;
         g->grads_local[0] = 1;
         return FG_OK;
