@@ -1,0 +1,121 @@
+"""The LuaJIT binding (lua/*.lua) cannot be executed here (no Lua in the image).  What can be pinned mechanically is:
+  * its ffi.cdef block is GENERATED from include/facegen_hip.h and up to date (scripts/gen_lua_cdef.py --check);
+  * every `C.fg_*(...)` call names an entry the header declares, with the declared number of arguments;
+  * every `C.FG_*` constant is an enumerator of the header;
+  * every optimizer path tells the net that its parameters moved (the round-1 shim left the packed weights stale);
+  * the shipped patches apply to the reference's own scripts (checked where /root/reference exists)."""
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LUA = sorted(glob.glob(os.path.join(ROOT, "lua", "*.lua")))
+
+
+def strip_lua_comments(src):
+    src = re.sub(r"--\[\[.*?\]\]", "", src, flags=re.S)
+    return re.sub(r"--[^\n]*", "", src)
+
+
+def lua_code(path):
+    """Lua source without comments and without the cdef block."""
+    src = open(path).read()
+    src = re.sub(r"ffi\.cdef\[\[.*?\]\]", "", src, flags=re.S)
+    return strip_lua_comments(src)
+
+
+def call_sites(code, prefix="C.fg_"):
+    """[(name, nargs)] for every `C.fg_xxx(...)` call: arguments counted at parenthesis depth 0."""
+    out = []
+    for m in re.finditer(r"\bC\.(fg_\w+)\s*\(", code):
+        i, depth, nargs, seen = m.end(), 1, 0, False
+        while depth > 0:
+            ch = code[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                nargs += 1
+            if depth > 0 and not ch.isspace():
+                seen = True
+            i += 1
+        out.append((m.group(1), nargs + 1 if seen else 0))
+    return out
+
+
+def test_cdef_block_is_generated_from_the_header():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_lua_cdef.py"), "--check"])
+    assert r.returncode == 0, "lua/facegen_hip.lua: cdef block is stale -- run python scripts/gen_lua_cdef.py"
+    from face_generator_amd import _lib
+    cdef = re.search(r"ffi\.cdef\[\[(.*?)\]\]", open(os.path.join(ROOT, "lua", "facegen_hip.lua")).read(), re.S).group(1)
+    declared = set(re.findall(r"\b(fg_\w+)\s*\(", cdef))
+    assert declared == set(_lib.parse_header()), declared ^ set(_lib.parse_header())
+
+
+def test_every_call_site_matches_a_declaration():
+    from face_generator_amd import _lib
+    decls = _lib.parse_header()
+    assert len(LUA) >= 2
+    n = 0
+    for path in LUA:
+        for name, nargs in call_sites(lua_code(path)):
+            assert name in decls, "%s calls C.%s, which include/facegen_hip.h does not declare" % (os.path.basename(path), name)
+            want = len(decls[name][1])
+            assert nargs == want, "%s: C.%s called with %d arguments, declared with %d" % (os.path.basename(path), name, nargs, want)
+            n += 1
+    assert n >= 40       # the binding is not a stub
+    # entries that must be bound for the two levels of SURVEY 8(b) and for data parallelism
+    used = {name for path in LUA for name, _ in call_sites(lua_code(path))}
+    for must in ("fg_net_create", "fg_net_forward", "fg_net_backward", "fg_net_params_changed", "fg_step_D", "fg_step_G",
+                 "fg_gan_update", "fg_gan_set_optimizer", "fg_comm_create", "fg_allreduce_sum", "fg_gan_set_comm",
+                 "fg_concat_channels", "fg_add"):
+        assert must in used, "the Lua binding never calls %s" % must
+
+
+def test_constants_are_header_enumerators():
+    hdr = open(os.path.join(ROOT, "include", "facegen_hip.h")).read()
+    enums = set(re.findall(r"\b(FG_[A-Z0-9_]+)\s*=", hdr))
+    for path in LUA:
+        for c in re.findall(r"\bC\.(FG_[A-Z0-9_]+)\b", lua_code(path)):
+            assert c in enums, "%s uses C.%s, not an enumerator of the header" % (os.path.basename(path), c)
+    code = lua_code(os.path.join(ROOT, "lua", "facegen_hip.lua"))
+    for must in ("FG_MAXPOOL2", "FG_CONV", "FG_STEP_NO_UPDATE", "FG_GAN_CONFUSION", "FG_PAUSED_SYNC"):
+        assert "C." + must in code
+
+
+def test_optimizers_mark_the_packed_weights_stale():
+    code = lua_code(os.path.join(ROOT, "lua", "facegen_hip.lua"))
+    for fn in ("interruptableAdam", "interruptableSgd", "interruptableAdagrad"):
+        body = code[code.index("function M." + fn):]
+        body = body[:body.index("\nend") + 4]
+        assert "paramsChanged" in body, "M.%s does not call fg_net_params_changed after the update" % fn
+    assert "function DeviceNet:paramsChanged() check(C.fg_net_params_changed(self.h)) end" in code
+    up = code[code.index("function DeviceNet:upload()"):]
+    assert "fg_net_params_changed" in up[:up.index("\nend")]
+    # stride-2 convolutions, the max-pool and both table front ends are mapped
+    assert "m.dW == 2" in code and "'nn.SpatialMaxPooling'" in code and "'nn.JoinTable'" in code and "fg_add" in code
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only present in the build container")
+def test_patches_apply_to_the_reference_scripts(tmp_path):
+    patches = sorted(glob.glob(os.path.join(ROOT, "lua", "patches", "*.patch")))
+    assert len(patches) >= 4
+    for p in patches:
+        r = subprocess.run(["patch", "-p1", "--dry-run", "-d", "/root/reference", "-i", p], capture_output=True, text=True)
+        assert r.returncode == 0, "%s does not apply: %s" % (os.path.basename(p), r.stdout + r.stderr)
+    # after patching, no CUDA rock is required on the training / sampling path
+    import shutil
+    for rel in ("train.lua", "sample.lua", "utils/nn_utils.lua", "layers/cudnnSpatialConvolutionUpsample.lua"):
+        os.makedirs(os.path.dirname(os.path.join(str(tmp_path), rel)), exist_ok=True)
+        shutil.copy(os.path.join("/root/reference", rel), os.path.join(str(tmp_path), rel))
+    for p in patches:
+        subprocess.run(["patch", "-p1", "-s", "-d", str(tmp_path), "-i", p], check=True)
+    for rel in ("train.lua", "sample.lua", "utils/nn_utils.lua", "layers/cudnnSpatialConvolutionUpsample.lua"):
+        code = strip_lua_comments(open(os.path.join(str(tmp_path), rel)).read())
+        assert not re.search(r"require\s+'(cutorch|cunn|cudnn)'", code), "%s still requires a CUDA rock" % rel
+        assert "cutorch." not in code and ":cuda()" not in code, "%s still calls into cutorch" % rel
