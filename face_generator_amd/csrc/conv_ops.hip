@@ -62,6 +62,12 @@ static void choose_igemm(long long M, int Npad, int ksteps, int P, int math, int
         if (use_ws < 0) { const char* e = getenv("FG_IGEMM_WS"); use_ws = e ? atoi(e) : 1; }
         const long long bw = (Npad % 64 == 0) ? (long long)fg_cdiv(M, 256) * (Npad / ((Npad % 128 == 0) ? 128 : 64)) * P : 0;
         if (use_ws && bw >= 256 && bw % 256 == 0 && M % 256 == 0) { *tile = 4; return; }
+        // fp32: layers whose 256x128 tiling leaves part of the chip idle but whose 256x64 tiling gives whole rounds of 256
+        // blocks (D's first mid-size convolution, G's first up-convolution at half batch): tile 5 = the same kernel, BN = 64
+        if (use_ws && math != 6 && Npad % 128 == 0 && M % 256 == 0) {
+            const long long bw64 = (long long)(M / 256) * (Npad / 64) * P;
+            if (bw64 >= 256 && bw64 % 256 == 0) { *tile = 5; return; }
+        }
         // bf16x6: a K-step is short and cheap, so mid-size layers also use the wave-specialised kernel (256x64 tiles for
         // layers with 64 output channels), split over K so that exactly one round of 256 blocks fills the chip
         // (>= 12 sixteen-channel steps per block)
@@ -221,8 +227,10 @@ static int maybe_split_operands(fg_ctx* ctx, IgemmArgs& a, int tile, long long p
 }
 
 int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* wp_fwd, const float* bias,
-                        float* y, float* scratch, long long scratch_floats, const void* wp6, void* x6_dst, int* x6_written) {
+                        float* y, float* scratch, long long scratch_floats, const void* wp6, void* x6_dst, int* x6_written,
+                        float* stats_part, long long stats_cap, int* stats_rows) {
     if (x6_written) *x6_written = 0;
+    if (stats_rows) *stats_rows = 0;
     if (g.B == 0) return FG_OK;
     WeightMap wm; fg_geom_weightmap(g, &wm);
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
@@ -261,6 +269,13 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
     }
     int rc;
     if ((rc = maybe_split_operands(ctx, a, tile, (long long)wm.P * wm.G * rf * cf, scratch, scratch_floats, wp6, nullptr, x6_dst, x6_written))) return rc;
+    if (stats_part && stats_rows && splits == 1 && !a.A6) {
+        // BatchNorm statistics in the epilogue: one partial row per wave row of every (M-tile, parity)
+        const int bm = tile >= 4 ? 256 : (tile == 2 ? 64 : 128);
+        const int wrows = (tile == 5 || (tile == 4 && rf % 128 != 0)) ? 4 : 2;
+        const long long rows = (long long)fg_cdiv(a.M, bm) * wm.P * wrows;
+        if (2 * rows * g.Cout <= stats_cap) { a.stats_part = stats_part; a.stats_rows = (int)rows; *stats_rows = (int)rows; }
+    }
     if ((rc = fg_launch_igemm(ctx, a, wm.P, tile))) return rc;
     if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, bias, g.Cout, y, out_count);
     return FG_OK;

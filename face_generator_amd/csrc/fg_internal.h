@@ -71,6 +71,8 @@ struct IgemmArgs {
     const void* A6;      // bf16x6 mode: A as split planes [pixel][Ca/16][3][16] bf16 (nullptr = fp32 path)
     const void* B6;      // bf16x6 mode: packed weights as split planes [P][G][Npad][Kpad/16][3][16] bf16
     float* Out;          // NHWC [Nb][Ho][Wo][N]  (or [splits][...] partials)
+    float* stats_part;   // optional (splits == 1): per-channel sum / sum of squares of the RAW accumulators (= output - bias) of
+    int stats_rows;      //   every wave's rows, [2][stats_rows][N] -- BatchNorm statistics without re-reading the output
     int Nb, Hm, Wm, M;   // M = Nb*Hm*Wm
     int lgH, lgW;        // log2(Hm), log2(Wm) if both are powers of two, else -1
     int Ha, Wa, Ca, Kpad;
@@ -140,12 +142,16 @@ int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
 struct PackJob {
     WeightMap wm;
     int mode;             // 0 forward pack, 1 data-grad pack (one thread per packed element: Linear + View permutations),
-                          // 5 / 6 the same for conv layers (one thread per channel pair), 2 thin pack [tap][I][O],
-                          // 3 thin pack [tap][O][I], 4 bias NCHW->NHWC perm
+                          // 7 both packs of a conv layer (one block per 16 x 16 channel patch, LDS-staged),
+                          // 2 thin pack [tap][I][O], 3 thin pack [tap][O][I], 4 bias NCHW->NHWC perm
     long long src_off;    // offset into the flat parameter vector
     float* dst;
     int rows, cols;       // padded tile dims (modes 0/1)
     long long start, count;
+    // mode 7: a conv layer's forward AND data-gradient packs from one LDS-staged pass over 16 x 16 (out, in) channel patches
+    float* dst2;          // data-gradient pack
+    int rows2, cols2;     // its padded dims (rows = in-channels, cols = out-channels)
+    int npo, npi;         // patches along the out / in channel axis (over the padded extents)
 };
 int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params);
 void fg_fold_window(int k, int pad, int* T, int* rmin);
@@ -170,6 +176,9 @@ struct BnArgs {
     float* mean; float* invstd;        // [C] saved stats (train)
     float* running_mean; float* running_var; float eps, momentum; int train;
     float* scratch;                    // >= (2*nblk*C + 4*C) floats, nblk <= 1024
+    // train mode, optional: partial sums left by the producing convolution's epilogue ([2][stats_rows][C], shifted by
+    // stats_pivot[c] = the conv bias) -- the statistics pass over x is skipped
+    const float* stats_part; int stats_rows; const float* stats_pivot;
 };
 int fg_launch_bn_forward(fg_ctx*, const BnArgs& a);
 struct BnBwdArgs {

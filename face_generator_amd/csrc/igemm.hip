@@ -55,6 +55,27 @@ __device__ __forceinline__ void fg_store_acc_tile(__amdgpu_buffer_rsrc_t orsrc, 
     }
 }
 
+// BatchNorm statistics from the accumulators (IgemmArgs::stats_part): lane l of a 32x32 tile holds 16 rows of column l & 31;
+// a wave's MI tiles x 16 rows x the two lane halves are summed in registers, so every wave leaves ONE partial row.
+template <int MI, int NI>
+__device__ __forceinline__ void fg_store_stats(const IgemmArgs& a, const f32x16 (&acc)[MI][NI], int row, int col0, int lane) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float v = acc[mi][ni][r]; s1 += v; s2 = fmaf(v, v, s2); }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const int col = col0 + ni * 32 + (lane & 31);
+        if (lane < 32 && col < a.N) {
+            a.stats_part[(size_t)row * a.N + col] = s1;
+            a.stats_part[((size_t)a.stats_rows + row) * a.N + col] = s2;
+        }
+    }
+}
+
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     constexpr int LDK = BK + 4;                 // padded row: conflict-free ds_read_b128 fragment reads
@@ -209,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 #undef FG_LOAD_TILE
 #undef FG_STORE_TILE
 
+    if (a.stats_part) fg_store_stats<MI, NI>(a, acc, (tile_m * np + p) * 2 + wm, tile_n * BN + wn * (BN / 2), lane);
     float* outp = a.Out + (size_t)split * a.split_stride;
     const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
@@ -406,6 +428,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
         __syncthreads();
     }
 
+    if (a.stats_part) fg_store_stats<MI, NI>(a, acc, (tile_m * np + p) * (4 / WNW) + wm, tile_n * BN + wn * 64, lane);
     float* outp = a.Out + (size_t)split * a.split_stride;
     const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
@@ -746,6 +769,7 @@ int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
         case 0: if (a.Npad % 128) break; return launch_igemm_t<128, 128, 32>(ctx, a, P);
         case 1: if (a.Npad % 64) break; return launch_igemm_t<128, 64, 32>(ctx, a, P);
         case 2: if (a.Npad % 64) break; return launch_igemm_t<64, 64, 32>(ctx, a, P);
+        case 5: if (a.Npad % 64 || a.A6) break; return launch_igemm_ws<64>(ctx, a, P);
         case 4:
             if (a.A6) { if (a.Npad % 64) break; return (a.Npad % 128 == 0) ? launch_igemm_ws6<128>(ctx, a, P) : launch_igemm_ws6<64>(ctx, a, P); }
             if (a.Npad % 64) break;
@@ -1071,16 +1095,104 @@ int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const flo
     return FG_OK;
 }
 
+// packed value from a pair's k*k taps held in LDS (same arithmetic and summation order as packed_weight_value)
+__device__ __forceinline__ float packed_from_taps(const WeightMap& wm, const float* w, int p, int g) {
+    if (wm.kind == 0) return w[g];
+    const int py = p >> 1, px = p & 1, ty = g / wm.T, tx = g - ty * wm.T;
+    const int dy0 = 2 * (ty + wm.rmin) - py + wm.pad, dx0 = 2 * (tx + wm.rmin) - px + wm.pad;
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int dy = dy0 + a;
+        if ((unsigned)dy >= (unsigned)wm.k) continue;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int dx = dx0 + b;
+            if ((unsigned)dx < (unsigned)wm.k) s += w[dy * wm.k + dx];
+        }
+    }
+    return s;
+}
+
+#define PK_ROW (16 * 49 + 1)    // LDS row of one out-channel: 16 in-channels x up to 7x7 taps, +1 so rows fall on distinct banks
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int njobs, long long total,
                                                         const float* __restrict__ params) {
+    __shared__ float taps[16 * PK_ROW];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
     int j = 0;
-    while (j + 1 < njobs && idx >= jobs[j + 1].start) ++j;
+    {   // block-uniform job lookup (every job's count is a multiple of 256)
+        const long long b0 = (long long)blockIdx.x * blockDim.x;
+        if (b0 >= total) return;
+        while (j + 1 < njobs && b0 >= jobs[j + 1].start) ++j;
+    }
     const PackJob& jb = jobs[j];
     const long long loc = idx - jb.start;
     const WeightMap& wm = jb.wm;
     const float* W = params + jb.src_off;
+    if (jb.mode == 7) {
+        // conv layer: both packs from one pass.  A block owns a 16 x 16 patch of (out, in) channel pairs: the reference
+        // weights of one out-channel and 16 consecutive in-channels are ONE contiguous run of 16*k*k floats, so the patch is
+        // 16 coalesced runs into LDS; every thread then forms the (tap-folded) values of its pair from LDS and writes them
+        // with the in-channel fastest (forward pack) and, in a second role, with the out-channel fastest (data-gradient pack).
+        const int kk = wm.k * wm.k, run = 16 * kk;
+        const int patch = (int)(loc >> 8), t = (int)(loc & 255);
+        const int po0 = (patch / jb.npi) * 16, pi0 = (patch % jb.npi) * 16;
+        for (int e = t; e < 16 * run; e += 256) {
+            const int a = e / run, off = e - a * run;
+            const int po = po0 + a, pi = pi0 + off / kk;
+            taps[a * PK_ROW + off] = (po < wm.O && pi < wm.I) ? W[((size_t)po * wm.I + pi0) * kk + off] : 0.f;
+        }
+        __syncthreads();
+        const int ng = wm.P * wm.G;
+        {   // forward pack [p][g][O_pad][I_pad]: lanes run over the in-channel
+            const int a = t >> 4, b = t & 15, po = po0 + a, pi = pi0 + b;
+            if (po < jb.rows && pi < jb.cols) {
+                const float* w = taps + a * PK_ROW + b * kk;
+                float* d = jb.dst + (size_t)po * jb.cols + pi;
+                const size_t tile = (size_t)jb.rows * jb.cols;
+                for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
+            }
+        }
+        {   // data-gradient pack [p][g][I_pad][O_pad]: lanes run over the out-channel
+            const int a = t & 15, b = t >> 4, po = po0 + a, pi = pi0 + b;
+            if (pi < jb.rows2 && po < jb.cols2) {
+                const float* w = taps + a * PK_ROW + b * kk;
+                float* d = jb.dst2 + (size_t)pi * jb.cols2 + po;
+                const size_t tile = (size_t)jb.rows2 * jb.cols2;
+                for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
+            }
+        }
+        return;
+    }
+    if (jb.mode == 8) {
+        // Linear layer (k = 1, optional View permutations on either axis): both packs from one pass over a 32 x 32 patch.
+        // The forward pack keeps the reference's in-feature-fastest order (coalesced both ways); the data-gradient pack is its
+        // transpose, written out-feature-fastest from an LDS tile (a thread-per-element transpose read one 4-byte word per
+        // cache line: 47 us per re-pack launch).
+        float* tl = taps;                                   // [32][33]
+        const int patch = (int)(loc >> 8), t = (int)(loc & 255);
+        const int po0 = (patch / jb.npi) * 32, pi0 = (patch % jb.npi) * 32;
+        const int c = t & 31, r0 = t >> 5;
+        for (int rr = r0; rr < 32; rr += 8) {
+            const int po = po0 + rr, pi = pi0 + c;
+            float v = 0.f;
+            if (po < wm.O && pi < wm.I) {
+                int o = po, i = pi;
+                if (wm.o_hw > 1) { int hw = po / wm.o_c, cc = po - hw * wm.o_c; o = cc * wm.o_hw + hw; }
+                if (wm.i_hw > 1) { int hw = pi / wm.i_c, cc = pi - hw * wm.i_c; i = cc * wm.i_hw + hw; }
+                v = W[(size_t)o * wm.I + i];
+            }
+            tl[rr * 33 + c] = v;
+            if (po < jb.rows && pi < jb.cols) jb.dst[(size_t)po * jb.cols + pi] = v;
+        }
+        __syncthreads();
+        for (int rr = r0; rr < 32; rr += 8) {
+            const int pi = pi0 + rr, po = po0 + c;
+            if (pi < jb.rows2 && po < jb.cols2) jb.dst2[(size_t)pi * jb.cols2 + po] = tl[c * 33 + rr];
+        }
+        return;
+    }
+    if (idx >= total || loc >= jb.count) return;
     if (jb.mode <= 1) {
         const int col = (int)(loc % jb.cols);
         long long t = loc / jb.cols;
@@ -1096,22 +1208,6 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
             v = packed_weight_value(wm, W, p, g, o, i);
         }
         jb.dst[loc] = v;
-    } else if (jb.mode == 5 || jb.mode == 6) {
-        // conv layers, one thread per (out, in) channel pair, all parities / taps in a loop: the pair's k*k reference
-        // weights are one contiguous run, re-read from L1 for every folded tap, and the lanes of a wave write consecutive
-        // packed elements (forward layout: in-channel fastest; data-grad layout: out-channel fastest)
-        const bool fwd = jb.mode == 5;
-        const long long tile = (long long)jb.rows * jb.cols;
-        const int part = (int)(loc / tile);                  // (parity, third of the taps): keeps the per-thread chain short
-        const long long e = loc - (long long)part * tile;
-        const int p = part / 3, third = part - p * 3;
-        const int fast = (int)(e % jb.cols), slow = (int)(e / jb.cols);         // (col, row) of the packed tile
-        const int po = fwd ? slow : fast, pi = fwd ? fast : slow;
-        const bool live = po < wm.O && pi < wm.I;
-        float* d = jb.dst + (long long)slow * jb.cols + fast;
-        const int g0 = third * wm.G / 3, g1 = (third + 1) * wm.G / 3;
-        for (int g = g0; g < g1; ++g)
-            d[(long long)(p * wm.G + g) * tile] = live ? packed_weight_value(wm, W, p, g, po, pi) : 0.f;
     } else if (jb.mode <= 3) {   // thin layouts [tap][s][c]
         const int kk = wm.k * wm.k;
         const int Cs = jb.mode == 2 ? wm.I : wm.O, Cw = jb.mode == 2 ? wm.O : wm.I;

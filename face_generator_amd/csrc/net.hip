@@ -47,6 +47,8 @@ struct Stage {
     long long out_off = 0, aux_off = 0;
     long long x6_off = -1;    // ST_CONV: split-bf16 planes of the stage input, kept from forward for the weight gradient
     int x6_valid = 0;
+    long long stats_off = -1, stats_cap = 0;   // ST_BNPRELU behind an ST_CONV: statistics partials left by the conv's epilogue
+    int stats_rows = 0;       //   rows the last forward's conv actually wrote (0: the statistics pass over x runs)
 };
 
 struct LayerInfo {
@@ -125,6 +127,10 @@ static void make_plan(fg_net* n, int B) {
         s.out_off = off; off += align64(osz);
         s.aux_off = off;
         if (s.kind == ST_BNPRELU) off += align64(2 * s.oc);
+        if (s.kind == ST_BNPRELU && &s != &n->st[0] && (&s)[-1].kind == ST_CONV) {
+            s.stats_cap = 2 * ((long long)B * s.ih * s.iw / 32 + 16) * s.ic;     // >= 2 x (wave rows of any tiling) x C
+            s.stats_off = off; off += align64(s.stats_cap);
+        }
         if (s.kind == ST_CONV && s.ic % 16 == 0) { s.x6_off = off; off += align64(((long long)B * s.ic * s.ih * s.iw * 3 + 1) / 2); }
         if (osz > maxact) maxact = osz;
         const long long isz = (long long)B * s.ic * s.ih * s.iw;
@@ -295,9 +301,14 @@ static int forward_run(fg_net* n, long long* out_offset) {
             case ST_CONV: {
                 ConvGeom g = s.geom; g.B = B;
                 s.x6_valid = 0;
+                // a BatchNorm directly behind this convolution takes its batch statistics from the epilogue
+                Stage* bn = (train && !n->sync_bn && si + 1 < (int)n->st.size() && n->st[si + 1].kind == ST_BNPRELU &&
+                             n->st[si + 1].stats_off >= 0) ? &n->st[si + 1] : nullptr;
+                if (bn) bn->stats_rows = 0;
                 rc = fg_conv_forward_run(ctx, g, cur, s.wp_fwd, s.bias_packed ? s.bias_packed : P + s.b_off, y, scratch,
                                          n->scratch_floats, n->planes_valid ? s.wp_fwd6 : nullptr,
-                                         (train && s.x6_off >= 0) ? (void*)(ws + s.x6_off) : nullptr, &s.x6_valid);
+                                         (train && s.x6_off >= 0) ? (void*)(ws + s.x6_off) : nullptr, &s.x6_valid,
+                                         bn ? ws + bn->stats_off : nullptr, bn ? bn->stats_cap : 0, bn ? &bn->stats_rows : nullptr);
                 break;
             }
             case ST_GEMV:
@@ -318,6 +329,12 @@ static int forward_run(fg_net* n, long long* out_offset) {
                 a.mean = ws + s.aux_off; a.invstd = ws + s.aux_off + s.ic;
                 a.running_mean = n->buffers + s.buf_off; a.running_var = n->buffers + s.buf_off + s.ic;
                 a.eps = s.eps; a.momentum = s.momentum; a.train = train; a.scratch = scratch;
+                if (train && !sync && s.stats_rows > 0 && si > 0) {
+                    const Stage& cv = n->st[si - 1];
+                    a.stats_part = ws + s.stats_off; a.stats_rows = s.stats_rows;
+                    a.stats_pivot = cv.bias_packed ? cv.bias_packed : P + cv.b_off;
+                }
+                s.stats_rows = 0;
                 if (!sync) { rc = fg_launch_bn_forward(ctx, a); break; }
                 if (n->run_phase == 0) {           // local fp64 sums -> pause for the cross-rank all-reduce
                     if (2LL * s.ic + 1 > n->sync_cap) return fg_set_err(ctx, FG_ERR_WORKSPACE, "sync-BN buffer too small");
@@ -648,16 +665,31 @@ static int build_pack_jobs(fg_net* n) {
         PackJob j; memset(&j, 0, sizeof(j));
         j.wm = wm; j.mode = mode; j.src_off = src; j.dst = dst; j.rows = rows; j.cols = cols; j.start = start; j.count = count;
         jobs.push_back(j);
-        start += count;
+        start += (count + 255) / 256 * 256;        // job spans are whole blocks: the kernel looks its job up per block
     };
     for (auto& s : n->st) {
         if (s.kind == ST_CONV) {
             ConvGeom g = s.geom; g.B = 1;
             WeightMap wm; fg_geom_weightmap(g, &wm);
             int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
-            if (wm.k > 1 && wm.o_hw <= 1 && wm.i_hw <= 1) {      // convolutions: threads = channel pairs x parities x 3 tap thirds
-                add(wm, 5, s.w_off, s.wp_fwd, rf, cf, (long long)rf * cf * wm.P * 3);
-                add(wm, 6, s.w_off, s.wp_bwd, rb, cb, (long long)rb * cb * wm.P * 3);
+            if (wm.k > 1 && wm.k <= 7 && wm.o_hw <= 1 && wm.i_hw <= 1) {   // convolutions: one LDS-staged job makes both packs
+                PackJob j; memset(&j, 0, sizeof(j));
+                j.wm = wm; j.mode = 7; j.src_off = s.w_off; j.dst = s.wp_fwd; j.rows = rf; j.cols = cf;
+                j.dst2 = s.wp_bwd; j.rows2 = rb; j.cols2 = cb;
+                const int opad = rf > cb ? rf : cb, ipad = cf > rb ? cf : rb;
+                j.npo = (opad + 15) / 16; j.npi = (ipad + 15) / 16;
+                j.start = start; j.count = (long long)j.npo * j.npi * 256;
+                jobs.push_back(j);
+                start += j.count;
+            } else if (wm.k == 1) {                           // Linear: both packs from one LDS-tiled pass (mode 8)
+                PackJob j; memset(&j, 0, sizeof(j));
+                j.wm = wm; j.mode = 8; j.src_off = s.w_off; j.dst = s.wp_fwd; j.rows = rf; j.cols = cf;
+                j.dst2 = s.wp_bwd; j.rows2 = rb; j.cols2 = cb;
+                const int opad = rf > cb ? rf : cb, ipad = cf > rb ? cf : rb;
+                j.npo = (opad + 31) / 32; j.npi = (ipad + 31) / 32;
+                j.start = start; j.count = (long long)j.npo * j.npi * 256;
+                jobs.push_back(j);
+                start += j.count;
             } else {
                 add(wm, 0, s.w_off, s.wp_fwd, rf, cf, (long long)wm.P * wm.G * rf * cf);
                 add(wm, 1, s.w_off, s.wp_bwd, rb, cb, (long long)wm.P * wm.G * rb * cb);
@@ -801,6 +833,18 @@ int fg_net_layer_output(const fg_net* n, int li, long long* off, int* c, int* h,
         return fg_set_err(n->ctx, FG_ERR_INVALID, "layer %d: the net's output was redirected by fg_net_forward_to", li);
     if (off) *off = s.out_off;
     if (c) *c = s.oc; if (h) *h = s.oh; if (w) *w = s.ow;
+    return FG_OK;
+}
+
+int fg_net_bn_saved_stats(const fg_net* n, int li, long long* mean_off, long long* invstd_off, int* c) {
+    if (!n || li < 0 || li >= (int)n->layers.size()) return FG_ERR_INVALID;
+    const LayerInfo& l = n->layers[li];
+    if (l.stage < 0 || n->st[l.stage].kind != ST_BNPRELU || n->st[l.stage].first_layer != li)
+        return fg_set_err(n->ctx, FG_ERR_INVALID, "layer %d is not a SpatialBatchNormalization", li);
+    const Stage& s = n->st[l.stage];
+    if (mean_off) *mean_off = s.aux_off;
+    if (invstd_off) *invstd_off = s.aux_off + s.ic;
+    if (c) *c = s.ic;
     return FG_OK;
 }
 

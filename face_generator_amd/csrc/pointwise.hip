@@ -383,7 +383,11 @@ static inline int bn_apply_blocks(long long total4, int C) {
 }
 int fg_launch_bn_forward(fg_ctx* ctx, const BnArgs& a) {
     if (a.C % 4) return fg_set_err(ctx, FG_ERR_INVALID, "bn: C %% 4");
-    if (a.train) {
+    if (a.train && a.stats_part) {
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(fg_cdiv(a.C, 64)), dim3(1024), 0, ctx->stream, a.stats_part, a.stats_pivot,
+                           a.stats_rows, a.M, a.C, a.eps, a.momentum, a.mean, a.invstd, a.running_mean, a.running_var);
+        FG_CHECK_LAUNCH(ctx);
+    } else if (a.train) {
         const int nrb = cr_rowblocks(a.M);
         if (cr4_ok(a.C))
             hipLaunchKernelGGL(bn_stats4_partial_kernel, dim3(nrb), dim3(CR4_NT), 0, ctx->stream, a.x, a.M, a.C, a.scratch);

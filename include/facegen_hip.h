@@ -151,6 +151,9 @@ int fg_net_forward_resume(fg_net* net, long long* out_offset);
 int fg_net_backward_resume(fg_net* net);
 /* debugging / parity: activation after reference layer `layer_index` of the last forward (must end a stage) */
 int fg_net_layer_output(const fg_net* net, int layer_index, long long* ws_offset, int* c, int* h, int* w);
+/* debugging / parity: where the last train-mode forward left the batch mean / 1/sqrt(var + eps) of BatchNorm layer
+ * `layer_index` inside ws (c floats each) -- what the backward pass recomputes the PReLU branch from */
+int fg_net_bn_saved_stats(const fg_net* net, int layer_index, long long* mean_offset, long long* invstd_offset, int* c);
 
 /* ---- criterion: nn.BCECriterion() (train.lua:148) fused forward+backward, plus D's confusion counts
  *      (adversarial.lua:112-117): confusion[pred*2 + target] ---- */

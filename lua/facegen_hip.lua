@@ -80,6 +80,7 @@ long long fg_net_sync_count(const fg_net* net);
 int fg_net_forward_resume(fg_net* net, long long* out_offset);
 int fg_net_backward_resume(fg_net* net);
 int fg_net_layer_output(const fg_net* net, int layer_index, long long* ws_offset, int* c, int* h, int* w);
+int fg_net_bn_saved_stats(const fg_net* net, int layer_index, long long* mean_offset, long long* invstd_offset, int* c);
 int fg_bce_forward_backward(fg_ctx* ctx, const float* prob, const float* target, int n, float* loss_dev, float* grad_dev, int* confusion_dev);
 int fg_adam_fused(fg_ctx* ctx, float* p, const float* g, float* m, float* v, long long n, float gscale, float l1_mul, float l2, float clamp, double lr, double beta1, double beta2, double eps, int t, float* g_out);
 int fg_sgd_fused(fg_ctx* ctx, float* p, const float* g, float* mom_buf, long long n, float gscale, float l1_mul, float l2, float clamp, double lr, double momentum, double dampening, double weight_decay, int nesterov, int first_step);

@@ -57,11 +57,12 @@ def adopt_device_branches(ctx, dn, onet, clear=False, params=None, also=()):
     decisions compares the gradients on identical branches at the plain SURVEY 8(c) bars, with no flip allowance.
 
     The pre-activation is read from the device plan: the stage output in front of the PReLU (conv / Linear[+View] / fused
-    PReLU in front of a max-pool); for the fused BatchNorm+PReLU stage z = gamma * xhat + beta is recomputed by the SAME
-    kernels through the module-level entry (fg_batchnorm_forward with slope = NULL evaluates the identical expression).
+    PReLU in front of a max-pool); for the fused BatchNorm+PReLU stage z = gamma * xhat + beta is re-evaluated from the
+    conv output and the batch statistics the forward saved (fg_net_bn_saved_stats), in float32 with every operation rounded
+    separately -- the expression bn_z() of pointwise.hip evaluates in forward and backward alike.
     `params`: the device's flat parameter vector as it was DURING that forward (the optimizer step that follows a backward
     moves gamma / beta); `also`: further oracle nets (e.g. the float64 twin) that receive the same decisions."""
-    import torch
+    import ctypes
     from oracle import torch7_nn as O
     mods = getattr(onet, "inner", onet).modules
     twins = [getattr(o, "inner", o).modules for o in also]
@@ -75,16 +76,22 @@ def adopt_device_branches(ctx, dn, onet, clear=False, params=None, also=()):
                 continue
             prev = mods[i - 1]
             if isinstance(prev, O.SpatialBatchNormalization):
-                x = dn.layer_output(i - 2).contiguous()
-                B, H, W, C = x.shape
+                # z = ((x - mean) * invstd) * gamma + beta, every operation rounded separately (bn_z in pointwise.hip), from the
+                # statistics the forward SAVED -- the same expression the device's backward takes its branch from
+                x = nchw(dn.layer_output(i - 2))
+                mo, io, cc = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_int()
+                ctx.check(lib.fg_net_bn_saved_stats(dn.h, i - 1, ctypes.byref(mo), ctypes.byref(io), ctypes.byref(cc)))
+                C = cc.value
+                mu = dn.ws[mo.value: mo.value + C].cpu().numpy().reshape(1, C, 1, 1)
+                istd = dn.ws[io.value: io.value + C].cpu().numpy().reshape(1, C, 1, 1)
                 wo, wn, bo, bn = dn.param_offsets(i - 1)
-                z = torch.empty_like(x)
-                aux = ctx.empty(4 * C)
-                scr = ctx.empty(int(lib.fg_bn_scratch_floats(C)))
-                ctx.check(lib.fg_batchnorm_forward(ctx.h, x.data_ptr(), z.data_ptr(), B * H * W, C,
-                                                   P[wo:wo + wn].data_ptr(), P[bo:bo + bn].data_ptr(), None,
-                                                   aux[:C].data_ptr(), aux[C:2 * C].data_ptr(), aux[2 * C:3 * C].data_ptr(),
-                                                   aux[3 * C:].data_ptr(), prev.eps, prev.momentum, 1, scr.data_ptr()))
+                gam = P[wo:wo + wn].cpu().numpy().reshape(1, C, 1, 1)
+                bet = P[bo:bo + bn].cpu().numpy().reshape(1, C, 1, 1)
+                zz = (((x - mu).astype(np.float32) * istd).astype(np.float32) * gam).astype(np.float32) + bet
+                pos = zz.astype(np.float32) > 0
+                for mm in [m] + [t[i] for t in twins]:
+                    mm.pos_override = pos
+                continue
             else:
                 z = dn.layer_output(i - 1)
             pos = nchw(z) > 0
