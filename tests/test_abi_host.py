@@ -143,3 +143,42 @@ def test_checkpoint_roundtrip_and_c2f_dataset(tmp_path):
     assert torch.allclose(res[1].diff + res[1].coarse, fine[1], atol=1e-6)
     assert (res.coarse - fine).abs().mean() > 1e-3 and res.getDiff(0, 2).shape[0] == 2
     S.reset()
+
+
+def test_checkpoint_roundtrip_16px_nets_and_failed_save_keeps_the_old_file(tmp_path, monkeypatch):
+    """`--scale 16` (create_D16_d: ConcatTable{conv branch, dense branch} -> JoinTable -> Linear) must survive the
+    `EPOCH % saveFreq == 0` hook -- per-part layer specs, every nested parameter -- and a save that fails must not cost the
+    previous checkpoint (the new file is renamed into place only after it was written)."""
+    from face_generator_amd import models, nn_utils
+    from face_generator_amd.state import S
+    S.reset()
+    S.MODEL_G = models.create_G((3, 16, 16), 100)
+    S.MODEL_D = models.create_D((3, 16, 16))
+    sd = nn_utils.state_dict(S.MODEL_D)
+    assert set(sd["layers"]) == {"branches", "tail"} and len(sd["layers"]["branches"]) == 2
+    assert sum(p.numel() for p in sd["params"]) == sum(getattr(m, n).numel() for m, n in S.MODEL_D.parameter_list())
+    fn = str(tmp_path / "logs" / "adversarial.net")
+    nn_utils.save_checkpoint(fn)
+    ck = nn_utils.load_checkpoint(fn)
+    D2 = models.create_D((3, 16, 16))
+    nn_utils.load_state_dict(D2, ck["D"])
+    for (m, n), (m2, n2) in zip(S.MODEL_D.parameter_list(), D2.parameter_list()):
+        assert torch.equal(getattr(m, n), getattr(m2, n2))
+    before = open(fn, "rb").read()
+
+    def boom(*a, **k):
+        raise IOError("disk full")
+    monkeypatch.setattr(torch, "save", boom)
+    with pytest.raises(IOError):
+        nn_utils.save_checkpoint(fn)
+    assert open(fn, "rb").read() == before and not os.path.exists(fn + ".old")
+    S.reset()
+
+
+def test_trainer_optstate_comes_from_opt():
+    """train.lua:180-191: OPTSTATE.sgd.{D,G} = {learningRate = OPT.*_SGD_lr (default 0.02), momentum = OPT.*_SGD_momentum};
+    OPTSTATE.adam.*.learningRate only when --*_adam_lr ~= -1 (the trainer used lr 1e-3 / momentum 0 for SGD)."""
+    import inspect
+    from face_generator_amd import adversarial
+    src = inspect.getsource(adversarial.Trainer.__init__)
+    assert '"D_SGD_lr", 0.02' in src and '"G_SGD_momentum", 0' in src and '_adam_lr", -1' in src
