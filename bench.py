@@ -367,6 +367,19 @@ def main():
     out["config"]["step_entry"] = ("fg_step_D / fg_step_G (C ABI, one call per closure)" if tr.gan is not None
                                    else "net-level entries driven from the host loop")
     measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops, out)
+    if args.workload == "cfg2" and world == 1:
+        # the reference's boundary hands over HOST tensors (dataset[i]:clone() into a FloatTensor, adversarial.lua:244-249):
+        # the same K steps with the real half coming from host memory every iteration (NCHW FloatTensor -> H2D -> NHWC);
+        # never `value` -- the PCIe-inclusive rate of the contract
+        real_host = real.permute(0, 3, 1, 2).contiguous().cpu().pin_memory()
+        for _ in range(3):
+            tr.step_D(ctx.to_device_nhwc(real_host), None); tr.step_G(B)
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step_D(ctx.to_device_nhwc(real_host), None); tr.step_G(B)
+        torch.cuda.synchronize()
+        out["host_input_images_per_sec"] = B * args.steps / (time.perf_counter() - th)
     out["reference_accounting_images_per_sec"] = out["value"] / 2   # adversarial.lua:305 counts B/2 per iteration
     if world > 1:
         dist.barrier()
