@@ -23,7 +23,8 @@ int fg_conv_pack(fg_ctx* ctx, const ConvGeom& g, const float* W, float* wp_fwd, 
 int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* wp_fwd, const float* bias,
                         float* y, float* scratch, long long scratch_floats, const void* wp6 = nullptr,
                         void* x6_dst = nullptr, int* x6_written = nullptr, float* stats_part = nullptr,
-                        long long stats_cap = 0, int* stats_rows = nullptr);
+                        long long stats_cap = 0, int* stats_rows = nullptr, const FgActFuse* act = nullptr);
+// act (optional): the PReLU [+ Dropout] behind the layer; act->applied tells whether this launch folded it in (split-K layers)
 // stats_part (optional, capacity stats_cap floats): the kernel's epilogue leaves per-channel sum / sum-of-squares partials of
 // the raw accumulators there ([2][*stats_rows][Cout]; *stats_rows = 0 if this launch could not: split-K, bf16x6)
 // x6_dst (forward): write the planes of x there instead of into the scratch (the caller keeps them for the weight

@@ -228,7 +228,8 @@ static int maybe_split_operands(fg_ctx* ctx, IgemmArgs& a, int tile, long long p
 
 int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* wp_fwd, const float* bias,
                         float* y, float* scratch, long long scratch_floats, const void* wp6, void* x6_dst, int* x6_written,
-                        float* stats_part, long long stats_cap, int* stats_rows) {
+                        float* stats_part, long long stats_cap, int* stats_rows, const FgActFuse* act) {
+    if (act) act->applied = 0;
     if (x6_written) *x6_written = 0;
     if (stats_rows) *stats_rows = 0;
     if (g.B == 0) return FG_OK;
@@ -277,7 +278,7 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
         if (2 * rows * g.Cout <= stats_cap) { a.stats_part = stats_part; a.stats_rows = (int)rows; *stats_rows = (int)rows; }
     }
     if ((rc = fg_launch_igemm(ctx, a, wm.P, tile))) return rc;
-    if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, bias, g.Cout, y, out_count);
+    if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, bias, g.Cout, y, out_count, act);
     return FG_OK;
 }
 

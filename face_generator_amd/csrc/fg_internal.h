@@ -93,8 +93,10 @@ int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a, int P, int tile);
 // sums split partials (+bias) : out[i] = bias[i % N] + sum_s part[s*stride + i]
 // fp32 rows [rows][C] (C % 16 == 0) -> split-bf16 planes [rows][C/16][3][16]: x = h + m + l exactly
 int fg_launch_split_planes(fg_ctx* ctx, const float* src, long long rows, int C, void* dst);
+// the nn.PReLU [+ nn.Dropout] behind a layer, folded into the pass that finishes the layer's output (split-K sum)
+struct FgActFuse { const float* slope; const float* mask; float mscale; float* y; mutable int applied; };
 int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long stride, const float* bias,
-                         int N, float* out, long long count);
+                         int N, float* out, long long count, const FgActFuse* act = nullptr);
 
 // ---------------------------------------------------------------------------------
 // Weight-gradient contraction: Part[pg][s][n][c] = sum_{m in split s} dY[pixd(m,p)][n] * X[pixx(m,pg)][c]

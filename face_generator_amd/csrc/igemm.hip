@@ -778,10 +778,16 @@ int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
     return fg_set_err(ctx, FG_ERR_INVALID, "igemm: bad tile %d for Npad %d", tile, a.Npad);
 }
 
+// act (optional): the PReLU [+ Dropout] that follows the layer, applied to the finished sum in the same pass --
+// act_y = prelu(out) [* mask * mscale], exactly prelu_fwd_kernel's expression; `out` (the pre-activation) is still written,
+// the backward pass needs it
 __global__ void sum_splits_kernel(const float* __restrict__ part, int splits, long long stride,
-                                  const float* __restrict__ bias, int N, float* __restrict__ out, long long count4) {
+                                  const float* __restrict__ bias, int N, float* __restrict__ out, long long count4,
+                                  const float* __restrict__ act_slope, const float* __restrict__ act_mask, float act_mscale,
+                                  float* __restrict__ act_y) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long step = (long long)gridDim.x * blockDim.x;
+    const float a = act_slope ? act_slope[0] : 1.f;
     for (; i < count4; i += step) {
         float4 s = ((const float4*)part)[i];
         for (int k = 1; k < splits; ++k) {
@@ -793,16 +799,28 @@ __global__ void sum_splits_kernel(const float* __restrict__ part, int splits, lo
             s.x += bias[c]; s.y += bias[c + 1]; s.z += bias[c + 2]; s.w += bias[c + 3];
         }
         ((float4*)out)[i] = s;
+        if (act_y) {
+            float4 r;
+            r.x = s.x > 0.f ? s.x : a * s.x; r.y = s.y > 0.f ? s.y : a * s.y;
+            r.z = s.z > 0.f ? s.z : a * s.z; r.w = s.w > 0.f ? s.w : a * s.w;
+            if (act_mask) {
+                const float4 m = ((const float4*)act_mask)[i];
+                r.x *= m.x * act_mscale; r.y *= m.y * act_mscale; r.z *= m.z * act_mscale; r.w *= m.w * act_mscale;
+            }
+            ((float4*)act_y)[i] = r;
+        }
     }
 }
 
 int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long stride, const float* bias, int N,
-                         float* out, long long count) {
+                         float* out, long long count, const FgActFuse* act) {
     if (count % 4 || N % 4 || stride % 4) return fg_set_err(ctx, FG_ERR_INVALID, "sum_splits: alignment");
     long long c4 = count / 4;
     int blocks = (int)min((long long)2048, (c4 + 255) / 256);
+    const bool fuse = act && act->y && act->slope && (!act->mask || ((uintptr_t)act->mask & 15) == 0);
     hipLaunchKernelGGL(sum_splits_kernel, dim3(blocks), dim3(256), 0, ctx->stream, part, splits, stride, bias, N, out,
-                       c4);
+                       c4, fuse ? act->slope : nullptr, fuse ? act->mask : nullptr, fuse ? act->mscale : 1.f, fuse ? act->y : nullptr);
+    if (act) act->applied = fuse ? 1 : 0;
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }

@@ -49,6 +49,7 @@ struct Stage {
     int x6_valid = 0;
     long long stats_off = -1, stats_cap = 0;   // ST_BNPRELU behind an ST_CONV: statistics partials left by the conv's epilogue
     int stats_rows = 0;       //   rows the last forward's conv actually wrote (0: the statistics pass over x runs)
+    int act_done = 0;         // ST_PRELU: this forward's producer already applied it (folded into its split-K sum)
 };
 
 struct LayerInfo {
@@ -305,10 +306,21 @@ static int forward_run(fg_net* n, long long* out_offset) {
                 Stage* bn = (train && !n->sync_bn && si + 1 < (int)n->st.size() && n->st[si + 1].kind == ST_BNPRELU &&
                              n->st[si + 1].stats_off >= 0) ? &n->st[si + 1] : nullptr;
                 if (bn) bn->stats_rows = 0;
+                // a PReLU [+ Dropout] directly behind a split-K layer (the Linear layers) rides on the pass that sums the splits
+                FgActFuse act; memset(&act, 0, sizeof(act));
+                Stage* pr = (si + 1 < (int)n->st.size() && n->st[si + 1].kind == ST_PRELU) ? &n->st[si + 1] : nullptr;
+                if (pr) {
+                    const bool dm = pr->mask_kind == 2 && train;
+                    act.slope = P + pr->slope_off; act.y = ws + pr->out_off;
+                    act.mask = dm ? n->mask_ptrs[pr->mask_idx] : nullptr; act.mscale = dm ? 1.f / (1.f - pr->p) : 1.f;
+                    pr->act_done = 0;
+                }
                 rc = fg_conv_forward_run(ctx, g, cur, s.wp_fwd, s.bias_packed ? s.bias_packed : P + s.b_off, y, scratch,
                                          n->scratch_floats, n->planes_valid ? s.wp_fwd6 : nullptr,
                                          (train && s.x6_off >= 0) ? (void*)(ws + s.x6_off) : nullptr, &s.x6_valid,
-                                         bn ? ws + bn->stats_off : nullptr, bn ? bn->stats_cap : 0, bn ? &bn->stats_rows : nullptr);
+                                         bn ? ws + bn->stats_off : nullptr, bn ? bn->stats_cap : 0, bn ? &bn->stats_rows : nullptr,
+                                         pr ? &act : nullptr);
+                if (pr && !rc) pr->act_done = act.applied;
                 break;
             }
             case ST_GEMV:
@@ -347,6 +359,7 @@ static int forward_run(fg_net* n, long long* out_offset) {
                 break;
             }
             case ST_PRELU: {
+                if (s.act_done) { s.act_done = 0; break; }      // written by the producing layer's split-K sum
                 const long long cnt = (long long)B * s.ic * s.ih * s.iw;
                 const float sc = (s.mask_kind == 2 && train) ? 1.f / (1.f - s.p) : 1.f;
                 rc = fg_launch_prelu_forward(ctx, cur, P + s.slope_off, train ? mask : nullptr, sc, y, cnt);

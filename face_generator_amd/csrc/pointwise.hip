@@ -524,11 +524,27 @@ __global__ __launch_bounds__(CR4_NT) void bn_bwd4_partial_kernel(const float* __
     });
 }
 // scratch layout: part[3][nrb][C], then coef[2][C]
+// (one extra block, when gslope is given, sums the nrb * C PReLU-slope partials that follow the two channel planes)
 __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ part, int nrb, long long M, int C,
                                                             float* __restrict__ coef, float* __restrict__ ggamma,
-                                                            float* __restrict__ gbeta, float acc) {
+                                                            float* __restrict__ gbeta, float acc, float* __restrict__ gslope) {
     __shared__ double sh[2][16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (gslope && blockIdx.x == gridDim.x - 1) {
+        const float* sp = part + (size_t)2 * nrb * C;
+        const int n = nrb * C;
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)sp[i];
+        s = wave_sum_d(s);
+        if (tx == 0) sh[0][0][ty] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int i = 0; i < 16; ++i) t += sh[0][0][i];
+            gslope[0] = (acc == 0.f ? 0.f : acc * gslope[0]) + (float)t;
+        }
+        return;
+    }
     const int c = blockIdx.x * 64 + tx;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
@@ -668,14 +684,10 @@ int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
         hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb, ncb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
                            a.beta, a.slope, a.mean, a.invstd, part);
     FG_CHECK_LAUNCH(ctx);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fg_cdiv(a.C, 64)), dim3(1024), 0, ctx->stream, part, nrb, a.M, a.C,
-                       coef, a.ggamma, a.gbeta, a.gbeta_acc);
+    float* gs = (a.slope && a.gslope) ? a.gslope : nullptr;
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fg_cdiv(a.C, 64) + (gs ? 1 : 0)), dim3(1024), 0, ctx->stream, part, nrb, a.M, a.C,
+                       coef, a.ggamma, a.gbeta, a.gbeta_acc, gs);
     FG_CHECK_LAUNCH(ctx);
-    if (a.slope && a.gslope) {
-        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, part + (size_t)2 * nrb * a.C,
-                           nrb * a.C, a.gslope, a.gbeta_acc);
-        FG_CHECK_LAUNCH(ctx);
-    }
     if (a.gx) {
         const long long t4 = a.M * a.C / 4;
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.gy, a.gx, t4, a.C,
