@@ -30,8 +30,11 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
 // x6_dst (forward): write the planes of x there instead of into the scratch (the caller keeps them for the weight
 // gradient); *x6_written tells whether the bf16x6 path ran.  gy6 (dgrad): planes of gy left by fg_conv_wgrad_run.
 // wp6: the packed weights as split-bf16 planes if the caller keeps them (bf16x6 mode), else they are built per call
+// actb (optional): the nn.PReLU in front of the layer -- the kernel's epilogue turns the gradient wrt the layer's input into
+// the gradient wrt the PReLU's input (actb->applied; un-split fp32 launches inside an fg_net backward pass)
 int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const float* wp_bwd, float* gx, float* scratch,
-                      long long scratch_floats, const void* wp6 = nullptr, const void* gy6 = nullptr);
+                      long long scratch_floats, const void* wp6 = nullptr, const void* gy6 = nullptr,
+                      const FgActBwd* actb = nullptr);
 // bf16x6 plane sharing (all optional): x6 = planes of x kept from the forward pass; *gy6_out = where this call left the
 // planes of gy (nullptr if it ran in fp32) and *used_out = scratch floats that must stay untouched while they are used
 int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* gy, float* gradW, float* gradb,

@@ -5,6 +5,12 @@
 #include <string.h>
 #include <stdlib.h>
 
+bool fg_fuse_prelu() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FG_FUSE_PRELU"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0;
+}
+
 static inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;
@@ -277,13 +283,19 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
         const long long rows = (long long)fg_cdiv(a.M, bm) * wm.P * wrows;
         if (2 * rows * g.Cout <= stats_cap) { a.stats_part = stats_part; a.stats_rows = (int)rows; *stats_rows = (int)rows; }
     }
+    // the PReLU behind an un-split layer rides on the kernel's epilogue (a same-shape mask does not: split-K layers only)
+    if (act && splits == 1 && !a.A6 && act->y && act->slope && !act->mask && fg_fuse_prelu()) {
+        a.act_y = act->y; a.act_slope = act->slope;
+    }
     if ((rc = fg_launch_igemm(ctx, a, wm.P, tile))) return rc;
+    if (a.act_y) act->applied = 1;
     if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, bias, g.Cout, y, out_count, act);
     return FG_OK;
 }
 
 int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const float* wp_bwd, float* gx, float* scratch,
-                      long long scratch_floats, const void* wp6, const void* gy6) {
+                      long long scratch_floats, const void* wp6, const void* gy6, const FgActBwd* actb) {
+    if (actb) actb->applied = 0;
     if (g.B == 0) return FG_OK;
     if (g.stride == 2) {
         // stride-2 data gradient = stride-1 data gradient of the zero-inserted output gradient (the layers that use it are
@@ -330,7 +342,19 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
     }
     int rc;
     if ((rc = maybe_split_operands(ctx, a, tile, (long long)a.G * rb * cb, scratch, scratch_floats, wp6, gy6, nullptr, nullptr))) return rc;
+    // the backward of the PReLU in front of the layer in the epilogue (un-split fp32 launches); its slope-gradient partials
+    // (4 per block) go through the batched deferred finals, so this needs the arena of an fg_net backward pass
+    long long nparts = 0;
+    if (actb && actb->x && actb->slope && splits == 1 && !a.A6 && fg_fuse_prelu()) {
+        nparts = 4 * fg_igemm_blocks(a, 1, tile);
+        float* dp = actb->gslope ? fg_defer_alloc(ctx, nparts) : nullptr;
+        if (!actb->gslope || dp) { a.act_x = actb->x; a.act_slope = actb->slope; a.act_part = dp; }
+    }
     if ((rc = fg_launch_igemm(ctx, a, 1, tile))) return rc;
+    if (a.act_x) {
+        actb->applied = 1;
+        if (a.act_part) fg_defer_push(ctx, a.act_part, (int)nparts, 1, 0.f, actb->gslope);
+    }
     if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, nullptr, g.Cin, gx, out_count);
     return FG_OK;
 }

@@ -85,16 +85,33 @@ struct IgemmArgs {
     int goff[4][FG_MAX_GROUPS];   // per (parity, group): (oy & 0xffff) | (ox << 16) pixel offsets into A
     signed char ooy[4], oox[4];
     long long a_bytes;   // size of the A tensor in bytes (< 2 GiB: raw-buffer addressing)
+    // an nn.PReLU folded into the epilogue (splits == 1, fp32 kernels).  Forward: the PReLU BEHIND the layer -- the
+    // pre-activation still goes to Out (backward needs it) and prelu(Out) to act_y (same layout).  Data gradient: the PReLU
+    // in FRONT of the layer -- act_x is its input (same layout as Out), the stored value is the gradient wrt that input,
+    // acc * (x > 0 ? 1 : slope), and every MFMA wave leaves its part of the slope gradient sum_{x <= 0} acc * x in
+    // act_part[block * 4 + wave] (optional).  Same expressions as prelu_fwd_kernel / prelu_bwd_kernel.
+    const float* act_slope;
+    float* act_y;
+    const float* act_x;
+    float* act_part;
     double alg_flops;    // host-side bookkeeping only: reference-formulation FLOPs of this launch
     const char* tag;     // host-side: profile label
 };
 // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64.  P = gridDim.z parities.
 int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a, int P, int tile);
+// blocks along x of that launch (act_part holds 4 floats per block); 0 = bad tile
+long long fg_igemm_blocks(const IgemmArgs& a, int P, int tile);
 // sums split partials (+bias) : out[i] = bias[i % N] + sum_s part[s*stride + i]
 // fp32 rows [rows][C] (C % 16 == 0) -> split-bf16 planes [rows][C/16][3][16]: x = h + m + l exactly
 int fg_launch_split_planes(fg_ctx* ctx, const float* src, long long rows, int C, void* dst);
 // the nn.PReLU [+ nn.Dropout] behind a layer, folded into the pass that finishes the layer's output (split-K sum)
 struct FgActFuse { const float* slope; const float* mask; float mscale; float* y; mutable int applied; };
+// the nn.PReLU in front of a layer, folded into the epilogue of the kernel that produces the gradient wrt the layer's input:
+// x = the PReLU's input, gslope = its slope gradient (nullptr: not wanted); applied tells whether the launch folded it in
+struct FgActBwd { const float* x; const float* slope; float* gslope; mutable int applied; };
+// FG_FUSE_PRELU=0 in the environment keeps every PReLU a pass of its own (A/B switch for measurements and for the parity
+// tests, which run both ways); default on
+bool fg_fuse_prelu();
 int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long stride, const float* bias,
                          int N, float* out, long long count, const FgActFuse* act = nullptr);
 
@@ -220,6 +237,10 @@ int fg_launch_leakyrelu_backward(fg_ctx*, const float* x, const float* gy, float
 int fg_launch_axpby(fg_ctx*, float a, const float* x, float b, float* y, long long n);  // y = a*x + b*y
 int fg_launch_maxpool_forward(fg_ctx*, const float* x, float* y, int B, int H, int W, int C);
 int fg_launch_maxpool_backward(fg_ctx*, const float* x, const float* gy, float* gx, int B, int H, int W, int C);
+// SpatialMaxPooling backward + the backward of the nn.PReLU in front of it in one pass: xpre = the PReLU's input (the
+// pooled tensor prelu(xpre) is re-evaluated, bit-identical to the forward), gx = gradient wrt xpre
+int fg_launch_maxpool_prelu_backward(fg_ctx*, const float* xpre, const float* gy, const float* slope, float* gx,
+                                     float* gslope, int B, int H, int W, int C, float* scratch);
 int fg_launch_mul_mask(fg_ctx*, const float* x, const float* mask, float scale, float* y, long long n);
 int fg_launch_concat(fg_ctx*, const float* a, const float* b, float* out, long long npix, int ca, int cb);
 int fg_launch_split(fg_ctx*, const float* g, float* ga, float* gb, long long npix, int ca, int cb);
@@ -236,8 +257,11 @@ int fg_launch_zero_insert2(fg_ctx*, const float* g, float* out, int B, int H, in
 
 // thin convolutions (3 <-> wide channels), NHWC, stride 1, "same" pad, odd k <= 7
 // thin-in : out[pix][c<Cw] = bias[c] + sum_{tap, s<Cs} in[pix+off(tap)][s] * Wp[tap][s][c]
+// actf / actb (optional, MFMA variants only; ->applied says whether it happened): the PReLU behind (forward) / in front of
+// (data gradient of a thin-output layer) the layer, folded into the epilogue like IgemmArgs::act_*
 int fg_launch_thin_in_conv(fg_ctx*, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
-                           int W, int Cs, int Cw, int k, int flip);
+                           int W, int Cs, int Cw, int k, int flip, const FgActFuse* actf = nullptr,
+                           const FgActBwd* actb = nullptr);
 // thin-out: out[pix][s<Cs] = act(bias[s] + sum_{tap, c<Cw} in[pix+off(tap)][c] * Wp[tap][s][c])
 int fg_launch_thin_out_conv(fg_ctx*, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
                             int W, int Cw, int Cs, int k, int flip, int sigmoid, float* rbuf = nullptr, long long rbuf_floats = 0)   /* rbuf: >= B*H*W*32 floats enables the two-pass 5x5/7x7 MFMA path */;

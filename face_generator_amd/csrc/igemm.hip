@@ -31,6 +31,9 @@ __device__ __forceinline__ void fg_decode_m(int m, int lgH, int lgW, int Hm, int
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define FG_OOB 0x7FFFFFF0   // voffset marker: beyond any buffer (< 2 GiB) -> the buffer load returns zeros
+// EPI == 2 epilogue: row offset (in floats) of a masked row -- (FG_ROW_MASKED + col) * 4 lands in [2 GiB, 4 GiB), out of range
+// of every buffer resource, without a per-element compare (128 lane masks per wave spilled the scalar registers)
+#define FG_ROW_MASKED 0x20000000
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's float4 struct array went to scratch)
 __device__ __forceinline__ f32x4 fg_buffer_load4(__amdgpu_buffer_rsrc_t r, int voff) {
@@ -55,6 +58,101 @@ __device__ __forceinline__ void fg_store_acc_tile(__amdgpu_buffer_rsrc_t orsrc, 
     }
 }
 
+// Epilogue of the fp32 kernels for one wave's MI x NI accumulator tiles (rows row_base + 32 mi, columns col_base + 32 ni):
+// plain store (+ bias), store + the PReLU behind the layer (act_y), or the backward of the PReLU in front of the layer
+// (act_x: 16 loads of x per tile in flight, then 16 stores; the wave's share of the slope gradient goes to
+// act_part[part_idx]).  EPI selects the variant at compile time (0 plain, 1 act_y, 2 act_x): the kernels without a fused
+// PReLU keep their register allocation.
+template <int MI, int NI, int EPI>
+__device__ __forceinline__ void fg_epilogue(const IgemmArgs& a, float* outp, const int* rowoff, int row_base, int col_base,
+                                            const f32x16 (&acc)[MI][NI], int lane, int part_idx) {
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
+    if constexpr (EPI == 2) {
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.act_x, 0, FG_OOB, 0x00020000);
+        const float sl = a.act_slope[0];
+        float s = 0.f;
+        // rows outermost: the 16 row offsets of a 32-row tile are read once and serve both column tiles; one tile's 16
+        // loads of x are in flight at a time (the accumulators already hold half of the register file)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            int ro[16];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int4 t = *(const int4*)(rowoff + row_base + mi * 32 + 8 * r4 + 4 * (lane >> 5));
+                ro[r4 * 4 + 0] = t.x; ro[r4 * 4 + 1] = t.y; ro[r4 * 4 + 2] = t.z; ro[r4 * 4 + 3] = t.w;
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col = col_base + ni * 32 + (lane & 31);
+                const bool colok = col < a.N;
+                float xv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int vo = colok ? (ro[i] + col) * 4 : FG_OOB;
+                    xv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo, 0, 0));
+                }
+                float t4[4] = {0.f, 0.f, 0.f, 0.f};       // four short chains per tile instead of one 128-long serial chain
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int vo = colok ? (ro[i] + col) * 4 : FG_OOB;
+                    const float g = acc[mi][ni][i];
+                    const bool pos = xv[i] > 0.f;
+                    t4[i & 3] = fmaf(pos ? 0.f : xv[i], g, t4[i & 3]);   // masked elements read x = 0: they add 0 * g
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pos ? g : sl * g), orsrc, vo, 0, 0);
+                }
+                s += (t4[0] + t4[1]) + (t4[2] + t4[3]);
+                // pin the sum here: LLVM otherwise sinks the whole reduction into the `if (act_part)` block below and keeps
+                // all 128 x values and lane masks alive until then (spills)
+                asm volatile("" : "+v"(s));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (a.act_part) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) a.act_part[part_idx] = s;
+        }
+        return;
+    }
+    const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
+    if constexpr (EPI == 1) {
+        const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.act_y, 0, FG_OOB, 0x00020000);
+        const float sl = a.act_slope[0];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = col_base + ni * 32 + (lane & 31);
+            const bool colok = col < a.N;
+            float bv = add_bias ? a.bias[colok ? col : 0] : 0.f;
+            asm volatile("" : "+v"(bv));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int4 ro = *(const int4*)(rowoff + row_base + mi * 32 + 8 * r4 + 4 * (lane >> 5));
+                    const int offs[4] = {ro.x, ro.y, ro.z, ro.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int voff = (offs[q] >= 0 && colok) ? (offs[q] + col) * 4 : FG_OOB;
+                        const float v = acc[mi][ni][r4 * 4 + q] + bv;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orsrc, voff, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v > 0.f ? v : sl * v), yrsrc, voff, 0, 0);
+                    }
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int col = col_base + ni * 32 + (lane & 31);
+        const bool colok = col < a.N;
+        float bv = add_bias ? a.bias[colok ? col : 0] : 0.f;
+        asm volatile("" : "+v"(bv));
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+            fg_store_acc_tile(orsrc, rowoff, row_base + mi * 32, col, colok, bv, acc[mi][ni], lane);
+    }
+}
+
 // BatchNorm statistics from the accumulators (IgemmArgs::stats_part): lane l of a 32x32 tile holds 16 rows of column l & 31;
 // a wave's MI tiles x 16 rows x the two lane halves are summed in registers, so every wave leaves ONE partial row.
 template <int MI, int NI>
@@ -76,8 +174,8 @@ __device__ __forceinline__ void fg_store_stats(const IgemmArgs& a, const f32x16 
     }
 }
 
-template <int BM, int BN, int BK>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
+template <int BM, int BN, int BK, int EPI>
+__device__ __forceinline__ void igemm_body(const IgemmArgs& a) {
     constexpr int LDK = BK + 4;                 // padded row: conflict-free ds_read_b128 fragment reads
     constexpr int LPR = BK / 4;                 // lanes (float4) per tile row
     constexpr int RPP = 256 / LPR;              // rows per load pass
@@ -110,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
     const int split = blockIdx.y;
 
     if (tid < BM) {
-        int m = tile_m * BM + tid, off = -1;
+        int m = tile_m * BM + tid, off = EPI == 2 ? FG_ROW_MASKED : -1;
         if (m < a.M) {
             int n, y, x;
             fg_decode_m(m, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
@@ -231,20 +329,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 #undef FG_STORE_TILE
 
     if (a.stats_part) fg_store_stats<MI, NI>(a, acc, (tile_m * np + p) * 2 + wm, tile_n * BN + wn * (BN / 2), lane);
-    float* outp = a.Out + (size_t)split * a.split_stride;
-    const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int col = tile_n * BN + wn * (BN / 2) + ni * 32 + (lane & 31);
-        const bool colok = col < a.N;
-        float bv = add_bias ? a.bias[colok ? col : 0] : 0.f;
-        asm volatile("" : "+v"(bv));
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-            fg_store_acc_tile(orsrc, rowoff, wm * (BM / 2) + mi * 32, col, colok, bv, acc[mi][ni], lane);
-    }
+    fg_epilogue<MI, NI, EPI>(a, a.Out + (size_t)split * a.split_stride, rowoff, wm * (BM / 2), tile_n * BN + wn * (BN / 2), acc,
+                             lane, blockIdx.x * 4 + wid);
 }
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) { igemm_body<BM, BN, BK, 0>(a); }
+// the same kernel with an nn.PReLU folded into the epilogue: EPI 1 = behind the layer (forward), 2 = in front (data gradient)
+template <int BM, int BN, int BK, int EPI>
+__global__ __launch_bounds__(256, 2) void igemm_act_kernel(const IgemmArgs a) { igemm_body<BM, BN, BK, EPI>(a); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-specialised variant for the large layers: ONE 512-thread block per CU; waves 0-3 only multiply (one per SIMD,
@@ -260,8 +352,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmArgs a) {
 #define WS_NS 4
 #define WS_STAGE ((WS_BM + WS_BN) * WS_LDK)
 // BN = 128: MFMA waves 2x2, each 128x64; BN = 64 (layers with 64 output channels): waves 4x1, each 64x64
-template <int BN>
-__global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
+template <int BN, int EPI>
+__device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
     constexpr int WNW = BN / 64, MI = WS_BM / ((4 / WNW) * 32), NI = 2, NB = BN / 64;
     constexpr int STAGE = (WS_BM + BN) * WS_LDK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -284,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
     const int split = blockIdx.y;
 
     if (tid < WS_BM) {
-        int m = tile_m * WS_BM + tid, off = -1;
+        int m = tile_m * WS_BM + tid, off = EPI == 2 ? FG_ROW_MASKED : -1;
         if (m < a.M) {
             int n, y, x;
             fg_decode_m(m, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
@@ -429,20 +521,13 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
     }
 
     if (a.stats_part) fg_store_stats<MI, NI>(a, acc, (tile_m * np + p) * (4 / WNW) + wm, tile_n * BN + wn * 64, lane);
-    float* outp = a.Out + (size_t)split * a.split_stride;
-    const bool add_bias = (a.bias != nullptr) && (a.splits == 1);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int col = tile_n * BN + wn * 64 + ni * 32 + (lane & 31);
-        const bool colok = col < a.N;
-        float bv = add_bias ? a.bias[colok ? col : 0] : 0.f;
-        asm volatile("" : "+v"(bv));
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-            fg_store_acc_tile(orsrc, rowoff, wm * MI * 32 + mi * 32, col, colok, bv, acc[mi][ni], lane);
-    }
+    fg_epilogue<MI, NI, EPI>(a, a.Out + (size_t)split * a.split_stride, rowoff, wm * MI * 32, tile_n * BN + wn * 64, acc, lane,
+                             blockIdx.x * 4 + wid);
 }
+template <int BN>
+__global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) { igemm_ws_body<BN, 0>(a); }
+template <int BN, int EPI>
+__global__ __launch_bounds__(512, 2) void igemm_ws_act_kernel(const IgemmArgs a) { igemm_ws_body<BN, EPI>(a); }
 
 template <int BN>
 static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
@@ -450,14 +535,20 @@ static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
     static bool attr_set = false;
     if (!attr_set) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_act_kernel<BN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_act_kernel<BN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / BN) * P, a.splits, 1);
     const double exec = 2.0 * (double)grid.x * WS_BM * BN * (double)a.G * a.Kpad;
+    const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
     char label[96];
-    snprintf(label, sizeof(label), "igemm_ws_kernel<%d>/%s", BN, a.tag ? a.tag : "?");
+    if (epi) snprintf(label, sizeof(label), "igemm_ws_act_kernel<%d, %d>/%s", BN, epi, a.tag ? a.tag : "?");
+    else snprintf(label, sizeof(label), "igemm_ws_kernel<%d>/%s", BN, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
-    hipLaunchKernelGGL(igemm_ws_kernel<BN>, grid, dim3(512), lds, ctx->stream, a);
+    if (epi == 2) hipLaunchKernelGGL((igemm_ws_act_kernel<BN, 2>), grid, dim3(512), lds, ctx->stream, a);
+    else if (epi == 1) hipLaunchKernelGGL((igemm_ws_act_kernel<BN, 1>), grid, dim3(512), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(igemm_ws_kernel<BN>, grid, dim3(512), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
@@ -744,22 +835,43 @@ static int launch_igemm_t(fg_ctx* ctx, const IgemmArgs& a, int P) {
     if (!attr_set) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_act_kernel<BM, BN, BK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_act_kernel<BM, BN, BK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
         attr_set = true;
     }
     dim3 grid(fg_cdiv(a.M, BM) * (a.Npad / BN) * P, a.splits, 1);
     // executed FLOPs: every tile runs the full padded contraction
     const double exec = 2.0 * (double)grid.x * BM * BN * (double)a.G * a.Kpad;
+    const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
     char label[96];
-    snprintf(label, sizeof(label), "igemm_kernel<%d,%d,%d>/%s", BM, BN, BK, a.tag ? a.tag : "?");
+    if (epi) snprintf(label, sizeof(label), "igemm_act_kernel<%d,%d,%d,%d>/%s", BM, BN, BK, epi, a.tag ? a.tag : "?");
+    else snprintf(label, sizeof(label), "igemm_kernel<%d,%d,%d>/%s", BM, BN, BK, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, BK>), grid, dim3(256), lds, ctx->stream, a);
+    if (epi == 2) hipLaunchKernelGGL((igemm_act_kernel<BM, BN, BK, 2>), grid, dim3(256), lds, ctx->stream, a);
+    else if (epi == 1) hipLaunchKernelGGL((igemm_act_kernel<BM, BN, BK, 1>), grid, dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((igemm_kernel<BM, BN, BK>), grid, dim3(256), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
+}
+
+long long fg_igemm_blocks(const IgemmArgs& a, int P, int tile) {
+    switch (tile) {
+        case 0: return (long long)fg_cdiv(a.M, 128) * (a.Npad / 128) * P;
+        case 1: return (long long)fg_cdiv(a.M, 128) * (a.Npad / 64) * P;
+        case 2: return (long long)fg_cdiv(a.M, 64) * (a.Npad / 64) * P;
+        case 5: return (long long)fg_cdiv(a.M, WS_BM) * (a.Npad / 64) * P;
+        case 4: return (long long)fg_cdiv(a.M, WS_BM) * (a.Npad / ((a.Npad % 128 == 0) ? 128 : 64)) * P;
+    }
+    return 0;
 }
 
 int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
     IgemmArgs a = a_in;
     a.P = P;
+    if ((a.act_y || a.act_x) && (a.splits != 1 || a.A6 || !a.act_slope || (a.act_y && a.act_x)))
+        return fg_set_err(ctx, FG_ERR_INVALID, "igemm: a fused PReLU needs splits == 1, the fp32 path and its slope");
     if (a.Ca % 4 != 0 || a.Kpad % 32 != 0) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: Ca %% 4 / Kpad %% 32");
     if ((long long)a.Nb * a.Ho * a.Wo * a.N * 4 >= (long long)FG_OOB)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "igemm: output tensor must be < 2 GiB per launch");

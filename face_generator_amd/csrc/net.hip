@@ -144,6 +144,9 @@ static void make_plan(fg_net* n, int B) {
         for (auto& s : n->st) {
             if (s.kind == ST_CONV || s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT || s.kind == ST_GEMV) dn += (long long)CR_ROWBLOCKS_MAX * s.oc + 64;
             if (s.has_prelu || s.kind == ST_PRELU || s.kind == ST_ACTPOOL) dn += 1024 + 64;
+            // a PReLU whose backward rides on the epilogue of the neighbouring contraction leaves 4 partials per block
+            if (s.kind == ST_PRELU && s.mask_kind == 0)
+                dn += 4LL * fg_cdiv((long long)B * s.ih * s.iw, 64) * fg_cdiv(s.ic, 64) + 8192LL * fg_cdiv(s.ic, 64) + 64;
         }
         n->defer_off = off; n->defer_floats = dn; off += align64(dn);
     }
@@ -172,8 +175,19 @@ static int backward_run_stages(fg_net* n) {
     float* Gp = n->grads;
     const float* gcur = n->bwd_gcur;
     int pp = n->bwd_pp, rc = FG_OK;
+    bool prelu_folded = false;       // the previous (= next deeper) stage's kernel already ran this PReLU's backward
     for (int si = n->run_stage; si >= stage_to; --si) {
         Stage& s = n->st[si];
+        if (prelu_folded) { prelu_folded = false; continue; }      // gcur already is the gradient wrt the PReLU's input
+        // a plain PReLU directly in front of this stage (inside this call's range, not the net's first stage): its backward
+        // can ride on the epilogue of the kernel that produces this stage's input gradient
+        FgActBwd actb; memset(&actb, 0, sizeof(actb));
+        const bool pf = si >= 2 && si - 1 >= stage_to && n->st[si - 1].kind == ST_PRELU && n->st[si - 1].mask_kind == 0 &&
+                        fg_fuse_prelu();
+        if (pf) {
+            actb.x = ws + n->st[si - 2].out_off; actb.slope = P + n->st[si - 1].slope_off;
+            actb.gslope = want_p ? Gp + n->st[si - 1].slope_off : nullptr;
+        }
         const float* xin = si == 0 ? x : ws + n->st[si - 1].out_off;
         const float* yout = (si + 1 == (int)n->st.size() && n->out_override) ? n->out_override : ws + s.out_off;
         const bool need_gx = si > 0 || want_x;
@@ -198,7 +212,8 @@ static int backward_run_stages(fg_net* n) {
                     }
                 }
                 if (!rc && need_gx) rc = fg_conv_dgrad_run(ctx, g, gcur, s.wp_bwd, gxb, scratch + gy6_used, n->scratch_floats - gy6_used,
-                                                         n->planes_valid ? s.wp_bwd6 : nullptr, gy6);
+                                                         n->planes_valid ? s.wp_bwd6 : nullptr, gy6, pf ? &actb : nullptr);
+                prelu_folded = pf && !rc && actb.applied;
                 break;
             }
             case ST_GEMV:
@@ -230,8 +245,11 @@ static int backward_run_stages(fg_net* n) {
                     if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 1, 0.f);
                     if (!rc) rc = fg_launch_colsum(ctx, gpre, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
                 }
-                if (!rc && need_gx)
-                    rc = fg_launch_thin_in_conv(ctx, gpre, s.wp_fwd, nullptr, gxb, B, s.ih, s.iw, s.oc, s.ic, k, 1);
+                if (!rc && need_gx) {
+                    rc = fg_launch_thin_in_conv(ctx, gpre, s.wp_fwd, nullptr, gxb, B, s.ih, s.iw, s.oc, s.ic, k, 1, nullptr,
+                                                pf ? &actb : nullptr);
+                    prelu_folded = pf && !rc && actb.applied;
+                }
                 break;
             }
             case ST_BNPRELU: {
@@ -272,7 +290,12 @@ static int backward_run_stages(fg_net* n) {
             case ST_UPSAMPLE: if (need_gx) rc = fg_launch_upsample_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
             case ST_AVGPOOL: if (need_gx) rc = fg_launch_avgpool_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
             case ST_SDROPOUT: if (need_gx) rc = fg_launch_scale_mask_nc(ctx, gcur, mask, 1.f, gxb, B, s.ih * s.iw, s.ic); break;
-            case ST_MAXPOOL: if (need_gx) rc = fg_launch_maxpool_backward(ctx, xin, gcur, gxb, B, s.ih, s.iw, s.ic); break;
+            case ST_MAXPOOL:
+                if (need_gx && pf) {     // pooled tensor = prelu(actb.x): both backward passes in one
+                    rc = fg_launch_maxpool_prelu_backward(ctx, actb.x, gcur, actb.slope, gxb, actb.gslope, B, s.ih, s.iw, s.ic, scratch);
+                    prelu_folded = !rc;
+                } else if (need_gx) rc = fg_launch_maxpool_backward(ctx, xin, gcur, gxb, B, s.ih, s.iw, s.ic);
+                break;
             case ST_DROPOUT:
                 if (need_gx) rc = fg_launch_mul_mask(ctx, gcur, mask, 1.f / (1.f - s.p), gxb, (long long)B * s.ic * s.ih * s.iw);
                 break;
@@ -311,7 +334,8 @@ static int forward_run(fg_net* n, long long* out_offset) {
                 Stage* pr = (si + 1 < (int)n->st.size() && n->st[si + 1].kind == ST_PRELU) ? &n->st[si + 1] : nullptr;
                 if (pr) {
                     const bool dm = pr->mask_kind == 2 && train;
-                    act.slope = P + pr->slope_off; act.y = ws + pr->out_off;
+                    act.slope = P + pr->slope_off;
+                    act.y = (si + 2 == (int)n->st.size() && n->out_override) ? n->out_override : ws + pr->out_off;
                     act.mask = dm ? n->mask_ptrs[pr->mask_idx] : nullptr; act.mscale = dm ? 1.f / (1.f - pr->p) : 1.f;
                     pr->act_done = 0;
                 }
@@ -326,9 +350,20 @@ static int forward_run(fg_net* n, long long* out_offset) {
             case ST_GEMV:
                 rc = fg_launch_gemv_forward(ctx, cur, P + s.w_off, P + s.b_off, y, B, s.ic, s.has_sigmoid);
                 break;
-            case ST_THIN_IN:
-                rc = fg_launch_thin_in_conv(ctx, cur, s.wp_fwd, P + s.b_off, y, B, s.ih, s.iw, s.ic, s.oc, s.geom.k, 0);
+            case ST_THIN_IN: {
+                // a plain PReLU directly behind rides on the MFMA kernel's epilogue
+                FgActFuse act; memset(&act, 0, sizeof(act));
+                Stage* pr = (si + 1 < (int)n->st.size() && n->st[si + 1].kind == ST_PRELU && n->st[si + 1].mask_kind == 0)
+                                ? &n->st[si + 1] : nullptr;
+                if (pr) {
+                    act.slope = P + pr->slope_off; act.mscale = 1.f; pr->act_done = 0;
+                    act.y = (si + 2 == (int)n->st.size() && n->out_override) ? n->out_override : ws + pr->out_off;
+                }
+                rc = fg_launch_thin_in_conv(ctx, cur, s.wp_fwd, P + s.b_off, y, B, s.ih, s.iw, s.ic, s.oc, s.geom.k, 0,
+                                            pr ? &act : nullptr, nullptr);
+                if (pr && !rc) pr->act_done = act.applied;
                 break;
+            }
             case ST_THIN_OUT:
                 rc = fg_launch_thin_out_conv(ctx, cur, s.wp_fwd, P + s.b_off, y, B, s.ih, s.iw, s.ic, s.oc, s.geom.k, 0,
                                              s.has_sigmoid, scratch, n->scratch_floats);

@@ -195,6 +195,20 @@ __global__ __launch_bounds__(1024) void multi_final_kernel(const FgFinalBatch b)
     while (j + 1 < b.n && (int)blockIdx.x >= b.jobs[j + 1].blk0) ++j;
     const FgFinalJob jb = b.jobs[j];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (jb.C == 1) {     // scalar jobs (PReLU slope gradients, up to a few thousand partials): all 1024 threads over the rows
+        double s1 = 0.0;
+        for (int r = threadIdx.x; r < jb.nrb; r += 1024) s1 += (double)jb.part[r];
+        s1 = wave_sum_d(s1);
+        if (tx == 0) sh[0][ty] = s1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += sh[0][i];
+            jb.out[0] = (jb.beta == 0.f) ? (float)t : jb.beta * jb.out[0] + (float)t;
+        }
+        return;
+    }
     const int c = ((int)blockIdx.x - jb.blk0) * 64 + tx;
     double s = 0.0;
     if (c < jb.C)
@@ -1041,6 +1055,62 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) gx[o[k]] = (k == am) ? g : 0.f;
     }
+}
+// maxpool backward + the backward of the PReLU in front of it: the pooled tensor was prelu(xpre) (re-evaluated with
+// prelu_fwd_kernel's expression, so the argmax is the forward's), gx = gradient wrt xpre, slope-gradient partials per block
+__global__ __launch_bounds__(256) void maxpool_prelu_bwd_kernel(const float* __restrict__ xpre, const float* __restrict__ gy,
+                                                                const float* __restrict__ slope, float* __restrict__ gx,
+                                                                float* __restrict__ part, int B, int H, int W, int C) {
+    __shared__ float sh[4];
+    const float a = slope[0];
+    const int H2 = H >> 1, W2 = W >> 1;
+    const long long total = (long long)B * H2 * W2 * C;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long t = i / C;
+        const int w2 = (int)(t % W2); t /= W2;
+        const int h2 = (int)(t % H2);
+        const int b = (int)(t / H2);
+        const size_t base = (((size_t)b * H + 2 * h2) * W + 2 * w2) * C + c;
+        const size_t o[4] = {base, base + C, base + (size_t)W * C, base + (size_t)W * C + C};
+        float xv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[k] = xpre[o[k]];
+        int am = 0;
+        float m = xv[0] > 0.f ? xv[0] : a * xv[0];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { const float v = xv[k] > 0.f ? xv[k] : a * xv[k]; if (v > m) { m = v; am = k; } }
+        const float g = gy[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool pos = xv[k] > 0.f;
+            const float gk = (k == am) ? g : 0.f;
+            gx[o[k]] = pos ? gk : a * gk;
+            if (k == am && !pos) s = fmaf(xv[k], g, s);
+        }
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0 && part) part[blockIdx.x] = s;
+}
+int fg_launch_maxpool_prelu_backward(fg_ctx* ctx, const float* xpre, const float* gy, const float* slope, float* gx,
+                                     float* gslope, int B, int H, int W, int C, float* scratch) {
+    if (H % 2 || W % 2) return fg_set_err(ctx, FG_ERR_INVALID, "maxpool: even H/W");
+    long long n = (long long)B * (H / 2) * (W / 2) * C;
+    if (n == 0) return FG_OK;
+    dim3 grid = FG_GRID(n, 256);
+    if (grid.x > 1024) grid.x = 1024;
+    float* dpart = gslope ? fg_defer_alloc(ctx, grid.x) : nullptr;
+    float* part = dpart ? dpart : (gslope ? scratch : nullptr);
+    hipLaunchKernelGGL(maxpool_prelu_bwd_kernel, grid, dim3(256), 0, ctx->stream, xpre, gy, slope, gx, part, B, H, W, C);
+    FG_CHECK_LAUNCH(ctx);
+    if (dpart) { fg_defer_push(ctx, dpart, (int)grid.x, 1, 0.f, gslope); return FG_OK; }
+    if (gslope) {
+        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, (int)grid.x, gslope, 0.f);
+        FG_CHECK_LAUNCH(ctx);
+    }
+    return FG_OK;
 }
 int fg_launch_maxpool_forward(fg_ctx* ctx, const float* x, float* y, int B, int H, int W, int C) {
     if (C % 4 || H % 2 || W % 2) return fg_set_err(ctx, FG_ERR_INVALID, "maxpool: C%%4, even H/W");

@@ -3,6 +3,7 @@
 // N or K of the GEMM view is 3 (or 27), so MFMA tiles would be > 90 % padding: these are HBM/VALU-bound and
 // run on the vector ALU with coalesced NHWC accesses and weights held in registers.
 #include "fg_internal.h"
+#include <string.h>
 typedef float tw_f32x16 __attribute__((ext_vector_type(16)));   // MFMA 32x32 accumulator
 
 __device__ __forceinline__ float wave_sum_x(float v) {
@@ -246,14 +247,44 @@ __global__ __launch_bounds__(256) void thin_in_generic_kernel(const float* __res
     }
 }
 
+// An nn.PReLU folded into the epilogue of the MFMA thin-input kernels (the same contract as IgemmArgs::act_*): y = also
+// write prelu(out) there (forward); x = the PReLU's input, the stored value becomes acc * (x > 0 ? 1 : slope) and the wave's
+// share of the slope gradient goes to part[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave] (data gradient of a thin-OUTPUT layer).
+struct ThinEpi { const float* slope; float* y; const float* x; float* part; };
+template <int EPI>
+__device__ __forceinline__ void thin_epi_store(const ThinEpi& e, float sl, float* __restrict__ out, size_t idx, float v0, float v1,
+                                               float& s) {
+    if constexpr (EPI == 2) {
+        const float x0 = e.x[idx], x1 = e.x[idx + 32];
+        s = fmaf(x0 > 0.f ? 0.f : x0, v0, s);
+        s = fmaf(x1 > 0.f ? 0.f : x1, v1, s);
+        out[idx] = x0 > 0.f ? v0 : sl * v0;
+        out[idx + 32] = x1 > 0.f ? v1 : sl * v1;
+    } else {
+        out[idx] = v0;
+        out[idx + 32] = v1;
+        if constexpr (EPI == 1) {
+            e.y[idx] = v0 > 0.f ? v0 : sl * v0;
+            e.y[idx + 32] = v1 > 0.f ? v1 : sl * v1;
+        }
+    }
+}
+__device__ __forceinline__ void thin_epi_finish(const ThinEpi& e, float s, int lane, int wave) {
+    if (!e.part) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) e.part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave] = s;
+}
+
 // 3x3 thin-input convolution (3 or 1 channels -> 64 / 128) on the fp32 matrix pipe: a 32-pixel x 32-channel tile is
 // ceil(9*CS / 2) v_mfma_f32_32x32x2_f32 with K = the (tap, channel) index; A = the shifted input values of the 32 pixels
 // (per-lane gather from the tiny input, zero outside the image), B = the packed weights held in registers for the whole
 // kernel, bias folded into the accumulator init.  Replaces the row-walking VALU kernel (26 us for a 33 MB output).
-template <int CS>
+template <int CS, int EPI>
 __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
                                                            const float* __restrict__ bias, float* __restrict__ out,
-                                                           int npix, int H, int W, int flip, int Cw, int lgH, int lgW) {
+                                                           int npix, int H, int W, int flip, int Cw, int lgH, int lgW,
+                                                           const ThinEpi epi) {
     constexpr int NA = 9 * CS;
     constexpr int KS = (NA + 1) / 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -274,6 +305,8 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
     const float b0 = bias ? bias[cb + j] : 0.f, b1 = bias ? bias[cb + 32 + j] : 0.f;
     const bool p2 = lgW >= 0 && lgH >= 0;
     const int ntiles = (npix + 31) / 32;
+    const float esl = EPI ? epi.slope[0] : 1.f;
+    float es = 0.f;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int pix = tile * 32 + j;
         const bool ok = pix < npix;
@@ -296,22 +329,20 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (p < npix) {
-                float* o = out + (size_t)p * Cw + cb + j;
-                o[0] = acc0[r];
-                o[32] = acc1[r];
-            }
+            if (p < npix) thin_epi_store<EPI>(epi, esl, out, (size_t)p * Cw + cb + j, acc0[r], acc1[r], es);
         }
     }
+    if constexpr (EPI == 2) thin_epi_finish(epi, es, lane, wave);
 }
 
 // The same contraction for the larger thin layers (5x5 / 7x7 kernels, 4-channel input: the c2f nets): K = K*K*CS is up to
 // 147, too many weight fragments for registers, so the packed weights of the block's 64 output channels live in LDS
 // ([K*K*CS][64] floats, one conflict-free ds_read_b32 per MFMA).
-template <int K, int CS>
+template <int K, int CS, int EPI>
 __global__ __launch_bounds__(256) void thin_in_mfma_lds_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
                                                                const float* __restrict__ bias, float* __restrict__ out,
-                                                               int npix, int H, int W, int flip, int Cw, int lgH, int lgW) {
+                                                               int npix, int H, int W, int flip, int Cw, int lgH, int lgW,
+                                                               const ThinEpi epi) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int NA = K * K * CS;
     constexpr int KS = (NA + 1) / 2;
@@ -332,6 +363,8 @@ __global__ __launch_bounds__(256) void thin_in_mfma_lds_kernel(const float* __re
     const float b0 = bias ? bias[cb + j] : 0.f, b1 = bias ? bias[cb + 32 + j] : 0.f;
     const bool p2 = lgW >= 0 && lgH >= 0;
     const int ntiles = (npix + 31) / 32;
+    const float esl = EPI ? epi.slope[0] : 1.f;
+    float es = 0.f;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int pix = tile * 32 + j;
         const bool ok = pix < npix;
@@ -356,17 +389,32 @@ __global__ __launch_bounds__(256) void thin_in_mfma_lds_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (p < npix) {
-                float* o = out + (size_t)p * Cw + cb + j;
-                o[0] = acc0[r];
-                o[32] = acc1[r];
-            }
+            if (p < npix) thin_epi_store<EPI>(epi, esl, out, (size_t)p * Cw + cb + j, acc0[r], acc1[r], es);
         }
     }
+    if constexpr (EPI == 2) thin_epi_finish(epi, es, lane, wave);
 }
 
 int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
-                           int W, int Cs, int Cw, int k, int flip) {
+                           int W, int Cs, int Cw, int k, int flip, const FgActFuse* actf, const FgActBwd* actb) {
+    if (actf) actf->applied = 0;
+    if (actb) actb->applied = 0;
+    ThinEpi epi; memset(&epi, 0, sizeof(epi));
+    // fold the neighbouring PReLU into the epilogue (MFMA variants): forward = plain PReLU only (no same-shape mask)
+    const bool want_f = actf && actf->y && actf->slope && !actf->mask && fg_fuse_prelu();
+    const bool want_b = !want_f && actb && actb->x && actb->slope && fg_fuse_prelu();
+    auto arm = [&](dim3 g) -> bool {      // false: the slope-gradient partials do not fit the deferred arena -> not folded
+        if (want_f) { epi.slope = actf->slope; epi.y = actf->y; return true; }
+        if (want_b) {
+            const long long np = (long long)g.x * g.y * 4;
+            float* dp = actb->gslope ? fg_defer_alloc(ctx, np) : nullptr;
+            if (actb->gslope && !dp) return false;
+            epi.slope = actb->slope; epi.x = actb->x; epi.part = dp;
+            if (dp) fg_defer_push(ctx, dp, (int)np, 1, 0.f, actb->gslope);
+        }
+        return true;
+    };
+    auto armed = [&]() { if (epi.y) actf->applied = 1; if (epi.x) actb->applied = 1; };
     if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_in: Cw %% 64");
     const int cblk = Cw >= 256 ? 256 : Cw;
     if (Cw % cblk || 256 % cblk) return fg_set_err(ctx, FG_ERR_INVALID, "thin_in: Cw=%d unsupported", Cw);
@@ -379,22 +427,31 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         int nb = fg_cdiv(fg_cdiv(npix, 32), 4);
         if (nb > 2048) nb = 2048;
         dim3 mgrid(nb, Cw / 64);
-        if (Cs == 3) hipLaunchKernelGGL((thin_in_mfma_kernel<3>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW);
-        else hipLaunchKernelGGL((thin_in_mfma_kernel<1>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW);
+        arm(mgrid);
+        const int em = epi.x ? 2 : (epi.y ? 1 : 0);
+#define TIM(CC, EE) hipLaunchKernelGGL((thin_in_mfma_kernel<CC, EE>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW, epi)
+        if (Cs == 3) { if (em == 2) TIM(3, 2); else if (em == 1) TIM(3, 1); else TIM(3, 0); }
+        else { if (em == 2) TIM(1, 2); else if (em == 1) TIM(1, 1); else TIM(1, 0); }
+#undef TIM
         FG_CHECK_LAUNCH(ctx);
+        armed();
         return FG_OK;
     }
-    if ((k == 5 || k == 7 || (k == 3 && Cs == 4)) && (Cs == 1 || Cs == 3 || Cs == 4)) {
+    if ((k == 3 && Cs == 4) || ((k == 5 || k == 7) && (Cs == 1 || Cs == 3))) {      // exactly the TIL(...) instances below
         int lgH = -1, lgW = -1;
         for (int q = 0; q < 15; ++q) { if ((1 << q) == H) lgH = q; if ((1 << q) == W) lgW = q; }
         int nb = fg_cdiv(fg_cdiv(npix, 32), 4);
         if (nb > 1024) nb = 1024;
         dim3 mgrid(nb, Cw / 64);
+        arm(mgrid);
+        const int em = epi.x ? 2 : (epi.y ? 1 : 0);
 #define TIL(KK, CC)                                                                                                  \
         if (k == KK && Cs == CC) {                                                                                   \
-            hipLaunchKernelGGL((thin_in_mfma_lds_kernel<KK, CC>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, \
-                               H, W, flip, Cw, lgH, lgW);                                                            \
+            if (em == 2) hipLaunchKernelGGL((thin_in_mfma_lds_kernel<KK, CC, 2>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW, epi); \
+            else if (em == 1) hipLaunchKernelGGL((thin_in_mfma_lds_kernel<KK, CC, 1>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW, epi); \
+            else hipLaunchKernelGGL((thin_in_mfma_lds_kernel<KK, CC, 0>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW, epi); \
             FG_CHECK_LAUNCH(ctx);                                                                                    \
+            armed();                                                                                                 \
             return FG_OK;                                                                                            \
         }
         TIL(3, 4) TIL(5, 1) TIL(5, 3) TIL(7, 1) TIL(7, 3)
