@@ -43,10 +43,10 @@ def alg_flops_per_iter(B, d_it=1, g_it=1):
 def parse_prof(text):
     rows = {}
     for line in text.strip().splitlines():
-        parts = line.split()
+        parts = line.rsplit(None, 5)        # the label may contain blanks (template argument lists)
         if len(parts) != 6:
             continue
-        name = parts[0]
+        name = parts[0].replace(" ", "")
         rows[name] = dict(calls=int(parts[1]), ms=float(parts[2]), alg=float(parts[3]), exe=float(parts[4]))
     return rows
 

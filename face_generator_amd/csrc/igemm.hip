@@ -543,7 +543,7 @@ static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
     const double exec = 2.0 * (double)grid.x * WS_BM * BN * (double)a.G * a.Kpad;
     const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
     char label[96];
-    if (epi) snprintf(label, sizeof(label), "igemm_ws_act_kernel<%d, %d>/%s", BN, epi, a.tag ? a.tag : "?");
+    if (epi) snprintf(label, sizeof(label), "igemm_ws_act_kernel<%d,%d>/%s", BN, epi, a.tag ? a.tag : "?");
     else snprintf(label, sizeof(label), "igemm_ws_kernel<%d>/%s", BN, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
     if (epi == 2) hipLaunchKernelGGL((igemm_ws_act_kernel<BN, 2>), grid, dim3(512), lds, ctx->stream, a);

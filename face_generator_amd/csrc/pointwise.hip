@@ -326,25 +326,52 @@ __global__ __launch_bounds__(CR4_NT) void bn_stats4_partial_kernel(const float* 
         acc[1].z = fmaf(dz, dz, acc[1].z); acc[1].w = fmaf(dw, dw, acc[1].w);
     });
 }
+// Final stage of the BatchNorm reductions: per-channel fp64 sums over the nrb rows of K partial planes ([K][nrb][C]).
+// Block = 16 channels x 64 row lanes (a 64-column block left 2-4 blocks walking up to 1024 rows 16 at a time: 13-15 us for
+// 2 MB of partials); a wave holds 4 row lanes of the 16 channels: shuffle-reduce those, then 16 waves through LDS.
+// Result valid in threads 0..15 (channel = blockIdx.x * 16 + threadIdx.x).
+template <int K>
+__device__ __forceinline__ void bn_final_sums(const float* __restrict__ part, int nrb, int C, double (&s)[K]) {
+    __shared__ double sh[K][16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
+#pragma unroll
+    for (int k = 0; k < K; ++k) s[k] = 0.0;
+    if (c < C)
+        for (int b = ty; b < nrb; b += 64) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) s[k] += (double)part[((size_t)k * nrb + b) * C + c];
+        }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        s[k] += __shfl_xor(s[k], 16, 64);
+        s[k] += __shfl_xor(s[k], 32, 64);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sh[k][w][lane] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t += sh[k][i][threadIdx.x];
+            s[k] = t;
+        }
+    }
+}
 __global__ __launch_bounds__(1024) void bn_stats_final_kernel(const float* __restrict__ part, const float* __restrict__ x,
                                                               int nrb, long long M, int C, float eps, float momentum,
                                                               float* __restrict__ mean, float* __restrict__ invstd,
                                                               float* __restrict__ rmean, float* __restrict__ rvar) {
-    __shared__ double sh[2][16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int b = ty; b < nrb; b += 16) {
-            s1 += (double)part[(size_t)b * C + c];
-            s2 += (double)part[((size_t)nrb + b) * C + c];
-        }
-    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
-    __syncthreads();
-    if (ty != 0 || c >= C) return;
-    s1 = 0.0; s2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { s1 += sh[0][i][tx]; s2 += sh[1][i][tx]; }
+    double s[2];
+    bn_final_sums<2>(part, nrb, C, s);
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (threadIdx.x >= 16 || c >= C) return;
+    const double s1 = s[0], s2 = s[1];
     const double n = (double)M;
     const double mu = (double)x[c] + s1 / n;
     double var = (s2 - s1 * s1 / n) / n;
@@ -398,7 +425,7 @@ static inline int bn_apply_blocks(long long total4, int C) {
 int fg_launch_bn_forward(fg_ctx* ctx, const BnArgs& a) {
     if (a.C % 4) return fg_set_err(ctx, FG_ERR_INVALID, "bn: C %% 4");
     if (a.train && a.stats_part) {
-        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(fg_cdiv(a.C, 64)), dim3(1024), 0, ctx->stream, a.stats_part, a.stats_pivot,
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(fg_cdiv(a.C, 16)), dim3(1024), 0, ctx->stream, a.stats_part, a.stats_pivot,
                            a.stats_rows, a.M, a.C, a.eps, a.momentum, a.mean, a.invstd, a.running_mean, a.running_var);
         FG_CHECK_LAUNCH(ctx);
     } else if (a.train) {
@@ -409,7 +436,7 @@ int fg_launch_bn_forward(fg_ctx* ctx, const BnArgs& a) {
             hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nrb, fg_cdiv(a.C, 64)), dim3(256), 0, ctx->stream, a.x, a.M,
                                a.C, a.scratch);
         FG_CHECK_LAUNCH(ctx);
-        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(fg_cdiv(a.C, 64)), dim3(1024), 0, ctx->stream, a.scratch, a.x,
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3(fg_cdiv(a.C, 16)), dim3(1024), 0, ctx->stream, a.scratch, a.x,
                            nrb, a.M, a.C, a.eps, a.momentum, a.mean, a.invstd, a.running_mean, a.running_var);
         FG_CHECK_LAUNCH(ctx);
     } else {
@@ -537,45 +564,29 @@ __global__ __launch_bounds__(CR4_NT) void bn_bwd4_partial_kernel(const float* __
 #undef FG_BNB
     });
 }
-// scratch layout: part[3][nrb][C], then coef[2][C]
-// (one extra block, when gslope is given, sums the nrb * C PReLU-slope partials that follow the two channel planes)
+// scratch layout: part[3][nrb][C], then coef[2][C], then slope_part[ceil(C/16)]
+// (when slope_part is given every block also leaves the sum of ITS 16 channels' PReLU-slope partials there; the few block
+// values are finished by the batched deferred final of the backward pass, or by scalar_final_kernel)
 __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ part, int nrb, long long M, int C,
                                                             float* __restrict__ coef, float* __restrict__ ggamma,
-                                                            float* __restrict__ gbeta, float acc, float* __restrict__ gslope) {
-    __shared__ double sh[2][16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    if (gslope && blockIdx.x == gridDim.x - 1) {
-        const float* sp = part + (size_t)2 * nrb * C;
-        const int n = nrb * C;
-        double s = 0.0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) s += (double)sp[i];
-        s = wave_sum_d(s);
-        if (tx == 0) sh[0][0][ty] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double t = 0.0;
-            for (int i = 0; i < 16; ++i) t += sh[0][0][i];
-            gslope[0] = (acc == 0.f ? 0.f : acc * gslope[0]) + (float)t;
-        }
-        return;
-    }
-    const int c = blockIdx.x * 64 + tx;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int b = ty; b < nrb; b += 16) {
-            s1 += (double)part[(size_t)b * C + c];
-            s2 += (double)part[((size_t)nrb + b) * C + c];
-        }
-    sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
-    __syncthreads();
-    if (ty != 0 || c >= C) return;
-    s1 = 0.0; s2 = 0.0;
+                                                            float* __restrict__ gbeta, float acc, float* __restrict__ slope_part) {
+    double s[3];
+    if (slope_part) bn_final_sums<3>(part, nrb, C, s);
+    else { double t[2]; bn_final_sums<2>(part, nrb, C, t); s[0] = t[0]; s[1] = t[1]; s[2] = 0.0; }
+    if (threadIdx.x >= 64) return;
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    const bool own = threadIdx.x < 16 && c < C;
+    if (slope_part) {                       // wave 0: lanes 0..15 hold the channel sums
+        double v = own ? s[2] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s1 += sh[0][i][tx]; s2 += sh[1][i][tx]; }
-    coef[c] = (float)(s1 / (double)M);
-    coef[C + c] = (float)(s2 / (double)M);
-    if (ggamma) ggamma[c] = (acc == 0.f ? 0.f : acc * ggamma[c]) + (float)s2;
-    if (gbeta) gbeta[c] = (acc == 0.f ? 0.f : acc * gbeta[c]) + (float)s1;
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (threadIdx.x == 0) slope_part[blockIdx.x] = (float)v;
+    }
+    if (!own) return;
+    coef[c] = (float)(s[0] / (double)M);
+    coef[C + c] = (float)(s[1] / (double)M);
+    if (ggamma) ggamma[c] = (acc == 0.f ? 0.f : acc * ggamma[c]) + (float)s[1];
+    if (gbeta) gbeta[c] = (acc == 0.f ? 0.f : acc * gbeta[c]) + (float)s[0];
 }
 __global__ __launch_bounds__(1024) void scalar_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out,
                                                             float acc) {
@@ -699,9 +710,17 @@ int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
                            a.beta, a.slope, a.mean, a.invstd, part);
     FG_CHECK_LAUNCH(ctx);
     float* gs = (a.slope && a.gslope) ? a.gslope : nullptr;
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(fg_cdiv(a.C, 64) + (gs ? 1 : 0)), dim3(1024), 0, ctx->stream, part, nrb, a.M, a.C,
-                       coef, a.ggamma, a.gbeta, a.gbeta_acc, gs);
+    const int nfb = fg_cdiv(a.C, 16);
+    float* dpart = gs ? fg_defer_alloc(ctx, nfb) : nullptr;          // inside fg_net backward: finished by the batched final
+    float* spart = gs ? (dpart ? dpart : coef + (size_t)2 * a.C) : nullptr;
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(nfb), dim3(1024), 0, ctx->stream, part, nrb, a.M, a.C,
+                       coef, a.ggamma, a.gbeta, a.gbeta_acc, spart);
     FG_CHECK_LAUNCH(ctx);
+    if (dpart) fg_defer_push(ctx, dpart, nfb, 1, a.gbeta_acc, gs);
+    else if (gs) {
+        hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, spart, nfb, gs, a.gbeta_acc);
+        FG_CHECK_LAUNCH(ctx);
+    }
     if (a.gx) {
         const long long t4 = a.M * a.C / 4;
         hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.gy, a.gx, t4, a.C,

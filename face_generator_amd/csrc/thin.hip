@@ -253,9 +253,8 @@ __global__ __launch_bounds__(256) void thin_in_generic_kernel(const float* __res
 struct ThinEpi { const float* slope; float* y; const float* x; float* part; };
 template <int EPI>
 __device__ __forceinline__ void thin_epi_store(const ThinEpi& e, float sl, float* __restrict__ out, size_t idx, float v0, float v1,
-                                               float& s) {
-    if constexpr (EPI == 2) {
-        const float x0 = e.x[idx], x1 = e.x[idx + 32];
+                                               float x0, float x1, float& s) {
+    if constexpr (EPI == 2) {          // x0 / x1: the PReLU input at idx / idx + 32, fetched before the tile's MFMA loop
         s = fmaf(x0 > 0.f ? 0.f : x0, v0, s);
         s = fmaf(x1 > 0.f ? 0.f : x1, v1, s);
         out[idx] = x0 > 0.f ? v0 : sl * v0;
@@ -266,6 +265,21 @@ __device__ __forceinline__ void thin_epi_store(const ThinEpi& e, float sl, float
         if constexpr (EPI == 1) {
             e.y[idx] = v0 > 0.f ? v0 : sl * v0;
             e.y[idx + 32] = v1 > 0.f ? v1 : sl * v1;
+        }
+    }
+}
+// EPI == 2: the 2 x 16 values of x a lane needs for one 32-pixel tile, requested BEFORE the tile's MFMA loop so the loads
+// are hidden behind it (issued in the epilogue they doubled the kernel's exposed memory time)
+template <int EPI>
+__device__ __forceinline__ void thin_epi_prefetch(const ThinEpi& e, int tile, int h, int npix, int Cw, int cbj, float (&x0)[16],
+                                                  float (&x1)[16]) {
+    if constexpr (EPI == 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const size_t idx = (size_t)(p < npix ? p : 0) * Cw + cbj;
+            x0[r] = e.x[idx];
+            x1[r] = e.x[idx + 32];
         }
     }
 }
@@ -314,6 +328,8 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
         if (p2) { x = pix & (W - 1); t = pix >> lgW; y = t & (H - 1); }
         else { t = pix / W; x = pix - t * W; y = t % H; }
         tw_f32x16 acc0, acc1;
+        float px0[16], px1[16];
+        thin_epi_prefetch<EPI>(epi, tile, h, npix, Cw, cb + j, px0, px1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
 #pragma unroll
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (p < npix) thin_epi_store<EPI>(epi, esl, out, (size_t)p * Cw + cb + j, acc0[r], acc1[r], es);
+            if (p < npix) thin_epi_store<EPI>(epi, esl, out, (size_t)p * Cw + cb + j, acc0[r], acc1[r], px0[r], px1[r], es);
         }
     }
     if constexpr (EPI == 2) thin_epi_finish(epi, es, lane, wave);
@@ -372,6 +388,8 @@ __global__ __launch_bounds__(256) void thin_in_mfma_lds_kernel(const float* __re
         if (p2) { x = pix & (W - 1); t = pix >> lgW; y = t & (H - 1); }
         else { t = pix / W; x = pix - t * W; y = t % H; }
         tw_f32x16 acc0, acc1;
+        float px0[16], px1[16];
+        thin_epi_prefetch<EPI>(epi, tile, h, npix, Cw, cb + j, px0, px1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
 #pragma unroll 2
@@ -389,7 +407,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_lds_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (p < npix) thin_epi_store<EPI>(epi, esl, out, (size_t)p * Cw + cb + j, acc0[r], acc1[r], es);
+            if (p < npix) thin_epi_store<EPI>(epi, esl, out, (size_t)p * Cw + cb + j, acc0[r], acc1[r], px0[r], px1[r], es);
         }
     }
     if constexpr (EPI == 2) thin_epi_finish(epi, es, lane, wave);
