@@ -4,7 +4,9 @@
 // run on the vector ALU with coalesced NHWC accesses and weights held in registers.
 #include "fg_internal.h"
 #include <string.h>
+#include <stdlib.h>
 typedef float tw_f32x16 __attribute__((ext_vector_type(16)));   // MFMA 32x32 accumulator
+typedef float tw_f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float wave_sum_x(float v) {
 #pragma unroll
@@ -301,6 +303,8 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
                                                            const ThinEpi epi) {
     constexpr int NA = 9 * CS;
     constexpr int KS = (NA + 1) / 2;
+    constexpr int TS_LD = 68;            // floats per staged pixel row (64 channels + 4: 16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) float tsm[EPI == 0 ? 4 : 1][EPI == 0 ? 32 * TS_LD : 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cb = blockIdx.y * 64;
     const int h = lane >> 5, j = lane & 31;
@@ -321,17 +325,13 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
     const int ntiles = (npix + 31) / 32;
     const float esl = EPI ? epi.slope[0] : 1.f;
     float es = 0.f;
-    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    // A fragments of one tile: lane (pixel j, k half h) gathers its KS shifted input values (zero outside the image)
+    auto load_a = [&](int tile, float (&av)[KS]) {
         const int pix = tile * 32 + j;
         const bool ok = pix < npix;
         int x, y, t;
         if (p2) { x = pix & (W - 1); t = pix >> lgW; y = t & (H - 1); }
         else { t = pix / W; x = pix - t * W; y = t % H; }
-        tw_f32x16 acc0, acc1;
-        float px0[16], px1[16];
-        thin_epi_prefetch<EPI>(epi, tile, h, npix, Cw, cb + j, px0, px1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d = kdesc[ks];
@@ -339,13 +339,54 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
             float a = 0.f;
             if (ok && (d >> 8) && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
                 a = in[(size_t)((t - y + yy) * W + xx) * CS + ((d >> 4) & 15)];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[ks][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wb[ks][1], acc1, 0, 0, 0);
+            av[ks] = a;
+        }
+    };
+    const int tstep = gridDim.x * 4;
+    int tile = blockIdx.x * 4 + wave;
+    float a_cur[KS], a_nxt[KS];
+    if (tile < ntiles) load_a(tile, a_cur);
+    for (; tile < ntiles; tile += tstep) {
+        // a wave owns several tiles: the next tile's gather is in flight while this one multiplies and stores
+        if (tile + tstep < ntiles) load_a(tile + tstep, a_nxt);
+        tw_f32x16 acc0, acc1;
+        float px0[16], px1[16];
+        thin_epi_prefetch<EPI>(epi, tile, h, npix, Cw, cb + j, px0, px1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ks], wb[ks][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[ks], wb[ks][1], acc1, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (p < npix) thin_epi_store<EPI>(epi, esl, out, (size_t)p * Cw + cb + j, acc0[r], acc1[r], px0[r], px1[r], es);
+        for (int ks = 0; ks < KS; ++ks) a_cur[ks] = a_nxt[ks];
+        if constexpr (EPI == 0) {
+            // the kernel is store-bound: transpose the wave's 32-pixel x 64-channel tile through LDS so that one store
+            // instruction writes four whole 256-byte channel rows as float4 (the accumulator layout gives 128-byte half rows,
+            // 32 store instructions per tile: 1.9 TB/s)
+            float* ts = tsm[wave];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pl = (r & 3) + 8 * (r >> 2) + 4 * h;
+                ts[pl * TS_LD + j] = acc0[r];
+                ts[pl * TS_LD + 32 + j] = acc1[r];
+            }
+            __builtin_amdgcn_wave_barrier();        // same wave, in-order LDS: only the compiler must not reorder
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int pl = i * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+                const tw_f32x4 v = *(const tw_f32x4*)(ts + pl * TS_LD + c4);
+                const int p = tile * 32 + pl;
+                if (p < npix) *(tw_f32x4*)(out + (size_t)p * Cw + cb + c4) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (p < npix) thin_epi_store<EPI>(epi, esl, out, (size_t)p * Cw + cb + j, acc0[r], acc1[r], px0[r], px1[r], es);
+            }
         }
     }
     if constexpr (EPI == 2) thin_epi_finish(epi, es, lane, wave);
@@ -442,8 +483,13 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
     if (k == 3 && (Cs == 1 || Cs == 3)) {
         int lgH = -1, lgW = -1;
         for (int q = 0; q < 15; ++q) { if ((1 << q) == H) lgH = q; if ((1 << q) == W) lgW = q; }
-        int nb = fg_cdiv(fg_cdiv(npix, 32), 4);
+        // tiles per wave: every wave first fetches its 2 x 14 weight fragments, so one tile per wave is all set-up latency
+        // (17.6 us for a 33 MB output); FG_THIN_IN_TPW overrides
+        static int tpw = -1;
+        if (tpw < 0) { const char* e = getenv("FG_THIN_IN_TPW"); tpw = e ? atoi(e) : 4; if (tpw < 1) tpw = 1; }
+        int nb = fg_cdiv(fg_cdiv(npix, 32), 4 * tpw);
         if (nb > 2048) nb = 2048;
+        if (nb < 1) nb = 1;
         dim3 mgrid(nb, Cw / 64);
         arm(mgrid);
         const int em = epi.x ? 2 : (epi.y ? 1 : 0);
@@ -777,6 +823,96 @@ __global__ __launch_bounds__(256) void thin_out_win_kernel(const float* __restri
     }
 }
 
+// 3x3 thin-output convolution on the matrix pipe, one pass (replaces thin_out_win_kernel where the shape allows: that kernel
+// re-loads every input pixel 4.5 times and is VALU-bound, 2.4 TB/s): a block owns R full-width output rows of one sample.
+//   phase 1: Z[q][n] = sum_c in[q][c] * Wt[c][n] for the (R + 2) x W input pixels q of the slab and the 9*CS <= 27 columns
+//            n = (tap, s) -- one 32-pixel x 32-column MFMA tile per wave pass, K = Cw.  A is read straight from global with
+//            the K permutation of the igemm kernels (lane (pixel i, half h) loads the float4 of channels 8jj + 4h .. + 3, so a
+//            pixel's 512-byte channel row is consumed whole by the two half-waves over the jj steps); B = the packed
+//            weights in registers; rows outside the image load zeros (raw-buffer range check) and give Z = 0.
+//   phase 2: out[y][x][s] = act(bias[s] + sum_tap Z[(y + dy - 1, x + dx - 1)][tap * CS + s]) gathered from the slab's Z in
+//            LDS (row stride 29 floats: conflict-free column reads).
+// Every input row is read once per block that needs it (1 + 2/R times from L2, once from HBM).
+template <int CJ, int CS>
+__global__ __launch_bounds__(256) void thin_out_slab_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
+                                                                 const float* __restrict__ bias, float* __restrict__ out,
+                                                                 int H, int W, int R, int flip, int sigmoid, int in_bytes) {
+    constexpr int Cw = CJ * 64;
+    constexpr int NJ = Cw / 8;                    // float4 loads per lane and tile
+    constexpr int ZLD = 29;
+    extern __shared__ __attribute__((aligned(16))) float tos_sm[];     // Z [(R + 2) * W][ZLD]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int nrb = (H + R - 1) / R;
+    const int b = blockIdx.x / nrb, y0 = (blockIdx.x - b * nrb) * R;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, in_bytes, 0x00020000);
+    // B fragments: lane (column n = i, half h) holds Wt[c = 8jj + 4h + t][n] = Wp[tap'][s][c], n = tap * CS + s
+    float wreg[NJ][4];
+    {
+        const int tap = i / CS, sc = i - tap * CS;
+        const bool live = i < 9 * CS;
+        const float* wp = Wp + ((size_t)(flip ? 8 - tap : tap) * CS + sc) * Cw + 4 * h;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const tw_f32x4 v = live ? *(const tw_f32x4*)(wp + 8 * jj) : tw_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wreg[jj][t] = v[t];
+        }
+    }
+    const int ntile = (R + 2) * W / 32;
+    auto load_a = [&](int tile, tw_f32x4 (&a)[NJ]) {
+        const int q = tile * 32 + i;                   // slab pixel of this lane's A row
+        const int qr = q / W, qx = q - qr * W;
+        const int yy = y0 - 1 + qr;
+        const int voff = ((unsigned)yy < (unsigned)H) ? (((b * H + yy) * W + qx) * Cw + 4 * h) * 4 : FG_OOB_T;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+            a[jj] = __builtin_bit_cast(tw_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, jj * 32, 0));
+    };
+    tw_f32x4 av[NJ], an[NJ];
+    if (wave < ntile) load_a(wave, av);
+    for (int tile = wave; tile < ntile; tile += 4) {
+        if (tile + 4 < ntile) load_a(tile + 4, an);    // the next tile's rows stream in behind this tile's 8 * CJ * 4 MFMAs
+        tw_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj][t], wreg[jj][t], acc, 0, 0, 0);
+        if (i < 9 * CS) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tos_sm[(tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * ZLD + i] = acc[r];
+        }
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) av[jj] = an[jj];
+    }
+    __syncthreads();
+    const int nout = R * W;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int ry = o / W, x = o - ry * W;
+        const int y = y0 + ry;
+        if (y >= H) continue;
+        float r[CS];
+#pragma unroll
+        for (int sc = 0; sc < CS; ++sc) r[sc] = bias ? bias[sc] : 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = x + dx - 1;
+                if ((unsigned)xx >= (unsigned)W) continue;
+                const float* z = tos_sm + ((ry + dy) * W + xx) * ZLD + (dy * 3 + dx) * CS;
+#pragma unroll
+                for (int sc = 0; sc < CS; ++sc) r[sc] += z[sc];
+            }
+        float* op = out + ((size_t)(b * H + y) * W + x) * CS;
+#pragma unroll
+        for (int sc = 0; sc < CS; ++sc) op[sc] = sigmoid ? 1.f / (1.f + expf(-r[sc])) : r[sc];
+    }
+}
+
 // 5x5 / 7x7 thin-OUTPUT convolution (e.g. 256 -> 3, 7x7: the c2f generator head, models_c2f.lua:131) in two passes:
 //   (1) R[pix][(dx, s)] = sum_{dy, c} in[y + dy - PAD][x][c] * W[dy][dx][c][s]   -- only the VERTICAL taps are folded into
 //       the contraction (K = K*Cw), so the N axis is the K*CS <= 21 (dx, s) columns of one 32-wide MFMA tile instead of 3;
@@ -892,6 +1028,48 @@ int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const
     }
     dim3 grid(fg_cdiv(npix, 64));
     const long long in_bytes = (long long)npix * Cw * 4;
+    {   // 3x3 on the matrix pipe (FG_THIN_SLAB=0: the sliding-window VALU kernel)
+        static int use_slab = -1;
+        if (use_slab < 0) { const char* e = getenv("FG_THIN_SLAB"); use_slab = e ? atoi(e) : 1; }
+        // rows per block: ONE round of ~256 blocks fills the chip (measured at B = 128, 32 x 32: R = 16 -> 256 blocks 23 us;
+        // R = 8 -> 512 blocks 32 us; R = 6 -> 768 blocks = 1.5 rounds of resident blocks 36 us), Z must fit 80 KB of LDS,
+        // (R + 2) * W must be whole 32-pixel tiles; prefer an R that divides H (equal blocks)
+        int R = 0;
+        if (W >= 4 && W <= 128) {
+            const int rmax = (80 * 1024 / (29 * 4)) / W - 2;
+            int rt = (int)(((long long)H * B + 255) / 256);
+            if (rt > rmax) rt = rmax;
+            if (rt > H) rt = H;
+            if (rt < 2) rt = 2;
+            for (int pass = 0; pass < 2 && !R; ++pass)
+                for (int r = rt; r >= 2; --r)
+                    if (((r + 2) * W) % 32 == 0 && (pass == 1 || H % r == 0)) { R = r; break; }
+            if (!R && rmax >= 2)
+                for (int r = rt + 1; r <= rmax; ++r) if (((r + 2) * W) % 32 == 0) { R = r; break; }
+        }
+        { static int rov = -1; if (rov < 0) { const char* e = getenv("FG_THIN_SLAB_R"); rov = e ? atoi(e) : 0; } if (rov >= 2) R = rov; }
+        if (use_slab && in_bytes < (long long)FG_OOB_T && k == 3 && R >= 2 && (Cw == 64 || Cw == 128) && Cs <= 3 &&
+            ((R + 2) * W) % 32 == 0) {
+            const int nblk = B * ((H + R - 1) / R);
+            size_t lds = (size_t)(R + 2) * W * 29 * sizeof(float);
+            { static int lpad = -1; if (lpad < 0) { const char* e = getenv("FG_THIN_SLAB_LDS"); lpad = e ? atoi(e) : 0; } if ((size_t)lpad * 1024 > lds) lds = (size_t)lpad * 1024; }
+#define TOS(JJ, CC)                                                                                                  \
+            if (Cw == JJ * 64 && Cs == CC) {                                                                         \
+                static bool attr = false;                                                                            \
+                if (!attr) {                                                                                         \
+                    FG_HIP(ctx, hipFuncSetAttribute((const void*)thin_out_slab_mfma_kernel<JJ, CC>,                  \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));        \
+                    attr = true;                                                                                     \
+                }                                                                                                    \
+                hipLaunchKernelGGL((thin_out_slab_mfma_kernel<JJ, CC>), dim3(nblk), dim3(256), lds, ctx->stream, in, Wp, bias, \
+                                   out, H, W, R, flip, sigmoid, (int)in_bytes);                                      \
+                FG_CHECK_LAUNCH(ctx);                                                                                \
+                return FG_OK;                                                                                        \
+            }
+            TOS(1, 1) TOS(1, 3) TOS(2, 1) TOS(2, 3)
+#undef TOS
+        }
+    }
     if (in_bytes < (long long)FG_OOB_T && k == 3 && W % 4 == 0) {
         int nblk = fg_cdiv(fg_cdiv(npix, 4), 4);
         if (nblk > 4096) nblk = 4096;
