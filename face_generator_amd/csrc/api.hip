@@ -65,6 +65,8 @@ int fg_ctx_create(int device, fg_ctx** out) {
     fg_ctx* c = new fg_ctx();
     c->device = device; c->stream = nullptr; c->err[0] = 0; c->sm_count = prop.multiProcessorCount;
     if (const char* m = getenv("FG_MATH")) c->math = atoi(m) == 6 ? 6 : 0;   // default arithmetic, see fg_set_math
+    if (const char* m = getenv("FG_FUSE_PRELU")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_PRELU;
+    if (const char* m = getenv("FG_THIN_SLAB")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_THIN_SLAB;
     *out = c;
     return FG_OK;
 }
@@ -76,6 +78,13 @@ int fg_set_math(fg_ctx* ctx, int mode) {
     return FG_OK;
 }
 int fg_get_math(fg_ctx* ctx) { return ctx ? ctx->math : -1; }
+int fg_set_fusion(fg_ctx* ctx, int flags) {
+    if (!ctx) return FG_ERR_INVALID;
+    if (flags & ~FG_FUSE_ALL) return fg_set_err(ctx, FG_ERR_INVALID, "fg_set_fusion: unknown bits in %d", flags);
+    ctx->fusion = flags;
+    return FG_OK;
+}
+int fg_get_fusion(fg_ctx* ctx) { return ctx ? ctx->fusion : -1; }
 
 int fg_prof_enable(fg_ctx* ctx, int on) { NEED(ctx, ctx, "null ctx"); ctx->prof = on != 0; return FG_OK; }
 // Synchronises, then writes one line per kernel label: "name calls total_ms alg_flops exec_flops bytes\n".

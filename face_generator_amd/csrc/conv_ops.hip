@@ -5,12 +5,6 @@
 #include <string.h>
 #include <stdlib.h>
 
-bool fg_fuse_prelu() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("FG_FUSE_PRELU"); on = e ? (atoi(e) != 0) : 1; }
-    return on != 0;
-}
-
 static inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int l = 0;
@@ -284,7 +278,7 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
         if (2 * rows * g.Cout <= stats_cap) { a.stats_part = stats_part; a.stats_rows = (int)rows; *stats_rows = (int)rows; }
     }
     // the PReLU behind an un-split layer rides on the kernel's epilogue (a same-shape mask does not: split-K layers only)
-    if (act && splits == 1 && !a.A6 && act->y && act->slope && !act->mask && fg_fuse_prelu()) {
+    if (act && splits == 1 && !a.A6 && act->y && act->slope && !act->mask && fg_fuse_prelu(ctx)) {
         a.act_y = act->y; a.act_slope = act->slope;
     }
     if ((rc = fg_launch_igemm(ctx, a, wm.P, tile))) return rc;
@@ -345,7 +339,7 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
     // the backward of the PReLU in front of the layer in the epilogue (un-split fp32 launches); its slope-gradient partials
     // (4 per block) go through the batched deferred finals, so this needs the arena of an fg_net backward pass
     long long nparts = 0;
-    if (actb && actb->x && actb->slope && splits == 1 && !a.A6 && fg_fuse_prelu()) {
+    if (actb && actb->x && actb->slope && splits == 1 && !a.A6 && fg_fuse_prelu(ctx)) {
         nparts = 4 * fg_igemm_blocks(a, 1, tile);
         float* dp = actb->gslope ? fg_defer_alloc(ctx, nparts) : nullptr;
         if (!actb->gslope || dp) { a.act_x = actb->x; a.act_slope = actb->slope; a.act_part = dp; }

@@ -29,6 +29,7 @@ struct fg_ctx {
     char err[512];
     int sm_count;
     int math = 0;        // 0: native fp32 MFMA; 6: fp32 emulated with six split-bf16 plane products (fg_set_math)
+    int fusion = FG_FUSE_ALL;   // fg_set_fusion: which optional kernel fusions / variants are on (default from the environment)
     // optional per-launch HIP-event timing of the contraction kernels (bench.py roofline leg)
     bool prof = false;
     std::vector<FgProfRec> prof_recs;
@@ -109,9 +110,9 @@ struct FgActFuse { const float* slope; const float* mask; float mscale; float* y
 // the nn.PReLU in front of a layer, folded into the epilogue of the kernel that produces the gradient wrt the layer's input:
 // x = the PReLU's input, gslope = its slope gradient (nullptr: not wanted); applied tells whether the launch folded it in
 struct FgActBwd { const float* x; const float* slope; float* gslope; mutable int applied; };
-// FG_FUSE_PRELU=0 in the environment keeps every PReLU a pass of its own (A/B switch for measurements and for the parity
-// tests, which run both ways); default on
-bool fg_fuse_prelu();
+// fg_set_fusion bit FG_FUSE_PRELU (default on; FG_FUSE_PRELU=0 in the environment clears it at context creation): off keeps
+// every PReLU a pass of its own -- the A/B switch for measurements and for the parity tests, which run both ways
+static inline bool fg_fuse_prelu(const fg_ctx* ctx) { return (ctx->fusion & FG_FUSE_PRELU) != 0; }
 int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long stride, const float* bias,
                          int N, float* out, long long count, const FgActFuse* act = nullptr);
 

@@ -183,7 +183,7 @@ static int backward_run_stages(fg_net* n) {
         // can ride on the epilogue of the kernel that produces this stage's input gradient
         FgActBwd actb; memset(&actb, 0, sizeof(actb));
         const bool pf = si >= 2 && si - 1 >= stage_to && n->st[si - 1].kind == ST_PRELU && n->st[si - 1].mask_kind == 0 &&
-                        fg_fuse_prelu();
+                        fg_fuse_prelu(ctx);
         if (pf) {
             actb.x = ws + n->st[si - 2].out_off; actb.slope = P + n->st[si - 1].slope_off;
             actb.gslope = want_p ? Gp + n->st[si - 1].slope_off : nullptr;

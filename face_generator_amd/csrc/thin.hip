@@ -460,8 +460,8 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
     if (actb) actb->applied = 0;
     ThinEpi epi; memset(&epi, 0, sizeof(epi));
     // fold the neighbouring PReLU into the epilogue (MFMA variants): forward = plain PReLU only (no same-shape mask)
-    const bool want_f = actf && actf->y && actf->slope && !actf->mask && fg_fuse_prelu();
-    const bool want_b = !want_f && actb && actb->x && actb->slope && fg_fuse_prelu();
+    const bool want_f = actf && actf->y && actf->slope && !actf->mask && fg_fuse_prelu(ctx);
+    const bool want_b = !want_f && actb && actb->x && actb->slope && fg_fuse_prelu(ctx);
     auto arm = [&](dim3 g) -> bool {      // false: the slope-gradient partials do not fit the deferred arena -> not folded
         if (want_f) { epi.slope = actf->slope; epi.y = actf->y; return true; }
         if (want_b) {
@@ -484,9 +484,8 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         int lgH = -1, lgW = -1;
         for (int q = 0; q < 15; ++q) { if ((1 << q) == H) lgH = q; if ((1 << q) == W) lgW = q; }
         // tiles per wave: every wave first fetches its 2 x 14 weight fragments, so one tile per wave is all set-up latency
-        // (17.6 us for a 33 MB output); FG_THIN_IN_TPW overrides
-        static int tpw = -1;
-        if (tpw < 0) { const char* e = getenv("FG_THIN_IN_TPW"); tpw = e ? atoi(e) : 4; if (tpw < 1) tpw = 1; }
+        // (1 -> 4 tiles per wave with the next tile's gather in flight: 17.6 -> 15.5 us for the 33 / 67 MB outputs)
+        const int tpw = 4;
         int nb = fg_cdiv(fg_cdiv(npix, 32), 4 * tpw);
         if (nb > 2048) nb = 2048;
         if (nb < 1) nb = 1;
@@ -1028,9 +1027,8 @@ int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const
     }
     dim3 grid(fg_cdiv(npix, 64));
     const long long in_bytes = (long long)npix * Cw * 4;
-    {   // 3x3 on the matrix pipe (FG_THIN_SLAB=0: the sliding-window VALU kernel)
-        static int use_slab = -1;
-        if (use_slab < 0) { const char* e = getenv("FG_THIN_SLAB"); use_slab = e ? atoi(e) : 1; }
+    {   // 3x3 on the matrix pipe (fg_set_fusion bit FG_FUSE_THIN_SLAB; off: the sliding-window VALU kernel)
+        const bool use_slab = (ctx->fusion & FG_FUSE_THIN_SLAB) != 0;
         // rows per block: ONE round of ~256 blocks fills the chip (measured at B = 128, 32 x 32: R = 16 -> 256 blocks 23 us;
         // R = 8 -> 512 blocks 32 us; R = 6 -> 768 blocks = 1.5 rounds of resident blocks 36 us), Z must fit 80 KB of LDS,
         // (R + 2) * W must be whole 32-pixel tiles; prefer an R that divides H (equal blocks)
@@ -1047,12 +1045,10 @@ int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const
             if (!R && rmax >= 2)
                 for (int r = rt + 1; r <= rmax; ++r) if (((r + 2) * W) % 32 == 0) { R = r; break; }
         }
-        { static int rov = -1; if (rov < 0) { const char* e = getenv("FG_THIN_SLAB_R"); rov = e ? atoi(e) : 0; } if (rov >= 2) R = rov; }
         if (use_slab && in_bytes < (long long)FG_OOB_T && k == 3 && R >= 2 && (Cw == 64 || Cw == 128) && Cs <= 3 &&
             ((R + 2) * W) % 32 == 0) {
             const int nblk = B * ((H + R - 1) / R);
-            size_t lds = (size_t)(R + 2) * W * 29 * sizeof(float);
-            { static int lpad = -1; if (lpad < 0) { const char* e = getenv("FG_THIN_SLAB_LDS"); lpad = e ? atoi(e) : 0; } if ((size_t)lpad * 1024 > lds) lds = (size_t)lpad * 1024; }
+            const size_t lds = (size_t)(R + 2) * W * 29 * sizeof(float);
 #define TOS(JJ, CC)                                                                                                  \
             if (Cw == JJ * 64 && Cs == CC) {                                                                         \
                 static bool attr = false;                                                                            \

@@ -45,6 +45,14 @@ class Context:
     def get_math(self):
         return self.lib.fg_get_math(self.h)
 
+    def set_fusion(self, flags):
+        """Optional kernel fusions (include/facegen_hip.h FG_FUSE_*): 1 = PReLU in the neighbouring contraction's epilogue,
+        2 = one-pass matrix-pipe 3x3 thin-output convolution; default 3."""
+        self.check(self.lib.fg_set_fusion(self.h, int(flags)))
+
+    def get_fusion(self):
+        return self.lib.fg_get_fusion(self.h)
+
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 

@@ -49,6 +49,20 @@ enum {
 int fg_set_math(fg_ctx* ctx, int mode);
 int fg_get_math(fg_ctx* ctx);
 
+/* Optional kernel fusions / variants (results equal to the un-fused path up to the summation order of a reduction; exposed so
+ * the parity tests and the bench can run both ways).  Default: all on; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 in the environment
+ * clear a bit at fg_ctx_create.  Replaces nothing in the reference. */
+enum {
+    FG_FUSE_PRELU = 1,      /* an nn.PReLU between two contraction layers (models_c2f.lua:118-130, 242-255) rides on their
+                             * epilogues: forward copy behind the producing layer, backward (+ slope-gradient partials) in
+                             * the kernel that produces its output gradient (data gradient / max-pool backward) */
+    FG_FUSE_THIN_SLAB = 2,  /* 3x3 convolutions with <= 3 output channels (models.lua:73, 385 backward) on the matrix pipe
+                             * in one pass instead of the sliding-window VALU kernel */
+    FG_FUSE_ALL = 3
+};
+int fg_set_fusion(fg_ctx* ctx, int flags);
+int fg_get_fusion(fg_ctx* ctx);
+
 /* ---- context / memory (replaces cutorch.setDevice / cutorch streams, train.lua:79-80) ---- */
 int fg_ctx_create(int device, fg_ctx** out);
 int fg_ctx_destroy(fg_ctx* ctx);

@@ -30,6 +30,9 @@ typedef struct fg_gan fg_gan;
 enum { FG_OK = 0, FG_ERR_INVALID = -1, FG_ERR_HIP = -2, FG_ERR_NOMEM = -3, FG_ERR_UNSUPPORTED = -4, FG_ERR_WORKSPACE = -5 };
 int fg_set_math(fg_ctx* ctx, int mode);
 int fg_get_math(fg_ctx* ctx);
+enum { FG_FUSE_PRELU = 1, FG_FUSE_THIN_SLAB = 2, FG_FUSE_ALL = 3 };
+int fg_set_fusion(fg_ctx* ctx, int flags);
+int fg_get_fusion(fg_ctx* ctx);
 int fg_ctx_create(int device, fg_ctx** out);
 int fg_ctx_destroy(fg_ctx* ctx);
 int fg_ctx_set_stream(fg_ctx* ctx, void* hip_stream);

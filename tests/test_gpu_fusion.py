@@ -1,0 +1,116 @@
+"""fg_set_fusion (include/facegen_hip.h FG_FUSE_*): the optional kernel fusions give the results of the un-fused path.
+* FG_FUSE_PRELU -- an nn.PReLU between two contraction layers of the coarse-to-fine nets (models_c2f.lua:118-130, 242-255)
+  rides on the neighbouring kernels' epilogues.  Forward outputs, input gradients and every weight / bias gradient are the
+  SAME fp32 operations in both paths (bit-identical); only a PReLU slope gradient is summed in a different order.
+* FG_FUSE_THIN_SLAB -- the 3x3 thin-output convolution (models.lua:73 forward, :385 data gradient) on the matrix pipe vs
+  the sliding-window VALU kernel: different summation order, compared at the SURVEY 8(c) forward bar, and both against the
+  oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch7_nn as O
+from gpu_util import nhwc, nchw, dev, close
+from test_gpu_c2f import build, masks_for, dev_masks
+
+pytestmark = pytest.mark.gpu
+
+FG_FUSE_PRELU, FG_FUSE_THIN_SLAB, FG_FUSE_ALL = 1, 2, 3
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from face_generator_amd.runtime import get_context
+    c = get_context(0)
+    yield c
+    c.set_fusion(FG_FUSE_ALL)
+
+
+def test_fusion_flags_roundtrip_and_reject_unknown_bits(ctx):
+    from face_generator_amd._lib import FgError
+    ctx.set_fusion(FG_FUSE_THIN_SLAB)
+    assert ctx.get_fusion() == FG_FUSE_THIN_SLAB
+    with pytest.raises(FgError):
+        ctx.set_fusion(8)
+    ctx.set_fusion(FG_FUSE_ALL)
+    assert ctx.get_fusion() == FG_FUSE_ALL
+
+
+@pytest.mark.parametrize("S,B", [(16, 4), (64, 8)])
+def test_prelu_in_epilogue_equals_separate_passes(ctx, S, B):
+    """c2f G_d and D_c forward + backward with the PReLUs folded into the contraction epilogues vs as passes of their own.
+    (64, 8) selects the wave-specialised kernels of the BASELINE size, (16, 4) the 64x64-tile kernels."""
+    st, Gd, Dd, rng = build(ctx, S, B, seed=900 + S)
+    d = ctx.device
+    cond = rng.uniform(0, 1, (B, 3, S, S)).astype(np.float32)
+    noise = rng.uniform(-1, 1, (B, 1, S, S)).astype(np.float32)
+    x = rng.uniform(-1, 1, (B, 3, S, S)).astype(np.float32)
+    gy = rng.standard_normal((B, 3, S, S)).astype(np.float32)
+    gyo = rng.standard_normal((B, 1)).astype(np.float32)
+    masks = dev_masks(masks_for(rng, B, S), d)
+    res = {}
+    for flags in (FG_FUSE_ALL, FG_FUSE_ALL & ~FG_FUSE_PRELU):
+        ctx.set_fusion(flags)
+        dn = Gd.inner.device_net
+        y = dn.forward(Gd.combine_device(ctx, nhwc(noise, d), nhwc(cond, d))).clone()
+        dn.backward(nhwc(gy, d), param_grads=True)
+        gG = dn.grads.clone()
+        dnD = Dd.inner.device_net
+        yd = dnD.forward(Dd.combine_device(ctx, nhwc(x, d), nhwc(cond, d)), masks=masks).clone()
+        gx = dnD.backward(dev(gyo, d), param_grads=True, input_grad=True).clone()
+        gD = dnD.grads.clone()
+        res[flags] = (y, gG, yd, gx, gD)
+    ctx.set_fusion(FG_FUSE_ALL)
+    a, b = res[FG_FUSE_ALL], res[FG_FUSE_ALL & ~FG_FUSE_PRELU]
+    assert torch.equal(a[0], b[0]), "G output"
+    assert torch.equal(a[2], b[2]), "D output"
+    assert torch.equal(a[3], b[3]), "D gradInput"
+    for name, net, ga, gb in (("G", st.G.inner, a[1], b[1]), ("D", st.D.inner, a[4], b[4])):
+        off = 0
+        for m in net.modules:
+            for (mm, pn, gn) in m.parameters():
+                n = getattr(mm, pn).size
+                da, db = ga[off:off + n], gb[off:off + n]
+                if isinstance(mm, O.PReLU):     # a 10^5..10^7-term cancelling sum, reduced in a different order
+                    scale = float(max(da.abs().max(), db.abs().max(), 1e-30))
+                    assert float((da - db).abs().max()) <= 2e-3 * scale + 1e-6, (name, type(mm).__name__, float(da), float(db))
+                else:
+                    assert torch.equal(da, db), (name, type(mm).__name__, pn, off)
+                off += n
+        assert off == ga.numel()
+
+
+@pytest.mark.parametrize("B,H,W,Cw,Cs,flip", [(3, 32, 32, 128, 3, 0), (128, 32, 32, 128, 3, 0), (5, 16, 16, 64, 1, 0),
+                                               (2, 64, 64, 64, 3, 1), (4, 8, 8, 128, 3, 1)])
+def test_thin_output_3x3_slab_kernel_equals_window_kernel_and_oracle(ctx, B, H, W, Cw, Cs, flip):
+    """flip = 0: forward of a Cw -> Cs convolution; flip = 1: the data gradient of a Cs -> Cw convolution (the same kernel
+    with mirrored taps), through the module-level entries."""
+    from face_generator_amd import ops
+    rng = np.random.default_rng(B * 1000 + H + Cw + flip)
+    d = ctx.device
+    if not flip:
+        x = rng.standard_normal((B, Cw, H, W)).astype(np.float32)
+        w = (rng.standard_normal((Cs, Cw, 3, 3)) * 0.1).astype(np.float32)
+        bias = rng.standard_normal(Cs).astype(np.float32)
+        conv = O.SpatialConvolution(Cw, Cs, 3, 3, 1, 1, 1, 1, rng)
+        conv.weight[...] = w; conv.bias[...] = bias
+        ref = conv.forward(x)
+        run = lambda: nchw(ops.conv2d_forward(nhwc(x, d), dev(w, d), dev(bias, d)))
+    else:
+        g = rng.standard_normal((B, Cw, H, W)).astype(np.float32)
+        w = (rng.standard_normal((Cw, Cs, 3, 3)) * 0.1).astype(np.float32)
+        conv = O.SpatialConvolution(Cs, Cw, 3, 3, 1, 1, 1, 1, rng)
+        conv.weight[...] = w
+        xin = rng.standard_normal((B, Cs, H, W)).astype(np.float32)
+        conv.forward(xin)
+        ref = conv.backward(xin, g)
+        run = lambda: nchw(ops.conv2d_backward_data(nhwc(g, d), dev(w, d), (H, W)))
+    out = {}
+    for flags in (FG_FUSE_ALL, FG_FUSE_ALL & ~FG_FUSE_THIN_SLAB):
+        ctx.set_fusion(flags)
+        out[flags] = run()
+    ctx.set_fusion(FG_FUSE_ALL)
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+    close(out[FG_FUSE_ALL], ref, atol=tol, what="slab kernel vs oracle")
+    close(out[FG_FUSE_ALL & ~FG_FUSE_THIN_SLAB], ref, atol=tol, what="window kernel vs oracle")
+    close(out[FG_FUSE_ALL], out[FG_FUSE_ALL & ~FG_FUSE_THIN_SLAB], atol=tol, what="slab vs window kernel")
