@@ -2,16 +2,16 @@
 # Round-end evidence on the GPU box: kernel traces of both workloads, PMC passes on the dominant kernels, final bench lines.
 # usage (through gpurun): bash scripts/collect_profiles.sh <tag>      -> everything under gpurun_out/<tag>_*
 set -u
-TAG=${1:-r02}
+TAG=${1:-r02b}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --workload c2f --steps 10 --warmup 3 > $OUT/${TAG}_bench_c2f.json 2> $OUT/${TAG}_bench_c2f.err
 rocprofv3 --kernel-trace --stats -d $OUT/p1 -o run -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-alt-math --no-roofline > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
-python scripts/rocpd_stats.py $OUT/p1/run_results.db 64 > $OUT/${TAG}_bench_kernel_stats.md
+python scripts/rocpd_stats.py $OUT/p1/run_results.db auto > $OUT/${TAG}_bench_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d $OUT/p2 -o run -- python bench.py --workload c2f --steps 6 --warmup 2 --no-cpu-baseline --no-alt-math --no-roofline > /dev/null 2>&1
-python scripts/rocpd_stats.py $OUT/p2/run_results.db 12 > $OUT/${TAG}_c2f_kernel_stats.md
+python scripts/rocpd_stats.py $OUT/p2/run_results.db auto > $OUT/${TAG}_c2f_kernel_stats.md
 for which in fwd wgrad; do
   for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
     d=$OUT/pmc_${which}_$(echo $pmc | tr ' ' '_')

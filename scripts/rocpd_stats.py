@@ -1,5 +1,6 @@
 """Summarise a rocprofv3 rocpd SQLite database (kernel trace) per kernel name: calls, total/avg ms, % of GPU time.
-usage: python scripts/rocpd_stats.py <results.db> [iters]   -> markdown table on stdout"""
+usage: python scripts/rocpd_stats.py <results.db> [iters | auto]   -> markdown table on stdout
+(auto: iterations = rng_multi_kernel launches / 2 -- every closure of the training loop starts with one Philox launch)"""
 import re
 import sqlite3
 import sys
@@ -13,7 +14,7 @@ def short(name):
 
 def main():
     db = sqlite3.connect(sys.argv[1])
-    iters = float(sys.argv[2]) if len(sys.argv) > 2 else None
+    iters = sys.argv[2] if len(sys.argv) > 2 else None      # a number, or "auto": one Philox launch per closure = 2 / iteration
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
@@ -23,6 +24,10 @@ def main():
         a = agg.setdefault(short(name), [0, 0.0])
         a[0] += 1
         a[1] += (e - s) / 1e6
+    if iters == "auto":
+        iters = agg.get("rng_multi_kernel", [0])[0] / 2.0 or None
+    elif iters is not None:
+        iters = float(iters)
     total = sum(v[1] for v in agg.values())
     span = (max(r[2] for r in rows) - min(r[1] for r in rows)) / 1e6
     print("| kernel | calls | total ms | avg us | % of kernel time |" + (" ms/iter |" if iters else ""))
@@ -31,6 +36,8 @@ def main():
         print("| %s | %d | %.3f | %.1f | %.1f |" % (k, n, ms, 1000 * ms / n, 100 * ms / total)
               + (" %.3f |" % (ms / iters) if iters else ""))
     print("\ntotal kernel time %.3f ms over %d dispatches; first-to-last span %.3f ms" % (total, len(rows), span))
+    if iters:
+        print("%.1f iterations: %.3f ms of kernel time and %.1f dispatches per iteration" % (iters, total / iters, len(rows) / iters))
 
 
 if __name__ == "__main__":
