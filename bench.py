@@ -152,30 +152,6 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
                             "algorithmic_tflops_per_gpu": flops_per_iter / (ms * 1e-3) / 1e12,
                             "algorithmic_frac_of_f32_mfma_peak": flops_per_iter / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}
 
-    alt = None
-    if args.math == "f32" and not args.no_alt_math:
-        # supplementary, never the headline: the same K steps with the large contractions in bf16x6 (fp32 emulated with
-        # six exact split-bf16 plane products, include/facegen_hip.h fg_set_math); every rank runs it (collectives)
-        try:
-            ctx.set_math(6)
-            for _ in range(min(args.warmup, 4)):
-                iteration()
-            tr.finish_pending()
-            sync_all()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                iteration()
-            tr.finish_pending()
-            sync_all()
-            dt6 = max_over_ranks(time.perf_counter() - t1)
-            alt = {"math": "bf16x6 (fp32 emulated: 6 exact bf16 split-plane products, fp32 accumulate; fg_set_math(ctx, 6))",
-                   "value": world * B * args.steps / dt6, "unit": "images/sec", "ms_per_step": 1000.0 * dt6 / args.steps,
-                   "note": "opt-in mode, parity-tested at the same tolerances (FG_MATH=6 pytest -m gpu); not the headline value"}
-        except Exception as e:      # supplementary only: never let it take the headline measurement down
-            alt = {"math": "bf16x6", "error": str(e)[:200]}
-        finally:
-            ctx.set_math(0)
-
     if not args.no_roofline:
         # every rank runs the extra iterations (they contain collectives); only rank 0 records HIP events
         import ctypes
@@ -230,6 +206,32 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
             out["kernels"] = {k: {"calls_per_iter": v["calls"] / args.prof_iters, "ms_per_iter": v["ms"] / args.prof_iters,
                                   "executed_tflops": v["exe"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0}
                               for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])}
+    # (the supplementary bf16x6 leg runs AFTER the roofline leg: it is power-bound and leaves the part at a lower clock for the
+    # next few hundred ms -- measured right behind it the fp32 kernels read 6-8 % slow)
+    alt = None
+    if args.math == "f32" and not args.no_alt_math:
+        # supplementary, never the headline: the same K steps with the large contractions in bf16x6 (fp32 emulated with
+        # six exact split-bf16 plane products, include/facegen_hip.h fg_set_math); every rank runs it (collectives)
+        try:
+            ctx.set_math(6)
+            for _ in range(min(args.warmup, 4)):
+                iteration()
+            tr.finish_pending()
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                iteration()
+            tr.finish_pending()
+            sync_all()
+            dt6 = max_over_ranks(time.perf_counter() - t1)
+            alt = {"math": "bf16x6 (fp32 emulated: 6 exact bf16 split-plane products, fp32 accumulate; fg_set_math(ctx, 6))",
+                   "value": world * B * args.steps / dt6, "unit": "images/sec", "ms_per_step": 1000.0 * dt6 / args.steps,
+                   "note": "opt-in mode, parity-tested at the same tolerances (FG_MATH=6 pytest -m gpu); not the headline value"}
+        except Exception as e:      # supplementary only: never let it take the headline measurement down
+            alt = {"math": "bf16x6", "error": str(e)[:200]}
+        finally:
+            ctx.set_math(0)
+
     if alt is not None:
         out["alt_math"] = alt
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -81,7 +81,9 @@ static void choose_igemm(long long M, int Npad, int ksteps, int P, int math, int
     if (b0 >= target) { *tile = 0; return; }
     if (b1 >= target) { *tile = 1; return; }
     *tile = 2;
-    if (b2 < 384 && ksteps >= 4) {      // split-K over K-steps, >= 2 steps per split
+    // (a contraction of <= 4 K-steps over >= 128 tiles -- G's first Linear, 100 -> 8192 -- is shorter than the extra pass that
+    // would sum its partials)
+    if (b2 < 384 && ksteps >= 4 && !(ksteps <= 4 && b2 >= 128)) {      // split-K over K-steps, >= 2 steps per split
         int s = fg_cdiv(target, b2 > 0 ? b2 : 1);
         if (s > ksteps / 2) s = ksteps / 2;
         if (s > 16) s = 16;
@@ -339,7 +341,7 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
     // the backward of the PReLU in front of the layer in the epilogue (un-split fp32 launches); its slope-gradient partials
     // (4 per block) go through the batched deferred finals, so this needs the arena of an fg_net backward pass
     long long nparts = 0;
-    if (actb && actb->x && actb->slope && splits == 1 && !a.A6 && fg_fuse_prelu(ctx)) {
+    if (actb && actb->x && actb->slope && !actb->mask && splits == 1 && !a.A6 && fg_fuse_prelu(ctx)) {
         nparts = 4 * fg_igemm_blocks(a, 1, tile);
         float* dp = actb->gslope ? fg_defer_alloc(ctx, nparts) : nullptr;
         if (!actb->gslope || dp) { a.act_x = actb->x; a.act_slope = actb->slope; a.act_part = dp; }
@@ -349,7 +351,11 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
         actb->applied = 1;
         if (a.act_part) fg_defer_push(ctx, a.act_part, (int)nparts, 1, 0.f, actb->gslope);
     }
-    if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, nullptr, g.Cin, gx, out_count);
+    if (splits > 1) {
+        // the pass that sums the partials also runs the backward of the PReLU [+ Dropout] in front of the layer
+        if (actb && g.Cin % 4 == 0) return fg_launch_sum_splits_actbwd(ctx, scratch, splits, out_count, gx, out_count, actb);
+        return fg_launch_sum_splits(ctx, scratch, splits, out_count, nullptr, g.Cin, gx, out_count);
+    }
     return FG_OK;
 }
 

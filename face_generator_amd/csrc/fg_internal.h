@@ -109,12 +109,18 @@ int fg_launch_split_planes(fg_ctx* ctx, const float* src, long long rows, int C,
 struct FgActFuse { const float* slope; const float* mask; float mscale; float* y; mutable int applied; };
 // the nn.PReLU in front of a layer, folded into the epilogue of the kernel that produces the gradient wrt the layer's input:
 // x = the PReLU's input, gslope = its slope gradient (nullptr: not wanted); applied tells whether the launch folded it in
-struct FgActBwd { const float* x; const float* slope; float* gslope; mutable int applied; };
+// mask / mscale: the nn.Dropout between that PReLU and the layer (gradient * mask * mscale first) -- only the pass that sums
+// split-K partials folds a masked PReLU, the contraction epilogues take plain ones
+struct FgActBwd { const float* x; const float* slope; float* gslope; const float* mask; float mscale; mutable int applied; };
 // fg_set_fusion bit FG_FUSE_PRELU (default on; FG_FUSE_PRELU=0 in the environment clears it at context creation): off keeps
 // every PReLU a pass of its own -- the A/B switch for measurements and for the parity tests, which run both ways
 static inline bool fg_fuse_prelu(const fg_ctx* ctx) { return (ctx->fusion & FG_FUSE_PRELU) != 0; }
 int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long stride, const float* bias,
                          int N, float* out, long long count, const FgActFuse* act = nullptr);
+// data-gradient form: out = PReLU'(x) * (sum_s part_s [* mask * mscale]), slope-gradient partials through the deferred final
+// (needs the arena of an fg_net backward pass when actb->gslope is set; actb->applied = 0 and a plain sum otherwise)
+int fg_launch_sum_splits_actbwd(fg_ctx* ctx, const float* part, int splits, long long stride, float* out, long long count,
+                                const FgActBwd* actb);
 
 // ---------------------------------------------------------------------------------
 // Weight-gradient contraction: Part[pg][s][n][c] = sum_{m in split s} dY[pixd(m,p)][n] * X[pixx(m,pg)][c]

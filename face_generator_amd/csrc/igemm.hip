@@ -937,6 +937,61 @@ int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long s
     return FG_OK;
 }
 
+// Split-K data gradient whose input is the output of an nn.PReLU [+ nn.Dropout]: the pass that sums the partials also runs that
+// PReLU's backward (prelu_bwd_kernel's expressions: g = sum [* mask * mscale]; gx = x > 0 ? g : slope * g; slope gradient
+// += x * g where x <= 0), one slope-gradient partial per block.
+__global__ __launch_bounds__(256) void sum_splits_actbwd_kernel(const float* __restrict__ part, int splits, long long stride,
+                                                                float* __restrict__ out, long long count4,
+                                                                const float* __restrict__ x, const float* __restrict__ slope,
+                                                                const float* __restrict__ mask, float mscale,
+                                                                float* __restrict__ spart) {
+    __shared__ float sh[4];
+    const float a = slope[0];
+    float acc = 0.f;
+    const long long step = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += step) {
+        float4 g = ((const float4*)part)[i];
+        for (int k = 1; k < splits; ++k) {
+            const float4 t = ((const float4*)(part + k * stride))[i];
+            g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+        }
+        if (mask) {
+            const float4 m = ((const float4*)mask)[i];
+            g.x *= m.x * mscale; g.y *= m.y * mscale; g.z *= m.z * mscale; g.w *= m.w * mscale;
+        }
+        const float4 v = ((const float4*)x)[i];
+        float4 o;
+        o.x = v.x > 0.f ? g.x : a * g.x; if (!(v.x > 0.f)) acc = fmaf(v.x, g.x, acc);
+        o.y = v.y > 0.f ? g.y : a * g.y; if (!(v.y > 0.f)) acc = fmaf(v.y, g.y, acc);
+        o.z = v.z > 0.f ? g.z : a * g.z; if (!(v.z > 0.f)) acc = fmaf(v.z, g.z, acc);
+        o.w = v.w > 0.f ? g.w : a * g.w; if (!(v.w > 0.f)) acc = fmaf(v.w, g.w, acc);
+        ((float4*)out)[i] = o;
+    }
+    // block sum (fixed shape: deterministic)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && spart) spart[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+int fg_launch_sum_splits_actbwd(fg_ctx* ctx, const float* part, int splits, long long stride, float* out, long long count,
+                                const FgActBwd* actb) {
+    if (actb) actb->applied = 0;
+    const bool ok = actb && actb->x && actb->slope && fg_fuse_prelu(ctx) && count % 4 == 0 && stride % 4 == 0 &&
+                    ((uintptr_t)actb->x & 15) == 0 && (!actb->mask || ((uintptr_t)actb->mask & 15) == 0);
+    const long long c4 = count / 4;
+    const int blocks = (int)min((long long)1024, (c4 + 255) / 256);
+    float* dp = (ok && actb->gslope) ? fg_defer_alloc(ctx, blocks) : nullptr;
+    if (!ok || (actb->gslope && !dp)) return fg_launch_sum_splits(ctx, part, splits, stride, nullptr, 4, out, count, nullptr);
+    hipLaunchKernelGGL(sum_splits_actbwd_kernel, dim3(blocks), dim3(256), 0, ctx->stream, part, splits, stride, out, c4,
+                       actb->x, actb->slope, actb->mask, actb->mscale, dp);
+    FG_CHECK_LAUNCH(ctx);
+    if (dp) fg_defer_push(ctx, dp, blocks, 1, 0.f, actb->gslope);
+    actb->applied = 1;
+    return FG_OK;
+}
+
 // ---------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------

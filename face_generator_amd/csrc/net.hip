@@ -182,11 +182,13 @@ static int backward_run_stages(fg_net* n) {
         // a plain PReLU directly in front of this stage (inside this call's range, not the net's first stage): its backward
         // can ride on the epilogue of the kernel that produces this stage's input gradient
         FgActBwd actb; memset(&actb, 0, sizeof(actb));
-        const bool pf = si >= 2 && si - 1 >= stage_to && n->st[si - 1].kind == ST_PRELU && n->st[si - 1].mask_kind == 0 &&
+        const bool pf = si >= 2 && si - 1 >= stage_to && n->st[si - 1].kind == ST_PRELU && n->st[si - 1].mask_kind != 1 &&
                         fg_fuse_prelu(ctx);
         if (pf) {
-            actb.x = ws + n->st[si - 2].out_off; actb.slope = P + n->st[si - 1].slope_off;
-            actb.gslope = want_p ? Gp + n->st[si - 1].slope_off : nullptr;
+            const Stage& ps = n->st[si - 1];
+            actb.x = ws + n->st[si - 2].out_off; actb.slope = P + ps.slope_off;
+            actb.gslope = want_p ? Gp + ps.slope_off : nullptr;
+            if (ps.mask_kind == 2) { actb.mask = n->mask_ptrs[ps.mask_idx]; actb.mscale = 1.f / (1.f - ps.p); }   // PReLU + Dropout
         }
         const float* xin = si == 0 ? x : ws + n->st[si - 1].out_off;
         const float* yout = (si + 1 == (int)n->st.size() && n->out_override) ? n->out_override : ws + s.out_off;
@@ -291,7 +293,7 @@ static int backward_run_stages(fg_net* n) {
             case ST_AVGPOOL: if (need_gx) rc = fg_launch_avgpool_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
             case ST_SDROPOUT: if (need_gx) rc = fg_launch_scale_mask_nc(ctx, gcur, mask, 1.f, gxb, B, s.ih * s.iw, s.ic); break;
             case ST_MAXPOOL:
-                if (need_gx && pf) {     // pooled tensor = prelu(actb.x): both backward passes in one
+                if (need_gx && pf && !actb.mask) {     // pooled tensor = prelu(actb.x): both backward passes in one
                     rc = fg_launch_maxpool_prelu_backward(ctx, actb.x, gcur, actb.slope, gxb, actb.gslope, B, s.ih, s.iw, s.ic, scratch);
                     prelu_folded = !rc;
                 } else if (need_gx) rc = fg_launch_maxpool_backward(ctx, xin, gcur, gxb, B, s.ih, s.iw, s.ic);

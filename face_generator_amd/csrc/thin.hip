@@ -461,7 +461,7 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
     ThinEpi epi; memset(&epi, 0, sizeof(epi));
     // fold the neighbouring PReLU into the epilogue (MFMA variants): forward = plain PReLU only (no same-shape mask)
     const bool want_f = actf && actf->y && actf->slope && !actf->mask && fg_fuse_prelu(ctx);
-    const bool want_b = !want_f && actb && actb->x && actb->slope && fg_fuse_prelu(ctx);
+    const bool want_b = !want_f && actb && actb->x && actb->slope && !actb->mask && fg_fuse_prelu(ctx);
     auto arm = [&](dim3 g) -> bool {      // false: the slope-gradient partials do not fit the deferred arena -> not folded
         if (want_f) { epi.slope = actf->slope; epi.y = actf->y; return true; }
         if (want_b) {

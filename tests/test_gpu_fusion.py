@@ -114,3 +114,45 @@ def test_thin_output_3x3_slab_kernel_equals_window_kernel_and_oracle(ctx, B, H, 
     close(out[FG_FUSE_ALL], ref, atol=tol, what="slab kernel vs oracle")
     close(out[FG_FUSE_ALL & ~FG_FUSE_THIN_SLAB], ref, atol=tol, what="window kernel vs oracle")
     close(out[FG_FUSE_ALL], out[FG_FUSE_ALL & ~FG_FUSE_THIN_SLAB], atol=tol, what="slab vs window kernel")
+
+
+@pytest.mark.parametrize("B", [6, 128])
+def test_cfg2_nets_fused_equal_unfused(ctx, B):
+    """The 32x32 nets (models.lua:57-81, 382-416): the PReLU [+ Dropout] backward behind D's Linear layers and G's first
+    Linear rides on the pass that sums the next layer's split-K data-gradient partials; G's first Linear runs un-split with
+    its PReLU in the epilogue.  Same operations on the same values: everything but the slope gradients is bit-identical."""
+    from test_gpu_net import build as build32, d_masks
+    st, Gd, Dd, rng = build32(ctx, 3, B, seed=700 + B)
+    d = ctx.device
+    noise = rng.uniform(-1, 1, (B, 100)).astype(np.float32)
+    x = rng.uniform(0, 1, (B, 3, 32, 32)).astype(np.float32)
+    gy = rng.standard_normal((B, 3, 32, 32)).astype(np.float32)
+    gyo = rng.standard_normal((B, 1)).astype(np.float32)
+    masks = [dev(m.reshape(-1), d) for m in d_masks(rng, B)]
+    res = {}
+    for flags in (FG_FUSE_ALL, FG_FUSE_ALL & ~FG_FUSE_PRELU):
+        ctx.set_fusion(flags)
+        dn = Gd.device_net
+        y = dn.forward(dev(noise, d)).clone()
+        dn.backward(nhwc(gy, d), param_grads=True, input_grad=False)
+        gG = dn.grads.clone()
+        dnD = Dd.device_net
+        yd = dnD.forward(nhwc(x, d), masks=masks).clone()
+        gx = dnD.backward(dev(gyo, d), param_grads=True, input_grad=True).clone()
+        res[flags] = (y, gG, yd, gx, dnD.grads.clone())
+    ctx.set_fusion(FG_FUSE_ALL)
+    a, b = res[FG_FUSE_ALL], res[FG_FUSE_ALL & ~FG_FUSE_PRELU]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    for name, net, ga, gb in (("G", st.G, a[1], b[1]), ("D", st.D, a[4], b[4])):
+        off = 0
+        for m in net.modules:
+            for (mm, pn, gn) in m.parameters():
+                n = getattr(mm, pn).size
+                da, db = ga[off:off + n], gb[off:off + n]
+                if isinstance(mm, O.PReLU):
+                    scale = float(max(da.abs().max(), db.abs().max(), 1e-30))
+                    assert float((da - db).abs().max()) <= 2e-3 * scale + 1e-6, (name, off, float(da), float(db))
+                else:
+                    assert torch.equal(da, db), (name, type(mm).__name__, pn, off)
+                off += n
+        assert off == ga.numel()
