@@ -23,7 +23,11 @@ int fg_conv_pack(fg_ctx* ctx, const ConvGeom& g, const float* W, float* wp_fwd, 
 int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* wp_fwd, const float* bias,
                         float* y, float* scratch, long long scratch_floats, const void* wp6 = nullptr,
                         void* x6_dst = nullptr, int* x6_written = nullptr, float* stats_part = nullptr,
-                        long long stats_cap = 0, int* stats_rows = nullptr, const FgActFuse* act = nullptr);
+                        long long stats_cap = 0, int* stats_rows = nullptr, const FgActFuse* act = nullptr,
+                        FgSplitParts* leave = nullptr);
+// leave (optional, forward and data gradient): when the launch splits K, do NOT run the pass that sums the partials -- describe
+// them in *leave (they sit at the head of `scratch`; leave->splits = 0 if the launch did not split) for the pointwise kernel
+// behind the layer, which sums them itself (PReLU + SpatialDropout + AvgPool forward / backward)
 // act (optional): the PReLU [+ Dropout] behind the layer; act->applied tells whether this launch folded it in (split-K layers)
 // stats_part (optional, capacity stats_cap floats): the kernel's epilogue leaves per-channel sum / sum-of-squares partials of
 // the raw accumulators there ([2][*stats_rows][Cout]; *stats_rows = 0 if this launch could not: split-K, bf16x6)
@@ -34,7 +38,7 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
 // the gradient wrt the PReLU's input (actb->applied; un-split fp32 launches inside an fg_net backward pass)
 int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const float* wp_bwd, float* gx, float* scratch,
                       long long scratch_floats, const void* wp6 = nullptr, const void* gy6 = nullptr,
-                      const FgActBwd* actb = nullptr);
+                      const FgActBwd* actb = nullptr, FgSplitParts* leave = nullptr);
 // bf16x6 plane sharing (all optional): x6 = planes of x kept from the forward pass; *gy6_out = where this call left the
 // planes of gy (nullptr if it ran in fp32) and *used_out = scratch floats that must stay untouched while they are used
 int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* gy, float* gradW, float* gradb,

@@ -230,7 +230,8 @@ static int maybe_split_operands(fg_ctx* ctx, IgemmArgs& a, int tile, long long p
 
 int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const float* wp_fwd, const float* bias,
                         float* y, float* scratch, long long scratch_floats, const void* wp6, void* x6_dst, int* x6_written,
-                        float* stats_part, long long stats_cap, int* stats_rows, const FgActFuse* act) {
+                        float* stats_part, long long stats_cap, int* stats_rows, const FgActFuse* act, FgSplitParts* leave) {
+    if (leave) memset(leave, 0, sizeof(*leave));
     if (act) act->applied = 0;
     if (x6_written) *x6_written = 0;
     if (stats_rows) *stats_rows = 0;
@@ -285,12 +286,17 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
     }
     if ((rc = fg_launch_igemm(ctx, a, wm.P, tile))) return rc;
     if (a.act_y) act->applied = 1;
+    if (splits > 1 && leave && !act && out_count % 4 == 0 && g.Cout % 4 == 0) {
+        leave->part = scratch; leave->splits = splits; leave->stride = out_count; leave->bias = bias; leave->N = g.Cout;
+        return FG_OK;
+    }
     if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, bias, g.Cout, y, out_count, act);
     return FG_OK;
 }
 
 int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const float* wp_bwd, float* gx, float* scratch,
-                      long long scratch_floats, const void* wp6, const void* gy6, const FgActBwd* actb) {
+                      long long scratch_floats, const void* wp6, const void* gy6, const FgActBwd* actb, FgSplitParts* leave) {
+    if (leave) memset(leave, 0, sizeof(*leave));
     if (actb) actb->applied = 0;
     if (g.B == 0) return FG_OK;
     if (g.stride == 2) {
@@ -350,6 +356,10 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
     if (a.act_x) {
         actb->applied = 1;
         if (a.act_part) fg_defer_push(ctx, a.act_part, (int)nparts, 1, 0.f, actb->gslope);
+    }
+    if (splits > 1 && leave && !actb && out_count % 4 == 0 && g.Cin % 4 == 0) {
+        leave->part = scratch; leave->splits = splits; leave->stride = out_count; leave->bias = nullptr; leave->N = g.Cin;
+        return FG_OK;
     }
     if (splits > 1) {
         // the pass that sums the partials also runs the backward of the PReLU [+ Dropout] in front of the layer

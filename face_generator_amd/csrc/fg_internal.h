@@ -226,11 +226,16 @@ int fg_launch_prelu_forward(fg_ctx*, const float* x, const float* slope, const f
 int fg_launch_prelu_backward(fg_ctx*, const float* x, const float* gy, const float* slope, const float* mask,
                              float mscale, float* gx, float* gslope, float acc, long long n, float* scratch);
 // fused PReLU -> SpatialDropout(mask[B][C], unscaled in train / (1-p) in eval) -> AvgPool2x2 on NHWC [B][H][W][C]
+// Split-K partials a contraction left un-summed for the pointwise pass behind it: value[i] = bias[i % N] + sum_s part[s * stride + i]
+// (fixed order = sum_splits_kernel's).  splits == 0: nothing pending.
+struct FgSplitParts { const float* part; int splits; long long stride; const float* bias; int N; };
+// sp (optional): x (forward) / gy (backward) is not materialised yet -- the kernel sums the partials itself; forward also
+// writes the finished pre-activation to xout (the backward pass needs it)
 int fg_launch_actpool_forward(fg_ctx*, const float* x, const float* slope, const float* mask, float mscale, float* y,
-                              int B, int H, int W, int C);
+                              int B, int H, int W, int C, const FgSplitParts* sp = nullptr, float* xout = nullptr);
 int fg_launch_actpool_backward(fg_ctx*, const float* x, const float* gy, const float* slope, const float* mask,
                                float mscale, float* gx, float* gslope, float acc, int B, int H, int W, int C,
-                               float* scratch);
+                               float* scratch, const FgSplitParts* sp = nullptr);
 // standalone pieces (module-level API)
 int fg_launch_scale_mask_nc(fg_ctx*, const float* x, const float* mask, float mscale, float* y, int B, int HW, int C);
 int fg_launch_avgpool_forward(fg_ctx*, const float* x, float* y, int B, int H, int W, int C);

@@ -97,6 +97,7 @@ struct fg_net {
     long long packed_total = 0;
     bool planes_valid = false;
     float* out_override = nullptr;    // fg_net_forward_to: the last stage writes here instead of into the workspace
+    FgSplitParts pend{};              // split-K partials the previous stage left for this one (ST_ACTPOOL sums them itself)
     int n_jobs = 0;
     long long jobs_total = 0;
 };
@@ -179,6 +180,7 @@ static int backward_run_stages(fg_net* n) {
     for (int si = n->run_stage; si >= stage_to; --si) {
         Stage& s = n->st[si];
         if (prelu_folded) { prelu_folded = false; continue; }      // gcur already is the gradient wrt the PReLU's input
+        if (s.kind != ST_ACTPOOL) n->pend.splits = 0;
         // a plain PReLU directly in front of this stage (inside this call's range, not the net's first stage): its backward
         // can ride on the epilogue of the kernel that produces this stage's input gradient
         FgActBwd actb; memset(&actb, 0, sizeof(actb));
@@ -213,8 +215,12 @@ static int backward_run_stages(fg_net* n) {
                         if (!rc) rc = fg_launch_nhwc_to_nchw(ctx, tb, Gp + s.b_off, 1, g.o_c, g.o_hw, 1);
                     }
                 }
+                // the fused PReLU + SpatialDropout + AvgPool backward in front of this layer sums split-K partials itself
+                const bool ap = si >= 1 && si - 1 >= stage_to && n->st[si - 1].kind == ST_ACTPOOL && fg_fuse_prelu(ctx);
+                n->pend.splits = 0;
                 if (!rc && need_gx) rc = fg_conv_dgrad_run(ctx, g, gcur, s.wp_bwd, gxb, scratch + gy6_used, n->scratch_floats - gy6_used,
-                                                         n->planes_valid ? s.wp_bwd6 : nullptr, gy6, pf ? &actb : nullptr);
+                                                         n->planes_valid ? s.wp_bwd6 : nullptr, gy6, pf ? &actb : nullptr,
+                                                         ap ? &n->pend : nullptr);
                 prelu_folded = pf && !rc && actb.applied;
                 break;
             }
@@ -279,10 +285,16 @@ static int backward_run_stages(fg_net* n) {
                                               want_p ? Gp + s.slope_off : nullptr, 0.f, cnt, scratch);
                 break;
             }
-            case ST_ACTPOOL:
+            case ST_ACTPOOL: {
+                // (pending partials sit at the head of the scratch: the slope-gradient partials go behind them)
+                const long long used = n->pend.splits ? ((n->pend.part - scratch) + (long long)n->pend.splits * n->pend.stride + 3) / 4 * 4 : 0;
+                if (used + 1024 > n->scratch_floats) { rc = fg_set_err(ctx, FG_ERR_WORKSPACE, "actpool backward: scratch"); break; }
                 rc = fg_launch_actpool_backward(ctx, xin, gcur, P + s.slope_off, mask, 1.f, gxb,
-                                                want_p ? Gp + s.slope_off : nullptr, 0.f, B, s.ih, s.iw, s.ic, scratch);
+                                                want_p ? Gp + s.slope_off : nullptr, 0.f, B, s.ih, s.iw, s.ic, scratch + used,
+                                                n->pend.splits ? &n->pend : nullptr);
+                n->pend.splits = 0;
                 break;
+            }
             case ST_SIGMOID:
                 if (need_gx) rc = fg_launch_sigmoid_backward(ctx, yout, gcur, gxb, (long long)B * s.ic * s.ih * s.iw);
                 break;
@@ -321,6 +333,7 @@ static int forward_run(fg_net* n, long long* out_offset) {
     int rc = FG_OK;
     for (int si = n->run_stage; si < (int)n->st.size(); ++si) {
         Stage& s = n->st[si];
+        if (s.kind != ST_ACTPOOL) n->pend.splits = 0;
         float* y = (si + 1 == (int)n->st.size() && n->out_override) ? n->out_override : ws + s.out_off;
         const float* mask = (s.mask_idx >= 0) ? n->mask_ptrs[s.mask_idx] : nullptr;
         switch (s.kind) {
@@ -345,7 +358,8 @@ static int forward_run(fg_net* n, long long* out_offset) {
                                          n->scratch_floats, n->planes_valid ? s.wp_fwd6 : nullptr,
                                          (train && s.x6_off >= 0) ? (void*)(ws + s.x6_off) : nullptr, &s.x6_valid,
                                          bn ? ws + bn->stats_off : nullptr, bn ? bn->stats_cap : 0, bn ? &bn->stats_rows : nullptr,
-                                         pr ? &act : nullptr);
+                                         pr ? &act : nullptr,
+                                         (si + 1 < (int)n->st.size() && n->st[si + 1].kind == ST_ACTPOOL && fg_fuse_prelu(ctx)) ? &n->pend : nullptr);
                 if (pr && !rc) pr->act_done = act.applied;
                 break;
             }
@@ -404,7 +418,11 @@ static int forward_run(fg_net* n, long long* out_offset) {
             }
             case ST_ACTPOOL: {
                 const float sc = train ? 1.f : (1.f - s.p);
-                rc = fg_launch_actpool_forward(ctx, cur, P + s.slope_off, train ? mask : nullptr, sc, y, B, s.ih, s.iw, s.ic);
+                // pending: the producing layer split K and left its partials -- this pass finishes the pre-activation into
+                // `cur` (the conv stage's output buffer, kept for backward) and pools it
+                rc = fg_launch_actpool_forward(ctx, cur, P + s.slope_off, train ? mask : nullptr, sc, y, B, s.ih, s.iw, s.ic,
+                                               n->pend.splits ? &n->pend : nullptr, n->pend.splits ? (float*)cur : nullptr);
+                n->pend.splits = 0;
                 break;
             }
             case ST_SIGMOID: rc = fg_launch_sigmoid_forward(ctx, cur, y, (long long)B * s.ic * s.ih * s.iw); break;

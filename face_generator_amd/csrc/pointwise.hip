@@ -784,9 +784,19 @@ int fg_launch_prelu_backward(fg_ctx* ctx, const float* x, const float* gy, const
 }
 
 // ------------------------------------------------------------------ PReLU -> SpatialDropout -> AvgPool(2,2,2,2)
+__device__ __forceinline__ float4 fg_sum_parts4(const FgSplitParts& sp, size_t i4, int c) {   // i4: float4 index, c: its channel
+    float4 v = ((const float4*)sp.part)[i4];
+    for (int k = 1; k < sp.splits; ++k) {
+        const float4 t = ((const float4*)(sp.part + k * sp.stride))[i4];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (sp.bias) { v.x += sp.bias[c]; v.y += sp.bias[c + 1]; v.z += sp.bias[c + 2]; v.w += sp.bias[c + 3]; }
+    return v;
+}
 __global__ __launch_bounds__(256) void actpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope,
                                                           const float* __restrict__ mask, float mscale,
-                                                          float* __restrict__ y, int B, int H, int W, int C) {
+                                                          float* __restrict__ y, int B, int H, int W, int C,
+                                                          const FgSplitParts sp, float* __restrict__ xout) {
     const float a = slope ? slope[0] : 1.f;
     const int H2 = H >> 1, W2 = W >> 1, C4 = C >> 2;
     const long long total = (long long)B * H2 * W2 * C4;
@@ -803,7 +813,12 @@ __global__ __launch_bounds__(256) void actpool_fwd_kernel(const float* __restric
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                float4 v = px[((size_t)dy * W + dx) * C4];
+                float4 v;
+                if (sp.splits) {       // the producing layer's split-K partials: finish the pre-activation here (and keep it)
+                    const size_t i4 = ((((size_t)b * H + 2 * h2 + dy) * W + 2 * w2 + dx) * C4) + c4;
+                    v = fg_sum_parts4(sp, i4, c4 * 4);
+                    ((float4*)xout)[i4] = v;
+                } else v = px[((size_t)dy * W + dx) * C4];
                 s.x += v.x > 0.f ? v.x : a * v.x;
                 s.y += v.y > 0.f ? v.y : a * v.y;
                 s.z += v.z > 0.f ? v.z : a * v.z;
@@ -819,19 +834,21 @@ __global__ __launch_bounds__(256) void actpool_fwd_kernel(const float* __restric
     }
 }
 int fg_launch_actpool_forward(fg_ctx* ctx, const float* x, const float* slope, const float* mask, float mscale,
-                              float* y, int B, int H, int W, int C) {
+                              float* y, int B, int H, int W, int C, const FgSplitParts* sp, float* xout) {
     if (C % 4 || H % 2 || W % 2) return fg_set_err(ctx, FG_ERR_INVALID, "actpool: C%%4, even H/W");
     long long n = (long long)B * (H / 2) * (W / 2) * (C / 4);
     if (n == 0) return FG_OK;
+    FgSplitParts none; memset(&none, 0, sizeof(none));
+    if (sp && sp->splits && (!xout || sp->stride % 4 || sp->N != C)) return fg_set_err(ctx, FG_ERR_INVALID, "actpool: bad split partials");
     hipLaunchKernelGGL(actpool_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, slope, mask, mscale, y, B, H,
-                       W, C);
+                       W, C, (sp && sp->splits) ? *sp : none, xout);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
 __global__ __launch_bounds__(256) void actpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                           const float* __restrict__ slope, const float* __restrict__ mask,
                                                           float mscale, float* __restrict__ gx, float* __restrict__ part,
-                                                          int B, int H, int W, int C) {
+                                                          int B, int H, int W, int C, const FgSplitParts sp) {
     __shared__ float sh[4];
     const float a = slope ? slope[0] : 1.f;
     const int H2 = H >> 1, W2 = W >> 1, C4 = C >> 2;
@@ -845,7 +862,8 @@ __global__ __launch_bounds__(256) void actpool_bwd_kernel(const float* __restric
         const int h = (int)(t % H);
         const int b = (int)(t / H);
         const float4 v = ((const float4*)x)[i];
-        float4 g = *((const float4*)(gy + (((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * C) + c4);
+        const size_t gi4 = (((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * C4 + c4;
+        float4 g = sp.splits ? fg_sum_parts4(sp, gi4, c4 * 4) : ((const float4*)gy)[gi4];      // pooled gradient (or its partials)
         float4 m = make_float4(mscale, mscale, mscale, mscale);
         if (mask) {
             const float4 mk = *(const float4*)(mask + (size_t)b * C + c4 * 4);
@@ -864,7 +882,9 @@ __global__ __launch_bounds__(256) void actpool_bwd_kernel(const float* __restric
 }
 int fg_launch_actpool_backward(fg_ctx* ctx, const float* x, const float* gy, const float* slope, const float* mask,
                                float mscale, float* gx, float* gslope, float acc, int B, int H, int W, int C,
-                               float* scratch) {
+                               float* scratch, const FgSplitParts* sp) {
+    FgSplitParts spv; memset(&spv, 0, sizeof(spv));
+    if (sp && sp->splits) { spv = *sp; if (spv.stride % 4 || spv.bias) return fg_set_err(ctx, FG_ERR_INVALID, "actpool: bad split partials"); }
     if (C % 4 || H % 2 || W % 2) return fg_set_err(ctx, FG_ERR_INVALID, "actpool: C%%4, even H/W");
     long long n = (long long)B * H * W * (C / 4);
     if (n == 0) return FG_OK;
@@ -873,7 +893,7 @@ int fg_launch_actpool_backward(fg_ctx* ctx, const float* x, const float* gy, con
     float* dpart = (slope && gslope) ? fg_defer_alloc(ctx, grid.x) : nullptr;
     if (dpart) scratch = dpart;
     hipLaunchKernelGGL(actpool_bwd_kernel, grid, dim3(256), 0, ctx->stream, x, gy, slope, mask, mscale, gx, scratch, B,
-                       H, W, C);
+                       H, W, C, spv);
     FG_CHECK_LAUNCH(ctx);
     if (dpart) { fg_defer_push(ctx, dpart, (int)grid.x, 1, acc, gslope); return FG_OK; }
     if (slope && gslope) {
