@@ -13,6 +13,7 @@
 // 32-row fragment feeds 4 MFMAs (k = kk+j for lanes<32, kk+4+j for lanes>=32 -- same permutation on A and B).
 #include "fg_internal.h"
 #include <stdio.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -880,7 +881,15 @@ int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
     switch (tile) {
         case 0: if (a.Npad % 128) break; return launch_igemm_t<128, 128, 32>(ctx, a, P);
         case 1: if (a.Npad % 64) break; return launch_igemm_t<128, 64, 32>(ctx, a, P);
-        case 2: if (a.Npad % 64) break; return launch_igemm_t<64, 64, 32>(ctx, a, P);
+        case 2: {
+            if (a.Npad % 64) break;
+            // 64-deep K-steps (half the barriers, 70 KB of LDS: still two blocks per CU) where the padded K allows: D's mid-size
+            // convolutions 56.7 -> 54.7 us, G's first data gradient 199.8 -> 193.8 (FG_IGEMM_BK64=0 switches back)
+            static int bk64 = -1;
+            if (bk64 < 0) { const char* e = getenv("FG_IGEMM_BK64"); bk64 = e ? atoi(e) : 1; }
+            if (bk64 && a.Kpad % 64 == 0 && ((a.G * (a.Kpad / 64)) % a.splits == 0)) return launch_igemm_t<64, 64, 64>(ctx, a, P);
+            return launch_igemm_t<64, 64, 32>(ctx, a, P);
+        }
         case 5: if (a.Npad % 64 || a.A6) break; return launch_igemm_ws<64>(ctx, a, P);
         case 4:
             if (a.A6) { if (a.Npad % 64) break; return (a.Npad % 128 == 0) ? launch_igemm_ws6<128>(ctx, a, P) : launch_igemm_ws6<64>(ctx, a, P); }
