@@ -1218,8 +1218,13 @@ int fg_launch_wgrad(fg_ctx* ctx, const WgradArgs& a, int P, int tile) {
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad: operands must be < 2 GiB per launch");
     // K-steps of 16 pixels at four blocks per CU (16 waves): measured 4-7 % faster than 32-pixel steps at two blocks per CU --
     // the kernel's limiter is load latency, and the extra resident waves hide it better than a longer step does
-    // (the 64-tile is the other way round: 89 vs 106 TFLOP/s)
+    // (the 64-tile is the other way round: 89 vs 106 TFLOP/s at 16 vs 32 pixels, and better again at 64)
     if (tile == 0 && a.Npad % 128 == 0 && a.Cpad % 128 == 0) return launch_wgrad_t<128, 16, 4>(ctx, a, P);
+    // the 64-tile (one accumulator tile per wave) wants LONG K-steps: 64 pixels 687 us, 32 pixels 737 us, 16 pixels slower
+    // still on the c2f 64-channel layers (FG_WGRAD64_BK=32 switches back)
+    static int w64 = -1;
+    if (w64 < 0) { const char* e = getenv("FG_WGRAD64_BK"); w64 = e ? atoi(e) : 64; }
+    if (tile == 2 && a.Npad % 64 == 0 && a.Cpad % 64 == 0 && w64 == 64) return launch_wgrad_t<64, 64, 2>(ctx, a, P);
     if (tile == 2 && a.Npad % 64 == 0 && a.Cpad % 64 == 0) return launch_wgrad_t<64, 32, 2>(ctx, a, P);
     return fg_set_err(ctx, FG_ERR_INVALID, "wgrad: bad tile %d for %dx%d", tile, a.Npad, a.Cpad);
 }
