@@ -110,7 +110,9 @@ static void choose_wgrad(long long M, int Cout, int Cin, int G, int P, int* tile
         // prefer fuller waves; among equals prefer fewer splits (less partial traffic)
         if (eff > best_eff + 0.02) { best_eff = eff; best = s; }
     }
-    int mp = fg_round_up((int)((M + best - 1) / best), 32);
+    // whole K-steps per split: 64 pixels for the 64-tile kernel (its fast address path takes the wave-uniform part of a step
+    // from the step's first pixel), 32 otherwise
+    int mp = fg_round_up((int)((M + best - 1) / best), bt == 64 ? 64 : 32);
     *mper = mp;
     *S = (int)((M + mp - 1) / mp);
 }

@@ -1224,7 +1224,7 @@ int fg_launch_wgrad(fg_ctx* ctx, const WgradArgs& a, int P, int tile) {
     // still on the c2f 64-channel layers (FG_WGRAD64_BK=32 switches back)
     static int w64 = -1;
     if (w64 < 0) { const char* e = getenv("FG_WGRAD64_BK"); w64 = e ? atoi(e) : 64; }
-    if (tile == 2 && a.Npad % 64 == 0 && a.Cpad % 64 == 0 && w64 == 64) return launch_wgrad_t<64, 64, 2>(ctx, a, P);
+    if (tile == 2 && a.Npad % 64 == 0 && a.Cpad % 64 == 0 && w64 == 64 && a.m_per_split % 64 == 0) return launch_wgrad_t<64, 64, 2>(ctx, a, P);
     if (tile == 2 && a.Npad % 64 == 0 && a.Cpad % 64 == 0) return launch_wgrad_t<64, 32, 2>(ctx, a, P);
     return fg_set_err(ctx, FG_ERR_INVALID, "wgrad: bad tile %d for %dx%d", tile, a.Npad, a.Cpad);
 }

@@ -937,41 +937,69 @@ __global__ __launch_bounds__(256) void thin_out_rows_mfma_kernel(const float* __
     const int tyi = bid % tiles_y;
     const int b = bid / tiles_y;
     const int x0 = txi * 32, y0 = tyi * 4;
-    tw_f32x16 acc;
+    // Round 2b: (i) the chunk of step c0 + 32 is fetched into registers while the chunk of step c0 multiplies (load and
+    // multiply phases used to alternate behind the block barriers); (ii) the weights are read with the channel fastest (128-byte
+    // runs instead of 4-byte words Cw floats apart) into [dy][c][33] (conflict-free both ways); (iii) two accumulators, so
+    // that consecutive MFMAs do not wait for each other's result.
+    constexpr int WLD = 33;
+    constexpr int NX = (NR * 32 * 8 + 255) / 256;     // float4 per thread and chunk of the input rows
+    constexpr int NWV = K * 32 * 32 / 256;            // weight floats per thread and chunk
+    tw_f32x16 acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int c0 = 0; c0 < Cw; c0 += 32) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < NR * 32 * 8; e += 256) {          // input rows y0-PAD .. y0+3+PAD, 32 pixels, 32 channels
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+    float4 px[NX];
+    float pw[NWV];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int e = threadIdx.x + 256 * u;
             const int c4 = e & 7, pp = e >> 3;
-            const int px = pp & 31, py = pp >> 5;
-            const int xx = x0 + px, yy = y0 + py - PAD;
+            const int pxx = pp & 31, py = pp >> 5;
+            const int xx = x0 + pxx, yy = y0 + py - PAD;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (xx < W && (unsigned)yy < (unsigned)H)
+            if (e < NR * 32 * 8 && xx < W && (unsigned)yy < (unsigned)H)
                 v = *(const float4*)(in + ((size_t)(b * H + yy) * W + xx) * Cw + c0 + c4 * 4);
-            *(float4*)(xs + pp * LDC + c4 * 4) = v;
+            px[u] = v;
         }
-        for (int e = threadIdx.x; e < K * 32 * 32; e += 256) {          // weights of this channel chunk: [dy][c][j = dx*CS + s]
-            const int j = e & 31, c = (e >> 5) & 31, dy = e >> 10;
-            float v = 0.f;
-            if (j < NJ) v = Wp[(size_t)((dy * K + j / CS) * CS + j % CS) * Cw + c0 + c];
-            wsm[e] = v;
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int c = e & 31, j = (e >> 5) & 31, dy = e >> 10;
+            pw[u] = (j < NJ) ? Wp[(size_t)((dy * K + j / CS) * CS + j % CS) * Cw + c0 + c] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < Cw; c0 += 32) {
+        __syncthreads();                                   // the previous chunk's fragment reads are done
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            if (e < NR * 32 * 8) *(float4*)(xs + (e >> 3) * LDC + (e & 7) * 4) = px[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            const int c = e & 31, j = (e >> 5) & 31, dy = e >> 10;
+            wsm[(dy * 32 + c) * WLD + j] = pw[u];
         }
         __syncthreads();
+        if (c0 + 32 < Cw) fetch(c0 + 32);                  // in flight behind this chunk's K * 16 MFMAs
 #pragma unroll
         for (int dy = 0; dy < K; ++dy) {
             const float* xrow = xs + ((wave + dy) * 32 + i) * LDC + 4 * h;
-            const float* wrow = wsm + dy * 1024 + i;                    // + c * 32
+            const float* wrow = wsm + dy * 32 * WLD + i;                // + c * WLD
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 xv = *(const float4*)(xrow + 8 * q);       // channels 8q + 4h + {0..3}
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.x, wrow[(8 * q + 4 * h + 0) * 32], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.y, wrow[(8 * q + 4 * h + 1) * 32], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.z, wrow[(8 * q + 4 * h + 2) * 32], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.w, wrow[(8 * q + 4 * h + 3) * 32], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.x, wrow[(8 * q + 4 * h + 0) * WLD], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.y, wrow[(8 * q + 4 * h + 1) * WLD], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.z, wrow[(8 * q + 4 * h + 2) * WLD], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xv.w, wrow[(8 * q + 4 * h + 3) * WLD], acc2, 0, 0, 0);
             }
         }
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
     const int y = y0 + wave;
     if (y < H) {
 #pragma unroll
@@ -1008,7 +1036,7 @@ int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const
         dim3 grid(B * ((H + 3) / 4) * ((W + 31) / 32));
 #define TOR(KK, CC)                                                                                                  \
         if (k == KK && Cs == CC) {                                                                                   \
-            const size_t lds = (size_t)((4 + KK - 1) * 32 * 36 + KK * 1024) * sizeof(float);                         \
+            const size_t lds = (size_t)((4 + KK - 1) * 32 * 36 + KK * 32 * 33) * sizeof(float);                      \
             static bool attr = false;                                                                                \
             if (!attr) {                                                                                             \
                 FG_HIP(ctx, hipFuncSetAttribute((const void*)thin_out_rows_mfma_kernel<KK, CC>,                      \
