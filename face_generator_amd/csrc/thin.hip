@@ -433,17 +433,32 @@ __global__ __launch_bounds__(256) void thin_in_mfma_lds_kernel(const float* __re
         thin_epi_prefetch<EPI>(epi, tile, h, npix, Cw, cb + j, px0, px1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
-#pragma unroll 2
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k = 2 * ks + h;
-            const int tap = k / CS, sc = k - tap * CS;
-            const int dy = tap / K, dx = tap - dy * K;
-            const int yy = y + dy - PAD, xx = x + dx - PAD;
-            float a = 0.f;
-            if (ok && k < NA && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                a = in[(size_t)((t - y + yy) * W + xx) * CS + sc];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wsh[k][j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wsh[k][32 + j], acc1, 0, 0, 0);
+        // the gather of a tile in groups of GQ values BEFORE their MFMAs (a load per MFMA pair behind its own
+        // `s_waitcnt vmcnt(0)` left the matrix pipe waiting one cache round trip per pair: 67 TFLOP/s on the 7x7 layers)
+        constexpr int GQ = 16;
+#pragma unroll 1
+        for (int ks0 = 0; ks0 < KS; ks0 += GQ) {
+            float av[GQ];
+#pragma unroll
+            for (int u = 0; u < GQ; ++u) {
+                const int k = 2 * (ks0 + u) + h;
+                const int tap = k / CS, sc = k - tap * CS;
+                const int dy = tap / K, dx = tap - dy * K;
+                const int yy = y + dy - PAD, xx = x + dx - PAD;
+                float a = 0.f;
+                if (ok && k < NA && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                    a = in[(size_t)((t - y + yy) * W + xx) * CS + sc];
+                av[u] = a;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < GQ; ++u) {
+                const int k = 2 * (ks0 + u) + h;
+                if (ks0 + u < KS) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], wsh[k][j], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], wsh[k][32 + j], acc1, 0, 0, 0);
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
