@@ -128,9 +128,11 @@ def test_c2f_S64_forward_backward(ctx):
     close(nchw(y), diff, atol=2e-5 * max(1, np.abs(diff).max()), what="c2f-64 G diff image")
     dn.backward(nhwc(gy, d), param_grads=True)
     # bf16x6 mode (opt-in, FG_MATH=6): its dropped plane products are a ONE-SIDED truncation (<= 2^-24 relative each); over the
-    # 4 M-term cancelling sum of a PReLU slope gradient at this size the bias adds up coherently (5.9e-4 relative measured),
-    # where independent fp32 roundings average out -- the slope bar is 256 instead of 32 ulp of the condition scale there
-    check_flat_grads(dn.grads.cpu().numpy(), st.G.inner, "c2f-64 G", prelu_ulps=256 if ctx.get_math() == 6 else 32)
+    # 4 M-term cancelling sum of a PReLU slope gradient at this size the bias adds up coherently (5.9e-4 of the gradient
+    # measured: 8.85e-4 on 1.51, the same value with every fusion / tiling switch of round 2 off), where independent fp32
+    # roundings average out -- in that mode the slope gradients get a 1e-3 relative bar; the default fp32-MFMA mode keeps the
+    # plain SURVEY 8(c) bar (+ 32 ulp of the sum's condition scale)
+    check_flat_grads(dn.grads.cpu().numpy(), st.G.inner, "c2f-64 G", prelu_rtol=1e-3 if ctx.get_math() == 6 else 0.0)
     for m in st.G.inner.modules:
         m.finput = None                                     # the oracle's im2col buffers are GBs at this size
     masks = C2F.masks_for(rng, B, S)

@@ -42,7 +42,7 @@ def build(ctx, C, B, seed, init="default"):
     return st, Gd, Dd, rng
 
 
-def check_flat_grads(g, net, name, prelu_ulps=32):
+def check_flat_grads(g, net, name, prelu_ulps=32, prelu_rtol=0.0):
     """Flat gradient vector vs the oracle, reported per parameter tensor (all failures listed).
     Tolerance: 1e-4 * max|g| + 1e-7 per tensor; a bias uses its module's weight-grad scale as well,
     because the bias grad of a conv feeding a BatchNorm is pure rounding noise around an exact zero; the single PReLU
@@ -60,6 +60,7 @@ def check_flat_grads(g, net, name, prelu_ulps=32):
             tol = 1e-4 * max(scale, wscale if pn == 'bias' else 0.0) + 1e-7
             if isinstance(mm, O.PReLU):     # scalar sum with cancellation: 32 fp32 ulps of its condition scale
                 tol += prelu_ulps * 6e-8 * getattr(mm, "gw_cond", 0.0)
+                tol = max(tol, prelu_rtol * scale)
             err = np.abs(got.astype(np.float64) - ref)
             if not (err <= tol).all():
                 msgs.append("%s module %d %s %s: %d/%d off, max err %.3g (tol %.3g, max|ref| %.3g)"
