@@ -89,13 +89,13 @@ __device__ __forceinline__ void fg_epilogue(const IgemmArgs& a, float* outp, con
                 float xv[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int vo = colok ? (ro[i] + col) * 4 : FG_OOB;
+                    const int vo = colok ? (int)(((unsigned)ro[i] + (unsigned)col) * 4u) : FG_OOB;   // unsigned: a masked row wraps past 2 GiB
                     xv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, vo, 0, 0));
                 }
                 float t4[4] = {0.f, 0.f, 0.f, 0.f};       // four short chains per tile instead of one 128-long serial chain
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int vo = colok ? (ro[i] + col) * 4 : FG_OOB;
+                    const int vo = colok ? (int)(((unsigned)ro[i] + (unsigned)col) * 4u) : FG_OOB;   // unsigned: a masked row wraps past 2 GiB
                     const float g = acc[mi][ni][i];
                     const bool pos = xv[i] > 0.f;
                     t4[i & 3] = fmaf(pos ? 0.f : xv[i], g, t4[i & 3]);   // masked elements read x = 0: they add 0 * g
