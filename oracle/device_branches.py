@@ -87,3 +87,10 @@ def count_branch_flips(onet):
         if isinstance(m, O.PReLU) and m.pos_override is not None:
             k += int(((x > 0) != m.pos_override.reshape(x.shape)).sum())
     return k
+
+
+def count_branch_units(onet):
+    """PReLU units of the oracle's last forward (the denominator of the flip bound the parity tests assert)."""
+    from oracle import torch7_nn as O
+    net = getattr(onet, "inner", onet)
+    return sum(int(x.size) for m, x in zip(net.modules, net._inputs) if isinstance(m, O.PReLU))

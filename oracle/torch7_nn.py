@@ -282,15 +282,21 @@ class SpatialUpSamplingNearest(Module):
         return self.gradInput
 
 
-def _im2col(x, kh, kw, ph, pw, dh=1, dw=1):
-    """THNN SpatialConvolutionMM's unfolded `finput`: [N][C*kh*kw][Ho*Wo]; Ho = floor((H + 2 ph - kh) / dh) + 1."""
+def _im2col(x, kh, kw, ph, pw, dh=1, dw=1, out=None):
+    """THNN SpatialConvolutionMM's unfolded `finput`: [N][C*kh*kw][Ho*Wo]; Ho = floor((H + 2 ph - kh) / dh) + 1.
+    A pure copy, one strided block per tap; `out` (a buffer of a previous call with the same geometry) is re-used --
+    fresh GB-sized allocations cost more than the copy at the BASELINE sizes (page faults)."""
     n, c, h, w = x.shape
-    xp = np.pad(x, ((0, 0), (0, 0), (ph, ph), (pw, pw)))
     ho, wo = (h + 2 * ph - kh) // dh + 1, (w + 2 * pw - kw) // dw + 1
-    win = np.lib.stride_tricks.sliding_window_view(xp, (kh, kw), axis=(2, 3))[:, :, ::dh, ::dw]  # n,c,ho,wo,kh,kw
-    win = win[:, :, :ho, :wo]
-    cols = win.transpose(0, 1, 4, 5, 2, 3).reshape(n, c * kh * kw, ho * wo)
-    return np.ascontiguousarray(cols), ho, wo
+    xp = np.zeros((n, c, h + 2 * ph, w + 2 * pw), x.dtype)
+    xp[:, :, ph:ph + h, pw:pw + w] = x
+    if out is None or out.shape != (n, c * kh * kw, ho * wo) or out.dtype != x.dtype:
+        out = np.empty((n, c * kh * kw, ho * wo), x.dtype)
+    cols = out.reshape(n, c, kh, kw, ho, wo)
+    for ky in range(kh):
+        for kx in range(kw):
+            cols[:, :, ky, kx] = xp[:, :, ky:ky + (ho - 1) * dh + 1:dh, kx:kx + (wo - 1) * dw + 1:dw]
+    return out, ho, wo
 
 
 class SpatialConvolution(Module):
@@ -313,7 +319,7 @@ class SpatialConvolution(Module):
 
     def updateOutput(self, x):
         n = x.shape[0]
-        cols, ho, wo = _im2col(x, self.kh, self.kw, self.padh, self.padw, self.dh, self.dw)
+        cols, ho, wo = _im2col(x, self.kh, self.kw, self.padh, self.padw, self.dh, self.dw, out=getattr(self, 'finput', None))
         self.finput = cols
         wm = self.weight.reshape(self.nout, -1)
         y = np.matmul(wm, cols) + self.bias[None, :, None]
@@ -330,7 +336,10 @@ class SpatialConvolution(Module):
             gz[:, :, 0:gy.shape[2] * self.dh:self.dh, 0:gy.shape[3] * self.dw:self.dw] = gy
             gy = gz
         wf = self.weight[:, :, ::-1, ::-1].transpose(1, 0, 2, 3)  # [I][O][kh][kw]
-        cols, ho, wo = _im2col(gy, self.kh, self.kw, self.kh - 1 - self.padh, self.kw - 1 - self.padw)
+        cols, ho, wo = _im2col(gy, self.kh, self.kw, self.kh - 1 - self.padh, self.kw - 1 - self.padw,
+                               out=getattr(self, '_gcols', None) if getattr(self, 'keep_buffers', False) else None)
+        if getattr(self, 'keep_buffers', False):
+            self._gcols = cols
         gx = np.matmul(np.ascontiguousarray(wf).reshape(c, -1), cols)
         self.gradInput = gx.reshape(n, c, ho, wo)
         assert ho == h and wo == w

@@ -49,4 +49,4 @@ def close_after_first_adam_step(p_dev, p_ref, g_dev, g_ref, what, lr=1e-3, beta2
                              "(g_dev %.3e g_ref %.3e)" % (what, bad.sum(), bad.size, i, err[i], tol[i], g_dev[i], g_ref[i]))
 
 
-from oracle.device_branches import adopt_device_branches, count_branch_flips   # noqa: E402,F401  (shared with smoke())
+from oracle.device_branches import adopt_device_branches, count_branch_flips, count_branch_units   # noqa: E402,F401  (shared with smoke())

@@ -17,7 +17,9 @@ import pytest
 import torch
 
 from oracle import torch7_nn as O
-from gpu_util import nhwc, nchw, dev, close, close_after_first_adam_step, adopt_device_branches, count_branch_flips
+from gpu_util import (nhwc, nchw, dev, close, close_after_first_adam_step, adopt_device_branches, count_branch_flips,
+                      count_branch_units)
+from oracle.chunked import ChunkedC2F, collect_branches
 from test_gpu_net import build, d_masks, check_flat_grads
 import test_gpu_c2f as C2F
 
@@ -38,33 +40,95 @@ def f64_state(st, opt=None):
     return O.GanState(G, D, opt if opt is not None else dict(st.opt))
 
 
-def check_vs_f64(name, g_dev, g32, g64, net64):
-    """Tight bars: whole flat vector <= 1e-4 * max|g| + 1e-7; every weight tensor (conv / linear / BN gamma)
-    <= 1e-4 * max|g_tensor| + 1e-7 against the float64 oracle.  Also reports how far the fp32 ORACLE itself is from float64,
-    so a device error is read against the rounding budget of the reference formulation."""
+FLIP_BOUND = 1e-5      # share of the PReLU units of a pass the oracle may decide differently from the device
+
+
+def assert_flips_bounded(what, onet, flips=None, units=None):
+    """The oracle adopts the device's branch decisions so that gradients are compared on identical branches; that is only
+    sound while the decisions differ for a handful of units within rounding of the kink.  A device whose pre-activations
+    drifted would flip thousands: bounded here at 1e-5 of the units (2-10 of ~10^7 are observed)."""
+    if flips is None:
+        flips, units = count_branch_flips(onet), count_branch_units(onet)
+    print("%s: %d of %d PReLU units decided differently by the device" % (what, flips, units))
+    assert flips <= max(1, FLIP_BOUND * units), "%s: %d of %d PReLU units flipped (bound %.0f)" % (what, flips, units, FLIP_BOUND * units)
+
+
+def check_every_tensor(name, g_dev, net64, g32=None, prelu_ulps=32, prelu_rtol=0.0):
+    """EVERY parameter tensor of the flat gradient -- weights, biases, BatchNorm gamma AND beta, PReLU slopes -- against the
+    float64 oracle at its own scale: err <= 1e-4 * max|g_tensor|, no absolute floor that a small-magnitude tensor
+    could hide under.  Where fp32 arithmetic itself cannot deliver that -- the fp32 ORACLE (the reference formulation, `g32`)
+    is further than that from float64 on the same tensor -- the bar is 4x the fp32 oracle's own error: the rounding budget of
+    the reference.  Two documented special cases:
+      * the bias of a convolution directly in front of a BatchNorm has an EXACTLY zero gradient (the BatchNorm removes the
+        mean), so what both implementations hold is rounding noise of the sums it cancels from: bar = that of the module's
+        weight gradient;
+      * the single PReLU slope gradient is one cancelling sum over the whole tensor: + 32 ulp of its condition scale
+        ||x * gy||_2 (`gw_cond`, oracle/torch7_nn.py)."""
     g_dev = g_dev.astype(np.float64)
-    tol = 1e-4 * np.abs(g64).max() + 1e-7
-    close(g_dev, g64, atol=tol, what="%s flat gradient vs the float64 oracle" % name)
-    off, msgs = 0, []
-    for (m, pn, gn) in net64.parameters():
-        r = getattr(m, gn).reshape(-1)
-        e = np.abs(g_dev[off:off + r.size] - r).max()
-        e32 = np.abs(g32[off:off + r.size].astype(np.float64) - r).max()
-        t = 1e-4 * np.abs(r).max() + 1e-7
-        if pn == 'weight' and not isinstance(m, O.PReLU) and e > t:
-            msgs.append("%s %s.%s: device err %.3e (fp32 oracle err %.3e) tol %.3e" % (name, type(m).__name__, pn, e, e32, t))
-        off += r.size
+    mods = getattr(net64, "inner", net64).modules
+    off, msgs, rows = 0, [], []
+    for i, m in enumerate(mods):
+        wtol = 0.0
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        for (mm, pn, gn) in m.parameters():
+            r = getattr(mm, gn).reshape(-1).astype(np.float64)
+            d = g_dev[off:off + r.size]
+            e = np.abs(d - r).max()
+            e32 = np.abs(g32[off:off + r.size].astype(np.float64) - r).max() if g32 is not None else 0.0
+            scale = np.abs(r).max()
+            tol = max(1e-4 * scale, 4.0 * e32) + 1e-12
+            if pn == 'weight':
+                wtol = tol
+            if pn == 'bias' and isinstance(nxt, O.SpatialBatchNormalization):
+                tol = max(tol, wtol)
+            if isinstance(mm, O.PReLU):
+                tol += prelu_ulps * 6e-8 * getattr(mm, "gw_cond", 0.0)
+                tol = max(tol, prelu_rtol * scale)
+            rows.append("  %-28s %-7s n=%-9d max|g| %.3e  dev err %.3e  fp32-oracle err %.3e  tol %.3e"
+                        % ("%d %s" % (i + 1, type(m).__name__), pn, r.size, scale, e, e32, tol))
+            if not e <= tol:
+                msgs.append("%s module %d %s.%s: device err %.3e > tol %.3e (fp32 oracle err %.3e, max|g| %.3e)"
+                            % (name, i + 1, type(m).__name__, pn, e, tol, e32, scale))
+            off += r.size
+    assert off == g_dev.size
+    print("%s: per-tensor gradient errors vs the float64 oracle\n%s" % (name, "\n".join(rows)))
+    assert not msgs, "\n".join(msgs)
+
+
+def compare_layer_outputs(name, dn, onet, rtol=5e-5):
+    """Intermediate activations at the BASELINE batch: every stage output the plan keeps
+    (fg_net_layer_output: conv / BatchNorm+PReLU / pooling / Linear outputs) against the oracle module's output,
+    |err| <= rtol * max|ref| + 1e-7 per tensor."""
+    mods = getattr(onet, "inner", onet).modules
+    msgs, rows = [], []
+    for i, m in enumerate(mods):
+        try:
+            y = dn.layer_output(i)
+        except Exception:
+            continue                                    # fused inside a stage / redirected output: not materialised
+        ref = np.asarray(m.output)
+        got = nchw(y).reshape(ref.shape)
+        e = np.abs(got.astype(np.float64) - ref).max()
+        tol = rtol * np.abs(ref).max() + 1e-7
+        rows.append("  %-28s %-22s max|y| %.3e  err %.3e  tol %.3e" % ("%d %s" % (i + 1, type(m).__name__), ref.shape, np.abs(ref).max(), e, tol))
+        if not e <= tol:
+            msgs.append("%s layer %d %s: err %.3e > %.3e" % (name, i + 1, type(m).__name__, e, tol))
+    assert rows, "%s: no stage output was readable" % name
+    print("%s: stage outputs vs the oracle\n%s" % (name, "\n".join(rows)))
     assert not msgs, "\n".join(msgs)
 
 
 @pytest.mark.parametrize("init", ["default", "reference"])
 def test_cfg2_full_step_at_batch_128(ctx, init):
-    """configs[1]: adversarial.lua:240-288 at 32x32x3, B = 128, Adam -- the headline configuration itself."""
+    """configs[1]: adversarial.lua:240-288 at 32x32x3, B = 128, Adam -- the headline configuration itself.  Both inits
+    (well-conditioned, and train.lua:137-138's N(0, 0.005^2) / N(0, 0.001^2)): outputs, loss, f, confusion, every stage output
+    the plan keeps, the flat gradient as a whole and EVERY parameter tensor of it against the float64 oracle, post-Adam
+    parameters; the branch decisions the oracle adopts from the device are bounded."""
     from face_generator_amd import adversarial
     B, C = 128, 3
     st, Gd, Dd, rng = build(ctx, C, B, seed=1400, init=init)
-    st64 = f64_state(st) if init == "default" else None
-    twinD, twinG = ([st64.D], [st64.G]) if st64 is not None else ((), ())
+    st64 = f64_state(st)
+    twinD, twinG = [st64.D], [st64.G]
     tr = adversarial.Trainer(ctx, Gd, Dd, dict(batchSize=B, noiseDim=100))
     d = ctx.device
     dnG, dnD = Gd.device_net, Dd.device_net
@@ -74,7 +138,9 @@ def test_cfg2_full_step_at_batch_128(ctx, init):
     got = tr.step_D(nhwc(real, d), dev(nz, d), [dev(m.reshape(-1), d) for m in masks], keep_grad=True)
     adopt_device_branches(ctx, dnD, st.D, also=twinD)
     ref = O.step_D(st, real, nz, masks)
-    print("cfg2 B=128 D-step [%s]: %d PReLU units decided differently by the device" % (init, count_branch_flips(st.D)))
+    assert_flips_bounded("cfg2 B=128 D-step [%s] D" % init, st.D)
+    compare_layer_outputs("cfg2 B=128 D-step [%s] G (B/2 noises, train mode)" % init, dnG, st.G)
+    compare_layer_outputs("cfg2 B=128 D-step [%s] D" % init, dnD, st.D)
     close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what="D-step D outputs (B=128)")
     assert abs(got["loss"].item() - ref["f_bce"]) <= 1e-5 * abs(ref["f_bce"])
     assert abs(got["f"] - ref["f"]) <= 1e-5 * abs(ref["f"])
@@ -82,10 +148,10 @@ def test_cfg2_full_step_at_batch_128(ctx, init):
     gD = got["grad"].cpu().numpy()
     close(gD, ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what="D-step flat gradient (B=128)")
     close_after_first_adam_step(Dd.getParameters()[0].cpu().numpy(), st.pD, gD, ref["grad"], "D params after Adam (B=128)")
-    if st64 is not None:
-        r64 = O.step_D(st64, real.astype(np.float64), nz.astype(np.float64), masks)
-        check_vs_f64("D-step", gD, ref["grad"], r64["grad"], st64.D)
-        st64.pG[...] = st.pG; st64.pD[...] = st.pD          # the next step starts from the fp32 oracle's state
+    r64 = O.step_D(st64, real.astype(np.float64), nz.astype(np.float64), masks)
+    close(gD, r64["grad"], atol=1e-4 * np.abs(r64["grad"]).max() + 1e-7, what="D-step flat gradient vs the float64 oracle")
+    check_every_tensor("cfg2 B=128 D-step [%s]" % init, gD, st64.D, ref["grad"])
+    st64.pG[...] = st.pG; st64.pD[...] = st.pD          # the next step starts from the fp32 oracle's state
     adopt_device_branches(ctx, dnD, st.D, clear=True, also=twinD)
     # G-step on the updated D (the oracle's D and the device's D agree to the Adam bar above)
     Dd.getParameters()[0].copy_(torch.tensor(st.pD)); dnD.params_changed()
@@ -96,17 +162,19 @@ def test_cfg2_full_step_at_batch_128(ctx, init):
     adopt_device_branches(ctx, dnD, st.D, also=twinD)
     adopt_device_branches(ctx, dnG, st.G, params=pG_before, also=twinG)
     ref = O.step_G(st, nz2, masks2)
-    print("cfg2 B=128 G-step [%s]: %d (D) + %d (G) PReLU units decided differently by the device"
-          % (init, count_branch_flips(st.D), count_branch_flips(st.G)))
+    assert_flips_bounded("cfg2 B=128 G-step [%s] D" % init, st.D)
+    assert_flips_bounded("cfg2 B=128 G-step [%s] G" % init, st.G)
+    compare_layer_outputs("cfg2 B=128 G-step [%s] G" % init, dnG, st.G)
+    compare_layer_outputs("cfg2 B=128 G-step [%s] D" % init, dnD, st.D)
     close(nchw(got["samples"]), ref["samples"], atol=1e-5, what="G-step samples (B=128)")
     close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what="G-step D outputs (B=128)")
     assert abs(got["loss"].item() - ref["f_bce"]) <= 1e-5 * abs(ref["f_bce"])
     gG = got["grad"].cpu().numpy()
     close(gG, ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what="G-step flat gradient (B=128)")
     close_after_first_adam_step(Gd.getParameters()[0].cpu().numpy(), st.pG, gG, ref["grad"], "G params after Adam (B=128)")
-    if st64 is not None:
-        r64 = O.step_G(st64, nz2.astype(np.float64), masks2)
-        check_vs_f64("G-step", gG, ref["grad"], r64["grad"], st64.G)
+    r64 = O.step_G(st64, nz2.astype(np.float64), masks2)
+    close(gG, r64["grad"], atol=1e-4 * np.abs(r64["grad"]).max() + 1e-7, what="G-step flat gradient vs the float64 oracle")
+    check_every_tensor("cfg2 B=128 G-step [%s]" % init, gG, st64.G, ref["grad"])
 
 
 def test_c2f_S64_forward_backward(ctx):
@@ -124,7 +192,7 @@ def test_c2f_S64_forward_backward(ctx):
     diff = st.G.forward([noise, cond])
     st.gG[...] = 0
     st.G.backward([noise, cond], gy)
-    print("c2f-64 G: %d PReLU units decided differently by the device" % count_branch_flips(st.G))
+    assert_flips_bounded("c2f-64 G", st.G)
     close(nchw(y), diff, atol=2e-5 * max(1, np.abs(diff).max()), what="c2f-64 G diff image")
     dn.backward(nhwc(gy, d), param_grads=True)
     # bf16x6 mode (opt-in, FG_MATH=6): its dropped plane products are a ONE-SIDED truncation (<= 2^-24 relative each); over the
@@ -145,7 +213,7 @@ def test_c2f_S64_forward_backward(ctx):
     out = st.D.forward([x, cond])
     st.gD[...] = 0
     gin = st.D.backward([x, cond], gyo)
-    print("c2f-64 D: %d PReLU units decided differently by the device" % count_branch_flips(st.D))
+    assert_flips_bounded("c2f-64 D", st.D)
     close(yd.cpu().numpy(), out, atol=1e-5, what="c2f-64 D probabilities")
     gx = dnD.backward(dev(gyo, d), param_grads=True, input_grad=True)
     close(nchw(gx), gin[0], atol=1e-4 * np.abs(gin[0]).max() + 1e-8, what="c2f-64 D gradInput[1]")
@@ -189,7 +257,7 @@ def test_c2f_S64_full_steps(ctx):
     got = tr.step_D(nhwc(diff_r, d), nhwc(cond_r, d), nhwc(nz, d), nhwc(cond_f, d), C2F.dev_masks(masks, d), keep_grad=True)
     adopt_device_branches(ctx, dnD, st.D)
     ref = O.step_D_c2f(st, diff_r, cond_r, nz, cond_f, masks)
-    print("c2f-64 D-step: %d units decided differently by the device" % count_branch_flips(st.D))
+    assert_flips_bounded("c2f-64 D-step D", st.D)
     close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what="c2f-64 D-step outputs")
     assert abs(got["loss"].item() - ref["f_bce"]) <= 1e-5 * abs(ref["f_bce"])
     close(got["grad"].cpu().numpy(), ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what="c2f-64 D-step grad")
@@ -204,9 +272,106 @@ def test_c2f_S64_full_steps(ctx):
     adopt_device_branches(ctx, dnD, st.D)
     adopt_device_branches(ctx, dnG, st.G)
     ref = O.step_G_c2f(st, nz2, cond2, masks2)
-    print("c2f-64 G-step: %d (D) + %d (G) units decided differently by the device" % (count_branch_flips(st.D), count_branch_flips(st.G)))
+    assert_flips_bounded("c2f-64 G-step D", st.D)
+    assert_flips_bounded("c2f-64 G-step G", st.G)
     close(nchw(got["samples"]), ref["samples"], atol=2e-5 * max(1, np.abs(ref["samples"]).max()), what="c2f-64 G-step samples")
     close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what="c2f-64 G-step D outputs")
     close(got["grad"].cpu().numpy(), ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what="c2f-64 G-step grad")
     close_after_first_adam_step(Gd.getParameters()[0].cpu().numpy(), st.pG, got["grad"].cpu().numpy(), ref["grad"],
                                 "c2f-64 G params after Adam")
+
+
+def adam_from(p, g, m, v, t):
+    """interruptable_optimizers.lua:49-94 / optim.adam in float64 from an explicit state: the parameters an exact optimizer
+    leaves when it is handed gradient `g` in state (p, m, v, t) -- pins the update arithmetic at ANY step count, free of the
+    gradient's own rounding."""
+    x = np.asarray(p, np.float64).copy()
+    state = dict(t=int(t), m=np.asarray(m, np.float64).copy(), v=np.asarray(v, np.float64).copy())
+    state['denom'] = np.zeros_like(x)
+    O.interruptable_adam(lambda _x: (0.0, np.asarray(g, np.float64)), x, {}, state)
+    return x
+
+
+def c2f_full_batch_steps(ctx, B, d_iterations, seed):
+    """adversarial_c2f.lua:123-187 at fineSize 64 and a BASELINE batch size: `d_iterations` D-steps and one G-step through
+    fg_step_D / fg_step_G against the float64 oracle walking the batch in chunks of 8 (oracle/chunked.py; G_d / D_c have no
+    BatchNorm, so the chunked sums ARE the whole-batch closure).  Each step is compared from a common state: after every
+    device update the oracle takes over the device's parameters and Adam moments (parity is per step)."""
+    from face_generator_amd import adversarial_c2f
+    S = 64
+    st32, Gd, Dd, rng = C2F.build(ctx, S, B, seed=seed)
+    st = f64_state(st32)
+    del st32
+    d = ctx.device
+    dnG, dnD = Gd.inner.device_net, Dd.inner.device_net
+    tr = adversarial_c2f.TrainerC2F(ctx, Gd, Dd, dict(batchSize=B))
+    assert tr.gan is not None
+    ch = ChunkedC2F(st, 8)
+    f8 = lambda a: a.astype(np.float64)
+    h = B // 2
+    nD = st.pD.size
+    for it in range(d_iterations):
+        diff_r = rng.uniform(-1, 1, (h, 3, S, S)).astype(np.float32)
+        cond_r = rng.uniform(0, 1, (h, 3, S, S)).astype(np.float32)
+        cond_f = rng.uniform(0, 1, (h, 3, S, S)).astype(np.float32)
+        nz = rng.uniform(-1, 1, (h, 1, S, S)).astype(np.float32)
+        masks = C2F.masks_for(rng, B, S)
+        name = "c2f-64 B=%d D-step %d/%d" % (B, it + 1, d_iterations)
+        p0 = dnD.params.cpu().numpy()
+        if it > 0:
+            os_ = tr.gan.view("OPT_STATE_D")
+            m0, v0 = os_[:nD].cpu().numpy(), os_[nD:2 * nD].cpu().numpy()
+        got = tr.step_D(nhwc(diff_r, d), nhwc(cond_r, d), nhwc(nz, d), nhwc(cond_f, d), C2F.dev_masks(masks, d), keep_grad=True)
+        adopt_device_branches(ctx, dnD, st.D)
+        ref = ch.step_D(f8(diff_r), f8(cond_r), f8(nz), f8(cond_f), masks, brD=collect_branches(st.D))
+        adopt_device_branches(ctx, dnD, st.D, clear=True)
+        assert_flips_bounded(name + " D", None, ch.flips["D"], ch.units["D"])
+        close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what=name + " outputs")
+        assert abs(got["loss"].item() - ref["f_bce"]) <= 1e-5 * abs(ref["f_bce"])
+        assert abs(got["f"] - ref["f"]) <= 1e-5 * abs(ref["f"])
+        assert (got["confusion"].cpu().numpy().reshape(2, 2) == ref["conf"]).all()
+        gD = got["grad"].cpu().numpy()
+        close(gD, ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what=name + " flat gradient")
+        check_every_tensor(name, gD, st.D)
+        pD = dnD.params.cpu().numpy()
+        if it == 0:
+            close_after_first_adam_step(pD, st.pD, gD, ref["grad"], name + " params after Adam")
+            close(pD, adam_from(p0, gD, np.zeros(nD), np.zeros(nD), 0), atol=1e-6, what=name + " optimizer arithmetic (t = 1)")
+        else:
+            assert tr.gan.steps(0) == it + 1
+            close(pD, adam_from(p0, gD, m0, v0, it), atol=1e-6, what=name + " optimizer arithmetic (t = %d)" % (it + 1))
+        # the next step starts from ONE state: the device's (parameters and Adam moments)
+        os_ = tr.gan.view("OPT_STATE_D")
+        st.pD[...] = pD
+        st.adamD['m'][...] = os_[:nD].cpu().numpy()
+        st.adamD['v'][...] = os_[nD:2 * nD].cpu().numpy()
+    nz2 = rng.uniform(-1, 1, (B, 1, S, S)).astype(np.float32)
+    cond2 = rng.uniform(0, 1, (B, 3, S, S)).astype(np.float32)
+    masks2 = C2F.masks_for(rng, B, S)
+    name = "c2f-64 B=%d G-step" % B
+    got = tr.step_G(nhwc(nz2, d), nhwc(cond2, d), C2F.dev_masks(masks2, d), keep_grad=True)
+    adopt_device_branches(ctx, dnD, st.D)
+    adopt_device_branches(ctx, dnG, st.G)
+    ref = ch.step_G(f8(nz2), f8(cond2), masks2, brD=collect_branches(st.D), brG=collect_branches(st.G))
+    assert_flips_bounded(name + " D", None, ch.flips["D"], ch.units["D"])
+    assert_flips_bounded(name + " G", None, ch.flips["G"], ch.units["G"])
+    close(nchw(got["samples"]), ref["samples"], atol=2e-5 * max(1, np.abs(ref["samples"]).max()), what=name + " samples")
+    close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what=name + " D outputs")
+    assert abs(got["loss"].item() - ref["f_bce"]) <= 1e-5 * abs(ref["f_bce"])
+    gG = got["grad"].cpu().numpy()
+    close(gG, ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what=name + " flat gradient")
+    check_every_tensor(name, gG, st.G, prelu_rtol=1e-3 if ctx.get_math() == 6 else 0.0)
+    close_after_first_adam_step(Gd.getParameters()[0].cpu().numpy(), st.pG, gG, ref["grad"], name + " params after Adam")
+
+
+def test_c2f_S64_full_steps_at_batch_128(ctx):
+    """BASELINE configs[3] at its own batch: 64x64 colour, B = 128, D_iterations = 1 -- forward AND backward (flat gradients
+    of both nets, per parameter tensor) vs the float64 chunked oracle; the weight-gradient reductions run over 524 288 pixels
+    at the split counts only this batch size selects."""
+    c2f_full_batch_steps(ctx, 128, 1, seed=570)
+
+
+def test_c2f_S64_full_steps_at_batch_64_two_D_iterations(ctx):
+    """BASELINE configs[4]'s per-GPU shard: B = 64, D_iterations = 2 (adversarial_c2f.lua:123-160 runs the D closure twice per
+    G closure; the second D update is Adam at t = 2)."""
+    c2f_full_batch_steps(ctx, 64, 2, seed=571)

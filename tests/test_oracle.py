@@ -404,3 +404,40 @@ def test_torch_cpu_baseline_matches_the_numpy_oracle():
     got = gan.step_D(torch.tensor(diff), [torch.tensor(nz), torch.tensor(cf)], cond=torch.tensor(np.concatenate([cr, cf])), masks=masks)
     assert np.abs(got["out"].numpy().reshape(-1) - ref["out"].reshape(-1)).max() < 1e-5
     assert np.abs(got["grad"].numpy() - ref["grad"]).max() < 1e-4 * np.abs(ref["grad"]).max() + 1e-7
+
+
+def test_chunked_c2f_closures_equal_the_whole_batch_closures():
+    """oracle/chunked.py (the B = 128 / B = 64 parity tests walk the batch in chunks of 8): G_d / D_c have no BatchNorm, so the
+    chunked closures must reproduce step_D_c2f / step_G_c2f on the whole batch -- float64, 1e-12."""
+    import copy
+    from oracle.chunked import ChunkedC2F
+    S, B = 16, 6
+    rng = np.random.default_rng(77)
+    G = O.create_G_d((3, S, S), rng).astype(np.float64)
+    D = O.create_D_c((3, S, S), rng).astype(np.float64)
+    a = O.GanState(G, D, O.C2F_OPT)
+    b = O.GanState(copy.deepcopy(G), copy.deepcopy(D), O.C2F_OPT)
+    h = B // 2
+    diff_r = rng.uniform(-1, 1, (h, 3, S, S)); cond_r = rng.uniform(0, 1, (h, 3, S, S))
+    cond_f = rng.uniform(0, 1, (h, 3, S, S)); nz = rng.uniform(-1, 1, (h, 1, S, S))
+    masks = [(rng.random((B, 256, S // 4, S // 4)) < 0.5).astype(np.float64), (rng.random((B, 512)) < 0.5).astype(np.float64)]
+    ch = ChunkedC2F(b, chunk=4)                       # 4 + 2: a ragged last chunk
+    for _ in range(2):                                # two D-steps: Adam at t = 1 and t = 2
+        ra = O.step_D_c2f(a, diff_r, cond_r, nz, cond_f, masks)
+        rb = ch.step_D(diff_r, cond_r, nz, cond_f, masks)
+        assert np.abs(ra["out"] - rb["out"]).max() < 1e-12
+        assert abs(ra["f"] - rb["f"]) < 1e-12 and abs(ra["f_bce"] - rb["f_bce"]) < 1e-12
+        assert (ra["conf"] == rb["conf"]).all()
+        assert np.abs(ra["grad"] - rb["grad"]).max() < 1e-12 * max(1, np.abs(ra["grad"]).max())
+        assert np.abs(a.pD - b.pD).max() < 1e-12
+    nz2 = rng.uniform(-1, 1, (B, 1, S, S)); cond2 = rng.uniform(0, 1, (B, 3, S, S))
+    ra = O.step_G_c2f(a, nz2, cond2, masks)
+    rb = ch.step_G(nz2, cond2, masks)
+    assert np.abs(ra["samples"] - rb["samples"]).max() < 1e-12
+    assert np.abs(ra["grad"] - rb["grad"]).max() < 1e-12 * max(1, np.abs(ra["grad"]).max())
+    assert np.abs(a.pG - b.pG).max() < 1e-12
+    assert ch.units["G"] == B * S * S * (64 + 64 + 128 + 256) and ch.flips["G"] == 0
+    # the condition scale of the whole-batch PReLU slope sums (the per-tensor bars of the GPU tests use it)
+    for ma, mb in zip(a.G.inner.modules, b.G.inner.modules):
+        if isinstance(ma, O.PReLU):
+            assert abs(ma.gw_cond - mb.gw_cond) <= 1e-9 * ma.gw_cond
