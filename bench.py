@@ -11,7 +11,9 @@ Philox inside the step, dropout masks drawn on device), reference init N(0,0.005
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  N > 1: weak scaling (B=128 per GPU; --strong: B=128 globally), RCCL all-reduce (sum)
+Prints ONE JSON line on rank 0.  The default run (no --workload) times the headline workload (configs[1], 32x32) and then, in the
+same process and the same JSON line, BASELINE configs[3] / [4] (c2f 64x64: B = 128, D_it = 1 on one GPU; 64 per GPU with D_it = 2 when
+N > 1) as the sub-record "c2f" with its own value / ms_per_step / roofline / step_roofline / cpu_baseline.  N > 1: weak scaling (B=128 per GPU; --strong: B=128 globally), RCCL all-reduce (sum)
 of the flat D / G gradient vectors each update through the library's own communicator (fg_comm_*), replicas identical.
 
 Roofline keys (dominant kernel, HIP events on the launch stream, live in this run):
@@ -98,20 +100,85 @@ def cpu_baselines(workload, batch):
     return out
 
 
-def load_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE cannot
-    be collected in-process); newest round first."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+def _sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+KERNEL_SOURCE = os.path.join(ROOT, "face_generator_amd", "csrc", "igemm.hip")
+# the dominant launch of the dominant kernel: nearest-x2 + 5x5 conv 256 -> 128 forward at B = 128 (models.lua:68-69):
+# reads the 33.5 MB input + 4.7 MB of folded weights, writes the 67.1 MB output
+DOMINANT_LAUNCH = dict(kernel="igemm_ws_kernel<128>", launch="nearest-x2 + 5x5 conv 256->128 forward, B=128 (models.lua:68-69)",
+                       algorithmic_bytes_per_launch=128 * 16 * 16 * 256 * 4 + 4 * 9 * 256 * 128 * 4 + 128 * 32 * 32 * 128 * 4 + 128 * 4)
+
+
+def live_traffic(kernel, timeout=150):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE, then WRITE_SIZE -- they do
+    not fit one pass; --kernel-trace only, as MI355X_MICROARCH.md prescribes) over scripts/bench_one.py, which launches exactly the
+    dominant launch.  FETCH_SIZE is doubled (gfx950: 128-byte requests tallied at 64 bytes for 16-byte-per-lane loads); both are KiB.
+    Returns None when rocprofv3 is unavailable or a pass fails (the caller then labels a committed file as stale or not)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if kernel != DOMINANT_LAUNCH["kernel"] or shutil.which("rocprofv3") is None:
+        return None
+    vals = {}
+    for pmc in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fg_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(["rocprofv3", "--pmc", pmc, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                            sys.executable, os.path.join(ROOT, "scripts", "bench_one.py"), "fwd", "4"],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            tot, launches = 0.0, set()
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Kernel_Name"].startswith("void igemm_ws_kernel<128>") or r["Kernel_Name"].startswith("igemm_ws_kernel<128>"):
+                        if r["Counter_Name"] == pmc:
+                            tot += float(r["Counter_Value"])
+                            launches.add(r["Dispatch_Id"])
+            if not launches:
+                return None
+            vals[pmc] = tot / len(launches)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    tj = dict(DOMINANT_LAUNCH)
+    tj.update(fetch_size_kb_raw=vals["FETCH_SIZE"], fetch_correction=2.0, write_size_kb=vals["WRITE_SIZE"],
+              hbm_bytes_per_launch=2.0 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024,
+              kernel_source_sha16=_sha16(KERNEL_SOURCE), freshness="live",
+              source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/bench_one.py fwd, spawned by this "
+                     "bench.py run")
+    return tj
+
+
+def load_traffic(kernel, live=True):
+    """HBM bytes per launch of the dominant kernel: measured by this run (live_traffic) when rocprofv3 is there, otherwise the newest
+    committed PMC summary, labelled `stale` unless it was taken from the kernel source this run executes (sha of igemm.hip)."""
+    if live:
+        tj = live_traffic(kernel)
+        if tj is not None:
+            return tj
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
             continue
         if tj.get("kernel") == kernel:
+            same = tj.get("kernel_source_sha16") is not None and tj.get("kernel_source_sha16") == _sha16(KERNEL_SOURCE)
+            tj["freshness"] = "committed file profiles/%s, same kernel source as this run" % name if same else \
+                              "stale: committed file profiles/%s from an earlier kernel source" % name
             return tj
     return None
 
 
-def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_iter, out):
+def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_iter, out, workload, steps, warmup, alt_math=True):
     """Timed region + roofline leg shared by both workloads.  Fills `out` in place."""
     def sync_all():
         torch.cuda.synchronize()
@@ -126,21 +193,21 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
             return float(t.item())
         return v
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         iteration()
     tr.finish_pending()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         iteration()
     tr.finish_pending()          # N > 1: the last D update is deferred behind the next G forward -- complete it in-region
     sync_all()
     dt = max_over_ranks(time.perf_counter() - t0)
-    ms = 1000.0 * dt / args.steps
-    out.update(value=world * B * args.steps / dt, ms_per_step=ms)
+    ms = 1000.0 * dt / steps
+    out.update(value=world * B * steps / dt, ms_per_step=ms)
     # host cost of a step (outside the timed region): wall time to ENQUEUE a short burst of steps on an idle queue, no
     # sync inside -- short enough that the launch queue never back-pressures, so it is the pure host-side cost
-    nb = min(4, args.steps)
+    nb = min(4, steps)
     tb = time.perf_counter()
     for _ in range(nb):
         iteration()
@@ -186,7 +253,7 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
             a = sym[dom]
             alg = a["alg"] / (a["ms"] * 1e-3) / 1e12
             exe = a["exe"] / (a["ms"] * 1e-3) / 1e12
-            tj = load_traffic(dom) if args.workload == "cfg2" else None
+            tj = load_traffic(dom, live=not args.no_live_traffic) if (workload == "cfg2" and world == 1) else None
             out["roofline"] = {"bound": "mfma", "achieved": exe, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": exe / PEAK_F32_MFMA_TFLOPS,
                                "traffic": tj["hbm_bytes_per_launch"] if tj else None,
@@ -194,6 +261,7 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
                                "traffic_over_algorithmic": (tj["hbm_bytes_per_launch"] / tj["algorithmic_bytes_per_launch"])
                                if tj and tj.get("algorithmic_bytes_per_launch") else None,
                                "traffic_note": (tj["launch"] + "; " + tj["source"]) if tj else None,
+                               "traffic_freshness": tj.get("freshness") if tj else None,
                                "kernel": dom, "avg_launch_ms": a["ms"] / a["calls"],
                                "launches_per_iter": a["calls"] / args.prof_iters,
                                "algorithmic_tflops": alg, "algorithmic_frac": alg / PEAK_F32_MFMA_TFLOPS,
@@ -209,23 +277,23 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
     # (the supplementary bf16x6 leg runs AFTER the roofline leg: it is power-bound and leaves the part at a lower clock for the
     # next few hundred ms -- measured right behind it the fp32 kernels read 6-8 % slow)
     alt = None
-    if args.math == "f32" and not args.no_alt_math:
+    if args.math == "f32" and not args.no_alt_math and alt_math:
         # supplementary, never the headline: the same K steps with the large contractions in bf16x6 (fp32 emulated with
         # six exact split-bf16 plane products, include/facegen_hip.h fg_set_math); every rank runs it (collectives)
         try:
             ctx.set_math(6)
-            for _ in range(min(args.warmup, 4)):
+            for _ in range(min(warmup, 4)):
                 iteration()
             tr.finish_pending()
             sync_all()
             t1 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(steps):
                 iteration()
             tr.finish_pending()
             sync_all()
             dt6 = max_over_ranks(time.perf_counter() - t1)
             alt = {"math": "bf16x6 (fp32 emulated: 6 exact bf16 split-plane products, fp32 accumulate; fg_set_math(ctx, 6))",
-                   "value": world * B * args.steps / dt6, "unit": "images/sec", "ms_per_step": 1000.0 * dt6 / args.steps,
+                   "value": world * B * steps / dt6, "unit": "images/sec", "ms_per_step": 1000.0 * dt6 / steps,
                    "note": "opt-in mode, parity-tested at the same tolerances (FG_MATH=6 pytest -m gpu); not the headline value"}
         except Exception as e:      # supplementary only: never let it take the headline measurement down
             alt = {"math": "bf16x6", "error": str(e)[:200]}
@@ -235,7 +303,85 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
     if alt is not None:
         out["alt_math"] = alt
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out.update(cpu_baselines(args.workload, B))
+        out.update(cpu_baselines(workload, B))
+
+
+C2F_D2_FLOP_PER_IMAGE = 45.130e9   # configs[4]: D_iterations = 2 -> 2888.30 GFLOP per B=64 iteration
+
+
+def build_cfg2(args, ctx, torch, coll, world, rank, B):
+    """configs[1] / [2]: G32 + D32b at 32x32x3 (models.lua:57-81, 382-416), reference init, Adam, D_it = G_it = 1."""
+    from face_generator_amd import models, nn_utils, adversarial
+    from face_generator_amd.state import S
+    C = 3
+    gen = torch.Generator().manual_seed(1)              # identical initial replicas on every rank
+    G = models.create_G((C, 32, 32), 100)
+    D = models.create_D((C, 32, 32))
+    nn_utils.initializeWeights(D, gen=gen)
+    nn_utils.initializeWeights(G, gen=gen)
+    G.cuda(ctx, max_batch=B)
+    D.cuda(ctx, max_batch=B)
+    S.OPT.update(batchSize=B, noiseDim=100)
+    S.noise_seed = 1 + rank                             # each rank draws its own shard of the global batch
+    G.device_net.mask_seed = D.device_net.mask_seed = 1000 + rank
+    S.OPT["sync_bn"] = bool(args.sync_bn)
+    tr = adversarial.Trainer(ctx, G, D, S.OPT, dist=coll)
+    real = ctx.uniform((B // 2, 32, 32, C), 0.0, 1.0, seed=77 + rank)
+
+    def iteration():
+        if tr.gan is not None:        # one C call per closure (fg_step_D / fg_step_G); noise + masks drawn inside it
+            tr.step_D(real, None)
+            tr.step_G(B)
+        else:
+            tr.step_D(real, S.next_noise(ctx, B // 2, 100))
+            tr.step_G(S.next_noise(ctx, B, 100))
+    return dict(tr=tr, iteration=iteration, flops=alg_flops_per_iter(B), real=real,
+                data="synthetic (U[0,1) images, U(-1,1) noise, reference init N(0,.005^2)/N(0,.001^2))",
+                config={"workload": "configs[1]: 32x32 color, noiseDim=100, batch 128 per GPU, Adam, D_it=G_it=1"
+                                    + ("" if world == 1 else "; configs[2]-style %s scaling, RCCL grad all-reduce"
+                                       % ("strong" if args.strong else "weak")),
+                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
+                        "batchnorm": "sync (global-batch statistics)" if (args.sync_bn and world > 1) else "per-GPU statistics"})
+
+
+def build_c2f(args, ctx, torch, coll, world, rank, B, d_it):
+    """configs[3] / [4]: coarse-to-fine G_d + D_c at 64x64x3 (models_c2f.lua:113-145, 237-278), Torch default init, Adam."""
+    from face_generator_amd import models_c2f, adversarial_c2f
+    from face_generator_amd.state import S
+    Sz = 64
+    gen = torch.Generator().manual_seed(1)
+    G = models_c2f.create_G((3, Sz, Sz), gen=gen).cuda(ctx, max_batch=B)
+    D = models_c2f.create_D((3, Sz, Sz), gen=gen).cuda(ctx, max_batch=B)
+    S.noise_seed = 1 + rank
+    G.inner.device_net.mask_seed = D.inner.device_net.mask_seed = 1000 + rank
+    tr = adversarial_c2f.TrainerC2F(ctx, G, D, dict(batchSize=B), dist=coll)
+    fine = ctx.uniform((B, Sz, Sz, 3), 0.0, 1.0, seed=70 + rank)
+    coarse = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(fine.permute(0, 3, 1, 2), 2), scale_factor=2)
+    coarse = coarse.permute(0, 2, 3, 1).contiguous()          # synthetic-input preparation (dataset_c2f.lua:49-61)
+    diff = (fine - coarse).contiguous()
+    h = B // 2
+    diff_r, coarse_r, coarse_f = diff[:h].contiguous(), coarse[:h].contiguous(), coarse[h:].contiguous()
+
+    def iteration():
+        for _ in range(d_it):             # adversarial_c2f.lua:123-160: D_iterations closures per G closure
+            if tr.gan is not None:        # one C call per closure; noise planes and dropout masks drawn inside it
+                tr.step_D(diff_r, coarse_r, None, coarse_f)
+            else:
+                tr.step_D(diff_r, coarse_r, S.next_noise(ctx, h, Sz * Sz).view(h, Sz, Sz, 1), coarse_f)
+        if tr.gan is not None:
+            tr.step_G(None, coarse)
+        else:
+            tr.step_G(S.next_noise(ctx, B, Sz * Sz).view(B, Sz, Sz, 1), coarse)
+    which = "configs[3]" if (world == 1 and d_it == 1) else "configs[4]-style"
+    return dict(tr=tr, iteration=iteration, flops=(C2F_FLOP_PER_IMAGE if d_it == 1 else C2F_D2_FLOP_PER_IMAGE) * B,
+                data="synthetic (U[0,1) fine images, coarse = 2x box down / nearest up, diff = fine - coarse, U(-1,1) noise planes)",
+                config={"workload": "%s: 64x64 color coarse-to-fine G_d/D_c, batch %d per GPU, Adam, D_it=%d, G_it=1" % (which, B, d_it),
+                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world})
+
+
+def step_entry(tr):
+    return ("fg_step_D / fg_step_G (C ABI, one call per closure)" if tr.gan is not None
+            else "net-level entries driven from the host loop")
 
 
 def main():
@@ -257,8 +403,14 @@ def main():
     ap.add_argument("--collective", choices=["auto", "fg_comm", "torch"], default="auto",
                     help="N > 1: gradient all-reduce through the library's own RCCL communicator (fg_comm_*, default) or "
                          "torch.distributed; auto = fg_comm, falling back (and saying so) if its self-test fails")
-    ap.add_argument("--workload", choices=["cfg2", "c2f"], default="cfg2",
-                    help="cfg2: 32x32 G32+D32b (BASELINE configs[1], the headline); c2f: 64x64 coarse-to-fine (configs[3])")
+    ap.add_argument("--workload", choices=["both", "cfg2", "c2f"], default="both",
+                    help="both (default): the headline cfg2 line plus the c2f sub-record; cfg2: 32x32 G32+D32b only (BASELINE "
+                         "configs[1]); c2f: 64x64 coarse-to-fine (configs[3]) as the line itself")
+    ap.add_argument("--c2f-steps", type=int, default=10, help="timed steps of the c2f sub-record (3 warm-up steps)")
+    ap.add_argument("--c2f-timeout", type=float, default=240.0,
+                    help="N > 1: if the c2f sub-record has not finished after this many seconds, rank 0 prints the line without it")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not spawn the two rocprofv3 PMC passes for roofline.traffic (a committed summary is used and labelled)")
     args = ap.parse_args()
 
     import torch
@@ -283,9 +435,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from face_generator_amd import models, nn_utils, adversarial, distributed
+    from face_generator_amd import distributed
     from face_generator_amd.runtime import get_context
-    from face_generator_amd.state import S
 
     ctx = get_context(local_rank)
     ctx.set_math(6 if args.math == "bf16x6" else 0)
@@ -299,8 +450,9 @@ def main():
     if world > 1:
         coll = distributed.make_collective(ctx, dist, prefer="torch" if (test_gloo or args.collective == "torch") else "fg_comm",
                                            strict=args.collective == "fg_comm")
+    headline = "c2f" if args.workload == "c2f" else "cfg2"
     out = {
-        "metric": "GAN train images/sec (G+D step) at 32x32x3 bs128" if args.workload == "cfg2"
+        "metric": "GAN train images/sec (G+D step) at 32x32x3 bs128" if headline == "cfg2"
                   else "GAN train images/sec (G+D step), c2f 64x64x3 bs128",
         "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
@@ -308,72 +460,24 @@ def main():
     }
     if world > 1:
         out["collective"] = coll.describe()
-    C = 3
-    if args.workload == "c2f":
-        from face_generator_amd import models_c2f, adversarial_c2f
-        Sz = 64
-        gen = torch.Generator().manual_seed(1)
-        G = models_c2f.create_G((3, Sz, Sz), gen=gen).cuda(ctx, max_batch=B)
-        D = models_c2f.create_D((3, Sz, Sz), gen=gen).cuda(ctx, max_batch=B)
-        S.noise_seed = 1 + rank
-        G.inner.device_net.mask_seed = D.inner.device_net.mask_seed = 1000 + rank
-        tr = adversarial_c2f.TrainerC2F(ctx, G, D, dict(batchSize=B), dist=coll)
-        fine = ctx.uniform((B, Sz, Sz, 3), 0.0, 1.0, seed=70 + rank)
-        coarse = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(fine.permute(0, 3, 1, 2), 2), scale_factor=2)
-        coarse = coarse.permute(0, 2, 3, 1).contiguous()          # synthetic-input preparation (dataset_c2f.lua:49-61)
-        diff = (fine - coarse).contiguous()
-        h = B // 2
-        diff_r, coarse_r, coarse_f = diff[:h].contiguous(), coarse[:h].contiguous(), coarse[h:].contiguous()
-
-        def iteration():
-            if tr.gan is not None:        # one C call per closure; noise planes and dropout masks drawn inside it
-                tr.step_D(diff_r, coarse_r, None, coarse_f)
-                tr.step_G(None, coarse)
-            else:
-                tr.step_D(diff_r, coarse_r, S.next_noise(ctx, h, Sz * Sz).view(h, Sz, Sz, 1), coarse_f)
-                tr.step_G(S.next_noise(ctx, B, Sz * Sz).view(B, Sz, Sz, 1), coarse)
-        out["data"] = "synthetic (U[0,1) fine images, coarse = 2x box down / nearest up, diff = fine - coarse, U(-1,1) noise planes)"
-        out["config"] = {"workload": "configs[3]: 64x64 color coarse-to-fine G_d/D_c, batch 128 per GPU, Adam, D_it=G_it=1",
-                         "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world}
-        flops = C2F_FLOP_PER_IMAGE * B
+        # loud, top-level: the gradient exchange is NOT the library's own communicator (Trainer then drives the closures from
+        # the host instead of fg_step_D / fg_step_G -- config.step_entry says so too)
+        out["collective_fallback"] = bool(coll.fallback)
+        out["rccl_ranks_seen"] = coll.ranks_seen
+    if headline == "c2f":
+        w = build_c2f(args, ctx, torch, coll, world, rank, B, 1)
     else:
-        gen = torch.Generator().manual_seed(1)              # identical initial replicas on every rank
-        G = models.create_G((C, 32, 32), 100)
-        D = models.create_D((C, 32, 32))
-        nn_utils.initializeWeights(D, gen=gen)
-        nn_utils.initializeWeights(G, gen=gen)
-        G.cuda(ctx, max_batch=B)
-        D.cuda(ctx, max_batch=B)
-        S.OPT.update(batchSize=B, noiseDim=100)
-        S.noise_seed = 1 + rank                             # each rank draws its own shard of the global batch
-        G.device_net.mask_seed = D.device_net.mask_seed = 1000 + rank
-        S.OPT["sync_bn"] = bool(args.sync_bn)
-        tr = adversarial.Trainer(ctx, G, D, S.OPT, dist=coll)
-        real = ctx.uniform((B // 2, 32, 32, C), 0.0, 1.0, seed=77 + rank)
-
-        def iteration():
-            if tr.gan is not None:        # one C call per closure (fg_step_D / fg_step_G); noise + masks drawn inside it
-                tr.step_D(real, None)
-                tr.step_G(B)
-            else:
-                tr.step_D(real, S.next_noise(ctx, B // 2, 100))
-                tr.step_G(S.next_noise(ctx, B, 100))
-        out["data"] = "synthetic (U[0,1) images, U(-1,1) noise, reference init N(0,.005^2)/N(0,.001^2))"
-        out["config"] = {"workload": "configs[1]: 32x32 color, noiseDim=100, batch 128 per GPU, Adam, D_it=G_it=1"
-                                     + ("" if world == 1 else "; configs[2]-style %s scaling, RCCL grad all-reduce"
-                                        % ("strong" if args.strong else "weak")),
-                         "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
-                         "batchnorm": "sync (global-batch statistics)" if (args.sync_bn and world > 1) else "per-GPU statistics"}
-        flops = alg_flops_per_iter(B)
-
-    out["config"]["step_entry"] = ("fg_step_D / fg_step_G (C ABI, one call per closure)" if tr.gan is not None
-                                   else "net-level entries driven from the host loop")
-    measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops, out)
-    if args.workload == "cfg2" and world == 1:
+        w = build_cfg2(args, ctx, torch, coll, world, rank, B)
+    tr = w["tr"]
+    out["data"] = w["data"]
+    out["config"] = w["config"]
+    out["config"]["step_entry"] = step_entry(tr)
+    measure(args, ctx, tr, w["iteration"], torch, dist, world, rank, B, w["flops"], out, headline, args.steps, args.warmup)
+    if headline == "cfg2" and world == 1:
         # the reference's boundary hands over HOST tensors (dataset[i]:clone() into a FloatTensor, adversarial.lua:244-249):
         # the same K steps with the real half coming from host memory every iteration (NCHW FloatTensor -> H2D -> NHWC);
         # never `value` -- the PCIe-inclusive rate of the contract
-        real_host = real.permute(0, 3, 1, 2).contiguous().cpu().pin_memory()
+        real_host = w["real"].permute(0, 3, 1, 2).contiguous().cpu().pin_memory()
         for _ in range(3):
             tr.step_D(ctx.to_device_nhwc(real_host), None); tr.step_G(B)
         torch.cuda.synchronize()
@@ -383,6 +487,38 @@ def main():
         torch.cuda.synchronize()
         out["host_input_images_per_sec"] = B * args.steps / (time.perf_counter() - th)
     out["reference_accounting_images_per_sec"] = out["value"] / 2   # adversarial.lua:305 counts B/2 per iteration
+
+    if args.workload == "both":
+        # BASELINE configs[3] (one GPU: B = 128, D_it = 1) / configs[4] (N > 1: 64 per GPU, D_it = 2) in the same driver-timed run
+        import threading
+        done = threading.Event()
+        if world > 1:
+            def bail():
+                # the headline must not be lost to a stall of the supplementary leg: print it and leave (every rank has this timer)
+                if not done.is_set():
+                    if rank == 0:
+                        out["c2f"] = {"error": "the c2f leg did not finish within %.0f s" % args.c2f_timeout}
+                        print(json.dumps(out), flush=True)
+                    os._exit(0)
+            timer = threading.Timer(args.c2f_timeout, bail)
+            timer.daemon = True
+            timer.start()
+        sub = {}
+        try:
+            del w, tr
+            torch.cuda.empty_cache()
+            cB, d_it = (B, 1) if world == 1 else (max(2, B // 2), 2)
+            cw = build_c2f(args, ctx, torch, coll, world, rank, cB, d_it)
+            sub = {"metric": "GAN train images/sec (G+D step), c2f 64x64x3", "value": None, "unit": "images/sec",
+                   "steps": args.c2f_steps, "warmup": 3, "ms_per_step": None, "dtype": out["dtype"], "data": cw["data"],
+                   "config": cw["config"]}
+            sub["config"]["step_entry"] = step_entry(cw["tr"])
+            measure(args, ctx, cw["tr"], cw["iteration"], torch, dist, world, rank, cB, cw["flops"], sub, "c2f", args.c2f_steps, 3,
+                    alt_math=False)
+        except Exception as e:          # supplementary: never let it take the headline measurement down
+            sub["error"] = str(e)[:300]
+        done.set()
+        out["c2f"] = sub
     if world > 1:
         dist.barrier()
         if coll is not None:

@@ -36,6 +36,8 @@ class Collective:
     """What the trainers need from a carrier.  All calls are in place and ordered on the context's stream."""
     name = "none"
     world, rank = 1, 0
+    fallback = False        # True: fg_comm was asked for and could not be used (make_collective fell back to torch.distributed)
+    ranks_seen = None       # the self-test's sum of ones over the carrier actually used (== world when it works)
 
     def get_world_size(self):
         return self.world
@@ -144,12 +146,20 @@ def as_collective(d):
     return TorchCollective(d)
 
 
+def _self_test(coll, ctx):
+    """Sum of ones over the carrier: `ranks_seen` (reported by bench.py as rccl_ranks_seen)."""
+    probe = torch.ones(4, dtype=torch.float32, device=ctx.device)
+    coll.allreduce_sum_(probe)
+    coll.ranks_seen = int(round(probe[0].item()))
+    return coll
+
+
 def make_collective(ctx, d=dist, prefer="fg_comm", strict=False):
     """The carrier for an initialised torch.distributed job: the library's own communicator unless `prefer` says torch.
     The 128-byte RCCL id is broadcast from rank 0 over `d`; a one-element self-test (sum of ones == world) runs on every
     rank, and unless `strict` a failure falls back to torch.distributed on ALL ranks (the decision is itself reduced)."""
     if prefer != "fg_comm":
-        return TorchCollective(d)
+        return _self_test(TorchCollective(d), ctx)
     rank, world = d.get_rank(), d.get_world_size()
     err, coll = "", None
     # (1) local, non-collective: can this rank bind librccl at all?  Decided jointly BEFORE the collective create, so a
@@ -165,6 +175,8 @@ def make_collective(ctx, d=dist, prefer="fg_comm", strict=False):
             raise RuntimeError("fg_comm unavailable on %d rank(s): %s" % (int(bad.item()), err or "(another rank)"))
         t = TorchCollective(d)
         t.name += " [fg_comm fell back: %s]" % (err or "another rank cannot bind librccl")[:160]
+        t.fallback = True
+        _self_test(t, ctx)
         return t
     try:
         idt = torch.zeros(128, dtype=torch.uint8, device=ctx.device)
@@ -175,6 +187,7 @@ def make_collective(ctx, d=dist, prefer="fg_comm", strict=False):
         probe = torch.ones(4, dtype=torch.float32, device=ctx.device)
         coll.allreduce_sum_(probe)
         torch.cuda.synchronize()
+        coll.ranks_seen = int(round(probe[0].item()))
         if probe.tolist() != [float(world)] * 4:
             raise RuntimeError("self-test: sum of ones = %s, expected %d" % (probe.tolist(), world))
     except Exception as e:        # noqa: BLE001 -- reported, and decided collectively below
@@ -189,6 +202,8 @@ def make_collective(ctx, d=dist, prefer="fg_comm", strict=False):
         coll.close()
     t = TorchCollective(d)
     t.name += " [fg_comm fell back: %s]" % (err or "another rank failed")[:160]
+    t.fallback = True
+    _self_test(t, ctx)
     return t
 
 

@@ -65,12 +65,17 @@ def test_trainer_with_rccl_world1_matches_plain_trainer():
 def test_bench_runs_under_torchrun_single_rank():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
-           "--warmup", "1", "--batch", "16", "--no-cpu-baseline"]
+           "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-live-traffic", "--c2f-steps", "2"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["unit"] == "images/sec" and "roofline" in j
+    # the default line carries BASELINE configs[3] as a driver-timed sub-record
+    c = j["c2f"]
+    assert "error" not in c, c
+    assert c["value"] > 0 and c["ms_per_step"] > 0 and c["config"]["workload"].startswith("configs[3]") and "roofline" in c
+    assert c["config"]["step_entry"].startswith("fg_step_D")
 
 
 def test_fg_comm_c_abi_world1():

@@ -60,7 +60,7 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     env = dict(os.environ, FG_BENCH_TEST_GLOO="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29583", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--batch", "16"]
+           "--batch", "16", "--c2f-steps", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -68,3 +68,7 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32 and j["value"] > 0 and j["scaling"] == "weak"
     assert "alt_math" in j and "error" not in j["alt_math"] and "roofline" in j and "cpu_baseline" not in j
+    assert j["collective_fallback"] is False and j["rccl_ranks_seen"] == 2          # (gloo was ASKED for here: not a fallback)
+    c = j["c2f"]                                                                     # configs[4]-style: B/2 per rank, D_it = 2
+    assert "error" not in c, c
+    assert c["value"] > 0 and c["config"]["batch_per_gpu"] == 8 and "D_it=2" in c["config"]["workload"]
