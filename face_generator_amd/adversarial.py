@@ -46,13 +46,15 @@ class Trainer:
         self.gscale = 1.0 / self.world   # BCE averages over the local batch: global mean = all-reduced sum / world
         self._targets = {}
         self._inputs = {}
-        if self.coll is not None and self.world > 1 and self.opt.get("sync_bn", False):
-            # exact B_global BatchNorm statistics: fp64 per-channel sums all-reduced at every BatchNorm
-            self.dnG.enable_sync_bn(self.coll.allreduce_sum_)
         self._pending_D = None    # loss of a D update deferred behind the next G forward (its all-reduce is in flight)
         self.overlap = True       # N > 1: hide D's gradient all-reduce under the G-step's generator forward
         self.gan = None           # runtime.FusedGan: one C call per closure (fg_step_D / fg_step_G)
         self._make_fused()
+        if self.gan is None and self.coll is not None and self.world > 1 and self.opt.get("sync_bn", False):
+            # host-driven closures: exact B_global BatchNorm statistics, fp64 per-channel sums all-reduced at every
+            # BatchNorm through a buffer owned by the DeviceNet.  (With the step object the library owns that buffer:
+            # FusedGan.set_comm points both DeviceNets at it.)
+            self.dnG.enable_sync_bn(self.coll.allreduce_sum_)
 
     table_inputs = 0              # 1: the {noise, cond} / {x, cond} table nets of adversarial_c2f.lua
 

@@ -533,6 +533,7 @@ int fg_gan_buffer(const fg_gan* g, int what, long long* offset_floats, long long
         case FG_GAN_OPT_STATE_G: o = g->o_opt[1]; c = 2 * g->nP[1]; break;
         case FG_GAN_D_OUTPUT: o = g->d_out_off; c = g->last_B[0] > g->last_B[1] ? g->last_B[0] : g->last_B[1]; break;
         case FG_GAN_D_MASKS: o = g->o_mask[0].empty() ? 0 : g->o_mask[0][0]; c = g->o_targets - o; break;
+        case FG_GAN_SYNC_BUF: o = g->o_sync; c = g->total - g->o_sync; break;
         default: return fg_set_err(g->ctx, FG_ERR_INVALID, "fg_gan_buffer: unknown buffer %d", what);
     }
     if (offset_floats) *offset_floats = o;

@@ -121,6 +121,8 @@ class DeviceNet:
     """An nn.Sequential compiled by fg_net_create, with its flat parameter / gradient vectors
     (== Module:getParameters(), train.lua:151-152), BN running stats and workspace as torch device tensors."""
 
+    _ordinal = 0
+
     def __init__(self, ctx, layers, in_dims, max_batch, params=None, grads=None):
         """params / grads: optional slices of a larger flat vector shared by several nets (nn.ConcatSequential)."""
         self.ctx, self.lib = ctx, ctx.lib
@@ -149,7 +151,10 @@ class DeviceNet:
         ctx.check(self.lib.fg_net_bind(h, self.params.data_ptr(), self.grads.data_ptr(), self.buffers.data_ptr()))
         self.train = True
         self.sync_buf, self._sync_reduce = None, None
-        self.mask_seed, self.mask_offset = 1, 0
+        # Philox streams are keyed by (seed, counter) only: the dropout masks must not share the noise stream's key (S.noise_seed
+        # defaults to 1), and two nets must not share one -- 1000 + creation ordinal, like the Lua binding's 1000 + seed
+        DeviceNet._ordinal += 1
+        self.mask_seed, self.mask_offset = 1000 + DeviceNet._ordinal, 0
         self._masks = None
         self._batch = 0
         self._x = None
@@ -409,7 +414,7 @@ class CompositeDeviceNet:
 class FusedGan:
     """fg_gan (include/facegen_hip.h, step level): one C call per closure of adversarial.lua / adversarial_c2f.lua.  The step
     workspace is a torch tensor owned here; results are views into it (valid until the next closure of the same kind)."""
-    BUF = dict(D_INPUT=0, NOISE=1, D_GRAD_INPUT=2, LOSS=3, CONFUSION=4, OPT_STATE_D=5, OPT_STATE_G=6, D_OUTPUT=7, D_MASKS=8)
+    BUF = dict(D_INPUT=0, NOISE=1, D_GRAD_INPUT=2, LOSS=3, CONFUSION=4, OPT_STATE_D=5, OPT_STATE_G=6, D_OUTPUT=7, D_MASKS=8, SYNC_BUF=9)
     NO_UPDATE = 1
 
     def __init__(self, ctx, dnG, dnD, table_inputs, max_batch):
@@ -458,6 +463,16 @@ class FusedGan:
 
     def set_comm(self, coll, sync_bn=False, overlap=1):
         self.ctx.check(self.lib.fg_gan_set_comm(self.h, coll.h if coll is not None else None, 1 if sync_bn else 0, int(overlap)))
+        # fg_gan_set_comm (re)bound the sync-BN exchange buffer of BOTH nets to the step workspace: a stand-alone
+        # DeviceNet.forward / backward afterwards (createImages, approxParzen run in training mode) must drain through that
+        # buffer and this carrier, not through a buffer of its own the library no longer looks at
+        on = bool(sync_bn) and coll is not None and coll.get_world_size() > 1
+        for dn in (self.dnG, self.dnD):
+            if on:
+                dn.sync_buf = self.view("SYNC_BUF").view(torch.float64)
+                dn._sync_reduce = coll.allreduce_sum_
+            else:
+                dn.sync_buf, dn._sync_reduce = None, None
 
     def set_seeds(self, noise_seed, noise_offset, mask_seed, mask_offset):
         self.ctx.check(self.lib.fg_gan_set_seeds(self.h, noise_seed, noise_offset, mask_seed, mask_offset))

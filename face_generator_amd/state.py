@@ -47,11 +47,13 @@ class _State:
         seed = self.OPT.get("seed", 1)
         self.rng = random.Random(seed + rank)
         self.noise_seed = seed + rank
+        k = 0
         for net in (self.MODEL_G, self.MODEL_D):
             dn = getattr(net._inner(), "device_net", None) if net is not None else None
             if dn is not None:
                 for d in ([dn] if not hasattr(dn, "_nets") else dn._nets()):
-                    d.mask_seed = 1000 * (seed + rank) + 1
+                    k += 1
+                    d.mask_seed = 1000 * (seed + rank) + k         # one key per net and rank, none shared with the noise stream
 
 
 S = _State()

@@ -242,7 +242,8 @@ enum fg_gan_buffer_id {
     FG_GAN_OPT_STATE_D = 5,   /* 2 * nparams(D): Adam m | v   (SGD: momentum buffer; Adagrad: variance)                */
     FG_GAN_OPT_STATE_G = 6,
     FG_GAN_D_OUTPUT = 7,      /* D's probabilities [B] of the last closure; offset relative to D's OWN workspace       */
-    FG_GAN_D_MASKS = 8        /* dropout masks the library drew (fg_gan_mask_offset per mask)                          */
+    FG_GAN_D_MASKS = 8,       /* dropout masks the library drew (fg_gan_mask_offset per mask)                          */
+    FG_GAN_SYNC_BUF = 9       /* sync-BN exchange buffer (doubles; count is in floats): what fg_gan_set_comm bound to both nets */
 };
 size_t fg_gan_workspace_bytes(const fg_net* G, const fg_net* D, int table_inputs, int max_batch);
 int fg_gan_create(fg_ctx* ctx, fg_net* G, fg_net* D, int table_inputs, int max_batch, void* ws, size_t ws_bytes,

@@ -43,7 +43,7 @@ function adversarial.train(dataset, maxAccuracyD, accsInterval)
     local countTrainedD, countNotTrainedD = 0, 0
     local c, h, w = IMG_DIMENSIONS[1], IMG_DIMENSIONS[2], IMG_DIMENSIONS[3]
     local useGate = maxAccuracyD <= 1.0          -- D_maxAcc = 1.01 (train.lua:37) can never fire: the update stays inside the step
-    local pending = {}
+    local pending, counts = {}, {0, 0, 0, 0}
 
     print(string.format("<trainer> Epoch #%d [batchSize = %d]", EPOCH, OPT.batchSize))
     for t = 1, N_epoch, dataBatchSize do
@@ -61,16 +61,23 @@ function adversarial.train(dataset, maxAccuracyD, accsInterval)
             for i = 1, half do real[i] = dataset[math.random(dataset:size())] end
             g:configure('D', OPT, OPTSTATE)
             g:stepD(thisBatchSize, FG.to_device_nhwc(real), nil, nil, useGate)
-            -- CONFUSION:add(c, targets[i] + 1) of adversarial.lua:112-117: the counts of this batch (host read, 32 bytes)
-            local lconf, gconf = g:confusion()                -- [pred * 2 + target]; the GLOBAL counts exist when the step held the update
-            local conf = useGate and gconf or lconf
-            for i = 1, 4 do pending[i] = (pending[i] or 0) + conf[i] end
-            local tV = (conf[1] + conf[4]) / math.max(1, conf[1] + conf[2] + conf[3] + conf[4])
-            adversarial.accs[#adversarial.accs + 1] = tV      -- adversarial.lua:156-159
-            if #adversarial.accs > accsInterval then table.remove(adversarial.accs, 1) end
-            local doTrainD = adversarial.mean(adversarial.accs) < maxAccuracyD
-            if useGate and doTrainD then g:update('D') end    -- not updating IS interruptableAdam's false,false path
-            if doTrainD then countTrainedD = countTrainedD + 1 else countNotTrainedD = countNotTrainedD + 1 end
+            if useGate then
+                -- CONFUSION:add(c, targets[i] + 1) of adversarial.lua:112-117 and the gate of :124-178: the counts of the GLOBAL
+                -- batch (host read, 32 bytes), the accuracy history, then the update -- or not
+                local _, conf = g:confusion()                 -- [pred * 2 + target]
+                for i = 1, 4 do counts[i] = counts[i] + conf[i] end
+                local tV = (conf[1] + conf[4]) / math.max(1, conf[1] + conf[2] + conf[3] + conf[4])
+                adversarial.accs[#adversarial.accs + 1] = tV  -- adversarial.lua:156-159
+                if #adversarial.accs > accsInterval then table.remove(adversarial.accs, 1) end
+                local doTrainD = adversarial.mean(adversarial.accs) < maxAccuracyD
+                if doTrainD then g:update('D') end            -- not updating IS interruptableAdam's false,false path
+                if doTrainD then countTrainedD = countTrainedD + 1 else countNotTrainedD = countNotTrainedD + 1 end
+            else
+                -- no gate to decide: the counts stay on the device (no host sync inside the epoch) and are read after the loop,
+                -- exactly as face_generator_amd/adversarial.py defers them
+                pending[#pending + 1] = g:confusionDevice()
+                countTrainedD = countTrainedD + 1
+            end
         end
 
         for k = 1, OPT.G_iterations do
@@ -79,6 +86,12 @@ function adversarial.train(dataset, maxAccuracyD, accsInterval)
         end
         xlua.progress(t + thisBatchSize, N_epoch)
     end
+    for _, t in ipairs(pending) do                            -- deferred: one host read per D closure, after the epoch's last launch
+        local conf = FG.readConfusion(t)
+        for i = 1, 4 do counts[i] = counts[i] + conf[i] end
+        adversarial.accs[#adversarial.accs + 1] = (conf[1] + conf[4]) / math.max(1, conf[1] + conf[2] + conf[3] + conf[4])
+        if #adversarial.accs > accsInterval then table.remove(adversarial.accs, 1) end
+    end
     g:finishPending()
 
     time = sys.clock() - time
@@ -86,7 +99,7 @@ function adversarial.train(dataset, maxAccuracyD, accsInterval)
     print(string.format("<trainer> time to learn 1 sample = %f ms", 1000 * time / N_epoch))
     print(string.format("<trainer> trained D %d of %d times.", countTrainedD, countTrainedD + countNotTrainedD))
     print("Confusion of normal D:")
-    for pred = 1, 2 do for target = 1, 2 do CONFUSION.mat[pred][target] = pending[(pred - 1) * 2 + target] or 0 end end
+    for pred = 1, 2 do for target = 1, 2 do CONFUSION.mat[pred][target] = counts[(pred - 1) * 2 + target] end end
     CONFUSION:updateValids()
     print(CONFUSION)
     local tV = CONFUSION.totalValid
@@ -97,10 +110,15 @@ function adversarial.train(dataset, maxAccuracyD, accsInterval)
         os.execute(string.format("mkdir -p %s", sys.dirname(filename)))
         if paths.filep(filename) then os.execute(string.format("mv %s %s.old", filename, filename)) end
         print(string.format("<trainer> saving network to %s", filename))
-        MODEL_D:get(2).fg:download(false); MODEL_G:get(2).fg:download(false)     -- device parameters -> the host modules
+        local innerD, innerG = MODEL_D:get(2), MODEL_G:get(2)
+        innerD.fg:download(false); innerG.fg:download(false)                     -- device parameters -> the host modules
         NN_UTILS.prepareNetworkForSave(MODEL_D)
         NN_UTILS.prepareNetworkForSave(MODEL_G)
-        torch.save(filename, {D = MODEL_D, G = MODEL_G, opt = OPT, epoch = EPOCH})
+        -- the device plan (FFI cdata) and the overriding closures are not serialisable: off for the save, back on after it
+        local savedD, savedG = FG.detach(innerD), FG.detach(innerG)
+        local ok, err = pcall(torch.save, filename, {D = MODEL_D, G = MODEL_G, opt = OPT, epoch = EPOCH})
+        FG.reattach(innerD, savedD); FG.reattach(innerG, savedG)
+        if not ok then error(err) end
     end
     EPOCH = EPOCH + 1
     return tV

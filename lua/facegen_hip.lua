@@ -103,7 +103,7 @@ int fg_allreduce_sum_f64(fg_comm* comm, double* buf, size_t n);
 int fg_allreduce_sum_i32(fg_comm* comm, int* buf, size_t n);
 int fg_broadcast(fg_comm* comm, float* buf, size_t n, int root);
 enum { FG_STEP_NO_UPDATE = 1 };
-enum fg_gan_buffer_id { FG_GAN_D_INPUT = 0, FG_GAN_NOISE = 1, FG_GAN_D_GRAD_INPUT = 2, FG_GAN_LOSS = 3, FG_GAN_CONFUSION = 4, FG_GAN_OPT_STATE_D = 5, FG_GAN_OPT_STATE_G = 6, FG_GAN_D_OUTPUT = 7, FG_GAN_D_MASKS = 8 };
+enum fg_gan_buffer_id { FG_GAN_D_INPUT = 0, FG_GAN_NOISE = 1, FG_GAN_D_GRAD_INPUT = 2, FG_GAN_LOSS = 3, FG_GAN_CONFUSION = 4, FG_GAN_OPT_STATE_D = 5, FG_GAN_OPT_STATE_G = 6, FG_GAN_D_OUTPUT = 7, FG_GAN_D_MASKS = 8, FG_GAN_SYNC_BUF = 9 };
 size_t fg_gan_workspace_bytes(const fg_net* G, const fg_net* D, int table_inputs, int max_batch);
 int fg_gan_create(fg_ctx* ctx, fg_net* G, fg_net* D, int table_inputs, int max_batch, void* ws, size_t ws_bytes, fg_gan** out);
 int fg_gan_destroy(fg_gan* gan);
@@ -303,6 +303,7 @@ function DeviceNet:upload()
     self.params:copy(flat)
     if self.nbuffers > 0 then self.buffers:copy(buf) end
     check(C.fg_net_params_changed(self.h))
+    self.device_newer = false                                -- host modules == device vectors
 end
 -- flat device vectors -> host modules (gradWeight / gradBias too when want_grads), e.g. before torch.save
 function DeviceNet:download(want_grads)
@@ -324,6 +325,17 @@ function DeviceNet:download(want_grads)
             boff = boff + 2 * k
         end
     end
+    self.device_newer = false                                -- host modules == device vectors
+end
+-- Which side holds the current parameters?  The module-level protocol (seq:forward / :backward below) treats the HOST modules as
+-- authoritative -- the reference's optimizers write the host flat vector of getParameters() -- and uploads them before a forward.
+-- The step-level entries (Gan:stepD / stepG / update) and the device optimizers (M.interruptable*) move only the DEVICE vectors
+-- (parameters, BatchNorm running statistics): they mark the net `device_newer`, and the next module-level forward then DOWNLOADS
+-- instead of uploading -- NN_UTILS.visualizeProgress runs MODEL_G:forward / MODEL_D:forward at the start of every epoch
+-- (train.lua:204, nn_utils.lua:52, 96) and must see, not overwrite, what adversarial.train learned.
+function DeviceNet:markDeviceNewer() self.device_newer = true end
+function DeviceNet:syncForModuleCall()
+    if self.device_newer then self:download(false) else self:upload() end
 end
 function DeviceNet:getParameters() return self.params, self.grads end
 function DeviceNet:paramsChanged() check(C.fg_net_params_changed(self.h)) end
@@ -385,7 +397,7 @@ function M.attach(seq, dims, max_batch, first)
         return out, B
     end
     function seq:updateOutput(input)
-        dn:upload()                                          -- the host copy is authoritative at this level
+        dn:syncForModuleCall()                               -- host copy authoritative unless a device-side update is newer
         local x, B = combine(input)
         local y = dn:forward(x, B)
         self.output = to_host_nchw(y, B, dn.out_dims[1], dn.out_dims[2], dn.out_dims[3])
@@ -418,6 +430,20 @@ function M.attach(seq, dims, max_batch, first)
     return seq
 end
 
+-- torch.save / Module:clone serialise every field of a module, closures with their upvalues included (File:writeObject), and cannot
+-- write FFI cdata: the device plan (seq.fg) and the per-instance overrides installed by M.attach (their upvalues are `dn`, `C`, `ctx`)
+-- must be taken off the module around a save or a clone.  detach() returns what it removed, reattach() puts it back.
+local ATTACHED = {'fg', 'updateOutput', 'backward', 'updateGradInput', 'accGradParameters', 'training', 'evaluate'}
+function M.detach(seq)
+    local saved = {}
+    for _, k in ipairs(ATTACHED) do saved[k] = rawget(seq, k); rawset(seq, k, nil) end
+    return saved
+end
+function M.reattach(seq, saved)
+    for _, k in ipairs(ATTACHED) do rawset(seq, k, saved[k]) end
+    return seq
+end
+
 -- interruptable_optimizers.lua on DEVICE vectors (x, dfdx = DeviceTensor); `fused` carries penalty / clamp / 1/world.
 -- `net` (a DeviceNet) is told that its parameters moved: the packed / tap-folded weights are rebuilt before its next use.
 local function fused_args(fused) fused = fused or {}; return fused.gscale or 1, fused.l1_mul or 0, fused.l2 or 0, fused.clamp or 0 end
@@ -431,7 +457,7 @@ function M.interruptableAdam(opfunc, x, config, state, fused, net)
     local gs, l1, l2, cl = fused_args(fused)
     check(C.fg_adam_fused(ctx, x.ptr, dfdx.ptr, state.m.ptr, state.v.ptr, x.n, gs, l1, l2, cl, config.learningRate or 0.001,
                           config.beta1 or 0.9, config.beta2 or 0.999, config.epsilon or 1e-8, state.t, nil))
-    if net then net:paramsChanged() end
+    if net then net:paramsChanged(); net:markDeviceNewer() end
     return x, {fx}
 end
 function M.interruptableSgd(opfunc, x, config, state, fused, net)
@@ -448,7 +474,7 @@ function M.interruptableSgd(opfunc, x, config, state, fused, net)
     check(C.fg_sgd_fused(ctx, x.ptr, dfdx.ptr, mom ~= 0 and state.dfdx.ptr or nil, x.n, gs, l1, l2, cl,
                          lr / (1 + state.evalCounter * lrd), mom, damp, wd, nesterov and 1 or 0, first))
     state.evalCounter = state.evalCounter + 1
-    if net then net:paramsChanged() end
+    if net then net:paramsChanged(); net:markDeviceNewer() end
     return x, {fx}
 end
 function M.interruptableAdagrad(opfunc, x, config, state, fused, net)
@@ -461,7 +487,7 @@ function M.interruptableAdagrad(opfunc, x, config, state, fused, net)
     local gs, l1, l2, cl = fused_args(fused)
     check(C.fg_adagrad_fused(ctx, x.ptr, dfdx.ptr, state.paramVariance.ptr, x.n, gs, l1, l2, cl, lr / (1 + state.evalCounter * lrd)))
     state.evalCounter = state.evalCounter + 1
-    if net then net:paramsChanged() end
+    if net then net:paramsChanged(); net:markDeviceNewer() end
     return x, {fx}
 end
 
@@ -532,15 +558,34 @@ function Gan:confusion()                -- {local = {c00, c01, c10, c11}, global
     check(C.fg_d2h(ctx, host, self.base + off[0], 32))
     return {host[0], host[1], host[2], host[3]}, {host[4], host[5], host[6], host[7]}
 end
+-- the same 8 counts left on the device (a stream-ordered 32-byte copy, no host sync): read later with Gan.readConfusion
+function Gan:confusionDevice()
+    local off, cnt = ffi.new('long long[1]'), ffi.new('long long[1]')
+    check(C.fg_gan_buffer(self.h, C.FG_GAN_CONFUSION, off, cnt))
+    local t = M.DeviceTensor(8)
+    check(C.fg_d2d(ctx, t.ptr, self.base + off[0], 32))
+    return t
+end
+function M.readConfusion(t)
+    local host = ffi.new('int[8]')
+    check(C.fg_d2h(ctx, host, t.ptr, 32))
+    return {host[0], host[1], host[2], host[3]}, {host[4], host[5], host[6], host[7]}
+end
 -- real / cond_*: DeviceTensor NHWC (cond_* only for the table nets); noise / masks nil: drawn by the library
 function Gan:stepD(batch, real, cond_real, cond_fake, hold)
     check(C.fg_step_D(self.h, batch, real.ptr, cond_real and cond_real.ptr or nil, cond_fake and cond_fake.ptr or nil,
                       nil, nil, hold and C.FG_STEP_NO_UPDATE or 0))
+    self.G:markDeviceNewer()                                 -- G ran in TRAIN mode: its BatchNorm running statistics moved
+    if not hold then self.D:markDeviceNewer() end
 end
 function Gan:stepG(batch, cond, hold)
     check(C.fg_step_G(self.h, batch, cond and cond.ptr or nil, nil, nil, hold and C.FG_STEP_NO_UPDATE or 0))
+    self.G:markDeviceNewer(); self.D:markDeviceNewer()       -- a deferred D update lands inside the G-step (N > 1)
 end
-function Gan:update(which) check(C.fg_gan_update(self.h, which == 'D' and 0 or 1)) end
+function Gan:update(which)
+    check(C.fg_gan_update(self.h, which == 'D' and 0 or 1))
+    if which == 'D' then self.D:markDeviceNewer() else self.G:markDeviceNewer() end
+end
 function Gan:finishPending() check(C.fg_gan_finish_pending(self.h)) end
 
 return M

@@ -119,3 +119,50 @@ def test_patches_apply_to_the_reference_scripts(tmp_path):
         code = strip_lua_comments(open(os.path.join(str(tmp_path), rel)).read())
         assert not re.search(r"require\s+'(cutorch|cunn|cudnn)'", code), "%s still requires a CUDA rock" % rel
         assert "cutorch." not in code and ":cuda()" not in code, "%s still calls into cutorch" % rel
+
+
+def _fn_body(code, header):
+    body = code[code.index(header):]
+    return body[:body.index("\nend") + 4]
+
+
+def test_device_side_updates_are_not_overwritten_by_a_module_level_forward():
+    """adversarial_hip.lua moves only the DEVICE vectors; NN_UTILS.visualizeProgress then calls
+    MODEL_G:forward / MODEL_D:forward (train.lua:204, nn_utils.lua:52, 96), whose override used to upload the stale host weights
+    unconditionally.  Pinned: the override synchronises in the right direction, and every path that moves device parameters says so."""
+    code = lua_code(os.path.join(ROOT, "lua", "facegen_hip.lua"))
+    fwd = _fn_body(code, "function seq:updateOutput(input)")
+    assert "dn:syncForModuleCall()" in fwd and "dn:upload()" not in fwd
+    sync = _fn_body(code, "function DeviceNet:syncForModuleCall()")
+    assert re.search(r"if self\.device_newer then self:download\(false\) else self:upload\(\) end", sync)
+    assert "self.device_newer = false" in _fn_body(code, "function DeviceNet:upload()")
+    assert "self.device_newer = false" in _fn_body(code, "function DeviceNet:download(want_grads)")
+    stepD, stepG, upd = (_fn_body(code, "function Gan:stepD("), _fn_body(code, "function Gan:stepG("), _fn_body(code, "function Gan:update("))
+    assert "self.G:markDeviceNewer()" in stepD and "if not hold then self.D:markDeviceNewer() end" in stepD
+    assert "self.G:markDeviceNewer()" in stepG and "self.D:markDeviceNewer()" in stepG
+    assert "self.D:markDeviceNewer()" in upd and "self.G:markDeviceNewer()" in upd
+    for fn in ("interruptableAdam", "interruptableSgd", "interruptableAdagrad"):
+        assert "net:markDeviceNewer()" in _fn_body(code, "function M." + fn)
+
+
+def test_nothing_unserialisable_is_on_a_module_during_save_or_clone():
+    """torch.save / Module:clone write every field of a module, closures with their upvalues included, and
+    cannot write FFI cdata -- the device plan and the overrides come off around both."""
+    code = lua_code(os.path.join(ROOT, "lua", "facegen_hip.lua"))
+    attached = re.search(r"local ATTACHED = \{(.*?)\}", code).group(1)
+    installed = set(re.findall(r"function seq:(\w+)\(", code)) | set(re.findall(r"\bseq\.(\w+)\s*=", code))
+    assert installed and installed <= set(re.findall(r"'(\w+)'", attached)), "a field M.attach installs is not in ATTACHED: %s" % installed
+    adv = lua_code(os.path.join(ROOT, "lua", "adversarial_hip.lua"))
+    save = adv[adv.index("FG.detach(innerD)"):]
+    assert save.index("FG.detach(innerG)") < save.index("torch.save") < save.index("FG.reattach(innerD, savedD)")
+    patch = open(os.path.join(ROOT, "lua", "patches", "utils_nn_utils.lua.patch")).read()
+    i = patch.index("FG.detach(inner)")
+    assert i < patch.index("pcall(inner.clone, inner)") < patch.index("FG.reattach(inner, saved)")
+
+
+def test_the_two_mirrors_of_adversarial_train_defer_the_confusion_counts_alike():
+    """without a gate neither mirror reads the counts inside the epoch; with one both read per D closure."""
+    adv = lua_code(os.path.join(ROOT, "lua", "adversarial_hip.lua"))
+    assert "pending[#pending + 1] = g:confusionDevice()" in adv and "FG.readConfusion(t)" in adv
+    py = open(os.path.join(ROOT, "face_generator_amd", "adversarial.py")).read()
+    assert "pending.append(r[\"confusion\"].clone())" in py and "if not use_gate:" in py
