@@ -389,6 +389,19 @@ int fg_upsample_nearest2x_forward(fg_ctx* ctx, const float* x, float* y, int b, 
     NEED(ctx, ctx && x && y, "null argument");
     return fg_launch_upsample_forward(ctx, x, y, b, h, w, c);
 }
+static int review_args_ok(fg_ctx* ctx, const void* a, const void* b_, int b, int h, int w, int c, int f) {
+    if (!ctx || !a || !b_ || b <= 0 || h <= 0 || w <= 0 || c <= 0 || f < 1 || c % (f * f))
+        return fg_set_err(ctx, FG_ERR_INVALID, "fg_conv_upsample_view: bad argument (c must be a multiple of factor^2)");
+    return FG_OK;
+}
+int fg_conv_upsample_view_forward(fg_ctx* ctx, const float* v, float* u, int b, int h, int w, int c, int f) {
+    int rc = review_args_ok(ctx, v, u, b, h, w, c, f);
+    return rc ? rc : fg_launch_nchw_review(ctx, v, u, b, h, w, c, f, 0);
+}
+int fg_conv_upsample_view_backward(fg_ctx* ctx, const float* gu, float* gv, int b, int h, int w, int c, int f) {
+    int rc = review_args_ok(ctx, gu, gv, b, h, w, c, f);
+    return rc ? rc : fg_launch_nchw_review(ctx, gu, gv, b, h, w, c, f, 1);
+}
 int fg_upsample_nearest2x_backward(fg_ctx* ctx, const float* gy, float* gx, int b, int h, int w, int c) {
     NEED(ctx, ctx && gy && gx, "null argument");
     return fg_launch_upsample_backward(ctx, gy, gx, b, h, w, c);

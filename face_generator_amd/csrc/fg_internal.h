@@ -242,6 +242,8 @@ int fg_launch_avgpool_forward(fg_ctx*, const float* x, float* y, int B, int H, i
 int fg_launch_avgpool_backward(fg_ctx*, const float* gy, float* gx, int B, int H, int W, int C);
 int fg_launch_upsample_forward(fg_ctx*, const float* x, float* y, int B, int H, int W, int C);
 int fg_launch_upsample_backward(fg_ctx*, const float* gy, float* gx, int B, int H, int W, int C);
+// SpatialConvolutionUpsample factor > 1: flat-NCHW re-view on NHWC tensors; src / dst hold B * C * h * w floats, C = nOut * f * f
+int fg_launch_nchw_review(fg_ctx*, const float* src, float* dst, int B, int h, int w, int C, int f, int dir);
 int fg_launch_sigmoid_forward(fg_ctx*, const float* x, float* y, long long n);
 int fg_launch_sigmoid_backward(fg_ctx*, const float* y, const float* gy, float* gx, long long n);
 int fg_launch_leakyrelu_forward(fg_ctx*, const float* x, float s, float* y, long long n);

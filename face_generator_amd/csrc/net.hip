@@ -25,7 +25,8 @@ enum StageKind {
     ST_AVGPOOL,
     ST_SDROPOUT,
     ST_MAXPOOL,
-    ST_DROPOUT        // standalone nn.Dropout (any shape)
+    ST_DROPOUT,       // standalone nn.Dropout (any shape)
+    ST_REVIEW         // the flat NCHW re-view behind a SpatialConvolutionUpsample with factor > 1
 };
 
 struct Stage {
@@ -43,6 +44,7 @@ struct Stage {
     int has_prelu = 0, has_sigmoid = 0;
     int mask_idx = -1, mask_kind = 0;  // 1 spatial [B][C], 2 elementwise
     float p = 0.f, eps = 1e-5f, momentum = 0.1f, negslope = 0.333f;
+    int factor = 1;           // ST_REVIEW
     // per-forward plan
     long long out_off = 0, aux_off = 0;
     long long x6_off = -1;    // ST_CONV: split-bf16 planes of the stage input, kept from forward for the weight gradient
@@ -302,6 +304,7 @@ static int backward_run_stages(fg_net* n) {
                 if (need_gx) rc = fg_launch_leakyrelu_backward(ctx, xin, gcur, s.negslope, gxb, (long long)B * s.ic * s.ih * s.iw);
                 break;
             case ST_UPSAMPLE: if (need_gx) rc = fg_launch_upsample_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
+            case ST_REVIEW: if (need_gx) rc = fg_launch_nchw_review(ctx, gcur, gxb, B, s.ih, s.iw, s.ic, s.factor, 1); break;
             case ST_AVGPOOL: if (need_gx) rc = fg_launch_avgpool_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
             case ST_SDROPOUT: if (need_gx) rc = fg_launch_scale_mask_nc(ctx, gcur, mask, 1.f, gxb, B, s.ih * s.iw, s.ic); break;
             case ST_MAXPOOL:
@@ -428,6 +431,7 @@ static int forward_run(fg_net* n, long long* out_offset) {
             case ST_SIGMOID: rc = fg_launch_sigmoid_forward(ctx, cur, y, (long long)B * s.ic * s.ih * s.iw); break;
             case ST_LEAKYRELU: rc = fg_launch_leakyrelu_forward(ctx, cur, s.negslope, y, (long long)B * s.ic * s.ih * s.iw); break;
             case ST_UPSAMPLE: rc = fg_launch_upsample_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
+            case ST_REVIEW: rc = fg_launch_nchw_review(ctx, cur, y, B, s.ih, s.iw, s.ic, s.factor, 0); break;
             case ST_AVGPOOL: rc = fg_launch_avgpool_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
             case ST_SDROPOUT:
                 rc = fg_launch_scale_mask_nc(ctx, cur, train ? mask : nullptr, train ? 1.f : 1.f - s.p, y, B, s.ih * s.iw, s.ic);
@@ -458,6 +462,7 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
     n->layers.resize(nl);
     int c = in_c, h = in_h, w = in_w;
     int perm_c = 0, perm_hw = 0;  // pending NCHW-flatten permutation for the next Linear
+    int review_factor = 0;        // the FG_CONV just parsed is a SpatialConvolutionUpsample with factor > 1
     long long poff = 0, boff = 0;
     int rc = FG_OK;
     auto fail = [&](int code, const char* msg, int i) {
@@ -536,6 +541,11 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
                 ConvGeom& g = s.geom; g.H = h; g.W = w; g.Cin = l.a; g.Cout = l.b; g.k = l.c; g.pad = l.d; g.fold = 0;
                 g.stride = (l.p == 2.f) ? 2 : 1;
                 s.oc = l.b; s.oh = h; s.ow = w;
+                if (l.q > 1.f) {       // cudnn.SpatialConvolutionUpsample(nIn, nOut, k, k, f): b = nOut * f * f planes, viewed behind
+                    const int f = (int)l.q;
+                    if ((float)f != l.q || l.b % (f * f) || g.stride != 1) { fail(FG_ERR_INVALID, "SpatialConvolutionUpsample: nOutputPlane must be a multiple of factor^2 (stride 1)", i); break; }
+                    review_factor = f;
+                }
                 if (g.stride == 2) {       // 3x3 stride-2 'same'-pad convs of create_D16_d (models.lua:289-291)
                     if ((h & 1) || (w & 1) || l.a % 4 || l.c * l.c > FG_MAX_GROUPS) { fail(FG_ERR_UNSUPPORTED, "stride-2 conv: even H/W, nIn % 4", i); break; }
                     s.oh = h / 2; s.ow = w / 2; s.kind = ST_CONV;
@@ -543,7 +553,7 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
                 if (l.a <= 4 && l.b % 64 == 0) s.kind = ST_THIN_IN;
                 else if (l.b <= 4 && l.a % 64 == 0) {
                     s.kind = ST_THIN_OUT;
-                    if (i + 1 < nl && L[i + 1].type == FG_SIGMOID) { s.has_sigmoid = 1; consumed = 2; }
+                    if (i + 1 < nl && L[i + 1].type == FG_SIGMOID && !(l.q > 1.f)) { s.has_sigmoid = 1; consumed = 2; }
                 } else if (l.a % 4 == 0 && l.c * l.c <= FG_MAX_GROUPS) s.kind = ST_CONV;
                 else fail(FG_ERR_UNSUPPORTED, "conv channel counts not supported", i);
                 break;
@@ -600,6 +610,18 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
                 // elementwise stages between the flatten and the Linear keep the pending permutation
             }
             n->st.push_back(s);
+            if (review_factor > 1) {
+                // the view stage: [c][h][w] (NCHW) re-read as [c / f^2][h f][w f]; layer i now ends HERE (fg_net_layer_output(i)
+                // is the module's output, like the reference's self.output), and nothing is fused across it
+                const int f = review_factor;
+                review_factor = 0;
+                if (s.has_sigmoid) { rc = fg_set_err(ctx, FG_ERR_UNSUPPORTED, "fg_net_create: layer %d: Sigmoid fused in front of the view", i); break; }
+                Stage v; v.kind = ST_REVIEW; v.first_layer = v.last_layer = i; v.factor = f;
+                v.ic = c; v.ih = h; v.iw = w; v.oc = c / (f * f); v.oh = h * f; v.ow = w * f;
+                n->layers[i].stage = (int)n->st.size();
+                c = v.oc; h = v.oh; w = v.ow;
+                n->st.push_back(v);
+            }
         } else if (!n->st.empty()) {
             n->layers[i].stage = (int)n->st.size() - 1;
             n->layers[i].ends_stage = 1;

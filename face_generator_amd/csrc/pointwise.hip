@@ -1004,6 +1004,41 @@ int fg_launch_upsample_backward(fg_ctx* ctx, const float* gy, float* gx, int B, 
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
+// cudnn.SpatialConvolutionUpsample with factor f > 1 (layers/cudnnSpatialConvolutionUpsample.lua:19-31): the convolution to
+// nOut * f * f planes is followed by a FLAT re-view of its contiguous NCHW output [N][nOut*f*f][h][w] as [N][nOut][h*f][w*f]
+// (Tensor:view -- not a pixel shuffle).  With NHWC activations inside, the view is an index map: element j of a sample's flat
+// NCHW order is (co, y, x) = (j / hw, (j % hw) / w, j % w) in the convolution's output and (cu, Y, X) = (j / (hf*wf), ...) in
+// the viewed tensor.  dir = 0: V[n][y][x][co] -> U[n][Y][X][cu] (forward); dir = 1: gU -> gV (updateGradInput /
+// accGradParameters view the gradient back, :34-58).  One thread per DESTINATION element.
+__global__ void nchw_review_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int h, int w, int C, int f, int dir) {
+    const int cu_n = C / (f * f), hf = h * f, wf = w * f;
+    const long long per = (long long)C * h * w, total = (long long)B * per;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / per;
+        long long r = i % per;
+        long long j, so;
+        if (dir == 0) {               // destination U, NHWC [hf][wf][cu]
+            const int cu = (int)(r % cu_n); r /= cu_n;
+            const int X = (int)(r % wf), Y = (int)(r / wf);
+            j = ((long long)cu * hf + Y) * wf + X;
+            const int co = (int)(j / ((long long)h * w)), q = (int)(j % ((long long)h * w));
+            so = ((long long)q) * C + co;                              // V NHWC: [y*w + x][co]
+        } else {                      // destination gV, NHWC [h][w][co]
+            const int co = (int)(r % C); r /= C;
+            j = (long long)co * h * w + r;                             // r = y*w + x
+            const int cu = (int)(j / ((long long)hf * wf)), q = (int)(j % ((long long)hf * wf));
+            so = ((long long)q) * cu_n + cu;                           // gU NHWC: [Y*wf + X][cu]
+        }
+        dst[i] = src[n * per + so];
+    }
+}
+int fg_launch_nchw_review(fg_ctx* ctx, const float* src, float* dst, int B, int h, int w, int C, int f, int dir) {
+    const long long n = (long long)B * C * h * w;
+    if (n == 0) return FG_OK;
+    hipLaunchKernelGGL(nchw_review_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, src, dst, B, h, w, C, f, dir);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
 __global__ void sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         y[i] = 1.f / (1.f + expf(-x[i]));

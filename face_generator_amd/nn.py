@@ -461,17 +461,54 @@ class SpatialMaxPooling(Module):
 
 
 class SpatialConvolutionUpsample(SpatialConvolution):
-    """layers/cudnnSpatialConvolutionUpsample.lua:4-58.  The reference always passes factor = 1 (models_c2f.lua:123-131),
-    which is exactly a 'same' convolution; factor > 1 (flat NCHW re-view, not pixel-shuffle) is not on any config."""
+    """layers/cudnnSpatialConvolutionUpsample.lua:4-58: a 'same' convolution to nOutputPlane * factor^2 planes whose contiguous
+    NCHW output is RE-VIEWED (Tensor:view -- a flat reinterpretation, not a pixel shuffle) as [N][nOutputPlane][h*f][w*f];
+    updateGradInput / accGradParameters view gradOutput back.  The reference's nets always pass factor = 1
+    (models_c2f.lua:123-131), where it is exactly a 'same' convolution; factor > 1 runs the same convolution kernels followed by
+    an index-mapped copy (fg_conv_upsample_view_*; inside a compiled net: one extra stage)."""
     _typename = "cudnn.SpatialConvolutionUpsample"
 
     def __init__(self, nInputPlane, nOutputPlane, kW, kH, factor=2, groups=None, gen=None):
         if kW % 2 != 1 or kH % 2 != 1:
             raise FgError("kW has to be odd / kH has to be odd")          # cudnnSpatialConvolutionUpsample.lua:7-8
-        if factor != 1:
-            raise FgError("SpatialConvolutionUpsample: factor %d not built (the reference only uses factor 1)" % factor)
-        super().__init__(nInputPlane, nOutputPlane, kW, kH, 1, 1, (kW - 1) // 2, (kH - 1) // 2, gen=gen)
+        factor = int(factor)
+        if factor < 1:
+            raise FgError("SpatialConvolutionUpsample: factor must be >= 1")
+        super().__init__(nInputPlane, nOutputPlane * factor * factor, kW, kH, 1, 1, (kW - 1) // 2, (kH - 1) // 2, gen=gen)
         self.factor = factor
+        self.nInputPlaneU, self.nOutputPlaneU = nInputPlane, nOutputPlane
+
+    def spec(self):
+        return ("CONV", self.nInputPlane, self.nOutputPlane, self.kW, self.padW, 1.0, float(self.factor))
+
+    def _view(self, t, backward):
+        """conv output NHWC [B][h][w][nOut f^2] <-> viewed NHWC [B][h f][w f][nOut] (gradients: the other way)."""
+        from .runtime import get_context
+        ctx = get_context(t.device.index)
+        f, C = self.factor, self.nOutputPlane
+        if backward:
+            B, hf, wf, _ = t.shape
+            h, w = hf // f, wf // f
+            out = ctx.empty(B, h, w, C)
+            ctx.check(ctx.lib.fg_conv_upsample_view_backward(ctx.h, t.contiguous().data_ptr(), out.data_ptr(), B, h, w, C, f))
+        else:
+            B, h, w, _ = t.shape
+            out = ctx.empty(B, h * f, w * f, C // (f * f))
+            ctx.check(ctx.lib.fg_conv_upsample_view_forward(ctx.h, t.contiguous().data_ptr(), out.data_ptr(), B, h, w, C, f))
+        return out
+
+    def updateOutput(self, input):
+        y = super().updateOutput(input)
+        self.output = y if self.factor == 1 else self._view(y, False)
+        return self.output
+
+    def updateGradInput(self, input, gradOutput):
+        g = self._dev(gradOutput)
+        return super().updateGradInput(input, g if self.factor == 1 else self._view(g, True))
+
+    def accGradParameters(self, input, gradOutput, scale=1.0):
+        g = self._dev(gradOutput)
+        return super().accGradParameters(input, g if self.factor == 1 else self._view(g, True), scale)
 
 
 class JoinTable(Module):

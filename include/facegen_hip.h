@@ -97,7 +97,9 @@ enum fg_layer_type {
     FG_VIEW = 2,            /* nn.View(a=C, b=H, c=W)  or nn.View(a=features) with b=c=0 */
     FG_PRELU = 3,           /* nn.PReLU() -- one shared slope */
     FG_UPSAMPLE2X = 4,      /* nn.SpatialUpSamplingNearest(2) */
-    FG_CONV = 5,            /* (cudnn|nn).SpatialConvolution(a=nIn, b=nOut, c=k, k, dW, dH, d=pad, pad); p = stride dW=dH (0/1: 1, 2: 2) */
+    FG_CONV = 5,            /* (cudnn|nn).SpatialConvolution(a=nIn, b=nOut, c=k, k, dW, dH, d=pad, pad); p = stride dW=dH (0/1: 1, 2: 2);
+                             * q = factor f of cudnn.SpatialConvolutionUpsample (0/1: none; f > 1: b = nOutputPlane * f * f planes, the
+                             * NCHW output re-viewed as [b / f^2][H * f][W * f], layers/cudnnSpatialConvolutionUpsample.lua:14-31) */
     FG_BATCHNORM = 6,       /* nn.SpatialBatchNormalization(a=nF), p=eps, q=momentum */
     FG_SPATIAL_DROPOUT = 7, /* nn.SpatialDropout(p) */
     FG_AVGPOOL2 = 8,        /* nn.SpatialAveragePooling(2,2,2,2) */
@@ -319,6 +321,11 @@ int fg_avgpool2x2_forward(fg_ctx* ctx, const float* x, float* y, int batch, int 
 int fg_avgpool2x2_backward(fg_ctx* ctx, const float* gy, float* gx, int batch, int h, int w, int c);
 int fg_upsample_nearest2x_forward(fg_ctx* ctx, const float* x, float* y, int batch, int h, int w, int c);
 int fg_upsample_nearest2x_backward(fg_ctx* ctx, const float* gy, float* gx, int batch, int h, int w, int c);
+/* cudnn.SpatialConvolutionUpsample, factor f > 1 (layers/cudnnSpatialConvolutionUpsample.lua:19-58): the flat re-view of the
+ * convolution's NCHW output [batch][c][h][w] (c = nOutputPlane * f * f) as [batch][c / f^2][h * f][w * f], on NHWC tensors.
+ * forward: conv output -> viewed output; backward: gradient wrt the viewed output -> gradient wrt the conv output. */
+int fg_conv_upsample_view_forward(fg_ctx* ctx, const float* conv_out, float* viewed, int batch, int h, int w, int c, int factor);
+int fg_conv_upsample_view_backward(fg_ctx* ctx, const float* g_viewed, float* g_conv_out, int batch, int h, int w, int c, int factor);
 /* nn.SpatialMaxPooling(2,2): backward recomputes the argmax (first max in scan order) from the saved input */
 int fg_maxpool2x2_forward(fg_ctx* ctx, const float* x, float* y, int batch, int h, int w, int c);
 int fg_maxpool2x2_backward(fg_ctx* ctx, const float* x, const float* gy, float* gx, int batch, int h, int w, int c);

@@ -142,6 +142,8 @@ int fg_avgpool2x2_forward(fg_ctx* ctx, const float* x, float* y, int batch, int 
 int fg_avgpool2x2_backward(fg_ctx* ctx, const float* gy, float* gx, int batch, int h, int w, int c);
 int fg_upsample_nearest2x_forward(fg_ctx* ctx, const float* x, float* y, int batch, int h, int w, int c);
 int fg_upsample_nearest2x_backward(fg_ctx* ctx, const float* gy, float* gx, int batch, int h, int w, int c);
+int fg_conv_upsample_view_forward(fg_ctx* ctx, const float* conv_out, float* viewed, int batch, int h, int w, int c, int factor);
+int fg_conv_upsample_view_backward(fg_ctx* ctx, const float* g_viewed, float* g_conv_out, int batch, int h, int w, int c, int factor);
 int fg_maxpool2x2_forward(fg_ctx* ctx, const float* x, float* y, int batch, int h, int w, int c);
 int fg_maxpool2x2_backward(fg_ctx* ctx, const float* x, const float* gy, float* gx, int batch, int h, int w, int c);
 int fg_dropout_apply(fg_ctx* ctx, const float* x, const float* mask, float scale, float* y, long long n);
@@ -240,9 +242,9 @@ local function spec_of(m)
     elseif tn == 'nn.SpatialConvolution' or tn == 'cudnn.SpatialConvolution' or tn == 'cudnn.SpatialConvolutionUpsample' then
         assert(m.kW == m.kH and m.dW == m.dH and (m.dW == 1 or m.dW == 2) and m.padW == m.padH and m.padW == (m.kW - 1) / 2,
                'only odd-k same-pad convolutions with stride 1 or 2 are built')
-        assert((m.factor or 1) == 1, 'SpatialConvolutionUpsample: only factor 1 is on the hot path (models_c2f.lua:123-131)')
-        -- fg_layer_spec: a = nIn, b = nOut, c = k, d = pad, p = stride (0 / 1: 1, 2: 2)
-        return {C.FG_CONV, m.nInputPlane, m.nOutputPlane, m.kW, m.padW, m.dW}
+        -- fg_layer_spec: a = nIn, b = nOut (the parent convolution's: nOutputPlaneU * factor^2), c = k, d = pad,
+        -- p = stride (0 / 1: 1, 2: 2), q = factor of cudnn.SpatialConvolutionUpsample (the flat NCHW re-view runs as its own stage)
+        return {C.FG_CONV, m.nInputPlane, m.nOutputPlane, m.kW, m.padW, m.dW, m.factor or 1}
     elseif tn == 'nn.SpatialBatchNormalization' then return {C.FG_BATCHNORM, m.running_mean:size(1), 0, 0, 0, m.eps, m.momentum}
     elseif tn == 'nn.SpatialDropout' then return {C.FG_SPATIAL_DROPOUT, 0, 0, 0, 0, m.p}
     elseif tn == 'nn.SpatialAveragePooling' then return {C.FG_AVGPOOL2}
