@@ -379,6 +379,75 @@ def build_c2f(args, ctx, torch, coll, world, rank, B, d_it):
                         "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world})
 
 
+def dry_collective(args):
+    """--dry-collective: everything a `--gpus N` job does on the HOST side of the gradient exchange, with no kernel launched and
+    no collective issued (planning-only context + dry communicators, include/facegen_hip.h).  For every rank of the job and every
+    combination of {maxAccuracyD gate: none / passes / holds} x {sync_bn} x {overlap}, one iteration (D closure, G closure, the
+    deferred D update) runs through fg_step_D / fg_step_G and the schedule the library recorded is printed: order, dtype, element
+    count and stream of every all-reduce.  All ranks must agree; under torch.distributed.run (gloo) every process walks its own
+    rank and rank 0 compares, otherwise one process walks all N ranks."""
+    import torch
+    import torch.distributed as dist
+    from face_generator_amd import models, nn_utils, adversarial, distributed
+    from face_generator_amd.runtime import get_context
+    from face_generator_amd.state import S
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    N = max(args.gpus, world_env)
+    if world_env > 1:
+        dist.init_process_group("gloo")
+        my_ranks = [int(os.environ["RANK"])]
+    else:
+        my_ranks = list(range(N))
+    ctx = get_context(-1)
+    B = min(args.batch, 8)                 # the schedule does not depend on the batch; keep the host buffers small
+    combos = [(g, sb, ov) for g in ("none", "pass", "hold") for sb in (0, 1) for ov in (0, 1)]
+    result = {}
+    for r in my_ranks:
+        coll = distributed.DryCollective(ctx, r, N)
+        gen = torch.Generator().manual_seed(1)
+        G = models.create_G((3, 32, 32), 100)
+        D = models.create_D((3, 32, 32))
+        nn_utils.initializeWeights(D, gen=gen)
+        nn_utils.initializeWeights(G, gen=gen)
+        G.cuda(ctx, max_batch=B)
+        D.cuda(ctx, max_batch=B)
+        real = ctx.zeros(B // 2, 32, 32, 3)
+        per = {}
+        for (gate, sb, ov) in combos:
+            opt = dict(batchSize=B, noiseDim=100, sync_bn=bool(sb))
+            tr = adversarial.Trainer(ctx, G, D, opt, dist=coll)
+            assert tr.gan is not None, "the step-level entries must carry the closures"
+            tr.gan.set_comm(coll, sync_bn=bool(sb), overlap=ov)
+            coll.schedule(reset=True)
+            g = None if gate == "none" else ((lambda acc: True) if gate == "pass" else (lambda acc: False))
+            tr.step_D(real, None, gate=g)
+            tr.step_G(B)
+            tr.finish_pending()
+            per["gate=%s sync_bn=%d overlap=%d" % (gate, sb, ov)] = coll.schedule(reset=True)
+            del tr
+        result[r] = per
+        coll.close()
+    if world_env > 1:
+        gathered = [None] * world_env
+        dist.all_gather_object(gathered, result)
+        result = {}
+        for g in gathered:
+            result.update(g)
+        dist.barrier()
+        dist.destroy_process_group()
+        if int(os.environ["RANK"]) != 0:
+            return
+    ranks = sorted(result)
+    agree = all(result[r] == result[ranks[0]] for r in ranks)
+    out = {"dry_collective": True, "n_gpus": N, "ranks_walked": ranks, "ranks_agree": agree, "schedule": result[ranks[0]],
+           "note": "one iteration (D closure, G closure, deferred D update) per combination; lines are <seq> <op> <dtype> <count> <stream>"}
+    if not agree:
+        out["per_rank"] = {str(r): result[r] for r in ranks}
+    print(json.dumps(out))
+    if not agree:
+        raise SystemExit(3)
+
+
 def step_entry(tr):
     return ("fg_step_D / fg_step_G (C ABI, one call per closure)" if tr.gan is not None
             else "net-level entries driven from the host loop")
@@ -411,7 +480,12 @@ def main():
                     help="N > 1: if the c2f sub-record has not finished after this many seconds, rank 0 prints the line without it")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not spawn the two rocprofv3 PMC passes for roofline.traffic (a committed summary is used and labelled)")
+    ap.add_argument("--dry-collective", action="store_true",
+                    help="no GPU needed: walk the gradient-exchange path of a --gpus N job for every rank with planning-only contexts "
+                         "and print the collective schedule (order, dtype, count, stream) every rank would issue; exit 3 on a mismatch")
     args = ap.parse_args()
+    if args.dry_collective:
+        return dry_collective(args)
 
     import torch
     import torch.distributed as dist

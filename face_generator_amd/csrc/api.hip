@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 static char g_err[512] = "";
+bool g_fg_dry = false;      // fg_internal.h: a planning-only context exists in this process
 
 int fg_set_err(fg_ctx* c, int code, const char* fmt, ...) {
     va_list ap;
@@ -48,8 +49,20 @@ extern "C" {
 
 const char* fg_version(void) { return "facegen_hip 0.1 (gfx950)"; }
 
+static int g_real_ctx = 0;       // live contexts bound to a device / planning-only ones: never both in one process
+static int g_dry_ctx = 0;
+
 int fg_ctx_create(int device, fg_ctx** out) {
     if (!out) return fg_set_err(nullptr, FG_ERR_INVALID, "fg_ctx_create: null out");
+    if (device == FG_DEVICE_NONE) {
+        if (g_real_ctx) return fg_set_err(nullptr, FG_ERR_INVALID, "fg_ctx_create: a planning-only context cannot join a process that holds a device context");
+        fg_ctx* c = new fg_ctx();
+        c->device = FG_DEVICE_NONE; c->stream = nullptr; c->err[0] = 0; c->sm_count = 256;     // MI355X: 256 CUs
+        g_fg_dry = true; ++g_dry_ctx;
+        *out = c;
+        return FG_OK;
+    }
+    if (g_dry_ctx) return fg_set_err(nullptr, FG_ERR_INVALID, "fg_ctx_create: this process holds a planning-only context (FG_DEVICE_NONE)");
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -67,10 +80,17 @@ int fg_ctx_create(int device, fg_ctx** out) {
     if (const char* m = getenv("FG_MATH")) c->math = atoi(m) == 6 ? 6 : 0;   // default arithmetic, see fg_set_math
     if (const char* m = getenv("FG_FUSE_PRELU")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_PRELU;
     if (const char* m = getenv("FG_THIN_SLAB")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_THIN_SLAB;
+    ++g_real_ctx;
     *out = c;
     return FG_OK;
 }
-int fg_ctx_destroy(fg_ctx* ctx) { delete ctx; return FG_OK; }
+int fg_ctx_destroy(fg_ctx* ctx) {
+    if (!ctx) return FG_OK;
+    if (ctx->device == FG_DEVICE_NONE) { if (--g_dry_ctx == 0) g_fg_dry = false; }
+    else --g_real_ctx;
+    delete ctx;
+    return FG_OK;
+}
 int fg_set_math(fg_ctx* ctx, int mode) {
     if (!ctx) return FG_ERR_INVALID;
     if (mode != 0 && mode != 6) return fg_set_err(ctx, FG_ERR_INVALID, "fg_set_math: mode %d (0 = fp32 MFMA, 6 = bf16x6)", mode);
@@ -119,23 +139,26 @@ const char* fg_last_error(const fg_ctx* ctx) { return ctx ? ctx->err : g_err; }
 int fg_stream_sync(fg_ctx* ctx) { NEED(ctx, ctx, "null ctx"); FG_HIP(ctx, hipStreamSynchronize(ctx->stream)); return FG_OK; }
 int fg_malloc(fg_ctx* ctx, size_t bytes, void** out) {
     NEED(ctx, ctx && out, "null argument");
-    if (hipMalloc(out, bytes) != hipSuccess) return fg_set_err(ctx, FG_ERR_NOMEM, "fg_malloc(%zu)", bytes);
+    if (fg_dev_alloc(out, bytes) != hipSuccess) return fg_set_err(ctx, FG_ERR_NOMEM, "fg_malloc(%zu)", bytes);
     return FG_OK;
 }
-int fg_free(fg_ctx* ctx, void* p) { NEED(ctx, ctx, "null ctx"); FG_HIP(ctx, hipFree(p)); return FG_OK; }
+int fg_free(fg_ctx* ctx, void* p) { NEED(ctx, ctx, "null ctx"); if (g_fg_dry) { free(p); return FG_OK; } FG_HIP(ctx, hipFree(p)); return FG_OK; }
 int fg_h2d(fg_ctx* ctx, void* d, const void* s, size_t n) {
     NEED(ctx, ctx && d && s, "null argument");
+    if (g_fg_dry) { memmove(d, s, n); return FG_OK; }
     FG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, ctx->stream));
     return FG_OK;
 }
 int fg_d2h(fg_ctx* ctx, void* d, const void* s, size_t n) {
     NEED(ctx, ctx && d && s, "null argument");
+    if (g_fg_dry) { memmove(d, s, n); return FG_OK; }
     FG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, ctx->stream));
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FG_OK;
 }
 int fg_d2d(fg_ctx* ctx, void* d, const void* s, size_t n) {
     NEED(ctx, ctx && d && s, "null argument");
+    if (g_fg_dry) { memmove(d, s, n); return FG_OK; }
     FG_HIP(ctx, hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, ctx->stream));
     return FG_OK;
 }
@@ -332,7 +355,7 @@ int fg_linear_backward_weight(fg_ctx* ctx, const float* x, const float* gy, floa
 }
 
 // ---------------------------------------------------------------- module-level pointwise
-long long fg_bn_scratch_floats(int c) { return (long long)3 * CR_ROWBLOCKS_MAX * c + 2 * c + 64; }
+long long fg_bn_scratch_floats(int c) { return (long long)5 * CR_ROWBLOCKS_MAX * c + 2 * c + 64; }   // 5 = BNB_PLANES (pointwise.hip)
 int fg_batchnorm_forward(fg_ctx* ctx, const float* x, float* y, long long rows, int c, const float* gamma,
                          const float* beta, const float* slope, float* save_mean, float* save_invstd, float* rmean,
                          float* rvar, float eps, float momentum, int train, float* scratch) {

@@ -46,13 +46,28 @@ struct FgProfScope {
 
 
 int fg_set_err(fg_ctx* c, int code, const char* fmt, ...);
+// Planning-only mode (fg_ctx_create(FG_DEVICE_NONE), include/facegen_hip.h): the process holds no HIP device.  Every kernel launch
+// and every HIP runtime call of the library becomes a no-op while ALL host-side control flow -- plan building, stage walks,
+// sync-BN pauses, bucket boundaries, the order / size / stream of every collective -- runs unchanged; "device" buffers are
+// host allocations nobody dereferences.  A process is either planning-only or real, never both.
+extern bool g_fg_dry;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                                            \
+    do { if (!g_fg_dry) hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__); } while (0)
 #define FG_HIP(ctx, call)                                                              \
     do {                                                                               \
+        if (g_fg_dry) break;                                                           \
         hipError_t e_ = (call);                                                        \
         if (e_ != hipSuccess)                                                          \
             return fg_set_err((ctx), FG_ERR_HIP, "%s: %s (%s:%d)", #call,              \
                               hipGetErrorString(e_), __FILE__, __LINE__);              \
     } while (0)
+// library-owned device allocations (packed weights, job tables): host memory in planning-only mode
+static inline hipError_t fg_dev_alloc(void** p, size_t bytes) {
+    if (g_fg_dry) { *p = calloc(1, bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+    return hipMalloc(p, bytes);
+}
+static inline void fg_dev_free(void* p) { if (g_fg_dry) free(p); else (void)hipFree(p); }
 #define FG_CHECK_LAUNCH(ctx) FG_HIP(ctx, hipGetLastError())
 
 static inline int fg_round_up(int x, int m) { return (x + m - 1) / m * m; }

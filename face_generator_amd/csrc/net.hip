@@ -110,7 +110,7 @@ static long long stage_scratch(const Stage& s, int B) {
     long long need = 4096;
     switch (s.kind) {
         case ST_CONV: { ConvGeom g = s.geom; g.B = B; need = fg_conv_scratch_floats(g); break; }
-        case ST_BNPRELU: need = (long long)3 * CR_ROWBLOCKS_MAX * s.oc + 2 * s.oc + 64; break;
+        case ST_BNPRELU: need = (long long)5 * CR_ROWBLOCKS_MAX * s.oc + 2 * s.oc + 64; break;    // 5 = BNB_PLANES (pointwise.hip)
         case ST_THIN_IN: case ST_THIN_OUT: {
             const int cw = s.kind == ST_THIN_IN ? s.oc : s.ic, cs = s.kind == ST_THIN_IN ? s.ic : s.oc;
             const long long na = (long long)s.geom.k * s.geom.k * cs;
@@ -641,8 +641,8 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
             }
         n->packed_total = tot;
         if (rc == FG_OK && tot > 0 &&
-            (hipMalloc((void**)&n->packed_all, tot * sizeof(float)) != hipSuccess ||
-             hipMalloc((void**)&n->planes_all, tot / 16 * 96) != hipSuccess))
+            (fg_dev_alloc((void**)&n->packed_all, tot * sizeof(float)) != hipSuccess ||
+             fg_dev_alloc((void**)&n->planes_all, tot / 16 * 96) != hipSuccess))
             rc = fg_set_err(ctx, FG_ERR_NOMEM, "fg_net_create: packed weights");
     }
     long long pk_off = 0;
@@ -653,10 +653,10 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
             long long nf = fg_geom_pack_floats(g, 0), nb = fg_geom_pack_floats(g, 1);
             s.wp_fwd = n->packed_all + pk_off; s.wp_fwd6 = n->planes_all + pk_off / 16 * 96; pk_off += nf;
             s.wp_bwd = n->packed_all + pk_off; s.wp_bwd6 = n->planes_all + pk_off / 16 * 96; pk_off += nb;
-            if (rc == FG_OK && g.o_hw > 1 && hipMalloc((void**)&s.bias_packed, s.b_n * sizeof(float)) != hipSuccess)
+            if (rc == FG_OK && g.o_hw > 1 && fg_dev_alloc((void**)&s.bias_packed, s.b_n * sizeof(float)) != hipSuccess)
                 rc = fg_set_err(ctx, FG_ERR_NOMEM, "fg_net_create: packed bias");
         } else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT) {
-            if (hipMalloc((void**)&s.wp_fwd, s.w_n * sizeof(float)) != hipSuccess)
+            if (fg_dev_alloc((void**)&s.wp_fwd, s.w_n * sizeof(float)) != hipSuccess)
                 rc = fg_set_err(ctx, FG_ERR_NOMEM, "fg_net_create: packed weights");
         }
     }
@@ -669,12 +669,12 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
 int fg_net_destroy(fg_net* n) {
     if (!n) return FG_OK;
     for (auto& s : n->st) {
-        if (s.kind != ST_CONV && s.wp_fwd) (void)hipFree(s.wp_fwd);
-        if (s.bias_packed) (void)hipFree(s.bias_packed);
+        if (s.kind != ST_CONV && s.wp_fwd) fg_dev_free(s.wp_fwd);
+        if (s.bias_packed) fg_dev_free(s.bias_packed);
     }
-    if (n->packed_all) (void)hipFree(n->packed_all);
-    if (n->planes_all) (void)hipFree(n->planes_all);
-    if (n->jobs_dev) (void)hipFree(n->jobs_dev);
+    if (n->packed_all) fg_dev_free(n->packed_all);
+    if (n->planes_all) fg_dev_free(n->planes_all);
+    if (n->jobs_dev) fg_dev_free(n->jobs_dev);
     delete n;
     return FG_OK;
 }
@@ -794,7 +794,7 @@ static int build_pack_jobs(fg_net* n) {
     n->n_jobs = (int)jobs.size();
     n->jobs_total = start;
     if (jobs.empty()) return FG_OK;
-    if (hipMalloc((void**)&n->jobs_dev, jobs.size() * sizeof(PackJob)) != hipSuccess)
+    if (fg_dev_alloc((void**)&n->jobs_dev, jobs.size() * sizeof(PackJob)) != hipSuccess)
         return fg_set_err(n->ctx, FG_ERR_NOMEM, "fg_net_create: pack jobs");
     FG_HIP(n->ctx, hipMemcpy(n->jobs_dev, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
     return FG_OK;

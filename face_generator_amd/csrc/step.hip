@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <string.h>
 #include <rccl/rccl.h>      // types and enums only: the library is bound with dlopen/dlsym (see rccl_bind)
+#include <vector>
 
 // ---------------------------------------------------------------------------------------------------------------------
 // adversarial.approxParzen (adversarial_c2f.lua:305-344): distance of the ground-truth fine image to each generation
@@ -83,10 +84,14 @@ static int rccl_bind(fg_ctx* ctx) {
     return FG_OK;
 }
 
+struct CommOp { char op; char dtype; char stream; size_t count; };     // op a/b/w, dtype f/d/i/-, stream c/s
 struct fg_comm {
     fg_ctx* ctx = nullptr;
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    bool dry = false;                  // fg_comm_create_dry: no transport, the schedule is all there is
+    bool trace = false;                // fg_comm_set_trace
+    std::vector<CommOp> ops;
     hipStream_t side = nullptr;        // the exchange runs here, ordered against the compute stream with events
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     int pending = 0;                   // all-reduces issued on `side` since the last fg_comm_wait
@@ -152,8 +157,37 @@ int fg_comm_create(fg_ctx* ctx, const char* id, size_t len, int rank, int world,
     return FG_OK;
 }
 
+int fg_comm_create_dry(fg_ctx* ctx, int rank, int world, fg_comm** out) {
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world) return fg_set_err(ctx, FG_ERR_INVALID, "fg_comm_create_dry: bad argument");
+    fg_comm* c = new fg_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->dry = true; c->trace = true;
+    *out = c;
+    return FG_OK;
+}
+int fg_comm_set_trace(fg_comm* c, int on) {
+    if (!c) return FG_ERR_INVALID;
+    c->trace = on != 0 || c->dry;
+    return FG_OK;
+}
+int fg_comm_schedule(fg_comm* c, char* buf, size_t len, int reset) {
+    if (!c || !buf || len == 0) return fg_set_err(c ? c->ctx : nullptr, FG_ERR_INVALID, "fg_comm_schedule: bad argument");
+    size_t off = 0;
+    buf[0] = 0;
+    int seq = 0;
+    for (const CommOp& o : c->ops) {
+        const char* op = o.op == 'a' ? "allreduce" : o.op == 'b' ? "broadcast" : "wait";
+        const char* dt = o.dtype == 'f' ? "f32" : o.dtype == 'd' ? "f64" : o.dtype == 'i' ? "i32" : "-";
+        int n = snprintf(buf + off, len - off, "%d %s %s %zu %s\n", seq++, op, dt, o.count, o.stream == 's' ? "side" : "compute");
+        if (n < 0 || (size_t)n >= len - off) return fg_set_err(c->ctx, FG_ERR_WORKSPACE, "fg_comm_schedule: buffer of %zu bytes too small", len);
+        off += n;
+    }
+    if (reset) c->ops.clear();
+    return FG_OK;
+}
+
 int fg_comm_destroy(fg_comm* c) {
     if (!c) return FG_OK;
+    if (c->dry) { delete c; return FG_OK; }
     if (c->side) { (void)hipStreamSynchronize(c->side); }
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
@@ -171,6 +205,8 @@ static int allreduce_typed(fg_comm* c, void* buf, size_t n, ncclDataType_t dt, i
     if (!c || !buf) return fg_set_err(c ? c->ctx : nullptr, FG_ERR_INVALID, "fg_allreduce: null argument");
     if (n == 0) return FG_OK;
     fg_ctx* ctx = c->ctx;
+    if (c->trace) c->ops.push_back(CommOp{'a', dt == ncclFloat32 ? 'f' : dt == ncclFloat64 ? 'd' : 'i', async ? 's' : 'c', n});
+    if (c->dry) { if (async) c->pending++; return FG_OK; }
     if (!async) {
         FG_NCCL(c, g_rccl.AllReduce(buf, buf, n, dt, ncclSum, c->comm, ctx->stream));
         return FG_OK;
@@ -192,6 +228,8 @@ int fg_allreduce_sum_i32(fg_comm* c, int* buf, size_t n) { return allreduce_type
 int fg_comm_wait(fg_comm* c) {
     if (!c) return FG_ERR_INVALID;
     if (!c->pending) return FG_OK;
+    if (c->trace) c->ops.push_back(CommOp{'w', '-', 'c', (size_t)c->pending});
+    if (c->dry) { c->pending = 0; return FG_OK; }
     FG_HIP(c->ctx, hipEventRecord(c->ev_done, c->side));
     FG_HIP(c->ctx, hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0));
     c->pending = 0;
@@ -201,6 +239,8 @@ int fg_comm_wait(fg_comm* c) {
 int fg_broadcast(fg_comm* c, float* buf, size_t n, int root) {
     if (!c || !buf || root < 0 || root >= c->world) return fg_set_err(c ? c->ctx : nullptr, FG_ERR_INVALID, "fg_broadcast: bad argument");
     if (n == 0) return FG_OK;
+    if (c->trace) c->ops.push_back(CommOp{'b', 'f', 'c', n});
+    if (c->dry) return FG_OK;
     FG_NCCL(c, g_rccl.Broadcast(buf, buf, n, ncclFloat32, root, c->comm, c->ctx->stream));
     return FG_OK;
 }
@@ -458,8 +498,8 @@ int fg_gan_create(fg_ctx* ctx, fg_net* G, fg_net* D, int table_inputs, int max_b
         gan_layout(g);
         if ((size_t)g->total * sizeof(float) > ws_bytes) rc = fg_set_err(ctx, FG_ERR_WORKSPACE, "fg_gan_create: workspace %zu < %lld bytes", ws_bytes, g->total * 4LL);
     }
-    if (!rc && hipMemsetAsync(g->ws + g->o_opt[0], 0, (size_t)(2 * g->nP[0]) * 4, ctx->stream) != hipSuccess) rc = fg_set_err(ctx, FG_ERR_HIP, "fg_gan_create: memset");
-    if (!rc && hipMemsetAsync(g->ws + g->o_opt[1], 0, (size_t)(2 * g->nP[1]) * 4, ctx->stream) != hipSuccess) rc = fg_set_err(ctx, FG_ERR_HIP, "fg_gan_create: memset");
+    if (!rc && !g_fg_dry && hipMemsetAsync(g->ws + g->o_opt[0], 0, (size_t)(2 * g->nP[0]) * 4, ctx->stream) != hipSuccess) rc = fg_set_err(ctx, FG_ERR_HIP, "fg_gan_create: memset");
+    if (!rc && !g_fg_dry && hipMemsetAsync(g->ws + g->o_opt[1], 0, (size_t)(2 * g->nP[1]) * 4, ctx->stream) != hipSuccess) rc = fg_set_err(ctx, FG_ERR_HIP, "fg_gan_create: memset");
     if (rc) { delete g; return rc; }
     gan_buckets(g, 900000);
     *out = g;

@@ -137,6 +137,27 @@ class FgCollective(Collective):
             self.h = None
 
 
+class DryCollective(FgCollective):
+    """fg_comm_create_dry: rank `rank` of a `world`-rank job with NO transport underneath -- every collective the step entries
+    would issue is recorded (order, dtype, count, stream) and skipped.  With a planning-only context (runtime.get_context(-1))
+    not even a GPU is needed: bench.py --dry-collective walks fg_step_D / fg_step_G's exchange path for every rank of an N-GPU
+    job in one process and checks that all ranks issue the same schedule (a mismatch would be a hang on the hardware)."""
+
+    def __init__(self, ctx, rank, world):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.world, self.rank = world, rank
+        h = ctypes.c_void_p()
+        ctx.check(self.lib.fg_comm_create_dry(ctx.h, rank, world, ctypes.byref(h)))
+        self.h = h
+        self.name = "fg_comm (dry: schedule only, rank %d of %d)" % (rank, world)
+
+    def schedule(self, reset=True):
+        """-> list of "<seq> <op> <dtype> <count> <stream>" lines since the last reset."""
+        buf = ctypes.create_string_buffer(1 << 20)
+        self.ctx.check(self.lib.fg_comm_schedule(self.h, buf, len(buf), 1 if reset else 0))
+        return buf.value.decode().splitlines()
+
+
 def as_collective(d):
     """Trainer argument -> Collective: None (single process), a Collective, or the torch.distributed module."""
     if d is None:

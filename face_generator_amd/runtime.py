@@ -17,6 +17,19 @@ class Context:
     """fg_ctx bound to one HIP device; launches go to torch's current stream of that device."""
 
     def __init__(self, device=0):
+        self.dry = device == -1
+        if self.dry:
+            # FG_DEVICE_NONE (include/facegen_hip.h): a PLANNING-ONLY context.  No kernel runs and nothing is computed -- this is
+            # not a CPU path -- but every host-side decision of the library (plans, stage walks, sync-BN pauses, gradient buckets,
+            # the collective schedule) is taken as on the GPU.  "Device" tensors are host tensors whose contents nobody reads.
+            self.lib = _lib.load_library()
+            self.device = torch.device("cpu")
+            h = ctypes.c_void_p()
+            rc = self.lib.fg_ctx_create(-1, ctypes.byref(h))
+            if rc != 0:
+                raise FgError("fg_ctx_create: %s" % self.lib.fg_last_error(None).decode())
+            self.h = h
+            return
         if not torch.cuda.is_available():
             raise FgError("no HIP device visible: the face_generator_amd compute path needs an MI355X "
                           "(there is no CPU fallback)")
@@ -54,6 +67,8 @@ class Context:
         return self.lib.fg_get_fusion(self.h)
 
     def empty(self, *shape):
+        if self.dry:
+            return torch.zeros(*shape, dtype=torch.float32)          # planning-only: deterministic "results" (all zero)
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
 
     def zeros(self, *shape):
@@ -99,8 +114,9 @@ class Context:
 
 
 def get_context(device=None):
+    """device = -1: the planning-only context (a process holds either that one or real ones)."""
     if device is None:
-        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        device = -1 if -1 in _CTX else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
     if device not in _CTX:
         _CTX[device] = Context(device)
     return _CTX[device]
@@ -425,7 +441,7 @@ class FusedGan:
         dnG.reserve(self.max_batch)
         dnD.reserve(self.max_batch)
         nbytes = self.lib.fg_gan_workspace_bytes(dnG.h, dnD.h, self.table, self.max_batch)
-        self.ws = torch.empty((nbytes + 3) // 4 + 64, dtype=torch.float32, device=ctx.device)
+        self.ws = (torch.zeros if ctx.dry else torch.empty)((nbytes + 3) // 4 + 64, dtype=torch.float32, device=ctx.device)
         base = self.ws.data_ptr()
         self._skip = ((-base) % 256) // 4                       # 256-byte aligned start inside the tensor
         h = ctypes.c_void_p()

@@ -63,7 +63,13 @@ enum {
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);
 
-/* ---- context / memory (replaces cutorch.setDevice / cutorch streams, train.lua:79-80) ---- */
+/* ---- context / memory (replaces cutorch.setDevice / cutorch streams, train.lua:79-80) ----
+ * fg_ctx_create(FG_DEVICE_NONE, ...) makes a PLANNING-ONLY context: the process needs no HIP device, no kernel is launched and no
+ * HIP runtime call is made, while every host-side decision of the library -- plan building, stage walks, sync-BN pauses, gradient
+ * buckets, and the order / size / stream of every collective a step issues (fg_comm_create_dry + fg_comm_schedule) -- runs
+ * unchanged.  Device pointers are then opaque tokens (host allocations of the right size that nothing dereferences); fg_malloc
+ * returns host memory, fg_h2d / fg_d2h / fg_d2d are plain copies.  A process holds either planning-only contexts or real ones. */
+enum { FG_DEVICE_NONE = -1 };
 int fg_ctx_create(int device, fg_ctx** out);
 int fg_ctx_destroy(fg_ctx* ctx);
 int fg_ctx_set_stream(fg_ctx* ctx, void* hip_stream); /* NULL = default stream */
@@ -212,6 +218,16 @@ int fg_comm_wait(fg_comm* comm);
 int fg_allreduce_sum_f64(fg_comm* comm, double* buf, size_t n);   /* sync-BN sums */
 int fg_allreduce_sum_i32(fg_comm* comm, int* buf, size_t n);      /* confusion counts of the global batch */
 int fg_broadcast(fg_comm* comm, float* buf, size_t n, int root);  /* identical initial replicas */
+/* The collective schedule.  fg_comm_set_trace(comm, 1) records every exchange call made on the communicator from then on;
+ * fg_comm_schedule writes one line per call, "<seq> <op> <dtype> <count> <stream>" -- op allreduce / broadcast / wait, stream
+ * "compute" (the context's stream) or "side" (the communicator's own) -- and optionally clears the record.  Every rank of a job
+ * must produce the same text: a mismatch is a hang on real hardware.
+ * fg_comm_create_dry builds a communicator of `world` ranks with NO transport underneath: its collectives are recorded (tracing is
+ * on from the start) and otherwise skipped, so one process -- with a planning-only context not even a GPU -- can walk the exact
+ * exchange path rank `rank` of an N-GPU job takes inside fg_step_D / fg_step_G (bench.py --dry-collective). */
+int fg_comm_create_dry(fg_ctx* ctx, int rank, int world, fg_comm** out);
+int fg_comm_set_trace(fg_comm* comm, int on);
+int fg_comm_schedule(fg_comm* comm, char* buf, size_t len, int reset);
 
 /* ---- step level (SURVEY.md 8(b) level (ii)): the two closures of the training loop as device-resident entries.
  *      fg_step_D = adversarial.lua:240-268 (batch assembly: B/2 real || B/2 fakes from G in TRAIN mode) + fevalD (:83-179:

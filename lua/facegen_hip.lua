@@ -33,6 +33,7 @@ int fg_get_math(fg_ctx* ctx);
 enum { FG_FUSE_PRELU = 1, FG_FUSE_THIN_SLAB = 2, FG_FUSE_ALL = 3 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);
+enum { FG_DEVICE_NONE = -1 };
 int fg_ctx_create(int device, fg_ctx** out);
 int fg_ctx_destroy(fg_ctx* ctx);
 int fg_ctx_set_stream(fg_ctx* ctx, void* hip_stream);
@@ -102,6 +103,9 @@ int fg_comm_wait(fg_comm* comm);
 int fg_allreduce_sum_f64(fg_comm* comm, double* buf, size_t n);
 int fg_allreduce_sum_i32(fg_comm* comm, int* buf, size_t n);
 int fg_broadcast(fg_comm* comm, float* buf, size_t n, int root);
+int fg_comm_create_dry(fg_ctx* ctx, int rank, int world, fg_comm** out);
+int fg_comm_set_trace(fg_comm* comm, int on);
+int fg_comm_schedule(fg_comm* comm, char* buf, size_t len, int reset);
 enum { FG_STEP_NO_UPDATE = 1 };
 enum fg_gan_buffer_id { FG_GAN_D_INPUT = 0, FG_GAN_NOISE = 1, FG_GAN_D_GRAD_INPUT = 2, FG_GAN_LOSS = 3, FG_GAN_CONFUSION = 4, FG_GAN_OPT_STATE_D = 5, FG_GAN_OPT_STATE_G = 6, FG_GAN_D_OUTPUT = 7, FG_GAN_D_MASKS = 8, FG_GAN_SYNC_BUF = 9 };
 size_t fg_gan_workspace_bytes(const fg_net* G, const fg_net* D, int table_inputs, int max_batch);

@@ -80,3 +80,90 @@ def test_shard_and_scale_single_process():
     assert D.shard(t, 1, 3).tolist() == [[4, 5], [6, 7]]
     assert D.grad_scale() == 1.0
     assert D.allreduce_sum_(torch.ones(3)).tolist() == [1, 1, 1]
+
+
+def _dry(cmd_prefix, gpus, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = cmd_prefix + [os.path.join(root, "bench.py"), "--gpus", str(gpus), "--dry-collective"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, **(env or {})))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def _check_schedule(j, world):
+    """What fg_step_D / fg_step_G must issue, per combination (csrc/step.hip): D's flat gradient (2 863 239 floats) once per
+    update -- on the side stream when overlapped, never when the gate holds the update --, G's (2 470 406) whole or in buckets that
+    add up to it, the gate's global confusion counts (4 x int32) only when a gate is given, and with sync-BN one fp64 exchange of
+    2C + 1 sums per BatchNorm pass of G (C = 256, 128: three forwards -- B/2 fakes, B samples -- and one backward each)."""
+    assert j["ranks_agree"] is True and j["ranks_walked"] == list(range(world)) and len(j["schedule"]) == 12
+    nD, nG = 2863239, 2470406
+    for name, lines in j["schedule"].items():
+        ops = [l.split() for l in lines]
+        f32 = [(int(o[3]), o[4]) for o in ops if o[1] == "allreduce" and o[2] == "f32"]
+        f64 = [int(o[3]) for o in ops if o[2] == "f64"]
+        i32 = [int(o[3]) for o in ops if o[2] == "i32"]
+        overlap, sync, gate = "overlap=1" in name, "sync_bn=1" in name, name.split()[0].split("=")[1]
+        d_red = [x for x in f32 if x[0] == nD]
+        g_red = [x for x in f32 if x[0] != nD]
+        assert len(d_red) == (0 if gate == "hold" else 1), (name, lines)
+        assert sum(n for n, _ in g_red) == nG, (name, lines)
+        if d_red:
+            assert d_red[0][1] == ("side" if overlap else "compute"), (name, lines)
+        assert all(st == ("side" if overlap else "compute") for _, st in g_red), (name, lines)
+        assert (len(g_red) > 1) == overlap, (name, lines)                     # bucketed under the backward only when overlapped
+        assert i32 == ([] if gate == "none" else [4]), (name, lines)
+        assert f64 == ([513, 257, 513, 257, 257, 513] if sync else []), (name, lines)
+        waits = [o for o in ops if o[1] == "wait"]
+        assert len(waits) == ((1 if d_red else 0) + 1 if overlap else 0), (name, lines)
+
+
+@pytest.mark.timeout(600)
+def test_dry_collective_schedule_is_identical_on_every_rank_gloo_world_2():
+    """two real processes (torch.distributed.run, gloo, no GPU) each walk their own rank of a 2-GPU job through
+    the library's step entries with planning-only contexts; rank 0 gathers and compares the schedules for
+    {gate none / passes / holds} x {sync_bn} x {overlap}."""
+    import sys
+    j = _dry([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", str(_free_port())], 2)
+    _check_schedule(j, 2)
+
+
+@pytest.mark.timeout(600)
+def test_dry_collective_schedule_eight_ranks_in_one_process():
+    import sys
+    _check_schedule(_dry([sys.executable], 8), 8)
+
+
+def test_planning_only_context_excludes_device_contexts():
+    """include/facegen_hip.h: a process holds either planning-only contexts or real ones; host 'device' buffers are plain memory."""
+    import ctypes
+    from face_generator_amd import _lib
+    lib = _lib.load_library()
+    h = ctypes.c_void_p()
+    if lib.fg_ctx_create(-1, ctypes.byref(h)) != 0:
+        assert b"device context" in lib.fg_last_error(None)
+        pytest.skip("this process already holds a device context")
+    try:
+        h2 = ctypes.c_void_p()
+        assert lib.fg_ctx_create(0, ctypes.byref(h2)) < 0 and b"planning-only" in lib.fg_last_error(None)
+        p = ctypes.c_void_p()
+        assert lib.fg_malloc(h, 64, ctypes.byref(p)) == 0
+        src = (ctypes.c_float * 4)(1, 2, 3, 4)
+        dst = (ctypes.c_float * 4)()
+        assert lib.fg_h2d(h, p, src, 16) == 0 and lib.fg_d2h(h, dst, p, 16) == 0 and list(dst) == [1, 2, 3, 4]
+        assert lib.fg_fill(h, p, 7.0, 4) == 0                                  # a launch: skipped, not an error
+        assert lib.fg_free(h, p) == 0
+        c = ctypes.c_void_p()
+        assert lib.fg_comm_create_dry(h, 1, 4, ctypes.byref(c)) == 0 and lib.fg_comm_world(c) == 4 and lib.fg_comm_rank(c) == 1
+        assert lib.fg_allreduce_sum_async(c, p, 10) == 0 and lib.fg_comm_wait(c) == 0 and lib.fg_allreduce_sum_i32(c, p, 4) == 0
+        buf = ctypes.create_string_buffer(256)
+        assert lib.fg_comm_schedule(c, buf, 256, 1) == 0
+        assert buf.value.decode().splitlines() == ["0 allreduce f32 10 side", "1 wait - 1 compute", "2 allreduce i32 4 compute"]
+        assert lib.fg_comm_destroy(c) == 0
+    finally:
+        lib.fg_ctx_destroy(h)

@@ -357,7 +357,9 @@ def c2f_full_batch_steps(ctx, B, d_iterations, seed):
     assert_flips_bounded(name + " G", None, ch.flips["G"], ch.units["G"])
     close(nchw(got["samples"]), ref["samples"], atol=2e-5 * max(1, np.abs(ref["samples"]).max()), what=name + " samples")
     close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what=name + " D outputs")
-    assert abs(got["loss"].item() - ref["f_bce"]) <= 1e-5 * abs(ref["f_bce"])
+    # the G-step's criterion is -mean log(p) with every p close to 1 once D is confident: f itself is ~1e-4 and an fp32 p near 1
+    # is only resolved to 6e-8, so the relative bar gets one fp32 ulp of a probability as its absolute floor
+    assert abs(got["loss"].item() - ref["f_bce"]) <= 1e-5 * abs(ref["f_bce"]) + 6e-8
     gG = got["grad"].cpu().numpy()
     close(gG, ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what=name + " flat gradient")
     check_every_tensor(name, gG, st.G, prelu_rtol=1e-3 if ctx.get_math() == 6 else 0.0)
