@@ -524,8 +524,8 @@ int fg_launch_bn_forward_sync2(fg_ctx* ctx, const BnArgs& a, const double* sync)
 // backward: dz = PReLU'(z) * gy with z = gamma*xhat + beta; sums: S_dz, S_dz_xhat per channel, S_slope global.
 // S_dz / M and S_dz_xhat / M come back into EVERY element of the input gradient (bn_bwd_apply_kernel): an error in them is
 // coherent over the channel and does not average out in the weight-gradient reductions of the layers in front -- with fp32
-// partial sums the flat gradient of G's first Linear was 2e-4 (relative to its scale) from the float64 oracle at B = 128,
-// where the fp32 oracle is at 5e-7 (tests/test_gpu_baseline_sizes.py, round 3).  So these two sums are carried in DOUBLE from
+// partial sums the flat gradient of G's first Linear was 2e-4 (relative to its scale) from a float64 evaluation at B = 128,
+// where a plain fp32 evaluation is at 5e-7 (tests/test_gpu_baseline_sizes.py, round 3).  So these two sums are carried in DOUBLE from
 // the first addend on and leave the block as (hi, lo) float pairs: planes [S_dz hi | S_dz_xhat hi | S_slope | S_dz lo |
 // S_dz_xhat lo] x [nrb][C].  The kernel stays HBM-bound (two 16-byte loads per 12 double operations).
 #define BNB_PLANES 5
