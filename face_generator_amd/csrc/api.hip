@@ -355,7 +355,7 @@ int fg_linear_backward_weight(fg_ctx* ctx, const float* x, const float* gy, floa
 }
 
 // ---------------------------------------------------------------- module-level pointwise
-long long fg_bn_scratch_floats(int c) { return (long long)5 * CR_ROWBLOCKS_MAX * c + 2 * c + 64; }   // 5 = BNB_PLANES (pointwise.hip)
+long long fg_bn_scratch_floats(int c) { return (long long)3 * CR_ROWBLOCKS_MAX * c + 2 * c + 64; }
 int fg_batchnorm_forward(fg_ctx* ctx, const float* x, float* y, long long rows, int c, const float* gamma,
                          const float* beta, const float* slope, float* save_mean, float* save_invstd, float* rmean,
                          float* rvar, float eps, float momentum, int train, float* scratch) {

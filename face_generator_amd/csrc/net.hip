@@ -110,7 +110,7 @@ static long long stage_scratch(const Stage& s, int B) {
     long long need = 4096;
     switch (s.kind) {
         case ST_CONV: { ConvGeom g = s.geom; g.B = B; need = fg_conv_scratch_floats(g); break; }
-        case ST_BNPRELU: need = (long long)5 * CR_ROWBLOCKS_MAX * s.oc + 2 * s.oc + 64; break;    // 5 = BNB_PLANES (pointwise.hip)
+        case ST_BNPRELU: need = (long long)3 * CR_ROWBLOCKS_MAX * s.oc + 2 * s.oc + 64; break;
         case ST_THIN_IN: case ST_THIN_OUT: {
             const int cw = s.kind == ST_THIN_IN ? s.oc : s.ic, cs = s.kind == ST_THIN_IN ? s.ic : s.oc;
             const long long na = (long long)s.geom.k * s.geom.k * cs;

@@ -521,55 +521,23 @@ int fg_launch_bn_forward_sync2(fg_ctx* ctx, const BnArgs& a, const double* sync)
     return FG_OK;
 }
 
-// backward: dz = PReLU'(z) * gy with z = gamma*xhat + beta; sums: S_dz, S_dz_xhat per channel, S_slope global.
-// S_dz / M and S_dz_xhat / M come back into EVERY element of the input gradient (bn_bwd_apply_kernel): an error in them is
-// coherent over the channel and does not average out in the weight-gradient reductions of the layers in front -- with fp32
-// partial sums the flat gradient of G's first Linear was 2e-4 (relative to its scale) from a float64 evaluation at B = 128,
-// where a plain fp32 evaluation is at 5e-7 (tests/test_gpu_baseline_sizes.py, round 3).  So these two sums are carried in DOUBLE from
-// the first addend on and leave the block as (hi, lo) float pairs: planes [S_dz hi | S_dz_xhat hi | S_slope | S_dz lo |
-// S_dz_xhat lo] x [nrb][C].  The kernel stays HBM-bound (two 16-byte loads per 12 double operations).
-#define BNB_PLANES 5
-__device__ __forceinline__ void bnb_store_pair(float* __restrict__ part, int k, int nrb, int C, int c, double t) {
-    const float hi = (float)t;
-    part[((size_t)k * nrb + blockIdx.x) * C + c] = hi;
-    part[((size_t)(3 + k) * nrb + blockIdx.x) * C + c] = (float)(t - (double)hi);
-}
+// backward: dz = PReLU'(z) * gy with z = gamma*xhat + beta; sums: S_dz, S_dz_xhat per channel, S_slope global
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                              long long M, int C, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              const float* __restrict__ slope,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, float* __restrict__ part) {
-    __shared__ double sh[3][4][64];
     const float a = slope ? slope[0] : 1.f;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.y * 64 + tx;
-    const int nrb = gridDim.x;
-    const long long rows_per = (M + nrb - 1) / nrb;
-    const long long r0 = blockIdx.x * rows_per;
-    const long long r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
-    double acc[3] = {0.0, 0.0, 0.0};
-    if (c < C)
-        for (long long r = r0 + ty; r < r1; r += 4) {
-            const float xh = bn_xhat(x[r * C + c], mean[c], invstd[c]);
-            const float z = __fadd_rn(__fmul_rn(xh, gamma[c]), beta[c]);
-            const float g = gy[r * C + c];
-            const float dz = z > 0.f ? g : a * g;
-            acc[0] += (double)dz;
-            acc[1] = fma((double)dz, (double)xh, acc[1]);
-            if (!(z > 0.f)) acc[2] = fma((double)z, (double)g, acc[2]);
-        }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) sh[k][ty][tx] = acc[k];
-    __syncthreads();
-    if (ty == 0 && c < C) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double t = (sh[k][0][tx] + sh[k][1][tx]) + (sh[k][2][tx] + sh[k][3][tx]);
-            if (k < 2) bnb_store_pair(part, k, nrb, C, c, t);
-            else part[((size_t)2 * nrb + blockIdx.x) * C + c] = (float)t;
-        }
-    }
+    colreduce_body<3>(M, C, part, [&](long long r, int c, float* acc) {
+        const float xh = bn_xhat(x[r * C + c], mean[c], invstd[c]);
+        const float z = __fadd_rn(__fmul_rn(xh, gamma[c]), beta[c]);
+        const float g = gy[r * C + c];
+        const float dz = z > 0.f ? g : a * g;
+        acc[0] += dz;
+        acc[1] = fmaf(dz, xh, acc[1]);
+        if (!(z > 0.f)) acc[2] = fmaf(z, g, acc[2]);
+    });
 }
 __global__ __launch_bounds__(CR4_NT) void bn_bwd4_partial_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                               long long M, int C, const float* __restrict__ gamma,
@@ -577,62 +545,34 @@ __global__ __launch_bounds__(CR4_NT) void bn_bwd4_partial_kernel(const float* __
                                                               const float* __restrict__ slope,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* __restrict__ part) {
-    __shared__ double sh[CR4_NT][4];          // 32 KB, one sum at a time
     const float a = slope ? slope[0] : 1.f;
-    const int c4n = C >> 2;
-    const int cx = threadIdx.x % c4n, ry = threadIdx.x / c4n, RY = CR4_NT / c4n;
-    const int cq = cx * 4;
+    const int cq = (threadIdx.x % (C >> 2)) * 4;
     const float4 mu = *(const float4*)(mean + cq), is = *(const float4*)(invstd + cq);
     const float4 g4 = *(const float4*)(gamma + cq), b4 = *(const float4*)(beta + cq);
-    const int nrb = gridDim.x;
-    const long long rows_per = (M + nrb - 1) / nrb;
-    const long long r0 = blockIdx.x * rows_per;
-    const long long r1 = (r0 + rows_per < M) ? r0 + rows_per : M;
-    double acc[3][4];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[k][j] = 0.0;
-    for (long long r = r0 + ry; r < r1; r += RY) {
+    colreduce4_body<3>(M, C, part, [&](long long r, int cx, float4* acc) {
         const float4 xv = *((const float4*)(x + r * C) + cx), gv = *((const float4*)(gy + r * C) + cx);
-#define FG_BNB(f, j)                                                                    \
+#define FG_BNB(f)                                                                       \
         {                                                                               \
             const float xh = bn_xhat(xv.f, mu.f, is.f);                                 \
             const float z = __fadd_rn(__fmul_rn(xh, g4.f), b4.f);                       \
             const float dz = z > 0.f ? gv.f : a * gv.f;                                 \
-            acc[0][j] += (double)dz;                                                    \
-            acc[1][j] = fma((double)dz, (double)xh, acc[1][j]);                         \
-            if (!(z > 0.f)) acc[2][j] = fma((double)z, (double)gv.f, acc[2][j]);        \
+            acc[0].f += dz;                                                             \
+            acc[1].f = fmaf(dz, xh, acc[1].f);                                          \
+            if (!(z > 0.f)) acc[2].f = fmaf(z, gv.f, acc[2].f);                         \
         }
-        FG_BNB(x, 0) FG_BNB(y, 1) FG_BNB(z, 2) FG_BNB(w, 3)
+        FG_BNB(x) FG_BNB(y) FG_BNB(z) FG_BNB(w)
 #undef FG_BNB
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sh[threadIdx.x][j] = acc[k][j];
-        __syncthreads();
-        if (ry == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                double t = sh[cx][j];
-                for (int q = 1; q < RY; ++q) t += sh[q * c4n + cx][j];
-                if (k < 2) bnb_store_pair(part, k, nrb, C, cq + j, t);
-                else part[((size_t)2 * nrb + blockIdx.x) * C + cq + j] = (float)t;
-            }
-        }
-        __syncthreads();
-    }
+    });
 }
-// scratch layout: part[BNB_PLANES][nrb][C], then coef[2][C], then slope_part[ceil(C/16)]
+// scratch layout: part[3][nrb][C], then coef[2][C], then slope_part[ceil(C/16)]
 // (when slope_part is given every block also leaves the sum of ITS 16 channels' PReLU-slope partials there; the few block
 // values are finished by the batched deferred final of the backward pass, or by scalar_final_kernel)
 __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const float* __restrict__ part, int nrb, long long M, int C,
                                                             float* __restrict__ coef, float* __restrict__ ggamma,
                                                             float* __restrict__ gbeta, float acc, float* __restrict__ slope_part) {
-    double s[BNB_PLANES];
-    bn_final_sums<BNB_PLANES>(part, nrb, C, s);
-    s[0] += s[3]; s[1] += s[4];             // (hi, lo) pairs of the two sums that feed back into the input gradient
+    double s[3];
+    if (slope_part) bn_final_sums<3>(part, nrb, C, s);
+    else { double t[2]; bn_final_sums<2>(part, nrb, C, t); s[0] = t[0]; s[1] = t[1]; s[2] = 0.0; }
     if (threadIdx.x >= 64) return;
     const int c = blockIdx.x * 16 + threadIdx.x;
     const bool own = threadIdx.x < 16 && c < C;
@@ -700,8 +640,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_sync_local_kernel(const float* __
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
         for (int b = ty; b < nrb; b += 16) {
-            s1 += (double)part[(size_t)b * C + c] + (double)part[((size_t)3 * nrb + b) * C + c];
-            s2 += (double)part[((size_t)nrb + b) * C + c] + (double)part[((size_t)4 * nrb + b) * C + c];
+            s1 += (double)part[(size_t)b * C + c];
+            s2 += (double)part[((size_t)nrb + b) * C + c];
         }
     sh[0][ty][tx] = s1; sh[1][ty][tx] = s2;
     __syncthreads();
@@ -744,7 +684,7 @@ int fg_launch_bn_backward_sync1(fg_ctx* ctx, const BnBwdArgs& a, double* sync) {
 }
 int fg_launch_bn_backward_sync2(fg_ctx* ctx, const BnBwdArgs& a, const double* sync) {
     const int nrb = cr_rowblocks(a.M);
-    float* coef = a.scratch + (size_t)BNB_PLANES * nrb * a.C;
+    float* coef = a.scratch + (size_t)3 * nrb * a.C;
     hipLaunchKernelGGL(bn_bwd_sync_global_kernel, dim3(fg_cdiv(a.C, 256)), dim3(256), 0, ctx->stream, sync, a.C, coef);
     FG_CHECK_LAUNCH(ctx);
     if (a.gx) {
@@ -761,7 +701,7 @@ int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
     const int nrb = cr_rowblocks(a.M);
     const int ncb = fg_cdiv(a.C, 64);
     float* part = a.scratch;
-    float* coef = a.scratch + (size_t)BNB_PLANES * nrb * a.C;
+    float* coef = a.scratch + (size_t)3 * nrb * a.C;
     if (cr4_ok(a.C))
         hipLaunchKernelGGL(bn_bwd4_partial_kernel, dim3(nrb), dim3(CR4_NT), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
                            a.beta, a.slope, a.mean, a.invstd, part);

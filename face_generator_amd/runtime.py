@@ -137,8 +137,6 @@ class DeviceNet:
     """An nn.Sequential compiled by fg_net_create, with its flat parameter / gradient vectors
     (== Module:getParameters(), train.lua:151-152), BN running stats and workspace as torch device tensors."""
 
-    _ordinal = 0
-
     def __init__(self, ctx, layers, in_dims, max_batch, params=None, grads=None):
         """params / grads: optional slices of a larger flat vector shared by several nets (nn.ConcatSequential)."""
         self.ctx, self.lib = ctx, ctx.lib
@@ -168,9 +166,9 @@ class DeviceNet:
         self.train = True
         self.sync_buf, self._sync_reduce = None, None
         # Philox streams are keyed by (seed, counter) only: the dropout masks must not share the noise stream's key (S.noise_seed
-        # defaults to 1), and two nets must not share one -- 1000 + creation ordinal, like the Lua binding's 1000 + seed
-        DeviceNet._ordinal += 1
-        self.mask_seed, self.mask_offset = 1000 + DeviceNet._ordinal, 0
+        # defaults to 1), and two different nets should not share one either -- 1000 (like the Lua binding's 1000 + seed) plus a
+        # salt taken from the net itself, so that the same program draws the same masks on every run
+        self.mask_seed, self.mask_offset = 1000 + self.n_params % 9973, 0
         self._masks = None
         self._batch = 0
         self._x = None

@@ -37,7 +37,7 @@ def test_view_entries_are_the_flat_nchw_view_and_its_inverse(ctx):
     assert ctx.lib.fg_conv_upsample_view_forward(ctx.h, vd.data_ptr(), ud.data_ptr(), 2, 8, 8, 30, 2) < 0     # 30 % 4 != 0
 
 
-@pytest.mark.parametrize("nin,nout,k,f,S", [(8, 4, 3, 2, 8), (16, 2, 5, 3, 6), (64, 1, 3, 2, 8)])
+@pytest.mark.parametrize("nin,nout,k,f,S", [(8, 4, 3, 2, 8), (16, 4, 5, 3, 6), (64, 1, 3, 2, 8)])
 def test_module_protocol_factor_gt_1(ctx, nin, nout, k, f, S):
     """updateOutput / updateGradInput / accGradParameters of the module itself (the last case is a thin-output convolution)."""
     from face_generator_amd import nn
