@@ -138,6 +138,13 @@ static int choose_wgrad6(long long M, int Cout, int Cin, int G, int P, int* S, i
     return cfg;
 }
 
+// experiment switch (round 3): FG_WGRAD_WS=1 routes the layers that tile 256 x 128 / 128 x 256 channels to wgrad_ws_kernel
+static bool fg_wgrad_ws_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FG_WGRAD_WS"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 static long long scratch_for_math(const ConvGeom& g, int math) {
     WeightMap wm; fg_geom_weightmap(g, &wm);
     const long long M = (long long)g.B * g.H * g.W;  // source-resolution M-space
@@ -421,6 +428,15 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         if ((rc = fg_launch_wgrad6(ctx, a, wm.P, cfg6))) return rc;
         if (gy6_out) *gy6_out = a.D6;
         if (used_out) *used_out = part + d6;
+    } else if (fg_wgrad_ws_on() && ctx->math != 6 && a.M >= 4096 && choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split) >= 0) {
+        // wave-specialised fp32 weight gradient (256 x 128 / 128 x 256 channel tiles, one round of ~256 blocks); the bias gradient
+        // takes the separate column-sum pass at the end of this function
+        const int cfgw = choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split);
+        a.Npad = g.Cout; a.Cpad = g.Cin;
+        const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;
+        if (need > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad (ws): scratch %lld > %lld", need, scratch_floats);
+        if ((rc = fg_launch_wgrad_ws(ctx, a, wm.P, cfgw))) return rc;
+        if ((rc = fg_launch_wgrad_finish(ctx, wm, scratch, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
     } else {
         choose_wgrad(a.M, g.Cout, g.Cin, wm.G, wm.P, &tile, &a.S, &a.m_per_split, &a.Npad, &a.Cpad);
         const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;

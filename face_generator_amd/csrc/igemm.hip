@@ -36,6 +36,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // of every buffer resource, without a per-element compare (128 lane masks per wave spilled the scalar registers)
 #define FG_ROW_MASKED 0x20000000
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's float4 struct array went to scratch)
 __device__ __forceinline__ f32x4 fg_buffer_load4(__amdgpu_buffer_rsrc_t r, int voff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
@@ -1460,6 +1461,197 @@ int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
                            float* gradW) {
     dim3 grid(fg_cdiv(wm.I, 128), wm.O, wm.k * wm.k);
     hipLaunchKernelGGL(wgrad_finish_kernel, grid, dim3(128), 0, ctx->stream, wm, Part, S, Npad, Cpad, beta, gradW);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised fp32 weight gradient (round 3): the block structure of igemm_ws_kernel on the PIXEL reduction -- one
+// 512-thread block per CU, waves 0-3 only multiply (one per SIMD, 128 x 64 channel pairs each = 8 accumulator tiles), waves 4-7
+// only move data (plain 16-byte loads of pixel rows, no transposes) three K-steps ahead into a 3-stage LDS ring; K-step = 16
+// pixels, LDS image pixel-major [pixel][channel] exactly as in HBM.
+// What makes it different from the two wave-specialised attempts of round 2: the MFMA fragments are read with ONE
+// ds_read_b128 (row operand) and ONE ds_read_b64 (column operand) per pixel pair and eight MFMAs.  v_mfma_f32_32x32x2_f32 takes
+// A[i][k] from lane 32 k + i: with lane (i, k) reading the 16 bytes at [pixel 2 kp + k][channel 4 i .. 4 i + 3], register j of
+// the read IS an A fragment whose 32 rows are the channels 4 i + j -- the channel <-> row assignment of an accumulator tile is
+// free, it only has to be undone when the tile is stored.  No per-MFMA ds_read_b32, no channel-major staging.
+// Block tile RT (row operand) x QT (column operand) = 256 x 128 channels; SWAP = 0: rows = dY channels, columns = X channels;
+// SWAP = 1: rows = X channels, columns = dY channels (layers whose input has the 256).  Part stays [pg][s][dY ch][X ch].
+// ---------------------------------------------------------------------------------------------------------------
+template <int SWAP>
+__global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
+    constexpr int RT = 256, QT = 128, MI = 4, NI = 2;
+    constexpr int STAGE = 16 * (RT + QT);                       // floats per ring stage
+    extern __shared__ __attribute__((aligned(16))) float smemw[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nd_t = SWAP ? a.Npad / QT : a.Npad / RT;          // tiles along dY channels
+    const int nx_t = SWAP ? a.Cpad / RT : a.Cpad / QT;          // tiles along X channels
+    int bt_, s, pg;
+    fg_wgrad_block(bt_, s, pg);
+    const int td = bt_ / nx_t, tx = bt_ - td * nx_t;
+    (void)nd_t;
+    const int p = pg / a.G, g = pg - p * a.G;
+    const int m0 = s * a.m_per_split;
+    const int m1 = min(a.M, m0 + a.m_per_split);
+    const int KT = (m1 > m0) ? (m1 - m0 + 15) / 16 : 0;
+
+    if (wid >= 4) {
+        // ------------------------------------------------------------------ loader waves (256 threads)
+        const int lt = tid - 256;
+        const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)a.d_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
+        const int doy = a.doy[p], dox = a.dox[p], xoy = a.xoy[p][g], xox = a.xox[p][g];
+        // dY tile: DT channels, X tile: XT channels; each loader lane owns one 16-byte chunk of 4 (resp. 2) pixel rows
+        constexpr int DT = SWAP ? QT : RT, XT = SWAP ? RT : QT;
+        constexpr int ND = 16 * DT / 4 / 256, NX = 16 * XT / 4 / 256;       // chunks per lane and K-step
+        constexpr int DPP = 256 / (DT / 4), XPP = 256 / (XT / 4);           // pixel rows covered by one pass of 256 lanes
+        const int dpix = lt / (DT / 4), dch = (lt - dpix * (DT / 4)) * 4;
+        const int xpix = lt / (XT / 4), xch = (lt - xpix * (XT / 4)) * 4;
+        const int d_lds0 = (SWAP ? 16 * RT : 0) + dpix * DT + dch;          // the row operand's image comes first
+        const int x_lds0 = (SWAP ? 0 : 16 * RT) + xpix * XT + xch;
+        const int gD = (td * DT + dch) * 4, gX = (tx * XT + xch) * 4;
+        const int dpixB = a.Nd * 4, xpixB = a.Cx * 4;
+        int mcur = m0;
+        f32x4 xd[ND], xx[NX], yd[ND], yx[NX], zd[ND], zx[NX];
+#define WW_LOAD(rd_, rx_)                                                                                \
+        {                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                             \
+                const int m = mcur + dpix + DPP * i;                                                     \
+                int n, y, x;                                                                             \
+                fg_decode_m(m < m1 ? m : m0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                         \
+                const int off = ((n * a.Hd + y * a.dsy + doy) * a.Wd + x * a.dsx + dox) * dpixB + gD;    \
+                rd_[i] = fg_buffer_load4(drsrc, m < m1 ? off : FG_OOB);                                  \
+            }                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                             \
+                const int m = mcur + xpix + XPP * i;                                                     \
+                int n, y, x;                                                                             \
+                fg_decode_m(m < m1 ? m : m0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                         \
+                const int yy = y * a.xsy + xoy, xc = x * a.xsx + xox;                                    \
+                const bool ok = m < m1 && (unsigned)yy < (unsigned)a.Hx && (unsigned)xc < (unsigned)a.Wx;\
+                rx_[i] = fg_buffer_load4(xrsrc, ok ? ((n * a.Hx + yy) * a.Wx + xc) * xpixB + gX : FG_OOB); \
+            }                                                                                            \
+            mcur += 16;                                                                                  \
+        }
+#define WW_STORE(st, rd_, rx_)                                                                           \
+        {                                                                                                \
+            float* S = smemw + (st) * STAGE;                                                             \
+            _Pragma("unroll") for (int i = 0; i < ND; ++i) *(f32x4*)(S + d_lds0 + DPP * i * DT) = rd_[i]; \
+            _Pragma("unroll") for (int i = 0; i < NX; ++i) *(f32x4*)(S + x_lds0 + XPP * i * XT) = rx_[i]; \
+        }
+        if (KT > 0) { WW_LOAD(xd, xx); WW_STORE(0, xd, xx); }
+        if (KT > 1) { WW_LOAD(xd, xx); WW_STORE(1, xd, xx); }
+        if (KT > 2) { WW_LOAD(xd, xx); }
+        if (KT > 3) { WW_LOAD(yd, yx); }
+        if (KT > 4) { WW_LOAD(zd, zx); }
+        __syncthreads();
+        for (int kt = 0; kt < KT; kt += 3) {
+            if (kt + 2 < KT) {
+                WW_STORE(2, xd, xx);
+                if (kt + 5 < KT) { WW_LOAD(xd, xx); }
+            }
+            __syncthreads();
+            if (kt + 1 < KT) {
+                if (kt + 3 < KT) {
+                    WW_STORE(0, yd, yx);
+                    if (kt + 6 < KT) { WW_LOAD(yd, yx); }
+                }
+                __syncthreads();
+            }
+            if (kt + 2 < KT) {
+                if (kt + 4 < KT) {
+                    WW_STORE(1, zd, zx);
+                    if (kt + 7 < KT) { WW_LOAD(zd, zx); }
+                }
+                __syncthreads();
+            }
+        }
+#undef WW_LOAD
+#undef WW_STORE
+        return;
+    }
+
+    // ---------------------------------------------------------------------- MFMA waves (one per SIMD)
+    const int wm = wid >> 1, wn = wid & 1;                      // 2 x 2 waves: 128 row channels x 64 column channels each
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    // lane (i = lane & 31, k = lane >> 5): rows = channels wm*128 + 4 i + j (j = register of the b128), columns = wn*64 + 2 n + j'
+    const int r_off = (lane >> 5) * RT + wm * 128 + (lane & 31) * 4;
+    const int q_off = 16 * RT + (lane >> 5) * QT + wn * 64 + (lane & 31) * 2;
+    f32x4 af[8];
+    f32x2 bf[8];
+    __syncthreads();                                            // tiles 0 and 1 are in the ring
+    if (KT > 0) {
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) {
+            af[kp] = *(const f32x4*)(smemw + r_off + 2 * kp * RT);
+            bf[kp] = *(const f32x2*)(smemw + q_off + 2 * kp * QT);
+        }
+    }
+    int sn = 1;
+    for (int kt = 0; kt < KT; ++kt) {
+        const float* Sn = smemw + sn * STAGE;
+        const bool nxt = kt + 1 < KT;
+#pragma unroll
+        for (int kp = 0; kp < 8; ++kp) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kp][mi], bf[kp][ni], acc[mi][ni], 0, 0, 0);
+            if (nxt) {          // this pair's registers are free: fetch the same pair of the next tile (already in the ring)
+                af[kp] = *(const f32x4*)(Sn + r_off + 2 * kp * RT);
+                bf[kp] = *(const f32x2*)(Sn + q_off + 2 * kp * QT);
+            }
+        }
+        sn = sn == 2 ? 0 : sn + 1;
+        asm volatile("s_barrier" ::: "memory");                 // bare: the fragment reads above may still be in flight
+    }
+
+    float* part = a.Part + ((size_t)pg * a.S + s) * a.Npad * a.Cpad;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int cq = wn * 64 + 2 * (lane & 31) + ni;      // column-operand channel inside the block tile
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int cr = wm * 128 + 4 * i + mi;             // row-operand channel inside the block tile
+                const int o = SWAP ? td * QT + cq : td * RT + cr;  // dY channel
+                const int c = SWAP ? tx * RT + cr : tx * QT + cq;  // X channel
+                part[(size_t)o * a.Cpad + c] = acc[mi][ni][r];
+            }
+        }
+}
+
+// cfg 0: 256 dY channels x 128 X channels per block, cfg 1: 128 x 256
+int fg_launch_wgrad_ws(fg_ctx* ctx, const WgradArgs& a, int P, int cfg) {
+    const int RTd = cfg == 0 ? 256 : 128, QTx = cfg == 0 ? 128 : 256;
+    const size_t lds = (size_t)3 * 16 * (256 + 128) * sizeof(float);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[cfg]) {
+        if (cfg == 0) FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set[cfg] = true;
+    }
+    if ((a.Nd % RTd) || (a.Cx % QTx) || a.Npad != a.Nd || a.Cpad != a.Cx)
+        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: %d x %d channels do not tile %d x %d", a.Nd, a.Cx, RTd, QTx);
+    if (a.d_bytes <= 0 || a.x_bytes <= 0 || a.d_bytes >= (long long)FG_OOB || a.x_bytes >= (long long)FG_OOB)
+        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: operands must be < 2 GiB per launch");
+    dim3 grid((a.Npad / RTd) * (a.Cpad / QTx), a.S, a.G * P);
+    const double exec = 2.0 * (double)a.Npad * a.Cpad * (double)P * a.G * (double)a.S * fg_round_up(a.m_per_split, 16);
+    char label[96];
+    snprintf(label, sizeof(label), "wgrad_ws_kernel<%d>/%s", cfg, a.tag ? a.tag : "?");
+    FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
+    if (cfg == 0) hipLaunchKernelGGL(wgrad_ws_kernel<0>, grid, dim3(512), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(512), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
