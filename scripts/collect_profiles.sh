@@ -1,14 +1,15 @@
 #!/bin/bash
-# Round-end evidence on the GPU box: kernel traces of both workloads, PMC passes on the dominant kernels, final bench lines.
-# usage (through gpurun): bash scripts/collect_profiles.sh <tag>      -> everything under gpurun_out/<tag>_*
+# Round-end evidence on the GPU box: the default bench line (cfg2 + the c2f sub-record, live PMC traffic), kernel traces of both
+# workloads, PMC passes on the dominant kernels.  usage (through gpurun): bash scripts/collect_profiles.sh <tag>
+#   -> gpurun_out/<tag>_*; copy what is to be judged into profiles/
 set -u
-TAG=${1:-r02b}
+TAG=${1:-r03}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --workload c2f --steps 10 --warmup 3 > $OUT/${TAG}_bench_c2f.json 2> $OUT/${TAG}_bench_c2f.err
-rocprofv3 --kernel-trace --stats -d $OUT/p1 -o run -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-alt-math --no-roofline > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $OUT/p1 -o run -- python bench.py --workload cfg2 --steps 50 --warmup 10 --no-cpu-baseline --no-alt-math --no-roofline > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
 python scripts/rocpd_stats.py $OUT/p1/run_results.db auto > $OUT/${TAG}_bench_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d $OUT/p2 -o run -- python bench.py --workload c2f --steps 6 --warmup 2 --no-cpu-baseline --no-alt-math --no-roofline > /dev/null 2>&1
 python scripts/rocpd_stats.py $OUT/p2/run_results.db auto > $OUT/${TAG}_c2f_kernel_stats.md
@@ -23,5 +24,18 @@ for which in fwd wgrad; do
   done
 done
 rm -rf $OUT/p1 $OUT/p2
+# the traffic record bench.py falls back to when rocprofv3 is not available: this run's live measurement, stamped with the kernel source
+python - <<PY
+import json
+d = json.loads(open("$OUT/${TAG}_bench.json").read().strip().splitlines()[-1])
+r = d["roofline"]
+if r.get("traffic_freshness") == "live":
+    import hashlib
+    sha = hashlib.sha256(open("face_generator_amd/csrc/igemm.hip", "rb").read()).hexdigest()[:16]
+    json.dump({"kernel": r["kernel"], "launch": r["traffic_note"].split(";")[0], "hbm_bytes_per_launch": r["traffic"],
+               "algorithmic_bytes_per_launch": r["algorithmic_bytes"], "kernel_source_sha16": sha,
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) spawned by bench.py, $TAG"},
+              open("$OUT/${TAG}_traffic.json", "w"), indent=1)
+PY
 tail -3 $OUT/${TAG}_bench_kernel_stats.md
-cat $OUT/${TAG}_pmc_raw.txt | head -80
+head -40 $OUT/${TAG}_pmc_raw.txt
