@@ -428,7 +428,8 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         if ((rc = fg_launch_wgrad6(ctx, a, wm.P, cfg6))) return rc;
         if (gy6_out) *gy6_out = a.D6;
         if (used_out) *used_out = part + d6;
-    } else if (fg_wgrad_ws_on() && ctx->math != 6 && a.M >= 4096 && choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split) >= 0) {
+    } else if (fg_wgrad_ws_on() && ctx->math != 6 && a.M >= 4096 && choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split) >= 0 &&
+               fg_wgrad_ws_shape_ok(a)) {
         // wave-specialised fp32 weight gradient (256 x 128 / 128 x 256 channel tiles, one round of ~256 blocks); the bias gradient
         // takes the separate column-sum pass at the end of this function
         const int cfgw = choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split);

@@ -1495,7 +1495,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
     const int p = pg / a.G, g = pg - p * a.G;
     const int m0 = s * a.m_per_split;
     const int m1 = min(a.M, m0 + a.m_per_split);
-    const int KT = (m1 > m0) ? (m1 - m0 + 15) / 16 : 0;
+    const int KT = (m1 > m0) ? (m1 - m0) >> 4 : 0;         // whole 16-pixel steps only (see the launcher)
 
     if (wid >= 4) {
         // ------------------------------------------------------------------ loader waves (256 threads)
@@ -1513,24 +1513,42 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
         const int x_lds0 = (SWAP ? 0 : 16 * RT) + xpix * XT + xch;
         const int gD = (td * DT + dch) * 4, gX = (tx * XT + xch) * 4;
         const int dpixB = a.Nd * 4, xpixB = a.Cx * 4;
+        // Address math (the launcher only selects this kernel when Hm, Wm are powers of two, 16 | Hm*Wm and 16 | m_per_split, so a
+        // K-step is 16 consecutive pixels of ONE sample -- part of a row, or 16 / Wm whole rows -- and no step is partial): a row's
+        // offsets are (wave-uniform base of the step, SALU) + (per-lane constant), one add per dY load, two adds + two compares
+        // per X load.  Every non-MFMA instruction issued on a SIMD costs its matrix pipe 6-9 idle cycles (PMC passes of round 3,
+        // profiles/r03_pmc_wgrad.md): the loader waves are written for instruction COUNT.
+        int cD[ND], cX[NX], cyy[NX], cxx[NX];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int j = dpix + DPP * i, yr = j >> a.lgW, xr = j & (a.Wm - 1);
+            cD[i] = (yr * a.dsy * a.Wd + xr * a.dsx) * dpixB + gD;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int j = xpix + XPP * i, yr = j >> a.lgW, xr = j & (a.Wm - 1);
+            cX[i] = (yr * a.xsy * a.Wx + xr * a.xsx) * xpixB + gX;
+            cyy[i] = yr * a.xsy + xoy;
+            cxx[i] = xr * a.xsx + xox;
+        }
         int mcur = m0;
+        // wave-uniform strides (bytes), hoisted: the per-step base is three multiply-adds per operand on the scalar unit
+        const int sDn = a.Hd * a.Wd * dpixB, sDy = a.dsy * a.Wd * dpixB, sDx = a.dsx * dpixB, sD0 = (doy * a.Wd + dox) * dpixB;
+        const int sXn = a.Hx * a.Wx * xpixB, sXy = a.xsy * a.Wx * xpixB, sXx = a.xsx * xpixB, sX0 = (xoy * a.Wx + xox) * xpixB;
+        const int lgW = a.lgW, lgH = a.lgH, wmask = a.Wm - 1, hmask = a.Hm - 1, xsy = a.xsy, xsx = a.xsx;
+        const unsigned Hx = (unsigned)a.Hx, Wx = (unsigned)a.Wx;
         f32x4 xd[ND], xx[NX], yd[ND], yx[NX], zd[ND], zx[NX];
 #define WW_LOAD(rd_, rx_)                                                                                \
         {                                                                                                \
-            _Pragma("unroll") for (int i = 0; i < ND; ++i) {                                             \
-                const int m = mcur + dpix + DPP * i;                                                     \
-                int n, y, x;                                                                             \
-                fg_decode_m(m < m1 ? m : m0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                         \
-                const int off = ((n * a.Hd + y * a.dsy + doy) * a.Wd + x * a.dsx + dox) * dpixB + gD;    \
-                rd_[i] = fg_buffer_load4(drsrc, m < m1 ? off : FG_OOB);                                  \
-            }                                                                                            \
+            const int rowi = mcur >> lgW, x0 = mcur & wmask;                                             \
+            const int yb = rowi & hmask, nb = rowi >> lgH;                                               \
+            const int bD = nb * sDn + yb * sDy + x0 * sDx + sD0;                                         \
+            const int bX = nb * sXn + yb * sXy + x0 * sXx + sX0;                                         \
+            const int ybs = yb * xsy, xbs = x0 * xsx;                                                    \
+            _Pragma("unroll") for (int i = 0; i < ND; ++i) rd_[i] = fg_buffer_load4(drsrc, bD + cD[i]);  \
             _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                             \
-                const int m = mcur + xpix + XPP * i;                                                     \
-                int n, y, x;                                                                             \
-                fg_decode_m(m < m1 ? m : m0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                         \
-                const int yy = y * a.xsy + xoy, xc = x * a.xsx + xox;                                    \
-                const bool ok = m < m1 && (unsigned)yy < (unsigned)a.Hx && (unsigned)xc < (unsigned)a.Wx;\
-                rx_[i] = fg_buffer_load4(xrsrc, ok ? ((n * a.Hx + yy) * a.Wx + xc) * xpixB + gX : FG_OOB); \
+                const bool ok = (unsigned)(ybs + cyy[i]) < Hx && (unsigned)(xbs + cxx[i]) < Wx;          \
+                rx_[i] = fg_buffer_load4(xrsrc, ok ? bX + cX[i] : FG_OOB);                               \
             }                                                                                            \
             mcur += 16;                                                                                  \
         }
@@ -1597,7 +1615,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
     int sn = 1;
     for (int kt = 0; kt < KT; ++kt) {
         const float* Sn = smemw + sn * STAGE;
-        const bool nxt = kt + 1 < KT;
 #pragma unroll
         for (int kp = 0; kp < 8; ++kp) {
 #pragma unroll
@@ -1605,10 +1622,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kp][mi], bf[kp][ni], acc[mi][ni], 0, 0, 0);
-            if (nxt) {          // this pair's registers are free: fetch the same pair of the next tile (already in the ring)
-                af[kp] = *(const f32x4*)(Sn + r_off + 2 * kp * RT);
-                bf[kp] = *(const f32x2*)(Sn + q_off + 2 * kp * QT);
-            }
+            // this pair's registers are free: fetch the same pair of the next tile (already in the ring; after the last tile the
+            // read returns a stale stage nobody uses -- unconditional, a branch per pair is an instruction the matrix pipe pays for)
+            af[kp] = *(const f32x4*)(Sn + r_off + 2 * kp * RT);
+            bf[kp] = *(const f32x2*)(Sn + q_off + 2 * kp * QT);
         }
         sn = sn == 2 ? 0 : sn + 1;
         asm volatile("s_barrier" ::: "memory");                 // bare: the fragment reads above may still be in flight
@@ -1631,6 +1648,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
         }
 }
 
+// the kernel's address math assumes whole 16-pixel steps inside one sample
+bool fg_wgrad_ws_shape_ok(const WgradArgs& a) {
+    return a.lgW >= 0 && a.lgH >= 0 && ((a.Hm * a.Wm) & 15) == 0 && (a.m_per_split & 15) == 0 && (a.M & 15) == 0;
+}
 // cfg 0: 256 dY channels x 128 X channels per block, cfg 1: 128 x 256
 int fg_launch_wgrad_ws(fg_ctx* ctx, const WgradArgs& a, int P, int cfg) {
     const int RTd = cfg == 0 ? 256 : 128, QTx = cfg == 0 ? 128 : 256;
@@ -1645,8 +1666,10 @@ int fg_launch_wgrad_ws(fg_ctx* ctx, const WgradArgs& a, int P, int cfg) {
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: %d x %d channels do not tile %d x %d", a.Nd, a.Cx, RTd, QTx);
     if (a.d_bytes <= 0 || a.x_bytes <= 0 || a.d_bytes >= (long long)FG_OOB || a.x_bytes >= (long long)FG_OOB)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: operands must be < 2 GiB per launch");
+    if (!fg_wgrad_ws_shape_ok(a))
+        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: needs power-of-two Hm, Wm with 16 | Hm*Wm and 16 | m_per_split");
     dim3 grid((a.Npad / RTd) * (a.Cpad / QTx), a.S, a.G * P);
-    const double exec = 2.0 * (double)a.Npad * a.Cpad * (double)P * a.G * (double)a.S * fg_round_up(a.m_per_split, 16);
+    const double exec = 2.0 * (double)a.Npad * a.Cpad * (double)P * a.G * (double)a.M;
     char label[96];
     snprintf(label, sizeof(label), "wgrad_ws_kernel<%d>/%s", cfg, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
