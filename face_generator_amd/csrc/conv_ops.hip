@@ -138,10 +138,11 @@ static int choose_wgrad6(long long M, int Cout, int Cin, int G, int P, int* S, i
     return cfg;
 }
 
-// experiment switch (round 3): FG_WGRAD_WS=1 routes the layers that tile 256 x 128 / 128 x 256 channels to wgrad_ws_kernel
+// A/B switch (round 3; default on): FG_WGRAD_WS=0 keeps the symmetric wgrad_kernel for the layers that tile 256 x 128 /
+// 128 x 256 channels instead of the wave-specialised wgrad_ws_kernel
 static bool fg_wgrad_ws_on() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("FG_WGRAD_WS"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char* e = getenv("FG_WGRAD_WS"); v = e ? atoi(e) : 1; }
     return v != 0;
 }
 
@@ -436,8 +437,21 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         a.Npad = g.Cout; a.Cpad = g.Cin;
         const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;
         if (need > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad (ws): scratch %lld > %lld", need, scratch_floats);
+        // bias gradient: the loader waves of the (X tile 0, tap 0) blocks leave per-channel sums of their dY rows
+        const int nrb = wm.P * a.S * fg_wgrad_ws_bias_rows(cfgw);
+        const long long nb = (long long)nrb * g.Cout;
+        bool deferred = false;
+        if (gradb && nrb <= CR_ROWBLOCKS_MAX) {
+            float* dp = fg_defer_alloc(ctx, nb);          // inside fg_net backward: final batched at the end
+            if (dp) { a.bias_part = dp; deferred = true; }
+            else if (need + nb <= scratch_floats) a.bias_part = scratch + need;
+        }
         if ((rc = fg_launch_wgrad_ws(ctx, a, wm.P, cfgw))) return rc;
         if ((rc = fg_launch_wgrad_finish(ctx, wm, scratch, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
+        if (gradb && a.bias_part) {
+            if (deferred) { fg_defer_push(ctx, a.bias_part, nrb, g.Cout, beta, gradb); return FG_OK; }
+            return fg_launch_colsum_final(ctx, a.bias_part, nrb, g.Cout, beta, gradb);
+        }
     } else {
         choose_wgrad(a.M, g.Cout, g.Cin, wm.G, wm.P, &tile, &a.S, &a.m_per_split, &a.Npad, &a.Cpad);
         const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;

@@ -354,19 +354,23 @@ __global__ __launch_bounds__(256, 2) void igemm_act_kernel(const IgemmArgs a) { 
 #define WS_NS 4
 #define WS_STAGE ((WS_BM + WS_BN) * WS_LDK)
 // BN = 128: MFMA waves 2x2, each 128x64; BN = 64 (layers with 64 output channels): waves 4x1, each 64x64
-template <int BN, int EPI>
+// BM = 512 (BN = 64 only, NS = 3 ring stages: 138 KB of LDS): the layers with 64 output channels at 64x64 (models_c2f.lua) --
+// a 256 x 64 tile pays one loader instruction stream per 32 MFMAs, a 512 x 64 tile (four MFMA waves of 128 x 64) per 64, and
+// every non-MFMA instruction issued on a SIMD costs its matrix pipe 6-9 cycles.
+template <int BN, int EPI, int BM = WS_BM, int NS = WS_NS>
 __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
-    constexpr int WNW = BN / 64, MI = WS_BM / ((4 / WNW) * 32), NI = 2, NB = BN / 64;
-    constexpr int STAGE = (WS_BM + BN) * WS_LDK;
+    constexpr int WNW = BN / 64, MI = BM / ((4 / WNW) * 32), NI = 2, NB = BN / 64, AR = BM / 64;
+    constexpr int STAGE = (BM + BN) * WS_LDK;
+    static_assert(NS == 4 || NS == 3, "ring of 3 or 4 stages");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* rowoff = (int*)(smem + WS_NS * STAGE);
+    int* rowoff = (int*)(smem + NS * STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntn = a.Npad / BN;
     const int np = a.P;
     const int per_m = ntn * np;
-    const int nmt = (a.M + WS_BM - 1) / WS_BM;
+    const int nmt = (a.M + BM - 1) / BM;
     int lin = blockIdx.x;
     if ((nmt & 7) == 0) {
         const int xcd = lin & 7, loc = lin >> 3;
@@ -377,8 +381,8 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
     const int tile_n = rem / np, p = rem - tile_n * np;
     const int split = blockIdx.y;
 
-    if (tid < WS_BM) {
-        int m = tile_m * WS_BM + tid, off = EPI == 2 ? FG_ROW_MASKED : -1;
+    if (tid < BM) {
+        int m = tile_m * BM + tid, off = EPI == 2 ? FG_ROW_MASKED : -1;
         if (m < a.M) {
             int n, y, x;
             fg_decode_m(m, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
@@ -397,10 +401,10 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
         const int lt = tid - 256;
         const int lrow = lt >> 2, lk = (lt & 3) * 4;           // 4 lanes per 16-float row, 64 rows per pass
         const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)a.a_bytes, 0x00020000);
-        int ry[4], rx[4], rn[4];
+        int ry[AR], rx[AR], rn[AR];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = tile_m * WS_BM + lrow + 64 * i;
+        for (int i = 0; i < AR; ++i) {
+            const int m = tile_m * BM + lrow + 64 * i;
             int n, y, x;
             fg_decode_m(m < a.M ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
             rn[i] = n * a.Ha * a.Wa;
@@ -410,12 +414,12 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
         const bool ktail = a.Ca != a.Kpad;
         int g = kt0 / kc;
         int col0 = (kt0 - g * kc) * WS_BK;
-        int voff[4];
+        int voff[AR];
 #define WS_SET_GROUP()                                                                                   \
         {                                                                                                \
             const int go = a.goff[p][g < a.G ? g : 0];                                                   \
             const int oy = (int)(short)(go & 0xffff), ox = go >> 16;                                     \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                              \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                             \
                 const int ya = ry[i] + oy, xa = rx[i] + ox;                                              \
                 const bool ok = (unsigned)ya < (unsigned)a.Ha && (unsigned)xa < (unsigned)a.Wa;          \
                 voff[i] = ok ? ((rn[i] + ya * a.Wa + xa) * a.Ca + lk) * 4 : FG_OOB;                      \
@@ -425,12 +429,12 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
         const float* bptr = a.Bp + ((size_t)(p * a.G + g) * a.Npad + tile_n * BN + lrow) * a.Kpad + col0 + lk;
         const size_t brow = (size_t)64 * a.Kpad;
         const size_t bjump = (size_t)(a.Npad - 1) * a.Kpad;
-        f32x4 xa[4], xb[NB], ya[4], yb[NB];     // two tiles in flight: a load has two full K-steps to land
+        f32x4 xa[AR], xb[NB], ya[AR], yb[NB];     // two tiles in flight: a load has two full K-steps to land
 #define WS_LOAD(ra, rb)                                                                                  \
         {                                                                                                \
             const int cb = col0 * 4;                                                                     \
             const bool kin = !ktail || (col0 + lk < a.Ca);                                               \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                               \
                 ra[i] = fg_buffer_load4(arsrc, kin ? voff[i] + cb : FG_OOB);                             \
             _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = *(const f32x4*)(bptr + i * brow);      \
             col0 += WS_BK; bptr += WS_BK;                                                                \
@@ -439,8 +443,8 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
 #define WS_STORE(st, ra, rb)                                                                             \
         {                                                                                                \
             float* As = smem + (st) * STAGE;                                                          \
-            float* Bs = As + WS_BM * WS_LDK;                                                             \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+            float* Bs = As + BM * WS_LDK;                                                                \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                               \
                 *(f32x4*)(As + (lrow + 64 * i) * WS_LDK + lk) = ra[i];                                   \
             _Pragma("unroll") for (int i = 0; i < NB; ++i)                                               \
                 *(f32x4*)(Bs + (lrow + 64 * i) * WS_LDK + lk) = rb[i];                                   \
@@ -451,17 +455,20 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
         if (KT > 2) { WS_LOAD(xa, xb); }
         if (KT > 3) { WS_LOAD(ya, yb); }
         __syncthreads();
+        int sw = 2;                                  // ring stage tile kt + 2 goes to (NS = 3: a counter; NS = 4: a mask)
         for (int kt = 0; kt < KT; kt += 2) {
             if (kt + 2 < KT) {
-                WS_STORE((kt + 2) & (WS_NS - 1), xa, xb);
+                WS_STORE(NS == 4 ? ((kt + 2) & 3) : sw, xa, xb);
                 if (kt + 4 < KT) { WS_LOAD(xa, xb); }
             }
+            if (NS == 3) sw = sw == 2 ? 0 : sw + 1;
             __syncthreads();
             if (kt + 1 < KT) {
                 if (kt + 3 < KT) {
-                    WS_STORE((kt + 3) & (WS_NS - 1), ya, yb);
+                    WS_STORE(NS == 4 ? ((kt + 3) & 3) : sw, ya, yb);
                     if (kt + 5 < KT) { WS_LOAD(ya, yb); }
                 }
+                if (NS == 3) sw = sw == 2 ? 0 : sw + 1;
                 __syncthreads();
             }
         }
@@ -481,7 +488,7 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     const int a_lds = (wm * MI * 32 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
-    const int b_lds = WS_BM * WS_LDK + (wn * 64 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
+    const int b_lds = BM * WS_LDK + (wn * 64 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
     f32x4 af[2][MI], bf[2][NI];     // [chunk parity][tile]
     __syncthreads();              // tiles 0 and 1 are in the ring
     if (KT > 0) {
@@ -490,9 +497,12 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *(const f32x4*)(smem + b_lds + ni * 32 * WS_LDK);
     }
+    int sr = 0;                                      // NS = 3: ring stage of tile kt
     for (int kt = 0; kt < KT; ++kt) {
-        const float* St = smem + (kt & (WS_NS - 1)) * STAGE;
-        const float* Sn = smem + ((kt + 1) & (WS_NS - 1)) * STAGE;
+        const int sr1 = sr == 2 ? 0 : sr + 1;
+        const float* St = smem + (NS == 4 ? (kt & 3) : sr) * STAGE;
+        const float* Sn = smem + (NS == 4 ? ((kt + 1) & 3) : sr1) * STAGE;
+        if (NS == 3) sr = sr1;
         // chunk 1 fragments of this tile
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) af[1][mi] = *(const f32x4*)(St + a_lds + mi * 32 * WS_LDK + 8);
@@ -530,9 +540,42 @@ template <int BN>
 __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) { igemm_ws_body<BN, 0>(a); }
 template <int BN, int EPI>
 __global__ __launch_bounds__(512, 2) void igemm_ws_act_kernel(const IgemmArgs a) { igemm_ws_body<BN, EPI>(a); }
+// 512 x 64 tiles, 3-stage ring (EPI 0 / 1 / 2 as above)
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void igemm_ws512_kernel(const IgemmArgs a) { igemm_ws_body<64, EPI, 512, 3>(a); }
+// the tile height launch_igemm_ws<64> picks: 512 when the layer gives whole rounds of 256 such blocks (FG_IGEMM_WS512=0: never)
+static int fg_ws64_bm(const IgemmArgs& a, int P) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FG_IGEMM_WS512"); on = e ? atoi(e) : 1; }
+    if (!on || a.stats_part || a.Npad != 64 || a.M % 512) return WS_BM;
+    const long long blocks = (long long)(a.M / 512) * P;
+    return (blocks >= 256 && blocks % 256 == 0) ? 512 : WS_BM;
+}
+static int launch_igemm_ws512(fg_ctx* ctx, const IgemmArgs& a, int P) {
+    const size_t lds = (size_t)(3 * (512 + 64) * WS_LDK + 512) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws512_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws512_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws512_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((a.M / 512) * P, a.splits, 1);
+    const double exec = 2.0 * (double)grid.x * 512 * 64 * (double)a.G * a.Kpad;
+    const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
+    char label[96];
+    snprintf(label, sizeof(label), "igemm_ws512_kernel<%d>/%s", epi, a.tag ? a.tag : "?");
+    FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
+    if (epi == 2) hipLaunchKernelGGL(igemm_ws512_kernel<2>, grid, dim3(512), lds, ctx->stream, a);
+    else if (epi == 1) hipLaunchKernelGGL(igemm_ws512_kernel<1>, grid, dim3(512), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(igemm_ws512_kernel<0>, grid, dim3(512), lds, ctx->stream, a);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
 
 template <int BN>
 static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
+    if (BN == 64 && fg_ws64_bm(a, P) == 512) return launch_igemm_ws512(ctx, a, P);
     const size_t lds = (size_t)(WS_NS * (WS_BM + BN) * WS_LDK + WS_BM) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -863,8 +906,8 @@ long long fg_igemm_blocks(const IgemmArgs& a, int P, int tile) {
         case 0: return (long long)fg_cdiv(a.M, 128) * (a.Npad / 128) * P;
         case 1: return (long long)fg_cdiv(a.M, 128) * (a.Npad / 64) * P;
         case 2: return (long long)fg_cdiv(a.M, 64) * (a.Npad / 64) * P;
-        case 5: return (long long)fg_cdiv(a.M, WS_BM) * (a.Npad / 64) * P;
-        case 4: return (long long)fg_cdiv(a.M, WS_BM) * (a.Npad / ((a.Npad % 128 == 0) ? 128 : 64)) * P;
+        case 5: return (long long)fg_cdiv(a.M, fg_ws64_bm(a, P)) * (a.Npad / 64) * P;
+        case 4: return (long long)fg_cdiv(a.M, (a.Npad % 128 == 0) ? WS_BM : fg_ws64_bm(a, P)) * (a.Npad / ((a.Npad % 128 == 0) ? 128 : 64)) * P;
     }
     return 0;
 }
@@ -1531,6 +1574,10 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
             cyy[i] = yr * a.xsy + xoy;
             cxx[i] = xr * a.xsx + xox;
         }
+        // bias gradient: the blocks of (X tile 0, tap 0) see every dY pixel of their split exactly once; each of their loader lanes
+        // leaves the sum of ITS pixel rows: bias_part [P][S][DPP][Nd] (DPP partial rows per split, finished by the batched final)
+        const bool want_bias = a.bias_part != nullptr && tx == 0 && g == 0;      // block-uniform
+        f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
         int mcur = m0;
         // wave-uniform strides (bytes), hoisted: the per-step base is three multiply-adds per operand on the scalar unit
         const int sDn = a.Hd * a.Wd * dpixB, sDy = a.dsy * a.Wd * dpixB, sDx = a.dsx * dpixB, sD0 = (doy * a.Wd + dox) * dpixB;
@@ -1555,6 +1602,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
 #define WW_STORE(st, rd_, rx_)                                                                           \
         {                                                                                                \
             float* S = smemw + (st) * STAGE;                                                             \
+            if (want_bias) { _Pragma("unroll") for (int i = 0; i < ND; ++i) bsum += rd_[i]; }            \
             _Pragma("unroll") for (int i = 0; i < ND; ++i) *(f32x4*)(S + d_lds0 + DPP * i * DT) = rd_[i]; \
             _Pragma("unroll") for (int i = 0; i < NX; ++i) *(f32x4*)(S + x_lds0 + XPP * i * XT) = rx_[i]; \
         }
@@ -1587,6 +1635,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
         }
 #undef WW_LOAD
 #undef WW_STORE
+        if (want_bias)
+            *(f32x4*)(a.bias_part + (((size_t)p * a.S + s) * DPP + dpix) * a.Nd + td * DT + dch) = bsum;
         return;
     }
 
@@ -1652,6 +1702,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
 bool fg_wgrad_ws_shape_ok(const WgradArgs& a) {
     return a.lgW >= 0 && a.lgH >= 0 && ((a.Hm * a.Wm) & 15) == 0 && (a.m_per_split & 15) == 0 && (a.M & 15) == 0;
 }
+// partial rows per (parity, split) the kernel leaves in bias_part: the pixel rows one pass of the 256 loader lanes covers
+int fg_wgrad_ws_bias_rows(int cfg) { return cfg == 0 ? 4 : 8; }
 // cfg 0: 256 dY channels x 128 X channels per block, cfg 1: 128 x 256
 int fg_launch_wgrad_ws(fg_ctx* ctx, const WgradArgs& a, int P, int cfg) {
     const int RTd = cfg == 0 ? 256 : 128, QTx = cfg == 0 ? 128 : 256;
