@@ -354,9 +354,7 @@ __global__ __launch_bounds__(256, 2) void igemm_act_kernel(const IgemmArgs a) { 
 #define WS_NS 4
 #define WS_STAGE ((WS_BM + WS_BN) * WS_LDK)
 // BN = 128: MFMA waves 2x2, each 128x64; BN = 64 (layers with 64 output channels): waves 4x1, each 64x64
-// BM = 512 (BN = 64 only, NS = 3 ring stages: 138 KB of LDS): the layers with 64 output channels at 64x64 (models_c2f.lua) --
-// a 256 x 64 tile pays one loader instruction stream per 32 MFMAs, a 512 x 64 tile (four MFMA waves of 128 x 64) per 64, and
-// every non-MFMA instruction issued on a SIMD costs its matrix pipe 6-9 cycles.
+// BM / NS are template parameters for the BN = 64 variants (NS = 3: see igemm_ws64x3_kernel).
 template <int BN, int EPI, int BM = WS_BM, int NS = WS_NS>
 __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
     constexpr int WNW = BN / 64, MI = BM / ((4 / WNW) * 32), NI = 2, NB = BN / 64, AR = BM / 64;
@@ -426,22 +424,32 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
             }                                                                                            \
         }
         WS_SET_GROUP();
-        const float* bptr = a.Bp + ((size_t)(p * a.G + g) * a.Npad + tile_n * BN + lrow) * a.Kpad + col0 + lk;
-        const size_t brow = (size_t)64 * a.Kpad;
-        const size_t bjump = (size_t)(a.Npad - 1) * a.Kpad;
+        // packed weights [P][G][Npad][Kpad]: < 2 GiB (the 33.5 M-weight Linear packs to 134 MB), raw-buffer addressing
+        const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.Bp, 0, FG_OOB, 0x00020000);
+        int boff = (int)((((size_t)(p * a.G + g) * a.Npad + tile_n * BN + lrow) * a.Kpad + col0 + lk) * 4);
+        const int browB = 64 * a.Kpad * 4;
+        const int bjumpB = (a.Npad - 1) * a.Kpad * 4;
         f32x4 xa[AR], xb[NB], ya[AR], yb[NB];     // two tiles in flight: a load has two full K-steps to land
+        // (instruction count matters here -- every instruction a loader wave issues costs the SIMD's matrix pipe 6-9 cycles, DESIGN
+        // 4.7: the K tail is a wave-uniform branch, not a select per load; the packed weights come through a raw buffer with a
+        // 32-bit per-lane offset, not a 64-bit pointer; one wait for all staged loads in front of the LDS stores)
 #define WS_LOAD(ra, rb)                                                                                  \
         {                                                                                                \
             const int cb = col0 * 4;                                                                     \
-            const bool kin = !ktail || (col0 + lk < a.Ca);                                               \
-            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                               \
-                ra[i] = fg_buffer_load4(arsrc, kin ? voff[i] + cb : FG_OOB);                             \
-            _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = *(const f32x4*)(bptr + i * brow);      \
-            col0 += WS_BK; bptr += WS_BK;                                                                \
-            if (col0 == a.Kpad) { col0 = 0; ++g; bptr += bjump; WS_SET_GROUP(); }                        \
+            if (ktail) {                                                                                 \
+                const bool kin = col0 + lk < a.Ca;                                                       \
+                _Pragma("unroll") for (int i = 0; i < AR; ++i)                                           \
+                    ra[i] = fg_buffer_load4(arsrc, kin ? voff[i] + cb : FG_OOB);                         \
+            } else {                                                                                     \
+                _Pragma("unroll") for (int i = 0; i < AR; ++i) ra[i] = fg_buffer_load4(arsrc, voff[i] + cb); \
+            }                                                                                            \
+            _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = fg_buffer_load4(brsrc, boff + i * browB); \
+            col0 += WS_BK; boff += WS_BK * 4;                                                            \
+            if (col0 == a.Kpad) { col0 = 0; ++g; boff += bjumpB; WS_SET_GROUP(); }                      \
         }
 #define WS_STORE(st, ra, rb)                                                                             \
         {                                                                                                \
+            __builtin_amdgcn_s_waitcnt(0x0f70);       /* vmcnt(0): these loads were issued two K-steps ago */ \
             float* As = smem + (st) * STAGE;                                                          \
             float* Bs = As + BM * WS_LDK;                                                                \
             _Pragma("unroll") for (int i = 0; i < AR; ++i)                                               \
@@ -540,42 +548,41 @@ template <int BN>
 __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) { igemm_ws_body<BN, 0>(a); }
 template <int BN, int EPI>
 __global__ __launch_bounds__(512, 2) void igemm_ws_act_kernel(const IgemmArgs a) { igemm_ws_body<BN, EPI>(a); }
-// 512 x 64 tiles, 3-stage ring (EPI 0 / 1 / 2 as above)
+// BN = 64 on a 3-stage ring: 77 KB of LDS and <= 128 VGPRs, so TWO blocks share a CU.  The layers with 64 output channels have
+// short K loops (3x3 x 64 channels = 36 sixteen-channel steps per tile): with one block per CU the matrix pipe idles through every
+// tile's prologue and epilogue; with two, one block's epilogue overlaps the other's K loop.  (A 512 x 64 tile that halves the
+// loader instructions per MFMA was measured first and changed nothing: 118.2 vs 118.5 TFLOP/s -- these layers are not issue-bound.)
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void igemm_ws512_kernel(const IgemmArgs a) { igemm_ws_body<64, EPI, 512, 3>(a); }
-// the tile height launch_igemm_ws<64> picks: 512 when the layer gives whole rounds of 256 such blocks (FG_IGEMM_WS512=0: never)
-static int fg_ws64_bm(const IgemmArgs& a, int P) {
+__global__ __launch_bounds__(512, 4) void igemm_ws64x3_kernel(const IgemmArgs a) { igemm_ws_body<64, EPI, WS_BM, 3>(a); }
+static bool fg_ws64_ns3() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("FG_IGEMM_WS512"); on = e ? atoi(e) : 1; }
-    if (!on || a.stats_part || a.Npad != 64 || a.M % 512) return WS_BM;
-    const long long blocks = (long long)(a.M / 512) * P;
-    return (blocks >= 256 && blocks % 256 == 0) ? 512 : WS_BM;
+    if (on < 0) { const char* e = getenv("FG_IGEMM_WS64_NS3"); on = e ? atoi(e) : 1; }
+    return on != 0;
 }
-static int launch_igemm_ws512(fg_ctx* ctx, const IgemmArgs& a, int P) {
-    const size_t lds = (size_t)(3 * (512 + 64) * WS_LDK + 512) * sizeof(float);
+static int launch_igemm_ws64x3(fg_ctx* ctx, const IgemmArgs& a, int P) {
+    const size_t lds = (size_t)(3 * (WS_BM + 64) * WS_LDK + WS_BM) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws512_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws512_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws512_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((a.M / 512) * P, a.splits, 1);
-    const double exec = 2.0 * (double)grid.x * 512 * 64 * (double)a.G * a.Kpad;
+    dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / 64) * P, a.splits, 1);
+    const double exec = 2.0 * (double)grid.x * WS_BM * 64 * (double)a.G * a.Kpad;
     const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
     char label[96];
-    snprintf(label, sizeof(label), "igemm_ws512_kernel<%d>/%s", epi, a.tag ? a.tag : "?");
+    snprintf(label, sizeof(label), "igemm_ws64x3_kernel<%d>/%s", epi, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
-    if (epi == 2) hipLaunchKernelGGL(igemm_ws512_kernel<2>, grid, dim3(512), lds, ctx->stream, a);
-    else if (epi == 1) hipLaunchKernelGGL(igemm_ws512_kernel<1>, grid, dim3(512), lds, ctx->stream, a);
-    else hipLaunchKernelGGL(igemm_ws512_kernel<0>, grid, dim3(512), lds, ctx->stream, a);
+    if (epi == 2) hipLaunchKernelGGL(igemm_ws64x3_kernel<2>, grid, dim3(512), lds, ctx->stream, a);
+    else if (epi == 1) hipLaunchKernelGGL(igemm_ws64x3_kernel<1>, grid, dim3(512), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(igemm_ws64x3_kernel<0>, grid, dim3(512), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
-
 template <int BN>
 static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
-    if (BN == 64 && fg_ws64_bm(a, P) == 512) return launch_igemm_ws512(ctx, a, P);
+    if (BN == 64 && fg_ws64_ns3()) return launch_igemm_ws64x3(ctx, a, P);
     const size_t lds = (size_t)(WS_NS * (WS_BM + BN) * WS_LDK + WS_BM) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -906,8 +913,8 @@ long long fg_igemm_blocks(const IgemmArgs& a, int P, int tile) {
         case 0: return (long long)fg_cdiv(a.M, 128) * (a.Npad / 128) * P;
         case 1: return (long long)fg_cdiv(a.M, 128) * (a.Npad / 64) * P;
         case 2: return (long long)fg_cdiv(a.M, 64) * (a.Npad / 64) * P;
-        case 5: return (long long)fg_cdiv(a.M, fg_ws64_bm(a, P)) * (a.Npad / 64) * P;
-        case 4: return (long long)fg_cdiv(a.M, (a.Npad % 128 == 0) ? WS_BM : fg_ws64_bm(a, P)) * (a.Npad / ((a.Npad % 128 == 0) ? 128 : 64)) * P;
+        case 5: return (long long)fg_cdiv(a.M, WS_BM) * (a.Npad / 64) * P;
+        case 4: return (long long)fg_cdiv(a.M, WS_BM) * (a.Npad / ((a.Npad % 128 == 0) ? 128 : 64)) * P;
     }
     return 0;
 }
@@ -1599,40 +1606,47 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
             }                                                                                            \
             mcur += 16;                                                                                  \
         }
-#define WW_STORE(st, rd_, rx_)                                                                           \
+#define WW_STORE(st, rd_, rx_, BIAS)                                                                     \
         {                                                                                                \
             float* S = smemw + (st) * STAGE;                                                             \
-            if (want_bias) { _Pragma("unroll") for (int i = 0; i < ND; ++i) bsum += rd_[i]; }            \
+            if (BIAS) { _Pragma("unroll") for (int i = 0; i < ND; ++i) bsum += rd_[i]; }                 \
             _Pragma("unroll") for (int i = 0; i < ND; ++i) *(f32x4*)(S + d_lds0 + DPP * i * DT) = rd_[i]; \
             _Pragma("unroll") for (int i = 0; i < NX; ++i) *(f32x4*)(S + x_lds0 + XPP * i * XT) = rx_[i]; \
         }
-        if (KT > 0) { WW_LOAD(xd, xx); WW_STORE(0, xd, xx); }
-        if (KT > 1) { WW_LOAD(xd, xx); WW_STORE(1, xd, xx); }
-        if (KT > 2) { WW_LOAD(xd, xx); }
-        if (KT > 3) { WW_LOAD(yd, yx); }
-        if (KT > 4) { WW_LOAD(zd, zx); }
-        __syncthreads();
-        for (int kt = 0; kt < KT; kt += 3) {
-            if (kt + 2 < KT) {
-                WW_STORE(2, xd, xx);
-                if (kt + 5 < KT) { WW_LOAD(xd, xx); }
-            }
-            __syncthreads();
-            if (kt + 1 < KT) {
-                if (kt + 3 < KT) {
-                    WW_STORE(0, yd, yx);
-                    if (kt + 6 < KT) { WW_LOAD(yd, yx); }
-                }
-                __syncthreads();
-            }
-            if (kt + 2 < KT) {
-                if (kt + 4 < KT) {
-                    WW_STORE(1, zd, zx);
-                    if (kt + 7 < KT) { WW_LOAD(zd, zx); }
-                }
-                __syncthreads();
-            }
+#define WW_PIPELINE(BIAS)                                                                                \
+        {                                                                                                \
+            if (KT > 0) { WW_LOAD(xd, xx); WW_STORE(0, xd, xx, BIAS); }                                  \
+            if (KT > 1) { WW_LOAD(xd, xx); WW_STORE(1, xd, xx, BIAS); }                                  \
+            if (KT > 2) { WW_LOAD(xd, xx); }                                                             \
+            if (KT > 3) { WW_LOAD(yd, yx); }                                                             \
+            if (KT > 4) { WW_LOAD(zd, zx); }                                                             \
+            __syncthreads();                                                                             \
+            for (int kt = 0; kt < KT; kt += 3) {                                                         \
+                if (kt + 2 < KT) {                                                                       \
+                    WW_STORE(2, xd, xx, BIAS);                                                           \
+                    if (kt + 5 < KT) { WW_LOAD(xd, xx); }                                                \
+                }                                                                                        \
+                __syncthreads();                                                                         \
+                if (kt + 1 < KT) {                                                                       \
+                    if (kt + 3 < KT) {                                                                   \
+                        WW_STORE(0, yd, yx, BIAS);                                                       \
+                        if (kt + 6 < KT) { WW_LOAD(yd, yx); }                                            \
+                    }                                                                                    \
+                    __syncthreads();                                                                     \
+                }                                                                                        \
+                if (kt + 2 < KT) {                                                                       \
+                    if (kt + 4 < KT) {                                                                   \
+                        WW_STORE(1, zd, zx, BIAS);                                                       \
+                        if (kt + 7 < KT) { WW_LOAD(zd, zx); }                                            \
+                    }                                                                                    \
+                    __syncthreads();                                                                     \
+                }                                                                                        \
+            }                                                                                            \
         }
+        // two copies of the pipeline: the bias sums (packed fp32 adds -- expensive beside MFMAs: all blocks paying for them cost
+        // the c2f step 0.8 ms) only exist in the code path of the 1 / (taps x X tiles) blocks that need them
+        if (want_bias) WW_PIPELINE(1) else WW_PIPELINE(0)
+#undef WW_PIPELINE
 #undef WW_LOAD
 #undef WW_STORE
         if (want_bias)
