@@ -438,10 +438,10 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;
         if (need > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad (ws): scratch %lld > %lld", need, scratch_floats);
         // bias gradient: the loader waves of the (X tile 0, tap 0) blocks leave per-channel sums of their dY rows
-        const int nrb = wm.P * a.S * fg_wgrad_ws_bias_rows(cfgw);
+        const int nrb = wm.P * a.S * fg_wgrad_ws_bias_rows(a, cfgw);
         const long long nb = (long long)nrb * g.Cout;
         bool deferred = false;
-        if (gradb && nrb <= CR_ROWBLOCKS_MAX) {
+        if (gradb && nrb <= 8 * CR_ROWBLOCKS_MAX) {
             float* dp = fg_defer_alloc(ctx, nb);          // inside fg_net backward: final batched at the end
             if (dp) { a.bias_part = dp; deferred = true; }
             else if (need + nb <= scratch_floats) a.bias_part = scratch + need;

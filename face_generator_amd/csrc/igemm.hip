@@ -1581,9 +1581,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
             cyy[i] = yr * a.xsy + xoy;
             cxx[i] = xr * a.xsx + xox;
         }
-        // bias gradient: the blocks of (X tile 0, tap 0) see every dY pixel of their split exactly once; each of their loader lanes
-        // leaves the sum of ITS pixel rows: bias_part [P][S][DPP][Nd] (DPP partial rows per split, finished by the batched final)
-        const bool want_bias = a.bias_part != nullptr && tx == 0 && g == 0;      // block-uniform
+        // bias gradient = per-channel sums of dY over all pixels.  Every (tap, X tile) block of a (parity, split, dY tile) streams
+        // the SAME dY rows, so the nb = G * nx_t of them share the work: block `mine` sums the K-steps kt = mine (mod nb) and leaves
+        // one partial row per loader pixel lane, bias_part [P][S][nb][DPP][Nd], finished by the batched final.  (Letting the tap-0
+        // blocks sum everything made THEM 18 % slower -- packed fp32 adds beside the MFMAs -- and a launch of one round of blocks
+        // lasts as long as its slowest block: 6.66 -> 7.44 ms on the c2f layers.)
+        const int nb = a.G * nx_t, mine = g * nx_t + tx;
+        const int bperiod = a.bias_part ? nb - 1 : -1;           // -1: never
+        int bcount = a.bias_part ? mine : -1;
         f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
         int mcur = m0;
         // wave-uniform strides (bytes), hoisted: the per-step base is three multiply-adds per operand on the scalar unit
@@ -1606,51 +1611,45 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
             }                                                                                            \
             mcur += 16;                                                                                  \
         }
-#define WW_STORE(st, rd_, rx_, BIAS)                                                                     \
+#define WW_STORE(st, rd_, rx_)                                                                           \
         {                                                                                                \
             float* S = smemw + (st) * STAGE;                                                             \
-            if (BIAS) { _Pragma("unroll") for (int i = 0; i < ND; ++i) bsum += rd_[i]; }                 \
+            if (bcount == 0) { _Pragma("unroll") for (int i = 0; i < ND; ++i) bsum += rd_[i]; }          \
+            bcount = bcount <= 0 ? bperiod : bcount - 1;                                                 \
             _Pragma("unroll") for (int i = 0; i < ND; ++i) *(f32x4*)(S + d_lds0 + DPP * i * DT) = rd_[i]; \
             _Pragma("unroll") for (int i = 0; i < NX; ++i) *(f32x4*)(S + x_lds0 + XPP * i * XT) = rx_[i]; \
         }
-#define WW_PIPELINE(BIAS)                                                                                \
-        {                                                                                                \
-            if (KT > 0) { WW_LOAD(xd, xx); WW_STORE(0, xd, xx, BIAS); }                                  \
-            if (KT > 1) { WW_LOAD(xd, xx); WW_STORE(1, xd, xx, BIAS); }                                  \
-            if (KT > 2) { WW_LOAD(xd, xx); }                                                             \
-            if (KT > 3) { WW_LOAD(yd, yx); }                                                             \
-            if (KT > 4) { WW_LOAD(zd, zx); }                                                             \
-            __syncthreads();                                                                             \
-            for (int kt = 0; kt < KT; kt += 3) {                                                         \
-                if (kt + 2 < KT) {                                                                       \
-                    WW_STORE(2, xd, xx, BIAS);                                                           \
-                    if (kt + 5 < KT) { WW_LOAD(xd, xx); }                                                \
-                }                                                                                        \
-                __syncthreads();                                                                         \
-                if (kt + 1 < KT) {                                                                       \
-                    if (kt + 3 < KT) {                                                                   \
-                        WW_STORE(0, yd, yx, BIAS);                                                       \
-                        if (kt + 6 < KT) { WW_LOAD(yd, yx); }                                            \
-                    }                                                                                    \
-                    __syncthreads();                                                                     \
-                }                                                                                        \
-                if (kt + 2 < KT) {                                                                       \
-                    if (kt + 4 < KT) {                                                                   \
-                        WW_STORE(1, zd, zx, BIAS);                                                       \
-                        if (kt + 7 < KT) { WW_LOAD(zd, zx); }                                            \
-                    }                                                                                    \
-                    __syncthreads();                                                                     \
-                }                                                                                        \
-            }                                                                                            \
+        if (KT > 0) { WW_LOAD(xd, xx); WW_STORE(0, xd, xx); }
+        if (KT > 1) { WW_LOAD(xd, xx); WW_STORE(1, xd, xx); }
+        if (KT > 2) { WW_LOAD(xd, xx); }
+        if (KT > 3) { WW_LOAD(yd, yx); }
+        if (KT > 4) { WW_LOAD(zd, zx); }
+        __syncthreads();
+        for (int kt = 0; kt < KT; kt += 3) {
+            if (kt + 2 < KT) {
+                WW_STORE(2, xd, xx);
+                if (kt + 5 < KT) { WW_LOAD(xd, xx); }
+            }
+            __syncthreads();
+            if (kt + 1 < KT) {
+                if (kt + 3 < KT) {
+                    WW_STORE(0, yd, yx);
+                    if (kt + 6 < KT) { WW_LOAD(yd, yx); }
+                }
+                __syncthreads();
+            }
+            if (kt + 2 < KT) {
+                if (kt + 4 < KT) {
+                    WW_STORE(1, zd, zx);
+                    if (kt + 7 < KT) { WW_LOAD(zd, zx); }
+                }
+                __syncthreads();
+            }
         }
-        // two copies of the pipeline: the bias sums (packed fp32 adds -- expensive beside MFMAs: all blocks paying for them cost
-        // the c2f step 0.8 ms) only exist in the code path of the 1 / (taps x X tiles) blocks that need them
-        if (want_bias) WW_PIPELINE(1) else WW_PIPELINE(0)
-#undef WW_PIPELINE
 #undef WW_LOAD
 #undef WW_STORE
-        if (want_bias)
-            *(f32x4*)(a.bias_part + (((size_t)p * a.S + s) * DPP + dpix) * a.Nd + td * DT + dch) = bsum;
+        if (a.bias_part)
+            *(f32x4*)(a.bias_part + ((((size_t)p * a.S + s) * nb + mine) * DPP + dpix) * a.Nd + td * DT + dch) = bsum;
         return;
     }
 
@@ -1716,8 +1715,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
 bool fg_wgrad_ws_shape_ok(const WgradArgs& a) {
     return a.lgW >= 0 && a.lgH >= 0 && ((a.Hm * a.Wm) & 15) == 0 && (a.m_per_split & 15) == 0 && (a.M & 15) == 0;
 }
-// partial rows per (parity, split) the kernel leaves in bias_part: the pixel rows one pass of the 256 loader lanes covers
-int fg_wgrad_ws_bias_rows(int cfg) { return cfg == 0 ? 4 : 8; }
+// partial rows per (parity, split) the kernel leaves in bias_part: (taps x X tiles) blocks x the pixel rows one pass of the 256
+// loader lanes covers
+int fg_wgrad_ws_bias_rows(const WgradArgs& a, int cfg) { return a.G * (a.Cpad / (cfg == 0 ? 128 : 256)) * (cfg == 0 ? 4 : 8); }
 // cfg 0: 256 dY channels x 128 X channels per block, cfg 1: 128 x 256
 int fg_launch_wgrad_ws(fg_ctx* ctx, const WgradArgs& a, int P, int cfg) {
     const int RTd = cfg == 0 ? 256 : 128, QTx = cfg == 0 ? 128 : 256;

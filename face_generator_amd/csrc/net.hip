@@ -145,7 +145,10 @@ static void make_plan(fg_net* n, int B) {
     {   // arena for the deferred finals: [row blocks][C] partials of every bias-gradient / slope-gradient reduction
         long long dn = 0;
         for (auto& s : n->st) {
-            if (s.kind == ST_CONV || s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT || s.kind == ST_GEMV) dn += (long long)CR_ROWBLOCKS_MAX * s.oc + 64;
+            // (ST_CONV: the wave-specialised weight gradient leaves one bias partial row per (parity, split, tap, X tile, loader
+            // pixel lane) -- up to ~1000 rows)
+            if (s.kind == ST_CONV) dn += 4LL * CR_ROWBLOCKS_MAX * s.oc + 64;
+            else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT || s.kind == ST_GEMV) dn += (long long)CR_ROWBLOCKS_MAX * s.oc + 64;
             if (s.has_prelu || s.kind == ST_PRELU || s.kind == ST_ACTPOOL) dn += 1024 + 64;
             // a PReLU whose backward rides on the epilogue of the neighbouring contraction leaves 4 partials per block
             if (s.kind == ST_PRELU && s.mask_kind == 0)
