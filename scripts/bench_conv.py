@@ -8,6 +8,14 @@ from face_generator_amd.runtime import get_context
 
 ctx = get_context(0); d = ctx.device
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+C2F = [  # the coarse-to-fine nets at 64x64 (models_c2f.lua:113-145, 237-278), B = 128
+    ("G2  3x3 64->64 @64", 128, 64, 64, 64, 64, 3, 0),
+    ("G3  5x5 64->128 @64", 128, 64, 64, 64, 128, 5, 0),
+    ("G4  5x5 128->256 @64", 128, 64, 64, 128, 256, 5, 0),
+    ("D2  3x3 64->64 @64", 128, 64, 64, 64, 64, 3, 0),
+    ("D3  3x3 64->128 @32", 128, 32, 32, 64, 128, 3, 0),
+    ("D4  3x3 128->256 @32", 128, 32, 32, 128, 256, 3, 0),
+]
 SHAPES = [  # name, B, H, W, Cin, Cout, k, up
     ("g9  up5x5 256->128 @16->32", 128, 16, 16, 256, 128, 5, 1),
     ("g5  up5x5 128->256 @8->16", 128, 8, 8, 128, 256, 5, 1),
@@ -15,6 +23,8 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, up
     ("d9  3x3 128->256 @8", 128, 8, 8, 128, 256, 3, 0),
     ("d13 3x3 256->512 @4", 128, 4, 4, 256, 512, 3, 0),
 ]
+if len(sys.argv) > 2 and sys.argv[2] == "c2f":
+    SHAPES = C2F
 g = torch.Generator(device='cpu').manual_seed(0)
 for (name, B, H, W, Cin, Cout, k, up) in SHAPES:
     f = 2 if up else 1
