@@ -122,7 +122,6 @@ def live_traffic(kernel, timeout=150):
     Returns None when rocprofv3 is unavailable or a pass fails (the caller then labels a committed file as stale or not)."""
     import csv
     import glob
-    import re
     import shutil
     import subprocess
     import tempfile
@@ -139,7 +138,7 @@ def live_traffic(kernel, timeout=150):
             tot, launches = 0.0, set()
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if re.match(r"(void )?igemm_ws2?_kernel<128", r["Kernel_Name"]):     # four / two loader waves: same label
+                    if r["Kernel_Name"].startswith("void igemm_ws_kernel<128>") or r["Kernel_Name"].startswith("igemm_ws_kernel<128>"):
                         if r["Counter_Name"] == pmc:
                             tot += float(r["Counter_Value"])
                             launches.add(r["Dispatch_Id"])

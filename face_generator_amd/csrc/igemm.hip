@@ -355,13 +355,9 @@ __global__ __launch_bounds__(256, 2) void igemm_act_kernel(const IgemmArgs a) { 
 #define WS_STAGE ((WS_BM + WS_BN) * WS_LDK)
 // BN = 128: MFMA waves 2x2, each 128x64; BN = 64 (layers with 64 output channels): waves 4x1, each 64x64
 // BM / NS are template parameters for the BN = 64 variants (NS = 3: see igemm_ws64x3_kernel).
-// LW = loader waves (4 or 2).  The per-K-step bookkeeping of a loader wave (loop, group change, descriptors: ~45 scalar
-// instructions) is paid per WAVE; two loader waves with twice the loads each issue a third fewer instructions per CU and K-step
-// than four, and every instruction issued on a SIMD costs its matrix pipe 6-9 cycles.
-template <int BN, int EPI, int BM = WS_BM, int NS = WS_NS, int LW = 4>
+template <int BN, int EPI, int BM = WS_BM, int NS = WS_NS>
 __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
-    constexpr int RP = LW * 16;                                 // tile rows one pass of the loader lanes covers (4 lanes per row)
-    constexpr int WNW = BN / 64, MI = BM / ((4 / WNW) * 32), NI = 2, NB = BN / RP, AR = BM / RP;
+    constexpr int WNW = BN / 64, MI = BM / ((4 / WNW) * 32), NI = 2, NB = BN / 64, AR = BM / 64;
     constexpr int STAGE = (BM + BN) * WS_LDK;
     static_assert(NS == 4 || NS == 3, "ring of 3 or 4 stages");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -401,12 +397,12 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
     if (wid >= 4) {
         // ------------------------------------------------------------------ loader waves (256 threads)
         const int lt = tid - 256;
-        const int lrow = lt >> 2, lk = (lt & 3) * 4;           // 4 lanes per 16-float row, RP rows per pass
+        const int lrow = lt >> 2, lk = (lt & 3) * 4;           // 4 lanes per 16-float row, 64 rows per pass
         const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)a.a_bytes, 0x00020000);
         int ry[AR], rx[AR], rn[AR];
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int m = tile_m * BM + lrow + RP * i;
+            const int m = tile_m * BM + lrow + 64 * i;
             int n, y, x;
             fg_decode_m(m < a.M ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
             rn[i] = n * a.Ha * a.Wa;
@@ -431,7 +427,7 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
         // packed weights [P][G][Npad][Kpad]: < 2 GiB (the 33.5 M-weight Linear packs to 134 MB), raw-buffer addressing
         const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.Bp, 0, FG_OOB, 0x00020000);
         int boff = (int)((((size_t)(p * a.G + g) * a.Npad + tile_n * BN + lrow) * a.Kpad + col0 + lk) * 4);
-        const int browB = RP * a.Kpad * 4;
+        const int browB = 64 * a.Kpad * 4;
         const int bjumpB = (a.Npad - 1) * a.Kpad * 4;
         f32x4 xa[AR], xb[NB], ya[AR], yb[NB];     // two tiles in flight: a load has two full K-steps to land
         // (instruction count matters here -- every instruction a loader wave issues costs the SIMD's matrix pipe 6-9 cycles, DESIGN
@@ -457,9 +453,9 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
             float* As = smem + (st) * STAGE;                                                          \
             float* Bs = As + BM * WS_LDK;                                                                \
             _Pragma("unroll") for (int i = 0; i < AR; ++i)                                               \
-                *(f32x4*)(As + (lrow + RP * i) * WS_LDK + lk) = ra[i];                                   \
+                *(f32x4*)(As + (lrow + 64 * i) * WS_LDK + lk) = ra[i];                                   \
             _Pragma("unroll") for (int i = 0; i < NB; ++i)                                               \
-                *(f32x4*)(Bs + (lrow + RP * i) * WS_LDK + lk) = rb[i];                                   \
+                *(f32x4*)(Bs + (lrow + 64 * i) * WS_LDK + lk) = rb[i];                                   \
         }
         // prologue: tiles 0 and 1 resident, tiles 2 and 3 in flight
         if (KT > 0) { WS_LOAD(xa, xb); WS_STORE(0, xa, xb); }
@@ -552,16 +548,6 @@ template <int BN>
 __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) { igemm_ws_body<BN, 0>(a); }
 template <int BN, int EPI>
 __global__ __launch_bounds__(512, 2) void igemm_ws_act_kernel(const IgemmArgs a) { igemm_ws_body<BN, EPI>(a); }
-// the same kernels with TWO loader waves (384 threads); FG_WS_LW=4 in the environment switches back
-template <int BN, int EPI>
-__global__ __launch_bounds__(384, 2) void igemm_ws2_kernel(const IgemmArgs a) { igemm_ws_body<BN, EPI, WS_BM, WS_NS, 2>(a); }
-template <int EPI>
-__global__ __launch_bounds__(384, 4) void igemm_ws64x3l2_kernel(const IgemmArgs a) { igemm_ws_body<64, EPI, WS_BM, 3, 2>(a); }
-static int fg_ws_lw() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FG_WS_LW"); v = (e && atoi(e) == 4) ? 4 : 2; }
-    return v;
-}
 // BN = 64 on a 3-stage ring: 77 KB of LDS and <= 128 VGPRs, so TWO blocks share a CU.  The layers with 64 output channels have
 // short K loops (3x3 x 64 channels = 36 sixteen-channel steps per tile): with one block per CU the matrix pipe idles through every
 // tile's prologue and epilogue; with two, one block's epilogue overlaps the other's K loop.  (A 512 x 64 tile that halves the
@@ -580,9 +566,6 @@ static int launch_igemm_ws64x3(fg_ctx* ctx, const IgemmArgs& a, int P) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3l2_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3l2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3l2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / 64) * P, a.splits, 1);
@@ -591,11 +574,6 @@ static int launch_igemm_ws64x3(fg_ctx* ctx, const IgemmArgs& a, int P) {
     char label[96];
     snprintf(label, sizeof(label), "igemm_ws64x3_kernel<%d>/%s", epi, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
-    if (fg_ws_lw() == 2) {
-        if (epi == 2) hipLaunchKernelGGL(igemm_ws64x3l2_kernel<2>, grid, dim3(384), lds, ctx->stream, a);
-        else if (epi == 1) hipLaunchKernelGGL(igemm_ws64x3l2_kernel<1>, grid, dim3(384), lds, ctx->stream, a);
-        else hipLaunchKernelGGL(igemm_ws64x3l2_kernel<0>, grid, dim3(384), lds, ctx->stream, a);
-    } else
     if (epi == 2) hipLaunchKernelGGL(igemm_ws64x3_kernel<2>, grid, dim3(512), lds, ctx->stream, a);
     else if (epi == 1) hipLaunchKernelGGL(igemm_ws64x3_kernel<1>, grid, dim3(512), lds, ctx->stream, a);
     else hipLaunchKernelGGL(igemm_ws64x3_kernel<0>, grid, dim3(512), lds, ctx->stream, a);
@@ -611,9 +589,6 @@ static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_act_kernel<BN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_act_kernel<BN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws2_kernel<BN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws2_kernel<BN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws2_kernel<BN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / BN) * P, a.splits, 1);
@@ -623,11 +598,6 @@ static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
     if (epi) snprintf(label, sizeof(label), "igemm_ws_act_kernel<%d,%d>/%s", BN, epi, a.tag ? a.tag : "?");
     else snprintf(label, sizeof(label), "igemm_ws_kernel<%d>/%s", BN, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
-    if (fg_ws_lw() == 2) {
-        if (epi == 2) hipLaunchKernelGGL((igemm_ws2_kernel<BN, 2>), grid, dim3(384), lds, ctx->stream, a);
-        else if (epi == 1) hipLaunchKernelGGL((igemm_ws2_kernel<BN, 1>), grid, dim3(384), lds, ctx->stream, a);
-        else hipLaunchKernelGGL((igemm_ws2_kernel<BN, 0>), grid, dim3(384), lds, ctx->stream, a);
-    } else
     if (epi == 2) hipLaunchKernelGGL((igemm_ws_act_kernel<BN, 2>), grid, dim3(512), lds, ctx->stream, a);
     else if (epi == 1) hipLaunchKernelGGL((igemm_ws_act_kernel<BN, 1>), grid, dim3(512), lds, ctx->stream, a);
     else hipLaunchKernelGGL(igemm_ws_kernel<BN>, grid, dim3(512), lds, ctx->stream, a);
