@@ -129,7 +129,6 @@ static int choose_wgrad6(long long M, int Cout, int Cin, int G, int P, int* S, i
     if (cfg < 0) return -1;
     const long long base = (long long)(Cout / RT[cfg]) * (Cin / QT[cfg]) * G * P;
     long long s = (256 + base / 2) / base;
-    if (base * s > 256 && s > 1 && base * s - 256 < base / 2) s -= 1;      // a few blocks over one round would double the launch
     if (s < 1) s = 1;
     const long long maxs = M / 192 > 0 ? M / 192 : 1;
     if (s > maxs) s = maxs;
@@ -149,7 +148,7 @@ static int choose_wgrad_ws(long long M, int Cout, int Cin, int G, int P, int* S,
     if (taps < 0) { const char* e = getenv("FG_WGRAD_WS_TAPS"); taps = e ? atoi(e) : 1; }
     if (!taps || Cin != 64 || Cout % 128 || G < 5) return -1;
     const long long base = (long long)(Cout / 128) * ((G + 3) / 4) * P;
-    long long s = 256 / base;            // ONE round: a 257th block would run alone after the other 256 (one block per CU)
+    long long s = (256 + base / 2) / base;
     if (s < 1) s = 1;
     const long long maxs = M / 192 > 0 ? M / 192 : 1;
     if (s > maxs) s = maxs;
