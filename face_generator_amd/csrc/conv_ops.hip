@@ -138,25 +138,6 @@ static int choose_wgrad6(long long M, int Cout, int Cin, int G, int P, int* S, i
     return cfg;
 }
 
-// tiling of the wave-specialised fp32 weight gradient: choose_wgrad6's two (256 x 128 / 128 x 256 channels), plus cfg 2 for a
-// 64-channel input with >= 128 output channels and >= 5 taps: 128 dY channels x (4 taps x 64 X channels) per block
-// (FG_WGRAD_WS_TAPS=0 switches cfg 2 off)
-static int choose_wgrad_ws(long long M, int Cout, int Cin, int G, int P, int* S, int* mper) {
-    const int c = choose_wgrad6(M, Cout, Cin, G, P, S, mper);
-    if (c >= 0) return c;
-    static int taps = -1;
-    if (taps < 0) { const char* e = getenv("FG_WGRAD_WS_TAPS"); taps = e ? atoi(e) : 1; }
-    if (!taps || Cin != 64 || Cout % 128 || G < 5) return -1;
-    const long long base = (long long)(Cout / 128) * ((G + 3) / 4) * P;
-    long long s = (256 + base / 2) / base;
-    if (s < 1) s = 1;
-    const long long maxs = M / 192 > 0 ? M / 192 : 1;
-    if (s > maxs) s = maxs;
-    int mp = fg_round_up((int)((M + s - 1) / s), 16);
-    *mper = mp;
-    *S = (int)((M + mp - 1) / mp);
-    return 2;
-}
 // A/B switch (round 3; default on): FG_WGRAD_WS=0 keeps the symmetric wgrad_kernel for the layers that tile 256 x 128 /
 // 128 x 256 channels instead of the wave-specialised wgrad_ws_kernel
 static bool fg_wgrad_ws_on() {
@@ -199,15 +180,6 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
                  256LL * 256 * 128 + 64 + ((long long)wm.P * wm.G * rb * cb * 3 + 1) / 2 + 64;
     }
     if (n3 > need) need = n3;
-    {   // the wave-specialised fp32 weight gradient picks its own split count (one round of ~256 blocks): partials + bias rows
-        int Sw, mperw;
-        const int cw = M >= 4096 ? choose_wgrad_ws(M, g.Cout, g.Cin, wm.G, wm.P, &Sw, &mperw) : -1;
-        if (cw >= 0) {
-            const long long rows = cw == 2 ? ((wm.G + 3) / 4) * 8LL : (long long)wm.G * (g.Cin / (cw == 0 ? 128 : 256)) * (cw == 0 ? 4 : 8);
-            const long long nw = (long long)wm.P * wm.G * Sw * g.Cout * g.Cin + (long long)wm.P * Sw * rows * g.Cout + 64;
-            if (nw > need) need = nw;
-        }
-    }
     long long n4 = (long long)(CR_ROWBLOCKS_MAX + 2) * g.Cout;
     if (n4 > need) need = n4;
     return need + 64;
@@ -457,11 +429,11 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         if ((rc = fg_launch_wgrad6(ctx, a, wm.P, cfg6))) return rc;
         if (gy6_out) *gy6_out = a.D6;
         if (used_out) *used_out = part + d6;
-    } else if (fg_wgrad_ws_on() && ctx->math != 6 && a.M >= 4096 && choose_wgrad_ws(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split) >= 0 &&
+    } else if (fg_wgrad_ws_on() && ctx->math != 6 && a.M >= 4096 && choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split) >= 0 &&
                fg_wgrad_ws_shape_ok(a)) {
-        // wave-specialised fp32 weight gradient (256 x 128 / 128 x 256 channel tiles, or 128 x (4 taps x 64) for a 64-channel
-        // input; one round of ~256 blocks)
-        const int cfgw = choose_wgrad_ws(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split);
+        // wave-specialised fp32 weight gradient (256 x 128 / 128 x 256 channel tiles, one round of ~256 blocks); the bias gradient
+        // takes the separate column-sum pass at the end of this function
+        const int cfgw = choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split);
         a.Npad = g.Cout; a.Cpad = g.Cin;
         const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;
         if (need > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad (ws): scratch %lld > %lld", need, scratch_floats);

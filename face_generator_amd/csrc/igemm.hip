@@ -1528,12 +1528,8 @@ int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
 // Block tile RT (row operand) x QT (column operand) = 256 x 128 channels; SWAP = 0: rows = dY channels, columns = X channels;
 // SWAP = 1: rows = X channels, columns = dY channels (layers whose input has the 256).  Part stays [pg][s][dY ch][X ch].
 // ---------------------------------------------------------------------------------------------------------------
-// TAPS = 4 (SWAP = 1 only): a layer whose input has 64 channels (models_c2f.lua:125: 64 -> 128, 5x5) -- the 256 row channels of
-// a block are FOUR TAPS x 64 X channels, every loader lane fetching its 16-byte chunk with its own tap's shift; the grid's
-// group axis counts ceil(G / 4) tap groups, taps >= G of the last group load zeros and are not stored.
-template <int SWAP, int TAPS = 1>
+template <int SWAP>
 __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
-    static_assert(TAPS == 1 || (TAPS == 4 && SWAP == 1), "multi-tap blocks: X is the row operand");
     constexpr int RT = 256, QT = 128, MI = 4, NI = 2;
     constexpr int STAGE = 16 * (RT + QT);                       // floats per ring stage
     extern __shared__ __attribute__((aligned(16))) float smemw[];
@@ -1541,13 +1537,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nd_t = SWAP ? a.Npad / QT : a.Npad / RT;          // tiles along dY channels
-    const int nx_t = TAPS > 1 ? 1 : (SWAP ? a.Cpad / RT : a.Cpad / QT);          // tiles along X channels
+    const int nx_t = SWAP ? a.Cpad / RT : a.Cpad / QT;          // tiles along X channels
     int bt_, s, pg;
     fg_wgrad_block(bt_, s, pg);
     const int td = bt_ / nx_t, tx = bt_ - td * nx_t;
     (void)nd_t;
-    const int GG = TAPS > 1 ? (a.G + TAPS - 1) / TAPS : a.G;    // groups along the grid's z axis
-    const int p = pg / GG, g = (pg - p * GG) * TAPS;            // g = (first) tap of this block
+    const int p = pg / a.G, g = pg - p * a.G;
     const int m0 = s * a.m_per_split;
     const int m1 = min(a.M, m0 + a.m_per_split);
     const int KT = (m1 > m0) ? (m1 - m0) >> 4 : 0;         // whole 16-pixel steps only (see the launcher)
@@ -1557,6 +1552,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
         const int lt = tid - 256;
         const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)a.d_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
+        const int doy = a.doy[p], dox = a.dox[p], xoy = a.xoy[p][g], xox = a.xox[p][g];
         // dY tile: DT channels, X tile: XT channels; each loader lane owns one 16-byte chunk of 4 (resp. 2) pixel rows
         constexpr int DT = SWAP ? QT : RT, XT = SWAP ? RT : QT;
         constexpr int ND = 16 * DT / 4 / 256, NX = 16 * XT / 4 / 256;       // chunks per lane and K-step
@@ -1565,12 +1561,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
         const int xpix = lt / (XT / 4), xch = (lt - xpix * (XT / 4)) * 4;
         const int d_lds0 = (SWAP ? 16 * RT : 0) + dpix * DT + dch;          // the row operand's image comes first
         const int x_lds0 = (SWAP ? 0 : 16 * RT) + xpix * XT + xch;
-        // multi-tap: this lane's chunk belongs to tap g + xch / 64 and to the real channels xch % 64 .. + 3
-        const int mytap = TAPS > 1 ? g + (xch >> 6) : g;
-        const bool tap_ok = mytap < a.G;
-        const int doy = a.doy[p], dox = a.dox[p];
-        const int xoy = a.xoy[p][tap_ok ? mytap : 0], xox = tap_ok ? a.xox[p][mytap] : (1 << 20);   // invalid tap: never in range
-        const int gD = (td * DT + dch) * 4, gX = TAPS > 1 ? (xch & 63) * 4 : (tx * XT + xch) * 4;
+        const int gD = (td * DT + dch) * 4, gX = (tx * XT + xch) * 4;
         const int dpixB = a.Nd * 4, xpixB = a.Cx * 4;
         // Address math (the launcher only selects this kernel when Hm, Wm are powers of two, 16 | Hm*Wm and 16 | m_per_split, so a
         // K-step is 16 consecutive pixels of ONE sample -- part of a row, or 16 / Wm whole rows -- and no step is partial): a row's
@@ -1586,7 +1577,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const int j = xpix + XPP * i, yr = j >> a.lgW, xr = j & (a.Wm - 1);
-            cX[i] = (yr * a.xsy * a.Wx + xr * a.xsx + (TAPS > 1 && tap_ok ? xoy * a.Wx + xox : 0)) * xpixB + gX;
+            cX[i] = (yr * a.xsy * a.Wx + xr * a.xsx) * xpixB + gX;
             cyy[i] = yr * a.xsy + xoy;
             cxx[i] = xr * a.xsx + xox;
         }
@@ -1595,15 +1586,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
         // one partial row per loader pixel lane, bias_part [P][S][nb][DPP][Nd], finished by the batched final.  (Letting the tap-0
         // blocks sum everything made THEM 18 % slower -- packed fp32 adds beside the MFMAs -- and a launch of one round of blocks
         // lasts as long as its slowest block: 6.66 -> 7.44 ms on the c2f layers.)
-        const int nb = GG * nx_t, mine = (g / TAPS) * nx_t + tx;
+        const int nb = a.G * nx_t, mine = g * nx_t + tx;
         const int bperiod = a.bias_part ? nb - 1 : -1;           // -1: never
         int bcount = a.bias_part ? mine : -1;
         f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
         int mcur = m0;
         // wave-uniform strides (bytes), hoisted: the per-step base is three multiply-adds per operand on the scalar unit
         const int sDn = a.Hd * a.Wd * dpixB, sDy = a.dsy * a.Wd * dpixB, sDx = a.dsx * dpixB, sD0 = (doy * a.Wd + dox) * dpixB;
-        const int sXn = a.Hx * a.Wx * xpixB, sXy = a.xsy * a.Wx * xpixB, sXx = a.xsx * xpixB,
-                  sX0 = TAPS > 1 ? 0 : (xoy * a.Wx + xox) * xpixB;    // (multi-tap: the tap shift is a per-lane constant)
+        const int sXn = a.Hx * a.Wx * xpixB, sXy = a.xsy * a.Wx * xpixB, sXx = a.xsx * xpixB, sX0 = (xoy * a.Wx + xox) * xpixB;
         const int lgW = a.lgW, lgH = a.lgH, wmask = a.Wm - 1, hmask = a.Hm - 1, xsy = a.xsy, xsx = a.xsx;
         const unsigned Hx = (unsigned)a.Hx, Wx = (unsigned)a.Wx;
         f32x4 xd[ND], xx[NX], yd[ND], yx[NX], zd[ND], zx[NX];
@@ -1704,7 +1694,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
         asm volatile("s_barrier" ::: "memory");                 // bare: the fragment reads above may still be in flight
     }
 
-    float* part = a.Part + ((size_t)(TAPS > 1 ? 0 : pg) * a.S + s) * a.Npad * a.Cpad;
+    float* part = a.Part + ((size_t)pg * a.S + s) * a.Npad * a.Cpad;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -1715,14 +1705,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int cr = wm * 128 + 4 * i + mi;             // row-operand channel inside the block tile
                 const int o = SWAP ? td * QT + cq : td * RT + cr;  // dY channel
-                if (TAPS > 1) {                                   // rows = (tap, X channel): one Part plane per tap
-                    const int tap = g + (cr >> 6);
-                    if (tap < a.G)
-                        a.Part[(((size_t)(p * a.G + tap) * a.S + s) * a.Npad + o) * a.Cpad + (cr & 63)] = acc[mi][ni][r];
-                } else {
-                    const int c = SWAP ? tx * RT + cr : tx * QT + cq;  // X channel
-                    part[(size_t)o * a.Cpad + c] = acc[mi][ni][r];
-                }
+                const int c = SWAP ? tx * RT + cr : tx * QT + cq;  // X channel
+                part[(size_t)o * a.Cpad + c] = acc[mi][ni][r];
             }
         }
 }
@@ -1731,38 +1715,32 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
 bool fg_wgrad_ws_shape_ok(const WgradArgs& a) {
     return a.lgW >= 0 && a.lgH >= 0 && ((a.Hm * a.Wm) & 15) == 0 && (a.m_per_split & 15) == 0 && (a.M & 15) == 0;
 }
-// partial rows per (parity, split) the kernel leaves in bias_part: (tap groups x X tiles) blocks x the pixel rows one pass of the
-// 256 loader lanes covers
-int fg_wgrad_ws_bias_rows(const WgradArgs& a, int cfg) {
-    if (cfg == 2) return ((a.G + 3) / 4) * 8;
-    return a.G * (a.Cpad / (cfg == 0 ? 128 : 256)) * (cfg == 0 ? 4 : 8);
-}
-// cfg 0: 256 dY channels x 128 X channels per block, cfg 1: 128 x 256, cfg 2: 128 dY channels x (4 taps x 64 X channels)
+// partial rows per (parity, split) the kernel leaves in bias_part: (taps x X tiles) blocks x the pixel rows one pass of the 256
+// loader lanes covers
+int fg_wgrad_ws_bias_rows(const WgradArgs& a, int cfg) { return a.G * (a.Cpad / (cfg == 0 ? 128 : 256)) * (cfg == 0 ? 4 : 8); }
+// cfg 0: 256 dY channels x 128 X channels per block, cfg 1: 128 x 256
 int fg_launch_wgrad_ws(fg_ctx* ctx, const WgradArgs& a, int P, int cfg) {
-    const int RTd = cfg == 0 ? 256 : 128, QTx = cfg == 0 ? 128 : (cfg == 1 ? 256 : 64);
+    const int RTd = cfg == 0 ? 256 : 128, QTx = cfg == 0 ? 128 : 256;
     const size_t lds = (size_t)3 * 16 * (256 + 128) * sizeof(float);
-    static bool attr_set[3] = {false, false, false};
+    static bool attr_set[2] = {false, false};
     if (!attr_set[cfg]) {
         if (cfg == 0) FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else if (cfg == 1) FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[cfg] = true;
     }
-    if ((a.Nd % RTd) || (cfg == 2 ? a.Cx != 64 : (a.Cx % QTx) != 0) || a.Npad != a.Nd || a.Cpad != a.Cx)
+    if ((a.Nd % RTd) || (a.Cx % QTx) || a.Npad != a.Nd || a.Cpad != a.Cx)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: %d x %d channels do not tile %d x %d", a.Nd, a.Cx, RTd, QTx);
     if (a.d_bytes <= 0 || a.x_bytes <= 0 || a.d_bytes >= (long long)FG_OOB || a.x_bytes >= (long long)FG_OOB)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: operands must be < 2 GiB per launch");
     if (!fg_wgrad_ws_shape_ok(a))
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: needs power-of-two Hm, Wm with 16 | Hm*Wm and 16 | m_per_split");
-    const int groups = cfg == 2 ? (a.G + 3) / 4 : a.G;
-    dim3 grid(cfg == 2 ? a.Npad / 128 : (a.Npad / RTd) * (a.Cpad / QTx), a.S, groups * P);
-    const double exec = 2.0 * (double)a.Npad * (cfg == 2 ? 64.0 * 4 * groups : (double)a.Cpad * a.G) * (double)P * (double)a.M;
+    dim3 grid((a.Npad / RTd) * (a.Cpad / QTx), a.S, a.G * P);
+    const double exec = 2.0 * (double)a.Npad * a.Cpad * (double)P * a.G * (double)a.M;
     char label[96];
     snprintf(label, sizeof(label), "wgrad_ws_kernel<%d>/%s", cfg, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
     if (cfg == 0) hipLaunchKernelGGL(wgrad_ws_kernel<0>, grid, dim3(512), lds, ctx->stream, a);
-    else if (cfg == 1) hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(512), lds, ctx->stream, a);
-    else hipLaunchKernelGGL((wgrad_ws_kernel<1, 4>), grid, dim3(512), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(512), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }

@@ -8,7 +8,7 @@ mkdir -p $OUT
 timeout 900 python -m pytest tests/test_gpu_c2f.py tests/test_gpu_baseline_sizes.py tests/test_gpu_ops.py tests/test_gpu_net.py tests/test_gpu_fullsize.py -m gpu -q -x -k "not batch_64_two" > $OUT/${TAG}_tests.log 2>&1
 echo "parity rc=$?" | tee $OUT/${TAG}_summary.txt
 timeout 200 python bench.py --workload c2f --steps 10 --warmup 3 --no-cpu-baseline --no-alt-math > $OUT/${TAG}_bench_c2f_new.json 2>/dev/null
-FG_WGRAD_WS_TAPS=0 timeout 200 python bench.py --workload c2f --steps 10 --warmup 3 --no-cpu-baseline --no-alt-math > $OUT/${TAG}_bench_c2f_notaps.json 2>/dev/null
+FG_WGRAD_WS=0 timeout 200 python bench.py --workload c2f --steps 10 --warmup 3 --no-cpu-baseline --no-alt-math > $OUT/${TAG}_bench_c2f_nowgradws.json 2>/dev/null
 timeout 200 python bench.py --workload cfg2 --no-cpu-baseline --no-alt-math --no-live-traffic > $OUT/${TAG}_bench_cfg2_new.json 2>/dev/null
 tail -3 $OUT/${TAG}_tests.log
 python - <<PY
