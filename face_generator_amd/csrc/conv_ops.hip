@@ -129,6 +129,7 @@ static int choose_wgrad6(long long M, int Cout, int Cin, int G, int P, int* S, i
     if (cfg < 0) return -1;
     const long long base = (long long)(Cout / RT[cfg]) * (Cin / QT[cfg]) * G * P;
     long long s = (256 + base / 2) / base;
+    if (base * s > 256 && s > 1 && base * s - 256 < base / 2) s -= 1;      // a few blocks over one round would double the launch
     if (s < 1) s = 1;
     const long long maxs = M / 192 > 0 ? M / 192 : 1;
     if (s > maxs) s = maxs;
