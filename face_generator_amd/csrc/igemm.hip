@@ -68,7 +68,7 @@ __device__ __forceinline__ void fg_store_acc_tile(__amdgpu_buffer_rsrc_t orsrc, 
 template <int MI, int NI, int EPI>
 __device__ __forceinline__ void fg_epilogue(const IgemmArgs& a, float* outp, const int* rowoff, int row_base, int col_base,
                                             const f32x16 (&acc)[MI][NI], int lane, int part_idx) {
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, a.dbg_nostore ? 0 : FG_OOB, 0x00020000);
     if constexpr (EPI == 2) {
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.act_x, 0, FG_OOB, 0x00020000);
         const float sl = a.act_slope[0];
@@ -922,6 +922,11 @@ long long fg_igemm_blocks(const IgemmArgs& a, int P, int tile) {
 int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
     IgemmArgs a = a_in;
     a.P = P;
+    {   // measurement only: how much of a launch is its output stores?
+        static int ns = -1;
+        if (ns < 0) { const char* e = getenv("FG_DEBUG_NOSTORE"); ns = e ? atoi(e) : 0; }
+        a.dbg_nostore = ns;
+    }
     if ((a.act_y || a.act_x) && (a.splits != 1 || a.A6 || !a.act_slope || (a.act_y && a.act_x)))
         return fg_set_err(ctx, FG_ERR_INVALID, "igemm: a fused PReLU needs splits == 1, the fp32 path and its slope");
     if (a.Ca % 4 != 0 || a.Kpad % 32 != 0) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: Ca %% 4 / Kpad %% 32");
