@@ -544,218 +544,6 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
     fg_epilogue<MI, NI, EPI>(a, a.Out + (size_t)split * a.split_stride, rowoff, wm * MI * 32, tile_n * BN + wn * 64, acc, lane,
                              blockIdx.x * 4 + wid);
 }
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent form of igemm_ws (round 3): ONE block per CU walks several output tiles.  Measured on every layer, a tile costs
-// its K loop plus a fixed ~35 us (rate = K / (K + ~350 channel-taps): 102 TFLOP/s at K = 576, 117 at 1152, 127 at 1600, 139 at
-// 3200 -- block dispatch, kernarg / row-offset set-up, the ring's cold start, the drain of the output stores before the block
-// can retire); two co-resident blocks did not hide it.  Here the K-step stream is CONTINUOUS across tiles: the loader waves'
-// cursor runs two stored + two in-flight steps ahead of the MFMA waves and simply crosses into the next tile, so the next tile's
-// first fragments are in the ring (and its row offsets in LDS) while the MFMA waves still store the previous tile; the MFMA
-// waves go from their last store instruction straight to the next tile's first MFMA.
-// Same tile (256 x BN), ring (4 stages), K-step (16) and epilogues as igemm_ws_body; tiles t = blockIdx.x, + gridDim.x, ...
-// ---------------------------------------------------------------------------------------------------------------
-template <int BN, int EPI>
-__device__ __forceinline__ void igemm_wsp_body(const IgemmArgs& a) {
-    constexpr int BM = WS_BM;
-    constexpr int WNW = BN / 64, MI = BM / ((4 / WNW) * 32), NI = 2, NB = BN / 64, AR = BM / 64;
-    constexpr int STAGE = (BM + BN) * WS_LDK;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* rowoff2 = (int*)(smem + WS_NS * STAGE);            // [2][BM]: row offsets of the tile being stored / the tile being loaded
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntn = a.Npad / BN;
-    const int np = a.P;
-    const int per_m = ntn * np;
-    const int nmt = (a.M + BM - 1) / BM;
-    const int ntiles = nmt * per_m;
-    const int split = blockIdx.y;
-    const int kc = a.Kpad / WS_BK;
-    const int kt_all = a.G * kc;
-    const int kt_per = (kt_all + a.splits - 1) / a.splits;
-    const int kt0 = split * kt_per;
-    const int KT = max(0, min(kt_all, kt0 + kt_per) - kt0);
-    const int my_tiles = ((int)blockIdx.x < ntiles) ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    const int total = my_tiles * KT;                          // K-steps this block runs, all tiles
-    // tile index -> (tile_m, tile_n, p), XCD-aware like igemm_ws_body (t and t + gridDim.x live on the same XCD: 8 | gridDim.x)
-#define WSP_TILE(t, tm_, tn_, p_)                                                                        \
-    {                                                                                                    \
-        int lin_ = (t);                                                                                  \
-        if ((nmt & 7) == 0) {                                                                            \
-            const int xcd_ = lin_ & 7, loc_ = lin_ >> 3;                                                 \
-            lin_ = (xcd_ * (nmt >> 3) + loc_ / per_m) * per_m + loc_ % per_m;                            \
-        }                                                                                                \
-        tm_ = lin_ / per_m;                                                                              \
-        const int rem_ = lin_ - tm_ * per_m;                                                             \
-        tn_ = rem_ / np; p_ = rem_ - tn_ * np;                                                           \
-    }
-
-    if (wid >= 4) {
-        // ------------------------------------------------------------------ loader waves (256 threads)
-        const int lt = tid - 256;
-        const int lrow = lt >> 2, lk = (lt & 3) * 4;
-        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)a.a_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.Bp, 0, FG_OOB, 0x00020000);
-        const bool ktail = a.Ca != a.Kpad;
-        const int browB = 64 * a.Kpad * 4;
-        const int bjumpB = (a.Npad - 1) * a.Kpad * 4;
-        // the LOAD cursor: tile (jl-th of this block), K-step inside it, tap group, column, weight offset, row decode
-        int jl = 0, ktl = 0, g = 0, col0 = 0, boff = 0, pl = 0;
-        int ry[AR], rx[AR], rn[AR], voff[AR];
-#define WSP_SET_GROUP()                                                                                  \
-        {                                                                                                \
-            const int go = a.goff[pl][g < a.G ? g : 0];                                                  \
-            const int oy = (int)(short)(go & 0xffff), ox = go >> 16;                                     \
-            _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                             \
-                const int ya_ = ry[i] + oy, xa_ = rx[i] + ox;                                            \
-                const bool ok = (unsigned)ya_ < (unsigned)a.Ha && (unsigned)xa_ < (unsigned)a.Wa;        \
-                voff[i] = ok ? ((rn[i] + ya_ * a.Wa + xa_) * a.Ca + lk) * 4 : FG_OOB;                    \
-            }                                                                                            \
-        }
-        // enter the jl-th tile of this block: row decode for the gathers, row offsets for its (later) epilogue, group 0
-#define WSP_ENTER_TILE()                                                                                 \
-        {                                                                                                \
-            int tm, tn;                                                                                  \
-            WSP_TILE((int)blockIdx.x + jl * (int)gridDim.x, tm, tn, pl);                                 \
-            _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                             \
-                const int m = tm * BM + lrow + 64 * i;                                                   \
-                int n, y, x;                                                                             \
-                fg_decode_m(m < a.M ? m : 0, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                         \
-                rn[i] = n * a.Ha * a.Wa;                                                                 \
-                ry[i] = m < a.M ? y * a.asy : -(1 << 20);                                                \
-                rx[i] = x * a.asx;                                                                       \
-            }                                                                                            \
-            {                                                                                            \
-                int m = tm * BM + lt, off = EPI == 2 ? FG_ROW_MASKED : -1;                               \
-                if (m < a.M) {                                                                           \
-                    int n, y, x;                                                                         \
-                    fg_decode_m(m, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);                                   \
-                    off = ((n * a.Ho + y * a.osy + a.ooy[pl]) * a.Wo + x * a.osx + a.oox[pl]) * a.N;     \
-                }                                                                                        \
-                rowoff2[(jl & 1) * BM + lt] = off;                                                       \
-            }                                                                                            \
-            g = kt0 / kc;                                                                                \
-            col0 = (kt0 - g * kc) * WS_BK;                                                               \
-            boff = (int)((((size_t)(pl * a.G + g) * a.Npad + tn * BN + lrow) * a.Kpad + col0 + lk) * 4); \
-            ktl = 0;                                                                                     \
-            WSP_SET_GROUP();                                                                             \
-        }
-        f32x4 xa[AR], xb[NB], ya[AR], yb[NB];
-#define WSP_LOAD(ra, rb)                                                                                 \
-        {                                                                                                \
-            const int cb = col0 * 4;                                                                     \
-            if (ktail) {                                                                                 \
-                const bool kin = col0 + lk < a.Ca;                                                       \
-                _Pragma("unroll") for (int i = 0; i < AR; ++i)                                           \
-                    ra[i] = fg_buffer_load4(arsrc, kin ? voff[i] + cb : FG_OOB);                         \
-            } else {                                                                                     \
-                _Pragma("unroll") for (int i = 0; i < AR; ++i) ra[i] = fg_buffer_load4(arsrc, voff[i] + cb); \
-            }                                                                                            \
-            _Pragma("unroll") for (int i = 0; i < NB; ++i) rb[i] = fg_buffer_load4(brsrc, boff + i * browB); \
-            col0 += WS_BK; boff += WS_BK * 4; ++ktl;                                                     \
-            if (ktl == KT) { ++jl; if (jl < my_tiles) WSP_ENTER_TILE(); }                                \
-            else if (col0 == a.Kpad) { col0 = 0; ++g; boff += bjumpB; WSP_SET_GROUP(); }                \
-        }
-#define WSP_STORE(st, ra, rb)                                                                            \
-        {                                                                                                \
-            __builtin_amdgcn_s_waitcnt(0x0f70);                                                          \
-            float* As = smem + (st) * STAGE;                                                             \
-            float* Bs = As + BM * WS_LDK;                                                                \
-            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                               \
-                *(f32x4*)(As + (lrow + 64 * i) * WS_LDK + lk) = ra[i];                                   \
-            _Pragma("unroll") for (int i = 0; i < NB; ++i)                                               \
-                *(f32x4*)(Bs + (lrow + 64 * i) * WS_LDK + lk) = rb[i];                                   \
-        }
-        if (total > 0) WSP_ENTER_TILE();
-        if (total > 0) { WSP_LOAD(xa, xb); WSP_STORE(0, xa, xb); }
-        if (total > 1) { WSP_LOAD(xa, xb); WSP_STORE(1, xa, xb); }
-        if (total > 2) { WSP_LOAD(xa, xb); }
-        if (total > 3) { WSP_LOAD(ya, yb); }
-        __syncthreads();
-        for (int gs = 0; gs < total; gs += 2) {
-            if (gs + 2 < total) {
-                WSP_STORE((gs + 2) & 3, xa, xb);
-                if (gs + 4 < total) { WSP_LOAD(xa, xb); }
-            }
-            __syncthreads();
-            if (gs + 1 < total) {
-                if (gs + 3 < total) {
-                    WSP_STORE((gs + 3) & 3, ya, yb);
-                    if (gs + 5 < total) { WSP_LOAD(ya, yb); }
-                }
-                __syncthreads();
-            }
-        }
-#undef WSP_SET_GROUP
-#undef WSP_ENTER_TILE
-#undef WSP_LOAD
-#undef WSP_STORE
-        return;
-    }
-
-    // ---------------------------------------------------------------------- MFMA waves (one per SIMD)
-    const int wm = wid / WNW, wn = wid - wm * WNW;
-    f32x16 acc[MI][NI];
-    const int a_lds = (wm * MI * 32 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
-    const int b_lds = BM * WS_LDK + (wn * 64 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
-    f32x4 af[2][MI], bf[2][NI];
-    __syncthreads();              // steps 0 and 1 are in the ring
-    if (total > 0) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[0][mi] = *(const f32x4*)(smem + a_lds + mi * 32 * WS_LDK);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *(const f32x4*)(smem + b_lds + ni * 32 * WS_LDK);
-    }
-    int gs = 0;
-    for (int j = 0; j < my_tiles; ++j) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        for (int kt = 0; kt < KT; ++kt, ++gs) {
-            const float* St = smem + (gs & 3) * STAGE;
-            const float* Sn = smem + ((gs + 1) & 3) * STAGE;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) af[1][mi] = *(const f32x4*)(St + a_lds + mi * 32 * WS_LDK + 8);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) bf[1][ni] = *(const f32x4*)(St + b_lds + ni * 32 * WS_LDK + 8);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][mi][jj], bf[0][ni][jj], acc[mi][ni], 0, 0, 0);
-            if (gs + 1 < total) {     // chunk 0 of the NEXT step -- of the next tile after this tile's last step
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) af[0][mi] = *(const f32x4*)(Sn + a_lds + mi * 32 * WS_LDK);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bf[0][ni] = *(const f32x4*)(Sn + b_lds + ni * 32 * WS_LDK);
-            }
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][mi][jj], bf[1][ni][jj], acc[mi][ni], 0, 0, 0);
-            __syncthreads();
-        }
-        int tm, tn, pp;
-        const int t = (int)blockIdx.x + j * (int)gridDim.x;
-        WSP_TILE(t, tm, tn, pp);
-        const int* rowoff = rowoff2 + (j & 1) * BM;
-        if (a.stats_part) fg_store_stats<MI, NI>(a, acc, (tm * np + pp) * (4 / WNW) + wm, tn * BN + wn * 64, lane);
-        fg_epilogue<MI, NI, EPI>(a, a.Out + (size_t)split * a.split_stride, rowoff, wm * MI * 32, tn * BN + wn * 64, acc, lane,
-                                 t * 4 + wid);
-    }
-#undef WSP_TILE
-}
-template <int BN, int EPI>
-__global__ __launch_bounds__(512, 2) void igemm_wsp_kernel(const IgemmArgs a) { igemm_wsp_body<BN, EPI>(a); }
-
 template <int BN>
 __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) { igemm_ws_body<BN, 0>(a); }
 template <int BN, int EPI>
@@ -794,33 +582,6 @@ static int launch_igemm_ws64x3(fg_ctx* ctx, const IgemmArgs& a, int P) {
 }
 template <int BN>
 static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
-    {   // persistent form (FG_WS_PERSIST=1; experiment): one block per CU walks the tiles
-        static int pers = -1;
-        if (pers < 0) { const char* e = getenv("FG_WS_PERSIST"); pers = e ? atoi(e) : 0; }
-        const long long ntiles = (long long)fg_cdiv(a.M, WS_BM) * (a.Npad / BN) * P;
-        const int kt_all = a.G * (a.Kpad / WS_BK), kt_per = (kt_all + a.splits - 1) / a.splits;
-        if ((pers & (BN == 128 ? 1 : 2)) && ntiles > 256 && kt_per >= 8) {      // bit 0: 256 x 128 tiles, bit 1: 256 x 64
-            const size_t ldsp = (size_t)(WS_NS * (WS_BM + BN) * WS_LDK + 2 * WS_BM) * sizeof(float);
-            static bool attr_p = false;
-            if (!attr_p) {
-                FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_wsp_kernel<BN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
-                FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_wsp_kernel<BN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
-                FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_wsp_kernel<BN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp));
-                attr_p = true;
-            }
-            dim3 gridp(256, a.splits, 1);
-            const double execp = 2.0 * (double)ntiles * WS_BM * BN * (double)a.G * a.Kpad;
-            const int epip = a.act_x ? 2 : (a.act_y ? 1 : 0);
-            char labelp[96];
-            snprintf(labelp, sizeof(labelp), "igemm_wsp_kernel<%d,%d>/%s", BN, epip, a.tag ? a.tag : "?");
-            FgProfScope profp(ctx, fg_intern(ctx, labelp), a.alg_flops, execp, 0.0);
-            if (epip == 2) hipLaunchKernelGGL((igemm_wsp_kernel<BN, 2>), gridp, dim3(512), ldsp, ctx->stream, a);
-            else if (epip == 1) hipLaunchKernelGGL((igemm_wsp_kernel<BN, 1>), gridp, dim3(512), ldsp, ctx->stream, a);
-            else hipLaunchKernelGGL((igemm_wsp_kernel<BN, 0>), gridp, dim3(512), ldsp, ctx->stream, a);
-            FG_CHECK_LAUNCH(ctx);
-            return FG_OK;
-        }
-    }
     if (BN == 64 && fg_ws64_ns3()) return launch_igemm_ws64x3(ctx, a, P);
     const size_t lds = (size_t)(WS_NS * (WS_BM + BN) * WS_LDK + WS_BM) * sizeof(float);
     static bool attr_set = false;
