@@ -908,21 +908,13 @@ static int launch_igemm_t(fg_ctx* ctx, const IgemmArgs& a, int P) {
     return FG_OK;
 }
 
-// tile 4 on a layer with a multiple of 128 output channels: 256 x 128 tiles -- unless its K loop is short (FG_WS64_MAXK, in
-// channels x taps; 0 = never), where two co-resident 256 x 64 blocks hide each other's prologue and epilogue
-static bool fg_ws_use64(const IgemmArgs& a) {
-    static int maxk = -1;
-    if (maxk < 0) { const char* e = getenv("FG_WS64_MAXK"); maxk = e ? atoi(e) : 0; }
-    if (a.Npad % 128 != 0) return true;
-    return maxk > 0 && !a.A6 && !a.stats_part && a.G * a.Kpad <= maxk;
-}
 long long fg_igemm_blocks(const IgemmArgs& a, int P, int tile) {
     switch (tile) {
         case 0: return (long long)fg_cdiv(a.M, 128) * (a.Npad / 128) * P;
         case 1: return (long long)fg_cdiv(a.M, 128) * (a.Npad / 64) * P;
         case 2: return (long long)fg_cdiv(a.M, 64) * (a.Npad / 64) * P;
         case 5: return (long long)fg_cdiv(a.M, WS_BM) * (a.Npad / 64) * P;
-        case 4: return (long long)fg_cdiv(a.M, WS_BM) * (a.Npad / (fg_ws_use64(a) ? 64 : 128)) * P;
+        case 4: return (long long)fg_cdiv(a.M, WS_BM) * (a.Npad / ((a.Npad % 128 == 0) ? 128 : 64)) * P;
     }
     return 0;
 }
@@ -958,7 +950,7 @@ int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
         case 4:
             if (a.A6) { if (a.Npad % 64) break; return (a.Npad % 128 == 0) ? launch_igemm_ws6<128>(ctx, a, P) : launch_igemm_ws6<64>(ctx, a, P); }
             if (a.Npad % 64) break;
-            return fg_ws_use64(a) ? launch_igemm_ws<64>(ctx, a, P) : launch_igemm_ws<128>(ctx, a, P);
+            return (a.Npad % 128 == 0) ? launch_igemm_ws<128>(ctx, a, P) : launch_igemm_ws<64>(ctx, a, P);
     }
     return fg_set_err(ctx, FG_ERR_INVALID, "igemm: bad tile %d for Npad %d", tile, a.Npad);
 }
