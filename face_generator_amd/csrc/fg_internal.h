@@ -112,7 +112,6 @@ struct IgemmArgs {
     float* act_part;
     double alg_flops;    // host-side bookkeeping only: reference-formulation FLOPs of this launch
     const char* tag;     // host-side: profile label
-    int prefetch_ahead;  // igemm_ws: > 0 = the loader waves touch the input rows of tile (block index + this) before they retire
     int dbg_nostore;     // measurement only (FG_DEBUG_NOSTORE=1): the epilogue's stores go to a zero-sized buffer (dropped by the hardware)
 };
 // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64.  P = gridDim.z parities.

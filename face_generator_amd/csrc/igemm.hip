@@ -483,32 +483,6 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
 #undef WS_SET_GROUP
 #undef WS_LOAD
 #undef WS_STORE
-        // L2 prefetch for the NEXT round (experiment, FG_WS_PREFETCH): all CUs run their tiles in lock-step, so the first-touch
-        // loads of a round of tiles hit HBM as one burst.  The loader waves are idle during the block's last two K-steps and its
-        // epilogue: they touch every 128-byte line of the input rows of the tile this CU will most likely run next (block index
-        // + the number of co-resident blocks of the chip; same XCD by the block map), so that tile's first gathers hit in L2.
-        if (a.prefetch_ahead > 0) {
-            int lin2 = (int)blockIdx.x + a.prefetch_ahead;
-            if (lin2 < nmt * per_m) {
-                if ((nmt & 7) == 0) {
-                    const int xcd = lin2 & 7, loc = lin2 >> 3;
-                    lin2 = (xcd * (nmt >> 3) + loc / per_m) * per_m + loc % per_m;
-                }
-                const int tm2 = lin2 / per_m;
-                float pf = 0.f;
-                for (int r = lt; r < BM; r += 256) {
-                    const int m = tm2 * BM + r;
-                    if (m < a.M) {
-                        int n, y, x;
-                        fg_decode_m(m, a.lgH, a.lgW, a.Hm, a.Wm, n, y, x);
-                        const int off = ((n * a.Ha + y * a.asy) * a.Wa + x * a.asx) * a.Ca * 4;
-                        for (int c = 0; c < a.Ca; c += 32)
-                            pf += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(arsrc, off + c * 4, 0, 0));
-                    }
-                }
-                if (pf == 1.2345678e-31f) rowoff[lt & (BM - 1)] = 0;       // keeps the loads; never true in practice, harmless if it is
-            }
-        }
         return;
     }
 
@@ -580,18 +554,12 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_act_kernel(const IgemmArgs a)
 // loader instructions per MFMA was measured first and changed nothing: 118.2 vs 118.5 TFLOP/s -- these layers are not issue-bound.)
 template <int EPI>
 __global__ __launch_bounds__(512, 4) void igemm_ws64x3_kernel(const IgemmArgs a) { igemm_ws_body<64, EPI, WS_BM, 3>(a); }
-static bool fg_ws_prefetch() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("FG_WS_PREFETCH"); on = e ? atoi(e) : 0; }
-    return on != 0;
-}
 static bool fg_ws64_ns3() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("FG_IGEMM_WS64_NS3"); on = e ? atoi(e) : 1; }
     return on != 0;
 }
 static int launch_igemm_ws64x3(fg_ctx* ctx, const IgemmArgs& a, int P) {
-    const_cast<IgemmArgs&>(a).prefetch_ahead = fg_ws_prefetch() ? 512 : 0;       // two blocks per CU
     const size_t lds = (size_t)(3 * (WS_BM + 64) * WS_LDK + WS_BM) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -615,7 +583,6 @@ static int launch_igemm_ws64x3(fg_ctx* ctx, const IgemmArgs& a, int P) {
 template <int BN>
 static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
     if (BN == 64 && fg_ws64_ns3()) return launch_igemm_ws64x3(ctx, a, P);
-    const_cast<IgemmArgs&>(a).prefetch_ahead = fg_ws_prefetch() ? 256 : 0;       // one block per CU
     const size_t lds = (size_t)(WS_NS * (WS_BM + BN) * WS_LDK + WS_BM) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
