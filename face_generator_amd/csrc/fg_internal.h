@@ -112,6 +112,7 @@ struct IgemmArgs {
     float* act_part;
     double alg_flops;    // host-side bookkeeping only: reference-formulation FLOPs of this launch
     const char* tag;     // host-side: profile label
+    unsigned long long* dbg_trace;   // measurement only (FG_WS_TRACE=1): s_memtime rows of igemm_ws_trace_kernel
     int dbg_nostore;     // measurement only (FG_DEBUG_NOSTORE=1): the epilogue's stores go to a zero-sized buffer (dropped by the hardware)
 };
 // tile: 0 = 128x128, 1 = 128x64, 2 = 64x64.  P = gridDim.z parities.

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void igemm_act_kernel(const IgemmArgs a) { 
 #define WS_STAGE ((WS_BM + WS_BN) * WS_LDK)
 // BN = 128: MFMA waves 2x2, each 128x64; BN = 64 (layers with 64 output channels): waves 4x1, each 64x64
 // BM / NS are template parameters for the BN = 64 variants (NS = 3: see igemm_ws64x3_kernel).
-template <int BN, int EPI, int BM = WS_BM, int NS = WS_NS>
+template <int BN, int EPI, int BM = WS_BM, int NS = WS_NS, int TRACE = 0>
 __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
     constexpr int WNW = BN / 64, MI = BM / ((4 / WNW) * 32), NI = 2, NB = BN / 64, AR = BM / 64;
     constexpr int STAGE = (BM + BN) * WS_LDK;
@@ -498,7 +498,15 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
     const int a_lds = (wm * MI * 32 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
     const int b_lds = BM * WS_LDK + (wn * 64 + (lane & 31)) * WS_LDK + (lane >> 5) * 4;
     f32x4 af[2][MI], bf[2][NI];     // [chunk parity][tile]
+    // TRACE (measurement kernel only): s_memtime of wave 0 at kernel entry, after the ring's first barrier, after every K-step
+    // barrier and after the epilogue -> dbg_trace[block][0 .. KT + 3]
+    unsigned long long* trc = nullptr;
+    if (TRACE) {
+        if (wid == 0 && a.dbg_trace) trc = a.dbg_trace + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 128;
+        if (trc && lane == 0) trc[0] = __builtin_amdgcn_s_memtime();
+    }
     __syncthreads();              // tiles 0 and 1 are in the ring
+    if (TRACE && trc && lane == 0) trc[1] = __builtin_amdgcn_s_memtime();
     if (KT > 0) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) af[0][mi] = *(const f32x4*)(smem + a_lds + mi * 32 * WS_LDK);
@@ -538,11 +546,17 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][mi][j], bf[1][ni][j], acc[mi][ni], 0, 0, 0);
         __syncthreads();
+        if (TRACE && trc && lane == 0 && kt < 120) trc[2 + kt] = __builtin_amdgcn_s_memtime();
     }
 
     if (a.stats_part) fg_store_stats<MI, NI>(a, acc, (tile_m * np + p) * (4 / WNW) + wm, tile_n * BN + wn * 64, lane);
     fg_epilogue<MI, NI, EPI>(a, a.Out + (size_t)split * a.split_stride, rowoff, wm * MI * 32, tile_n * BN + wn * 64, acc, lane,
                              blockIdx.x * 4 + wid);
+    if (TRACE && trc && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // the stores have left the wave
+        trc[(KT < 120 ? KT : 120) + 2] = __builtin_amdgcn_s_memtime();
+        trc[127] = (unsigned long long)__builtin_amdgcn_s_getreg(((3 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)KT << 32);   // XCC_ID, KT
+    }
 }
 template <int BN>
 __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) { igemm_ws_body<BN, 0>(a); }
@@ -554,6 +568,49 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_act_kernel(const IgemmArgs a)
 // loader instructions per MFMA was measured first and changed nothing: 118.2 vs 118.5 TFLOP/s -- these layers are not issue-bound.)
 template <int EPI>
 __global__ __launch_bounds__(512, 4) void igemm_ws64x3_kernel(const IgemmArgs a) { igemm_ws_body<64, EPI, WS_BM, 3>(a); }
+template <int BN>
+__global__ __launch_bounds__(512, 2) void igemm_ws_trace_kernel(const IgemmArgs a) { igemm_ws_body<BN, 0, WS_BM, (BN == 64 ? 3 : WS_NS), 1>(a); }
+// FG_WS_TRACE=1 (measurement only): EPI-0 launches run the trace kernel; the per-block s_memtime rows are copied back after the
+// launch (synchronously) and written to the file FG_WS_TRACE_FILE
+static int fg_ws_trace_launch(fg_ctx* ctx, const IgemmArgs& a_in, int BN, dim3 grid, size_t lds) {
+    IgemmArgs a = a_in;
+    const size_t nblk = (size_t)grid.x * grid.y;
+    unsigned long long* dev = nullptr;
+    if (hipMalloc((void**)&dev, nblk * 128 * 8) != hipSuccess) return fg_set_err(ctx, FG_ERR_NOMEM, "trace buffer");
+    (void)hipMemset(dev, 0, nblk * 128 * 8);
+    a.dbg_trace = dev;
+    if (BN == 64) {
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_trace_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(igemm_ws_trace_kernel<64>, grid, dim3(512), lds, ctx->stream, a);
+    } else {
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_trace_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(igemm_ws_trace_kernel<128>, grid, dim3(512), lds, ctx->stream, a);
+    }
+    FG_CHECK_LAUNCH(ctx);
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned long long> host(nblk * 128);
+    FG_HIP(ctx, hipMemcpy(host.data(), dev, nblk * 128 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dev);
+    const char* path = getenv("FG_WS_TRACE_FILE");
+    FILE* f = fopen(path ? path : "/tmp/fg_ws_trace.txt", "a");
+    if (f) {
+        fprintf(f, "# launch %s BN=%d blocks=%zu M=%d Npad=%d G=%d Kpad=%d\n", a.tag ? a.tag : "?", BN, nblk, a.M, a.Npad, a.G, a.Kpad);
+        for (size_t b = 0; b < nblk; ++b) {
+            const unsigned long long* r = host.data() + b * 128;
+            const int kt = (int)(r[127] >> 32), xcc = (int)(r[127] & 0xffffffff);
+            fprintf(f, "%zu %d %d", b, xcc, kt);
+            for (int i = 0; i < (kt < 120 ? kt : 120) + 3; ++i) fprintf(f, " %llu", r[i]);
+            fprintf(f, "\n");
+        }
+        fclose(f);
+    }
+    return FG_OK;
+}
+static bool fg_ws_trace_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FG_WS_TRACE"); on = e ? atoi(e) : 0; }
+    return on != 0;
+}
 static bool fg_ws64_ns3() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("FG_IGEMM_WS64_NS3"); on = e ? atoi(e) : 1; }
@@ -571,6 +628,7 @@ static int launch_igemm_ws64x3(fg_ctx* ctx, const IgemmArgs& a, int P) {
     dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / 64) * P, a.splits, 1);
     const double exec = 2.0 * (double)grid.x * WS_BM * 64 * (double)a.G * a.Kpad;
     const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
+    if (fg_ws_trace_on() && epi == 0 && !a.stats_part) return fg_ws_trace_launch(ctx, a, 64, grid, lds);
     char label[96];
     snprintf(label, sizeof(label), "igemm_ws64x3_kernel<%d>/%s", epi, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
@@ -594,6 +652,7 @@ static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
     dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / BN) * P, a.splits, 1);
     const double exec = 2.0 * (double)grid.x * WS_BM * BN * (double)a.G * a.Kpad;
     const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
+    if (BN == 128 && fg_ws_trace_on() && epi == 0 && !a.stats_part) return fg_ws_trace_launch(ctx, a, 128, grid, lds);
     char label[96];
     if (epi) snprintf(label, sizeof(label), "igemm_ws_act_kernel<%d,%d>/%s", BN, epi, a.tag ? a.tag : "?");
     else snprintf(label, sizeof(label), "igemm_ws_kernel<%d>/%s", BN, a.tag ? a.tag : "?");
