@@ -556,6 +556,7 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
         __builtin_amdgcn_s_waitcnt(0x0f70);        // the stores have left the wave
         trc[(KT < 120 ? KT : 120) + 2] = __builtin_amdgcn_s_memtime();
         trc[127] = (unsigned long long)__builtin_amdgcn_s_getreg(((3 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)KT << 32);   // XCC_ID, KT
+        trc[126] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);                                    // HW_ID (cu / sh / se)
     }
 }
 template <int BN>
@@ -598,7 +599,7 @@ static int fg_ws_trace_launch(fg_ctx* ctx, const IgemmArgs& a_in, int BN, dim3 g
         for (size_t b = 0; b < nblk; ++b) {
             const unsigned long long* r = host.data() + b * 128;
             const int kt = (int)(r[127] >> 32), xcc = (int)(r[127] & 0xffffffff);
-            fprintf(f, "%zu %d %d", b, xcc, kt);
+            fprintf(f, "%zu %d %d %llu", b, xcc, kt, r[126]);
             for (int i = 0; i < (kt < 120 ? kt : 120) + 3; ++i) fprintf(f, " %llu", r[i]);
             fprintf(f, "\n");
         }

@@ -8,8 +8,8 @@ def report():
     if not rows:
         return
     kt = rows[0][2]
-    T = np.array([r[3:3 + kt + 3] for r in rows if r[2] == kt and len(r) >= kt + 6], dtype=np.float64)
-    xcc = np.array([r[1] for r in rows if r[2] == kt and len(r) >= kt + 6])
+    T = np.array([r[4:4 + kt + 3] for r in rows if r[2] == kt and len(r) >= kt + 7], dtype=np.float64)
+    xcc = np.array([r[1] for r in rows if r[2] == kt and len(r) >= kt + 7])
     t_start = T[:, 0].min()
     entry, first, steps, epi = T[:, 0] - t_start, T[:, 1] - T[:, 0], np.diff(T[:, 1:kt + 2], axis=1), T[:, kt + 2] - T[:, kt + 1]
     total = T[:, kt + 2] - T[:, 0]
