@@ -573,6 +573,42 @@ template <int BN>
 __global__ __launch_bounds__(512, 2) void igemm_ws_trace_kernel(const IgemmArgs a) { igemm_ws_body<BN, 0, WS_BM, (BN == 64 ? 3 : WS_NS), 1>(a); }
 // FG_WS_TRACE=1 (measurement only): EPI-0 launches run the trace kernel; the per-block s_memtime rows are copied back after the
 // launch (synchronously) and written to the file FG_WS_TRACE_FILE
+// calibration for the trace: 4 waves per CU x 2 blocks issue nothing but MFMAs; s_memtime cycles per MFMA and the wall time of the
+// launch give what the counter counts and the clock the chip grants a pure matrix loop
+__global__ __launch_bounds__(256) void trace_calib_kernel(unsigned long long* out, int n, float seed) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = seed;
+    float x = seed + threadIdx.x, y = seed - threadIdx.x;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < n; ++k) {
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[i], 0, 0, 0);
+    }
+    float r = 0.f;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) r += acc[i][j];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) { out[blockIdx.x * 2] = t1 - t0; out[blockIdx.x * 2 + 1] = (unsigned long long)(r != 12345.f); }
+}
+static void fg_trace_calibrate(fg_ctx* ctx, FILE* f) {
+    unsigned long long* dev = nullptr;
+    const int nblk = 512, n = 20000;
+    if (hipMalloc((void**)&dev, nblk * 16) != hipSuccess) return;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int it = 0; it < 3; ++it) {
+        (void)hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL(trace_calib_kernel, dim3(nblk), dim3(256), 0, ctx->stream, dev, n, 1.0f);
+        (void)hipEventRecord(e1, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+        std::vector<unsigned long long> h(nblk * 2);
+        (void)hipMemcpy(h.data(), dev, nblk * 16, hipMemcpyDeviceToHost);
+        double cyc = 0; for (int b = 0; b < nblk; ++b) cyc += (double)h[b * 2];
+        cyc /= nblk;
+        fprintf(f, "# calib mfma-only: %d x 4 MFMA per wave, 8 waves per CU: %.0f counter ticks per block = %.2f per MFMA-slot (64 = shader clock), wall %.1f us -> %.3f GHz, %.1f TFLOP/s\n",
+                n, cyc, cyc / (n * 4.0 * 2.0), ms * 1e3, cyc / (ms * 1e-3) / 1e9, (double)nblk * 4 * n * 4.0 * 2 * 32 * 32 * 2 / (ms * 1e-3) / 1e12);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(dev);
+}
 static int fg_ws_trace_launch(fg_ctx* ctx, const IgemmArgs& a_in, int BN, dim3 grid, size_t lds) {
     IgemmArgs a = a_in;
     const size_t nblk = (size_t)grid.x * grid.y;
@@ -580,22 +616,33 @@ static int fg_ws_trace_launch(fg_ctx* ctx, const IgemmArgs& a_in, int BN, dim3 g
     if (hipMalloc((void**)&dev, nblk * 128 * 8) != hipSuccess) return fg_set_err(ctx, FG_ERR_NOMEM, "trace buffer");
     (void)hipMemset(dev, 0, nblk * 128 * 8);
     a.dbg_trace = dev;
-    if (BN == 64) {
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_trace_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(igemm_ws_trace_kernel<64>, grid, dim3(512), lds, ctx->stream, a);
-    } else {
-        FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_trace_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(igemm_ws_trace_kernel<128>, grid, dim3(512), lds, ctx->stream, a);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float wall_ms = 0.f;
+    for (int rep = 0; rep < 4; ++rep) {                   // three to settle the clocks, the fourth is the one reported
+        (void)hipEventRecord(e0, ctx->stream);
+        if (BN == 64) {
+            FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_trace_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(igemm_ws_trace_kernel<64>, grid, dim3(512), lds, ctx->stream, a);
+        } else {
+            FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_trace_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(igemm_ws_trace_kernel<128>, grid, dim3(512), lds, ctx->stream, a);
+        }
+        (void)hipEventRecord(e1, ctx->stream);
     }
     FG_CHECK_LAUNCH(ctx);
     FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipEventElapsedTime(&wall_ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     std::vector<unsigned long long> host(nblk * 128);
     FG_HIP(ctx, hipMemcpy(host.data(), dev, nblk * 128 * 8, hipMemcpyDeviceToHost));
     (void)hipFree(dev);
     const char* path = getenv("FG_WS_TRACE_FILE");
     FILE* f = fopen(path ? path : "/tmp/fg_ws_trace.txt", "a");
     if (f) {
-        fprintf(f, "# launch %s BN=%d blocks=%zu M=%d Npad=%d G=%d Kpad=%d\n", a.tag ? a.tag : "?", BN, nblk, a.M, a.Npad, a.G, a.Kpad);
+        static bool calibrated = false;
+        if (!calibrated) { calibrated = true; fg_trace_calibrate(ctx, f); }
+        fprintf(f, "# launch %s BN=%d blocks=%zu M=%d Npad=%d G=%d Kpad=%d wall_us=%.1f\n", a.tag ? a.tag : "?", BN, nblk, a.M, a.Npad, a.G, a.Kpad, wall_ms * 1e3);
         for (size_t b = 0; b < nblk; ++b) {
             const unsigned long long* r = host.data() + b * 128;
             const int kt = (int)(r[127] >> 32), xcc = (int)(r[127] & 0xffffffff);

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-OUT=gpurun_out; TAG=${1:-r3s}
+OUT=gpurun_out; TAG=${1:-r3t}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; mkdir -p $OUT
 rm -f $OUT/${TAG}_trace.txt
 for shape in "128 64 64 64 64 3 0" "128 32 32 128 256 3 0" "128 64 64 128 256 5 0"; do

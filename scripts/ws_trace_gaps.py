@@ -31,11 +31,16 @@ def rep():
     print("  span per CU (first entry -> last exit), cycles: median %.0f  min %.0f  max %.0f" % (np.median(spans), spans.min(), spans.max()))
     print("  gap between consecutive blocks of a slot, cycles: n %d  median %.0f  p90 %.0f  max %.0f  (sum per CU median %.0f)"
           % (len(gaps), np.median(gaps), np.percentile(gaps, 90), gaps.max(), gaps.sum() / len(spans)))
-    if li < len(walls):
-        print("  wall %.1f us -> shader clock implied by the median span: %.2f GHz" % (walls[li], np.median(spans) / walls[li] / 1e3))
+    import re
+    m = re.search(r"wall_us=([0-9.]+)", launch)
+    if m:
+        w = float(m.group(1)); kt_steps = kt
+        print("  wall %.1f us -> counter rate implied by the median span: %.3f GHz (2.4 = nominal)" % (w, np.median(spans) / w / 1e3))
     li += 1
 for line in op(sys.argv[1], "rt"):
-    if line.startswith("#"):
+    if line.startswith("# calib"):
+        print(line.strip())
+    elif line.startswith("#"):
         rep(); rows = []; launch = line
     else:
         rows.append([int(v) for v in line.split()])
