@@ -575,37 +575,60 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_trace_kernel(const IgemmArgs 
 // launch (synchronously) and written to the file FG_WS_TRACE_FILE
 // calibration for the trace: 4 waves per CU x 2 blocks issue nothing but MFMAs; s_memtime cycles per MFMA and the wall time of the
 // launch give what the counter counts and the clock the chip grants a pure matrix loop
+template <int MODE>
 __global__ __launch_bounds__(256) void trace_calib_kernel(unsigned long long* out, int n, float seed) {
     f32x16 acc[4];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = seed;
     float x = seed + threadIdx.x, y = seed - threadIdx.x;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int k = 0; k < n; ++k) {
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[i], 0, 0, 0);
+    if (MODE == 0) {
+        for (int k = 0; k < n; ++k)
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[i], 0, 0, 0);
+    } else if (MODE == 1) {
+        for (int k = 0; k < n; ++k) {                       // 16 x (s_nop 15) = 256 cycles of sequencer time per trip
+            asm volatile("s_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\n"
+                         "s_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15\ns_nop 15" ::: "memory");
+        }
+    } else {
+        for (int k = 0; k < n; ++k) {                       // 16 dependent v_fma_f32
+            asm volatile("v_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\n"
+                         "v_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\n"
+                         "v_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\n"
+                         "v_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1\nv_fma_f32 %0, %0, %1, %1"
+                         : "+v"(x) : "v"(y));
+        }
     }
-    float r = 0.f;
+    float r = x;
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) r += acc[i][j];
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0) { out[blockIdx.x * 2] = t1 - t0; out[blockIdx.x * 2 + 1] = (unsigned long long)(r != 12345.f); }
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[blockIdx.x * 2] = t1 - t0; out[blockIdx.x * 2 + 1] = (r1 - r0) + (unsigned long long)(r == 12345.f); }
 }
 static void fg_trace_calibrate(fg_ctx* ctx, FILE* f) {
     unsigned long long* dev = nullptr;
-    const int nblk = 512, n = 20000;
-    if (hipMalloc((void**)&dev, nblk * 16) != hipSuccess) return;
+    if (hipMalloc((void**)&dev, 512 * 16) != hipSuccess) return;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int it = 0; it < 3; ++it) {
+    const char* what[3] = {"80000 MFMA 32x32x2 f32 per wave", "320000 x (s_nop 15) per wave", "320000 dependent v_fma_f32 per wave"};
+    for (int mode = 0; mode < 3; ++mode) for (int nblk = 256; nblk <= 512; nblk *= 2) for (int it = 0; it < 2; ++it) {
+        const int n = 20000;
         (void)hipEventRecord(e0, ctx->stream);
-        hipLaunchKernelGGL(trace_calib_kernel, dim3(nblk), dim3(256), 0, ctx->stream, dev, n, 1.0f);
+        if (mode == 0) hipLaunchKernelGGL(trace_calib_kernel<0>, dim3(nblk), dim3(256), 0, ctx->stream, dev, n, 1.0f);
+        if (mode == 1) hipLaunchKernelGGL(trace_calib_kernel<1>, dim3(nblk), dim3(256), 0, ctx->stream, dev, n, 1.0f);
+        if (mode == 2) hipLaunchKernelGGL(trace_calib_kernel<2>, dim3(nblk), dim3(256), 0, ctx->stream, dev, n, 1.0f);
         (void)hipEventRecord(e1, ctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
         float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
         std::vector<unsigned long long> h(nblk * 2);
         (void)hipMemcpy(h.data(), dev, nblk * 16, hipMemcpyDeviceToHost);
-        double cyc = 0; for (int b = 0; b < nblk; ++b) cyc += (double)h[b * 2];
-        cyc /= nblk;
-        fprintf(f, "# calib mfma-only: %d x 4 MFMA per wave, 8 waves per CU: %.0f counter ticks per block = %.2f per MFMA-slot (64 = shader clock), wall %.1f us -> %.3f GHz, %.1f TFLOP/s\n",
-                n, cyc, cyc / (n * 4.0 * 2.0), ms * 1e3, cyc / (ms * 1e-3) / 1e9, (double)nblk * 4 * n * 4.0 * 2 * 32 * 32 * 2 / (ms * 1e-3) / 1e12);
+        double cyc = 0, rt = 0; for (int b = 0; b < nblk; ++b) { cyc += (double)h[b * 2]; rt += (double)h[b * 2 + 1]; }
+        cyc /= nblk; rt /= nblk;
+        const double per = mode == 0 ? cyc / (n * 4.0) : cyc / (n * 16.0);
+        fprintf(f, "# calib %s, %d wave(s) per SIMD: %.0f s_memtime ticks per block = %.2f per instruction of one wave; s_memrealtime %.0f ticks "
+                   "(100 MHz -> s_memtime at %.3f GHz); wall %.1f us", what[mode], nblk / 256, cyc, per, rt, cyc / rt * 0.1, ms * 1e3);
+        if (mode == 0) fprintf(f, " -> %.1f TFLOP/s", (double)nblk * 4 * n * 4.0 * 2 * 32 * 32 * 2 / (ms * 1e-3) / 1e12);
+        fprintf(f, "\n");
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(dev);
 }
