@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_MFMA_TFLOPS = 2516.6   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense, spec (16x the fp32 form)
+NOMINAL_CLOCK_GHZ = 2.4       # the clock the peaks below are quoted at (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
 # algorithmic FLOPs per image for cfg2/3: 7.962 GFLOP/img, 1019.19 GFLOP per B=128 iteration
 MG, MD, G1, D1 = 1052934144, 59703808, 819200, 1769472
@@ -224,10 +225,20 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
         import ctypes
         if rank == 0:
             ctx.check(ctx.lib.fg_prof_enable(ctx.h, 1))
+            # the clock the chip grants this workload: a one-wave probe on its own stream, asleep beside the iterations
+            ctx.check(ctx.lib.fg_prof_clock_start(ctx.h, ctypes.c_double(max(1.0, 0.9 * ms * args.prof_iters))))
         for _ in range(args.prof_iters):
             iteration()
         tr.finish_pending()
         sync_all()
+        if rank == 0:
+            ghz, cov = ctypes.c_double(0.0), ctypes.c_double(0.0)
+            ctx.check(ctx.lib.fg_prof_clock_read(ctx.h, ctypes.byref(ghz), ctypes.byref(cov)))
+            if ghz.value > 0:
+                out["step_roofline"].update({
+                    "granted_clock_ghz": ghz.value, "nominal_clock_ghz": NOMINAL_CLOCK_GHZ, "clock_probe_ms": cov.value,
+                    "clock_note": "shader cycles (s_memtime) / 100 MHz ticks (s_memrealtime) read by a sleeping one-wave probe while the "
+                                  "iterations of the roofline leg run; the part clocks to its power budget, the peaks here are at 2.4 GHz"})
     if rank == 0 and not args.no_roofline:
         buf = ctypes.create_string_buffer(1 << 16)
         ctx.check(ctx.lib.fg_prof_report(ctx.h, buf, len(buf), 1))
@@ -262,6 +273,9 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
                                if tj and tj.get("algorithmic_bytes_per_launch") else None,
                                "traffic_note": (tj["launch"] + "; " + tj["source"]) if tj else None,
                                "traffic_freshness": tj.get("freshness") if tj else None,
+                               "granted_clock_ghz": out["step_roofline"].get("granted_clock_ghz"),
+                               "frac_at_granted_clock": (exe / (PEAK_F32_MFMA_TFLOPS * out["step_roofline"]["granted_clock_ghz"] / NOMINAL_CLOCK_GHZ))
+                               if out["step_roofline"].get("granted_clock_ghz") else None,
                                "kernel": dom, "avg_launch_ms": a["ms"] / a["calls"],
                                "launches_per_iter": a["calls"] / args.prof_iters,
                                "algorithmic_tflops": alg, "algorithmic_frac": alg / PEAK_F32_MFMA_TFLOPS,

@@ -88,6 +88,7 @@ int fg_ctx_destroy(fg_ctx* ctx) {
     if (!ctx) return FG_OK;
     if (ctx->device == FG_DEVICE_NONE) { if (--g_dry_ctx == 0) g_fg_dry = false; }
     else --g_real_ctx;
+    if (ctx->clk_stream) { (void)hipStreamSynchronize(ctx->clk_stream); (void)hipStreamDestroy(ctx->clk_stream); (void)hipFree(ctx->clk_dev); }
     delete ctx;
     return FG_OK;
 }
@@ -106,6 +107,45 @@ int fg_set_fusion(fg_ctx* ctx, int flags) {
 }
 int fg_get_fusion(fg_ctx* ctx) { return ctx ? ctx->fusion : -1; }
 
+// one wave: sleeps in 4096-cycle naps until `ticks` of the 100 MHz counter have passed (bounded by max_naps)
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, unsigned long long ticks, long long max_naps) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r = r0;
+    for (long long i = 0; i < max_naps && r - r0 < ticks; ++i) {
+        __builtin_amdgcn_s_sleep(64);
+        r = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    r = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r - r0; }
+}
+int fg_prof_clock_start(fg_ctx* ctx, double ms) {
+    NEED(ctx, ctx && ms > 0 && ms < 60000, "bad argument");
+    if (g_fg_dry) return FG_OK;
+    if (!ctx->clk_stream) {
+        FG_HIP(ctx, hipStreamCreateWithFlags(&ctx->clk_stream, hipStreamNonBlocking));
+        FG_HIP(ctx, hipMalloc((void**)&ctx->clk_dev, 16));
+    }
+    FG_HIP(ctx, hipMemsetAsync(ctx->clk_dev, 0, 16, ctx->clk_stream));
+    const unsigned long long ticks = (unsigned long long)(ms * 1e5);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, ctx->clk_stream, ctx->clk_dev, ticks, (long long)(ms * 2.4e6 / 4096.0) + 16);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_prof_clock_read(fg_ctx* ctx, double* ghz, double* covered_ms) {
+    NEED(ctx, ctx && ghz, "bad argument");
+    *ghz = 0.0;
+    if (covered_ms) *covered_ms = 0.0;
+    if (g_fg_dry) return FG_OK;
+    NEED(ctx, ctx->clk_stream, "fg_prof_clock_read before fg_prof_clock_start");
+    unsigned long long h[2] = {0, 0};
+    FG_HIP(ctx, hipStreamSynchronize(ctx->clk_stream));
+    FG_HIP(ctx, hipMemcpy(h, ctx->clk_dev, 16, hipMemcpyDeviceToHost));
+    if (h[1]) *ghz = (double)h[0] / (double)h[1] * 0.1;
+    if (covered_ms) *covered_ms = (double)h[1] * 1e-5;
+    return FG_OK;
+}
 int fg_prof_enable(fg_ctx* ctx, int on) { NEED(ctx, ctx, "null ctx"); ctx->prof = on != 0; return FG_OK; }
 // Synchronises, then writes one line per kernel label: "name calls total_ms alg_flops exec_flops bytes\n".
 int fg_prof_report(fg_ctx* ctx, char* buf, size_t len, int reset) {

@@ -35,6 +35,9 @@ struct fg_ctx {
     std::vector<FgProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     std::vector<std::string*> names;
+    // fg_prof_clock_*: a one-wave probe on its own stream (s_memtime against the 100 MHz s_memrealtime)
+    hipStream_t clk_stream = nullptr;
+    unsigned long long* clk_dev = nullptr;
 };
 const char* fg_intern(fg_ctx* ctx, const char* s);  // stable pointer for a profile label
 // RAII helper: records an event pair around one launch when profiling is on

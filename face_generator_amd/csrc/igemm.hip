@@ -546,7 +546,7 @@ __device__ __forceinline__ void igemm_ws_body(const IgemmArgs& a) {
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][mi][j], bf[1][ni][j], acc[mi][ni], 0, 0, 0);
         __syncthreads();
-        if (TRACE && trc && lane == 0 && kt < 120) trc[2 + kt] = __builtin_amdgcn_s_memtime();
+        if (TRACE && trc && lane == 0) trc[2 + (kt < 119 ? kt : 119)] = __builtin_amdgcn_s_memtime();   // KT > 120: slot 121 ends up with the LAST step
     }
 
     if (a.stats_part) fg_store_stats<MI, NI>(a, acc, (tile_m * np + p) * (4 / WNW) + wm, tile_n * BN + wn * 64, lane);

@@ -80,6 +80,12 @@ int fg_stream_sync(fg_ctx* ctx);
  * fg_prof_report synchronises and writes "label calls total_ms algorithmic_flops executed_flops bytes" lines. */
 int fg_prof_enable(fg_ctx* ctx, int on);
 int fg_prof_report(fg_ctx* ctx, char* buf, size_t len, int reset);
+/* the shader clock the chip grants WHILE other work runs (measurement only): fg_prof_clock_start puts a one-wave probe on a
+ * stream of its own that sleeps for about `ms` milliseconds between two readings of the shader-cycle counter (s_memtime) and of
+ * the constant 100 MHz counter (s_memrealtime); fg_prof_clock_read waits for it and returns cycles / time in GHz and the time
+ * the probe covered.  gfx950 clocks to its power budget: a contraction loop is granted 1.9 - 2.2 GHz of the nominal 2.4. */
+int fg_prof_clock_start(fg_ctx* ctx, double ms);
+int fg_prof_clock_read(fg_ctx* ctx, double* ghz, double* covered_ms);
 int fg_malloc(fg_ctx* ctx, size_t bytes, void** out);
 int fg_free(fg_ctx* ctx, void* p);
 int fg_h2d(fg_ctx* ctx, void* dst, const void* src, size_t bytes);

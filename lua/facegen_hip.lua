@@ -42,6 +42,8 @@ const char* fg_version(void);
 int fg_stream_sync(fg_ctx* ctx);
 int fg_prof_enable(fg_ctx* ctx, int on);
 int fg_prof_report(fg_ctx* ctx, char* buf, size_t len, int reset);
+int fg_prof_clock_start(fg_ctx* ctx, double ms);
+int fg_prof_clock_read(fg_ctx* ctx, double* ghz, double* covered_ms);
 int fg_malloc(fg_ctx* ctx, size_t bytes, void** out);
 int fg_free(fg_ctx* ctx, void* p);
 int fg_h2d(fg_ctx* ctx, void* dst, const void* src, size_t bytes);
