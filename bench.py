@@ -226,12 +226,13 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
         if rank == 0:
             ctx.check(ctx.lib.fg_prof_enable(ctx.h, 1))
             # the clock the chip grants this workload: a one-wave probe on its own stream, asleep beside the iterations
-            ctx.check(ctx.lib.fg_prof_clock_start(ctx.h, ctypes.c_double(max(1.0, 0.9 * ms * args.prof_iters))))
+            if not args.no_clock_probe:
+                ctx.check(ctx.lib.fg_prof_clock_start(ctx.h, ctypes.c_double(max(1.0, 0.9 * ms * args.prof_iters))))
         for _ in range(args.prof_iters):
             iteration()
         tr.finish_pending()
         sync_all()
-        if rank == 0:
+        if rank == 0 and not args.no_clock_probe:
             ghz, cov = ctypes.c_double(0.0), ctypes.c_double(0.0)
             ctx.check(ctx.lib.fg_prof_clock_read(ctx.h, ctypes.byref(ghz), ctypes.byref(cov)))
             if ghz.value > 0:
@@ -492,6 +493,7 @@ def main():
     ap.add_argument("--c2f-steps", type=int, default=10, help="timed steps of the c2f sub-record (3 warm-up steps)")
     ap.add_argument("--c2f-timeout", type=float, default=240.0,
                     help="N > 1: if the c2f sub-record has not finished after this many seconds, rank 0 prints the line without it")
+    ap.add_argument("--no-clock-probe", action="store_true", help="do not run the one-wave clock probe beside the roofline leg")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not spawn the two rocprofv3 PMC passes for roofline.traffic (a committed summary is used and labelled)")
     ap.add_argument("--dry-collective", action="store_true",

@@ -2,6 +2,7 @@
 (fg_prof_clock_start / _read) and report the HIP-event rate of the kernel, the granted clock, and the rate re-priced at 2.4 GHz.
 usage: clock_by_kernel.py [cfg2|c2f]"""
 import sys, ctypes, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from face_generator_amd import ops
 from face_generator_amd.runtime import get_context
 ctx = get_context(0); d = ctx.device
