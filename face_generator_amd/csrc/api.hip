@@ -80,6 +80,8 @@ int fg_ctx_create(int device, fg_ctx** out) {
     if (const char* m = getenv("FG_MATH")) c->math = atoi(m) == 6 ? 6 : 0;   // default arithmetic, see fg_set_math
     if (const char* m = getenv("FG_FUSE_PRELU")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_PRELU;
     if (const char* m = getenv("FG_THIN_SLAB")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_THIN_SLAB;
+    if (const char* m = getenv("FG_DEFER_WFINISH")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WFINISH_BATCH;
+    if (const char* m = getenv("FG_ADAM_PACK")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_ADAM_PACK;
     ++g_real_ctx;
     *out = c;
     return FG_OK;

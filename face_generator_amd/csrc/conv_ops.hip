@@ -147,6 +147,22 @@ static bool fg_wgrad_ws_on() {
     return v != 0;
 }
 
+// floats of split-K / parity partials the fp32 weight gradient of this layer leaves (upper bound over its two kernels): what the
+// deferred-finals arena of a net reserves per convolution so that the partials survive until the end of the backward pass
+long long fg_conv_wgrad_part_floats(const ConvGeom& g) {
+    WeightMap wm; fg_geom_weightmap(g, &wm);
+    const int st = g.stride == 2 ? 2 : 1;
+    const long long M = (long long)g.B * (g.H / st) * (g.W / st);
+    int wt, S, mper, Np, Cp, S6, mper6;
+    choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
+    long long n = (long long)wm.P * wm.G * S * Np * Cp;
+    if (M >= 4096 && choose_wgrad6(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) >= 0) {
+        const long long n6 = (long long)wm.P * wm.G * S6 * g.Cout * g.Cin;
+        if (n6 > n) n = n6;
+    }
+    return n + 64;
+}
+
 static long long scratch_for_math(const ConvGeom& g, int math) {
     WeightMap wm; fg_geom_weightmap(g, &wm);
     const long long M = (long long)g.B * g.H * g.W;  // source-resolution M-space
@@ -447,8 +463,11 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
             if (dp) { a.bias_part = dp; deferred = true; }
             else if (need + nb <= scratch_floats) a.bias_part = scratch + need;
         }
+        float* wp = (ctx->fusion & FG_FUSE_WFINISH_BATCH) ? fg_defer_alloc(ctx, need) : nullptr;    // inside fg_net backward: summed at the end
+        if (wp) a.Part = wp;
         if ((rc = fg_launch_wgrad_ws(ctx, a, wm.P, cfgw))) return rc;
-        if ((rc = fg_launch_wgrad_finish(ctx, wm, scratch, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
+        if (!(wp && fg_defer_push_wfinish(ctx, wm, a.Part, a.S, a.Npad, a.Cpad, beta, gradW)) &&
+            (rc = fg_launch_wgrad_finish(ctx, wm, a.Part, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
         if (gradb && a.bias_part) {
             if (deferred) { fg_defer_push(ctx, a.bias_part, nrb, g.Cout, beta, gradb); return FG_OK; }
             return fg_launch_colsum_final(ctx, a.bias_part, nrb, g.Cout, beta, gradb);
@@ -466,8 +485,11 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
             if (dp) { a.bias_part = dp; deferred = true; }
             else if (need + nb <= scratch_floats) a.bias_part = scratch + need;
         }
+        float* wp = (ctx->fusion & FG_FUSE_WFINISH_BATCH) ? fg_defer_alloc(ctx, need) : nullptr;    // inside fg_net backward: summed at the end
+        if (wp) a.Part = wp;
         if ((rc = fg_launch_wgrad(ctx, a, wm.P, tile))) return rc;
-        if ((rc = fg_launch_wgrad_finish(ctx, wm, scratch, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
+        if (!(wp && fg_defer_push_wfinish(ctx, wm, a.Part, a.S, a.Npad, a.Cpad, beta, gradW)) &&
+            (rc = fg_launch_wgrad_finish(ctx, wm, a.Part, a.S, a.Npad, a.Cpad, beta, gradW))) return rc;
         if (gradb && a.bias_part) {
             if (deferred) { fg_defer_push(ctx, a.bias_part, nrb, g.Cout, beta, gradb); return FG_OK; }
             return fg_launch_colsum_final(ctx, a.bias_part, nrb, g.Cout, beta, gradb);

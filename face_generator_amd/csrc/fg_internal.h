@@ -21,6 +21,10 @@ struct FgDefer {
     long long cap = 0, used = 0;
     FgFinalJob jobs[FG_DEFER_MAX];
     int n = 0, blocks = 0;
+    // the split-K / parity sums of the weight gradients (wgrad_finish): same idea, one launch for all layers of the pass
+    struct FgWFinishJob* wjobs = nullptr;    // FG_DEFER_WMAX entries (owned by the net)
+    int wn = 0;
+    long long wblocks = 0;
 };
 struct fg_ctx {
     FgDefer* defer = nullptr;        // non-null only inside fg_net backward
@@ -188,12 +192,19 @@ int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const flo
 // gradW_ref = beta*gradW_ref + sum over splits / parities of Part ([P*G][S][Npad][Cpad], n = O, c = I)
 int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,
                            float* gradW);
+// the same reduction queued for the end of the backward pass (fg_defer_flush); false = not inside fg_net backward / table full
+#define FG_DEFER_WMAX 16
+struct FgWFinishJob { WeightMap wm; const float* part; float* gradW; int S, Npad, Cpad, ib; float beta; long long blk0; };
+long long fg_conv_wgrad_part_floats(const struct ConvGeom& g);
+bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta, float* gradW);
+int fg_launch_wgrad_finish_jobs(fg_ctx* ctx, const FgWFinishJob* jobs, int n, long long blocks);
 // One launch re-packs every layer of a net after an optimizer step.
 struct PackJob {
     WeightMap wm;
     int mode;             // 0 forward pack, 1 data-grad pack (one thread per packed element: Linear + View permutations),
                           // 7 both packs of a conv layer (one block per 16 x 16 channel patch, LDS-staged),
-                          // 2 thin pack [tap][I][O], 3 thin pack [tap][O][I], 4 bias NCHW->NHWC perm
+                          // 2 thin pack [tap][I][O], 3 thin pack [tap][O][I], 4 bias NCHW->NHWC perm,
+                          // 8 both packs of a Linear layer, 9 no pack: optimizer update only (fused launch)
     long long src_off;    // offset into the flat parameter vector
     float* dst;
     int rows, cols;       // padded tile dims (modes 0/1)
@@ -333,6 +344,37 @@ struct AdamArgs {
     float* gout;             // optional: write the penalised+clamped gradient back (feval's return value)
 };
 int fg_launch_adam(fg_ctx*, const AdamArgs& a);
+// One element of penalty + clamp + Torch7-Adam, shared by adam_kernel and the fused optimizer + re-pack launch.  Every operation
+// is an explicitly rounded one (no contraction into FMAs): the two kernels must give the same bits, and the reference (TH's
+// cmul / cadd / addcmul loops) rounds every product and sum as well.
+__device__ __forceinline__ float fg_sgnf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+__device__ __forceinline__ float fg_prep_grad(float g, float p, float gscale, float l1mul, float l2, float clamp) {
+    g = __fmul_rn(g, gscale);
+    if (l1mul != 0.f || l2 != 0.f) g = __fadd_rn(g, __fadd_rn(__fmul_rn(fg_sgnf(p), l1mul), __fmul_rn(p, l2)));   // adversarial.lua:109 / :223
+    if (clamp != 0.f) g = fminf(fmaxf(g, -clamp), clamp);                                                         // adversarial.lua:121-123
+    return g;
+}
+struct AdamScalars { float step, ob1, ob2; };      // lr * sqrt(1 - b2^t) / (1 - b1^t), 1 - b1, 1 - b2 (host side, in double)
+AdamScalars fg_adam_scalars(const AdamArgs& a);
+__device__ __forceinline__ float fg_adam_elem(const AdamArgs& a, const AdamScalars& k, long long i) {
+    const float p = a.p[i];
+    const float g = fg_prep_grad(a.g[i], p, a.gscale, a.l1_mul, a.l2, a.clamp);
+    // interruptable_optimizers.lua:78-90 : m = b1*m + (1-b1) g ; v = b2*v + (1-b2) g*g ; denom = sqrt(v)+eps
+    const float m = __fadd_rn(__fmul_rn(a.m[i], a.beta1), __fmul_rn(k.ob1, g));
+    const float v = __fadd_rn(__fmul_rn(a.v[i], a.beta2), __fmul_rn(__fmul_rn(k.ob2, g), g));
+    const float denom = __fadd_rn(__fsqrt_rn(v), a.eps);
+    const float pn = __fsub_rn(p, __fmul_rn(k.step, __fdiv_rn(m, denom)));
+    a.m[i] = m;
+    a.v[i] = v;
+    a.p[i] = pn;
+    if (a.gout) a.gout[i] = g;
+    return pn;
+}
+// the optimizer step and the re-pack in ONE pass: every pack job takes its weights from the Adam update of that element (each
+// parameter is read by exactly one job; mode 9 jobs update the parameters no pack reads)
+struct fg_net;
+int fg_net_adam_step(fg_net* n, const AdamArgs& a);
+int fg_launch_adam_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const AdamArgs& a);
 int fg_launch_sgd(fg_ctx*, float* p, const float* g, float* mom, long long n, float gscale, float l1mul, float l2,
                   float clamp, float lr, float momentum, float dampening, float wd, int nesterov, int first);
 int fg_launch_adagrad(fg_ctx*, float* p, const float* g, float* var, long long n, float gscale, float l1mul, float l2,

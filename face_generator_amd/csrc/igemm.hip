@@ -1502,8 +1502,17 @@ __device__ __forceinline__ float packed_from_taps(const WeightMap& wm, const flo
 }
 
 #define PK_ROW (16 * 49 + 1)    // LDS row of one out-channel: 16 in-channels x up to 7x7 taps, +1 so rows fall on distinct banks
+// ADAM = true: the fused optimizer + re-pack launch.  Every weight a job reads is the freshly UPDATED value of that element
+// (fg_adam_elem: penalty, clamp, Adam; parameter and moments written back) -- each parameter is read by exactly one thread of
+// exactly one job, so the update happens once.  `params` is the flat parameter vector (ADAM: == ad.p).
+template <bool ADAM>
+__device__ __forceinline__ float pk_load(const float* __restrict__ params, const AdamArgs& ad, const AdamScalars& ak, long long idx) {
+    if constexpr (ADAM) return fg_adam_elem(ad, ak, idx);
+    else return params[idx];
+}
+template <bool ADAM>
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int njobs, long long total,
-                                                        const float* __restrict__ params) {
+                                                        const float* __restrict__ params, const AdamArgs ad, const AdamScalars ak) {
     __shared__ float taps[16 * PK_ROW];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int j = 0;
@@ -1515,7 +1524,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
     const PackJob& jb = jobs[j];
     const long long loc = idx - jb.start;
     const WeightMap& wm = jb.wm;
-    const float* W = params + jb.src_off;
+    const long long w0 = jb.src_off;         // this job's weights start here in the flat parameter vector
     if (jb.mode == 7) {
         // conv layer: both packs from one pass.  A block owns a 16 x 16 patch of (out, in) channel pairs: the reference
         // weights of one out-channel and 16 consecutive in-channels are ONE contiguous run of 16*k*k floats, so the patch is
@@ -1527,7 +1536,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         for (int e = t; e < 16 * run; e += 256) {
             const int a = e / run, off = e - a * run;
             const int po = po0 + a, pi = pi0 + off / kk;
-            taps[a * PK_ROW + off] = (po < wm.O && pi < wm.I) ? W[((size_t)po * wm.I + pi0) * kk + off] : 0.f;
+            taps[a * PK_ROW + off] = (po < wm.O && pi < wm.I) ? pk_load<ADAM>(params, ad, ak, w0 + ((long long)po * wm.I + pi0) * kk + off) : 0.f;
         }
         __syncthreads();
         const int ng = wm.P * wm.G;
@@ -1567,7 +1576,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                 int o = po, i = pi;
                 if (wm.o_hw > 1) { int hw = po / wm.o_c, cc = po - hw * wm.o_c; o = cc * wm.o_hw + hw; }
                 if (wm.i_hw > 1) { int hw = pi / wm.i_c, cc = pi - hw * wm.i_c; i = cc * wm.i_hw + hw; }
-                v = W[(size_t)o * wm.I + i];
+                v = pk_load<ADAM>(params, ad, ak, w0 + (long long)o * wm.I + i);
             }
             tl[rr * 33 + c] = v;
             if (po < jb.rows && pi < jb.cols) jb.dst[(size_t)po * jb.cols + pi] = v;
@@ -1580,7 +1589,12 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         return;
     }
     if (idx >= total || loc >= jb.count) return;
+    if (jb.mode == 9) {          // parameters no pack reads (BatchNorm, PReLU slopes, unpacked biases): the update alone
+        if (ADAM) (void)fg_adam_elem(ad, ak, w0 + loc);
+        return;
+    }
     if (jb.mode <= 1) {
+        const float* W = params + w0;        // (never in a fused launch: these jobs read a weight more than once)
         const int col = (int)(loc % jb.cols);
         long long t = loc / jb.cols;
         const int row = (int)(t % jb.rows);
@@ -1602,24 +1616,34 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         const int t = (int)(loc / Cw);
         const int sidx = t % Cs, tap = t / Cs;
         const int o = jb.mode == 2 ? c : sidx, i = jb.mode == 2 ? sidx : c;
-        jb.dst[loc] = W[((size_t)o * wm.I + i) * kk + tap];
+        jb.dst[loc] = pk_load<ADAM>(params, ad, ak, w0 + ((long long)o * wm.I + i) * kk + tap);
     } else {                     // bias: packed[hw*C + c] = ref[c*HW + hw]
         const int c = (int)(loc % wm.o_c), hw = (int)(loc / wm.o_c);
-        jb.dst[loc] = W[(size_t)c * wm.o_hw + hw];
+        jb.dst[loc] = pk_load<ADAM>(params, ad, ak, w0 + (long long)c * wm.o_hw + hw);
     }
 }
 int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params) {
     if (total == 0 || njobs == 0) return FG_OK;
-    hipLaunchKernelGGL(pack_jobs_kernel, dim3(fg_cdiv(total, 256)), dim3(256), 0, ctx->stream, jobs_dev, njobs, total, params);
+    AdamArgs none = AdamArgs();
+    hipLaunchKernelGGL(pack_jobs_kernel<false>, dim3(fg_cdiv(total, 256)), dim3(256), 0, ctx->stream, jobs_dev, njobs, total, params,
+                       none, AdamScalars{0.f, 0.f, 0.f});
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_adam_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const AdamArgs& a) {
+    if (total == 0 || njobs == 0) return FG_OK;
+    hipLaunchKernelGGL(pack_jobs_kernel<true>, dim3(fg_cdiv(total, 256)), dim3(256), 0, ctx->stream, jobs_dev, njobs, total,
+                       (const float*)a.p, a, fg_adam_scalars(a));
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
 
 __global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
-                                    float beta, float* __restrict__ gradW) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;  // packed in-channel (coalesced partial reads)
-    const int po = blockIdx.y;                              // packed out-channel
-    const int wi = blockIdx.z;                              // tap dy*k+dx
+                                    float beta, float* __restrict__ gradW);
+
+// one element of the reduction (shared by the per-layer launch and the batched one: same order of additions)
+__device__ __forceinline__ void wgrad_finish_one(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
+                                                 float beta, float* __restrict__ gradW, int pi, int po, int wi) {
     if (pi >= wm.I || po >= wm.O) return;
     int o = po, i = pi;
     if (wm.o_hw > 1) { int hw = po / wm.o_c, c = po - hw * wm.o_c; o = c * wm.o_hw + hw; }
@@ -1641,7 +1665,44 @@ __global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict_
     float* gw = gradW + ((size_t)o * wm.I + i) * wm.k * wm.k + wi;
     *gw = (beta == 0.f) ? sum : beta * (*gw) + sum;
 }
+// all weight-gradient reductions of a backward pass in one launch: block -> job by a scan over <= FG_DEFER_WMAX entries; inside
+// a job the blocks run (in-channel block, out-channel, tap) exactly as the grid of wgrad_finish_kernel does
+struct FgWFinishBatch { FgWFinishJob jobs[FG_DEFER_WMAX]; int n; };
+__global__ __launch_bounds__(128) void wgrad_finish_jobs_kernel(const FgWFinishBatch b) {
+    int j = 0;
+    while (j + 1 < b.n && (long long)blockIdx.x >= b.jobs[j + 1].blk0) ++j;
+    const FgWFinishJob& jb = b.jobs[j];
+    long long l = (long long)blockIdx.x - jb.blk0;
+    const int bx = (int)(l % jb.ib); l /= jb.ib;
+    const int po = (int)(l % jb.wm.O), wi = (int)(l / jb.wm.O);
+    wgrad_finish_one(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx * 128 + (int)threadIdx.x, po, wi);
+}
+int fg_launch_wgrad_finish_jobs(fg_ctx* ctx, const FgWFinishJob* jobs, int n, long long blocks) {
+    if (n == 0) return FG_OK;
+    FgWFinishBatch b;
+    for (int i = 0; i < n; ++i) b.jobs[i] = jobs[i];
+    b.n = n;
+    hipLaunchKernelGGL(wgrad_finish_jobs_kernel, dim3((unsigned)blocks), dim3(128), 0, ctx->stream, b);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta, float* gradW) {
+    FgDefer* d = ctx->defer;
+    if (!d || !d->wjobs || d->wn >= FG_DEFER_WMAX) return false;
+    const long long nb = (long long)fg_cdiv(wm.I, 128) * wm.O * wm.k * wm.k;
+    if (d->wblocks + nb > 0x7fffffffLL) return false;
+    FgWFinishJob& j = d->wjobs[d->wn++];
+    j.wm = wm; j.part = Part; j.gradW = gradW; j.S = S; j.Npad = Npad; j.Cpad = Cpad; j.ib = fg_cdiv(wm.I, 128); j.beta = beta;
+    j.blk0 = d->wblocks;
+    d->wblocks += nb;
+    return true;
+}
 
+__global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
+                                    float beta, float* __restrict__ gradW) {
+    // x: packed in-channel (coalesced partial reads), y: packed out-channel, z: tap dy*k+dx
+    wgrad_finish_one(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, blockIdx.z);
+}
 int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,
                            float* gradW) {
     dim3 grid(fg_cdiv(wm.I, 128), wm.O, wm.k * wm.k);

@@ -9,6 +9,8 @@
 #include "conv_ops.h"
 #include "../../include/facegen_hip.h"
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include <string.h>
 
 enum StageKind {
@@ -93,6 +95,7 @@ struct fg_net {
     // one-launch weight re-pack
     PackJob* jobs_dev = nullptr;
     FgDefer defer;                    // deferred final reductions of a backward pass (arena inside the workspace)
+    FgWFinishJob wjobs[FG_DEFER_WMAX];  // its queued weight-gradient reductions
     long long defer_off = 0, defer_floats = 0;
     float* packed_all = nullptr;      // packed weights of every contraction stage, contiguous (one split launch)
     unsigned char* planes_all = nullptr;
@@ -100,8 +103,11 @@ struct fg_net {
     bool planes_valid = false;
     float* out_override = nullptr;    // fg_net_forward_to: the last stage writes here instead of into the workspace
     FgSplitParts pend{};              // split-K partials the previous stage left for this one (ST_ACTPOOL sums them itself)
-    int n_jobs = 0;
+    int n_jobs = 0;                   // pack jobs
     long long jobs_total = 0;
+    int n_jobs_all = 0;               // ... + the update-only jobs of the fused optimizer launch
+    long long jobs_total_all = 0;
+    bool adam_fusable = false;
 };
 
 static inline long long align64(long long v) { return (v + 63) / 64 * 64; }
@@ -148,6 +154,8 @@ static void make_plan(fg_net* n, int B) {
             // (ST_CONV: the wave-specialised weight gradient leaves one bias partial row per (parity, split, tap, X tile, loader
             // pixel lane) -- up to ~1000 rows)
             if (s.kind == ST_CONV) dn += 4LL * CR_ROWBLOCKS_MAX * s.oc + 64;
+            // ... and its split-K / parity partials stay until the batched weight-gradient reduction at the end of the pass
+            if (s.kind == ST_CONV && s.w_n > 0) { ConvGeom g = s.geom; g.B = B; dn += (fg_conv_wgrad_part_floats(g) + 63) / 64 * 64; }
             else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT || s.kind == ST_GEMV) dn += (long long)CR_ROWBLOCKS_MAX * s.oc + 64;
             if (s.has_prelu || s.kind == ST_PRELU || s.kind == ST_ACTPOOL) dn += 1024 + 64;
             // a PReLU whose backward rides on the epilogue of the neighbouring contraction leaves 4 partials per block
@@ -738,12 +746,28 @@ int fg_net_params_changed(fg_net* n) {
     return FG_OK;
 }
 
+// Adam over the net's flat parameter vector + the re-pack of every layer, one launch (a.p must be the net's own vector)
+extern "C++" int fg_net_adam_step(fg_net* n, const AdamArgs& a) {
+    if (!n) return FG_ERR_INVALID;
+    if (!n->adam_fusable || !(n->ctx->fusion & FG_FUSE_ADAM_PACK) || a.p != n->params || a.n != n->n_params || a.gout || n->n_jobs_all == 0) {
+        const int rc = fg_launch_adam(n->ctx, a);
+        n->dirty = true;
+        return rc;
+    }
+    const int rc = fg_launch_adam_pack_jobs(n->ctx, n->jobs_dev, n->n_jobs_all, n->jobs_total_all, a);
+    if (rc) { n->dirty = true; return rc; }
+    n->dirty = false;
+    n->planes_valid = false;
+    return FG_OK;
+}
+
 // backward with the per-layer final reductions batched into one launch per call (also on a sync-BN pause or an error:
 // nothing deferred may survive the return to the caller)
 static int backward_run(fg_net* n) {
     fg_ctx* ctx = n->ctx;
     n->defer.arena = n->run_ws + n->defer_off; n->defer.cap = n->defer_floats;
     n->defer.used = 0; n->defer.n = 0; n->defer.blocks = 0;
+    n->defer.wjobs = n->wjobs; n->defer.wn = 0; n->defer.wblocks = 0;
     ctx->defer = &n->defer;
     const int rc = backward_run_stages(n);
     const int rf = fg_defer_flush(ctx);
@@ -796,6 +820,29 @@ static int build_pack_jobs(fg_net* n) {
     }
     n->n_jobs = (int)jobs.size();
     n->jobs_total = start;
+    // the fused optimizer + re-pack launch (fg_net_adam_step): possible when every pack job reads each of its weights once
+    // (all but the generic modes 0 / 1); the parameters NO job reads get update-only jobs (mode 9) behind the pack jobs
+    n->adam_fusable = true;
+    std::vector<std::pair<long long, long long>> cov;          // [from, to) of the flat parameter vector read by a pack job
+    for (auto& j : jobs) {
+        if (j.mode <= 1) n->adam_fusable = false;
+        const long long cnt = (j.mode == 7 || j.mode == 8) ? (long long)j.wm.O * j.wm.I * j.wm.k * j.wm.k : j.count;
+        cov.push_back({j.src_off, j.src_off + cnt});
+    }
+    std::sort(cov.begin(), cov.end());
+    {
+        WeightMap none; memset(&none, 0, sizeof(none));
+        long long at = 0;
+        auto gap = [&](long long from, long long to) { if (to > from) add(none, 9, from, nullptr, 0, 0, to - from); };
+        for (auto& c : cov) {
+            if (c.first < at) n->adam_fusable = false;          // two jobs over one weight: not fusable
+            gap(at, c.first);
+            if (c.second > at) at = c.second;
+        }
+        gap(at, n->n_params);
+    }
+    n->n_jobs_all = (int)jobs.size();
+    n->jobs_total_all = start;
     if (jobs.empty()) return FG_OK;
     if (fg_dev_alloc((void**)&n->jobs_dev, jobs.size() * sizeof(PackJob)) != hipSuccess)
         return fg_set_err(n->ctx, FG_ERR_NOMEM, "fg_net_create: pack jobs");

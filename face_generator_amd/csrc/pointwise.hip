@@ -239,6 +239,11 @@ void fg_defer_push(fg_ctx* ctx, const float* part, int nrb, int C, float beta, f
 }
 int fg_defer_flush(fg_ctx* ctx) {
     FgDefer* d = ctx->defer;
+    if (d && d->wn > 0) {
+        const int rc = fg_launch_wgrad_finish_jobs(ctx, d->wjobs, d->wn, d->wblocks);
+        d->wn = 0; d->wblocks = 0;
+        if (rc) { d->n = 0; d->used = 0; d->blocks = 0; return rc; }
+    }
     if (!d || d->n == 0) { if (d) { d->used = 0; d->blocks = 0; } return FG_OK; }
     FgFinalBatch b;
     memcpy(b.jobs, d->jobs, sizeof(FgFinalJob) * d->n);
@@ -1409,35 +1414,24 @@ int fg_launch_bce(fg_ctx* ctx, const float* prob, const float* target, float* lo
 }
 
 // ------------------------------------------------------------------ optimizers over the flat vector
-__device__ __forceinline__ float sgnf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+__device__ __forceinline__ float sgnf(float v) { return fg_sgnf(v); }
 __device__ __forceinline__ float prep_grad(float g, float p, float gscale, float l1mul, float l2, float clamp) {
-    g *= gscale;
-    if (l1mul != 0.f || l2 != 0.f) g += sgnf(p) * l1mul + p * l2;   // adversarial.lua:109 / :223
-    if (clamp != 0.f) g = fminf(fmaxf(g, -clamp), clamp);           // adversarial.lua:121-123
-    return g;
+    return fg_prep_grad(g, p, gscale, l1mul, l2, clamp);
 }
-__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a, float step, float ob1, float ob2) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n;
-         i += (long long)gridDim.x * blockDim.x) {
-        const float p = a.p[i];
-        const float g = prep_grad(a.g[i], p, a.gscale, a.l1_mul, a.l2, a.clamp);
-        // interruptable_optimizers.lua:78-90 : m = b1*m + (1-b1) g ; v = b2*v + (1-b2) g*g ; denom = sqrt(v)+eps
-        const float m = a.m[i] * a.beta1 + ob1 * g;
-        const float v = a.v[i] * a.beta2 + ob2 * g * g;
-        const float denom = sqrtf(v) + a.eps;
-        a.m[i] = m;
-        a.v[i] = v;
-        a.p[i] = p - step * (m / denom);
-        if (a.gout) a.gout[i] = g;
-    }
+__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a, const AdamScalars k) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x)
+        (void)fg_adam_elem(a, k, i);
+}
+AdamScalars fg_adam_scalars(const AdamArgs& a) {
+    const double bc1 = 1.0 - pow(a.beta1_d, (double)a.t);
+    const double bc2 = 1.0 - pow(a.beta2_d, (double)a.t);
+    AdamScalars k;
+    k.step = (float)(a.lr_d * sqrt(bc2) / bc1); k.ob1 = (float)(1.0 - a.beta1_d); k.ob2 = (float)(1.0 - a.beta2_d);
+    return k;
 }
 int fg_launch_adam(fg_ctx* ctx, const AdamArgs& a) {
     if (a.n == 0) return FG_OK;
-    const double bc1 = 1.0 - pow(a.beta1_d, (double)a.t);
-    const double bc2 = 1.0 - pow(a.beta2_d, (double)a.t);
-    const float step = (float)(a.lr_d * sqrt(bc2) / bc1);
-    hipLaunchKernelGGL(adam_kernel, FG_GRID(a.n, 256), dim3(256), 0, ctx->stream, a, step, (float)(1.0 - a.beta1_d),
-                       (float)(1.0 - a.beta2_d));
+    hipLaunchKernelGGL(adam_kernel, FG_GRID(a.n, 256), dim3(256), 0, ctx->stream, a, fg_adam_scalars(a));
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }

@@ -377,7 +377,7 @@ static int gan_optimize(fg_gan* g, int w) {
         a.p = p; a.g = gr; a.m = s0; a.v = s0 + n; a.n = n; a.gscale = gscale; a.l1_mul = l1mul; a.l2 = l2; a.clamp = g->clamp[w];
         a.lr_d = o.lr < 0 ? 1e-3 : o.lr; a.beta1_d = o.beta1; a.beta2_d = o.beta2;
         a.beta1 = (float)o.beta1; a.beta2 = (float)o.beta2; a.eps = (float)o.eps; a.t = o.steps; a.gout = nullptr;
-        rc = fg_launch_adam(ctx, a);
+        return fg_net_adam_step(net, a);          // one launch: penalty + clamp + Adam + the re-pack of every layer
     } else if (o.method == 1) {
         const double lr = o.lr < 0 ? 1e-3 : o.lr, damp = o.dampening < 0 ? o.momentum : o.dampening;
         if (o.nesterov && (o.momentum <= 0 || damp != 0)) return fg_set_err(ctx, FG_ERR_INVALID, "Nesterov momentum requires a momentum and zero dampening");

@@ -50,15 +50,21 @@ int fg_set_math(fg_ctx* ctx, int mode);
 int fg_get_math(fg_ctx* ctx);
 
 /* Optional kernel fusions / variants (results equal to the un-fused path up to the summation order of a reduction; exposed so
- * the parity tests and the bench can run both ways).  Default: all on; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 in the environment
- * clear a bit at fg_ctx_create.  Replaces nothing in the reference. */
+ * the parity tests and the bench can run both ways).  Default: all on; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 / FG_DEFER_WFINISH=0 / FG_ADAM_PACK=0 in
+ * the environment clear a bit at fg_ctx_create.  Replaces nothing in the reference. */
 enum {
     FG_FUSE_PRELU = 1,      /* an nn.PReLU between two contraction layers (models_c2f.lua:118-130, 242-255) rides on their
                              * epilogues: forward copy behind the producing layer, backward (+ slope-gradient partials) in
                              * the kernel that produces its output gradient (data gradient / max-pool backward) */
     FG_FUSE_THIN_SLAB = 2,  /* 3x3 convolutions with <= 3 output channels (models.lua:73, 385 backward) on the matrix pipe
                              * in one pass instead of the sliding-window VALU kernel */
-    FG_FUSE_ALL = 3
+    FG_FUSE_WFINISH_BATCH = 4, /* the split-K / parity sums of ALL weight gradients of a backward pass in one launch at its end
+                                * (the partials stay in the net's workspace until then) instead of one launch per layer; same
+                                * order of additions, bit-identical gradients */
+    FG_FUSE_ADAM_PACK = 8,  /* fg_step_D / fg_step_G / fg_gan_update with Adam: penalty + clamp + Adam + the re-pack of every
+                             * layer's weights into the kernels' layouts in ONE launch (each pack job takes its weights from the
+                             * update of that element) instead of two; bit-identical parameters */
+    FG_FUSE_ALL = 15
 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);

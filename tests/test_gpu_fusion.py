@@ -15,7 +15,7 @@ from test_gpu_c2f import build, masks_for, dev_masks
 
 pytestmark = pytest.mark.gpu
 
-FG_FUSE_PRELU, FG_FUSE_THIN_SLAB, FG_FUSE_ALL = 1, 2, 3
+FG_FUSE_PRELU, FG_FUSE_THIN_SLAB, FG_FUSE_WFINISH_BATCH, FG_FUSE_ADAM_PACK, FG_FUSE_ALL = 1, 2, 4, 8, 15
 
 
 @pytest.fixture(scope="module")
@@ -31,7 +31,7 @@ def test_fusion_flags_roundtrip_and_reject_unknown_bits(ctx):
     ctx.set_fusion(FG_FUSE_THIN_SLAB)
     assert ctx.get_fusion() == FG_FUSE_THIN_SLAB
     with pytest.raises(FgError):
-        ctx.set_fusion(8)
+        ctx.set_fusion(16)
     ctx.set_fusion(FG_FUSE_ALL)
     assert ctx.get_fusion() == FG_FUSE_ALL
 
@@ -156,3 +156,61 @@ def test_cfg2_nets_fused_equal_unfused(ctx, B):
                     assert torch.equal(da, db), (name, type(mm).__name__, pn, off)
                 off += n
         assert off == ga.numel()
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_batched_weight_gradient_sums_and_adam_in_the_repack_are_bit_identical(ctx, B):
+    """FG_FUSE_WFINISH_BATCH (all split-K / parity sums of a backward pass in one launch, partials kept in the workspace) and
+    FG_FUSE_ADAM_PACK (penalty + clamp + Adam inside the re-pack launch) change neither the order of any addition nor any
+    rounding: three whole iterations of the 32x32 step (adversarial.lua:69-257) give the same bits with each of them off."""
+    from test_gpu_step_abi import make32, masks32
+    opt = dict(D_L1=1e-5, D_L2=1e-4, G_L2=1e-5)
+    outs = {}
+    for flags in (FG_FUSE_ALL, FG_FUSE_ALL & ~FG_FUSE_WFINISH_BATCH, FG_FUSE_ALL & ~FG_FUSE_ADAM_PACK,
+                  FG_FUSE_ALL & ~(FG_FUSE_WFINISH_BATCH | FG_FUSE_ADAM_PACK)):
+        ctx.set_fusion(flags)
+        tr, G, D = make32(ctx, B, opt, True, seed=11)
+        assert tr.gan is not None
+        real = ctx.uniform((B // 2, 32, 32, 3), 0.0, 1.0, seed=9)
+        for it in range(3):
+            r1 = tr.step_D(real, ctx.uniform((B // 2, 100), -1.0, 1.0, seed=10 + it), masks32(ctx, B, 20 + it))
+            d_loss = r1["loss"].clone()
+            r2 = tr.step_G(ctx.uniform((B, 100), -1.0, 1.0, seed=40 + it), masks32(ctx, B, 50 + it))
+        tr.finish_pending()
+        # one more forward through the RE-PACKED weights: a wrong pack would not show in the flat vectors
+        y = G.device_net.forward(ctx.uniform((B, 100), -1.0, 1.0, seed=77)).clone()
+        outs[flags] = dict(pG=G.getParameters()[0].clone(), pD=D.getParameters()[0].clone(), gG=G.getParameters()[1].clone(),
+                           gD=D.getParameters()[1].clone(), d_loss=d_loss, g_loss=r2["loss"].clone(), samples=r2["samples"].clone(), y=y)
+    ctx.set_fusion(FG_FUSE_ALL)
+    ref = outs[FG_FUSE_ALL]
+    for flags, o in outs.items():
+        for k in ref:
+            assert torch.equal(ref[k], o[k]), "fusion flags %d: %s differs from the all-on run" % (flags, k)
+
+
+def test_c2f_batched_weight_gradient_sums_and_adam_in_the_repack_are_bit_identical(ctx):
+    """the same on the coarse-to-fine nets (thin 3-channel layers with their own packs, a Linear behind a View, PReLU slopes
+    and biases that no pack reads: the update-only jobs of the fused launch)"""
+    from face_generator_amd import models_c2f, adversarial_c2f
+    S, B = 16, 8
+    outs = {}
+    for flags in (FG_FUSE_ALL, FG_FUSE_ALL & ~FG_FUSE_WFINISH_BATCH, FG_FUSE_ALL & ~FG_FUSE_ADAM_PACK):
+        ctx.set_fusion(flags)
+        gen = torch.Generator().manual_seed(5)
+        G = models_c2f.create_G((3, S, S), gen=gen).cuda(ctx, max_batch=B)
+        D = models_c2f.create_D((3, S, S), gen=gen).cuda(ctx, max_batch=B)
+        tr = adversarial_c2f.TrainerC2F(ctx, G, D, dict(batchSize=B))
+        assert tr.gan is not None
+        u = lambda shape, lo, hi, seed: ctx.uniform(shape, lo, hi, seed=seed)
+        masks = [ctx.bernoulli((B * 256 * (S // 4) ** 2,), 0.5, 7), ctx.bernoulli((B * 512,), 0.5, 8)]
+        for it in range(2):
+            tr.step_D(u((B // 2, S, S, 3), -1, 1, 11), u((B // 2, S, S, 3), 0, 1, 12), u((B // 2, S, S, 1), -1, 1, 13 + it),
+                      u((B // 2, S, S, 3), 0, 1, 14), masks)
+            r2 = tr.step_G(u((B, S, S, 1), -1, 1, 15 + it), u((B, S, S, 3), 0, 1, 16), masks)
+        outs[flags] = dict(pG=G.getParameters()[0].clone(), pD=D.getParameters()[0].clone(), gG=G.getParameters()[1].clone(),
+                           gD=D.getParameters()[1].clone(), samples=r2["samples"].clone(), g_out=r2["outputs"].clone())
+    ctx.set_fusion(FG_FUSE_ALL)
+    ref = outs[FG_FUSE_ALL]
+    for flags, o in outs.items():
+        for k in ref:
+            assert torch.equal(ref[k], o[k]), "fusion flags %d: %s differs from the all-on run (c2f)" % (flags, k)
