@@ -1588,6 +1588,52 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         }
         return;
     }
+    if (jb.mode == 10) {
+        // Linear behind a View (in-features permuted: reference column i = c*HW + hw <-> packed column pi = hw*C + c): three arrays
+        // with three different fastest axes -- the reference weights run along hw, the forward pack along c, the data-gradient
+        // pack along the out-feature.  A block owns a 16 (out) x 16 (c) x 16 (hw) brick, read and written in 64-byte runs along
+        // each array's own fastest axis through LDS (the 32 x 32 patch of mode 8 read this weight one word per cache line:
+        // 270 us per re-pack of the 65536 -> 512 layer of models_c2f.lua:262, and seven such streams in the fused optimizer launch).
+        float* br = taps;                                    // [16 o][16 c][16 hw], strides 273 / 17 / 1
+        const int brick = (int)(loc >> 8), t = (int)(loc & 255);
+        const int C = wm.i_c, HW = wm.i_hw;
+        const int nc = (C + 15) / 16, nhw = jb.npi;          // bricks along c / hw (hw over the padded column extent)
+        const int bo = brick / (nc * nhw), rem = brick - bo * (nc * nhw), bc = rem / nhw, bh = rem - bc * nhw;
+        const int o0 = bo * 16, c0 = bc * 16, h0 = bh * 16;
+        {   // read: lanes along hw
+            const int hw = h0 + (t & 15), c = c0 + (t >> 4);
+#pragma unroll 4
+            for (int oo = 0; oo < 16; ++oo) {
+                const int po = o0 + oo;
+                float v = 0.f;
+                if (po < wm.O && c < C && hw < HW) {
+                    int o = po;
+                    if (wm.o_hw > 1) { int ohw = po / wm.o_c, cc = po - ohw * wm.o_c; o = cc * wm.o_hw + ohw; }
+                    v = pk_load<ADAM>(params, ad, ak, w0 + (long long)o * wm.I + (long long)c * HW + hw);
+                }
+                br[oo * 273 + (t >> 4) * 17 + (t & 15)] = v;
+            }
+        }
+        __syncthreads();
+        {   // forward pack [po][hw*C + c]: lanes along c
+            const int c = c0 + (t & 15), hw = h0 + (t >> 4);
+            const long long pi = (long long)hw * C + c;
+            if (c < C && pi < jb.cols)
+#pragma unroll 4
+                for (int oo = 0; oo < 16; ++oo)
+                    if (o0 + oo < jb.rows) jb.dst[(size_t)(o0 + oo) * jb.cols + pi] = br[oo * 273 + (t & 15) * 17 + (t >> 4)];
+        }
+        {   // data-gradient pack [hw*C + c][po]: lanes along the out-feature
+            const int po = o0 + (t & 15), cc = t >> 4;
+            if (po < jb.cols2)
+#pragma unroll 4
+                for (int hh = 0; hh < 16; ++hh) {
+                    const long long pi = (long long)(h0 + hh) * C + c0 + cc;
+                    if (c0 + cc < C && pi < jb.rows2) jb.dst2[(size_t)pi * jb.cols2 + po] = br[(t & 15) * 273 + cc * 17 + hh];
+                }
+        }
+        return;
+    }
     if (idx >= total || loc >= jb.count) return;
     if (jb.mode == 9) {          // parameters no pack reads (BatchNorm, PReLU slopes, unpacked biases): the update alone
         if (ADAM) (void)fg_adam_elem(ad, ak, w0 + loc);

@@ -798,6 +798,16 @@ static int build_pack_jobs(fg_net* n) {
                 j.start = start; j.count = (long long)j.npo * j.npi * 256;
                 jobs.push_back(j);
                 start += j.count;
+            } else if (wm.k == 1 && wm.i_hw > 1 && wm.i_c > 0) {   // Linear behind a View: 16 x 16 x 16 bricks (mode 10)
+                PackJob j; memset(&j, 0, sizeof(j));
+                j.wm = wm; j.mode = 10; j.src_off = s.w_off; j.dst = s.wp_fwd; j.rows = rf; j.cols = cf;
+                j.dst2 = s.wp_bwd; j.rows2 = rb; j.cols2 = cb;
+                const int opad = rf > cb ? rf : cb, ipad = cf > rb ? cf : rb;
+                j.npo = (opad + 15) / 16;
+                j.npi = ((ipad + wm.i_c - 1) / wm.i_c + 15) / 16;            // bricks along hw, over the padded column extent
+                j.start = start; j.count = (long long)j.npo * ((wm.i_c + 15) / 16) * j.npi * 256;
+                jobs.push_back(j);
+                start += j.count;
             } else if (wm.k == 1) {                           // Linear: both packs from one LDS-tiled pass (mode 8)
                 PackJob j; memset(&j, 0, sizeof(j));
                 j.wm = wm; j.mode = 8; j.src_off = s.w_off; j.dst = s.wp_fwd; j.rows = rf; j.cols = cf;
@@ -826,7 +836,7 @@ static int build_pack_jobs(fg_net* n) {
     std::vector<std::pair<long long, long long>> cov;          // [from, to) of the flat parameter vector read by a pack job
     for (auto& j : jobs) {
         if (j.mode <= 1) n->adam_fusable = false;
-        const long long cnt = (j.mode == 7 || j.mode == 8) ? (long long)j.wm.O * j.wm.I * j.wm.k * j.wm.k : j.count;
+        const long long cnt = (j.mode == 7 || j.mode == 8 || j.mode == 10) ? (long long)j.wm.O * j.wm.I * j.wm.k * j.wm.k : j.count;
         cov.push_back({j.src_off, j.src_off + cnt});
     }
     std::sort(cov.begin(), cov.end());
