@@ -344,26 +344,35 @@ struct AdamArgs {
     float* gout;             // optional: write the penalised+clamped gradient back (feval's return value)
 };
 int fg_launch_adam(fg_ctx*, const AdamArgs& a);
-// One element of penalty + clamp + Torch7-Adam, shared by adam_kernel and the fused optimizer + re-pack launch.  Every operation
-// is an explicitly rounded one (no contraction into FMAs): the two kernels must give the same bits, and the reference (TH's
-// cmul / cadd / addcmul loops) rounds every product and sum as well.
+// One element of penalty + clamp + Torch7-Adam, shared by adam_kernel and the fused optimizer + re-pack launch.  No product is
+// contracted into an FMA (`#pragma clang fp contract(off)`; HIP's __fmul_rn & co. are plain operators and do get contracted): the
+// two kernels must give the same bits, and the reference (TH's cmul / cadd / addcmul loops) rounds every product and sum as well.
 __device__ __forceinline__ float fg_sgnf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
 __device__ __forceinline__ float fg_prep_grad(float g, float p, float gscale, float l1mul, float l2, float clamp) {
-    g = __fmul_rn(g, gscale);
-    if (l1mul != 0.f || l2 != 0.f) g = __fadd_rn(g, __fadd_rn(__fmul_rn(fg_sgnf(p), l1mul), __fmul_rn(p, l2)));   // adversarial.lua:109 / :223
-    if (clamp != 0.f) g = fminf(fmaxf(g, -clamp), clamp);                                                         // adversarial.lua:121-123
+#pragma clang fp contract(off)
+    g = g * gscale;
+    if (l1mul != 0.f || l2 != 0.f) {                                  // adversarial.lua:109 / :223
+        const float a = fg_sgnf(p) * l1mul, b = p * l2;
+        g = g + (a + b);
+    }
+    if (clamp != 0.f) g = fminf(fmaxf(g, -clamp), clamp);             // adversarial.lua:121-123
     return g;
 }
 struct AdamScalars { float step, ob1, ob2; };      // lr * sqrt(1 - b2^t) / (1 - b1^t), 1 - b1, 1 - b2 (host side, in double)
 AdamScalars fg_adam_scalars(const AdamArgs& a);
 __device__ __forceinline__ float fg_adam_elem(const AdamArgs& a, const AdamScalars& k, long long i) {
+#pragma clang fp contract(off)
     const float p = a.p[i];
     const float g = fg_prep_grad(a.g[i], p, a.gscale, a.l1_mul, a.l2, a.clamp);
     // interruptable_optimizers.lua:78-90 : m = b1*m + (1-b1) g ; v = b2*v + (1-b2) g*g ; denom = sqrt(v)+eps
-    const float m = __fadd_rn(__fmul_rn(a.m[i], a.beta1), __fmul_rn(k.ob1, g));
-    const float v = __fadd_rn(__fmul_rn(a.v[i], a.beta2), __fmul_rn(__fmul_rn(k.ob2, g), g));
-    const float denom = __fadd_rn(__fsqrt_rn(v), a.eps);
-    const float pn = __fsub_rn(p, __fmul_rn(k.step, __fdiv_rn(m, denom)));
+    const float m1 = a.m[i] * a.beta1, m2 = k.ob1 * g;
+    const float m = m1 + m2;
+    const float v1 = a.v[i] * a.beta2, v2 = (k.ob2 * g) * g;
+    const float v = v1 + v2;
+    const float denom = sqrtf(v) + a.eps;
+    const float q = m / denom;
+    const float u = k.step * q;
+    const float pn = p - u;
     a.m[i] = m;
     a.v[i] = v;
     a.p[i] = pn;

@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-OUT=gpurun_out; TAG=${1:-r3y}
+OUT=gpurun_out; TAG=${1:-r3z}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; mkdir -p $OUT
 timeout 900 python -m pytest tests/test_gpu_fusion.py tests/test_gpu_step_abi.py tests/test_gpu_net.py tests/test_gpu_c2f.py -x -q -m gpu 2>&1 | tail -25 | tee $OUT/${TAG}_tests.log
 for env in "" "FG_DEFER_WFINISH=0" "FG_ADAM_PACK=0" "FG_DEFER_WFINISH=0 FG_ADAM_PACK=0" ""; do
