@@ -33,7 +33,7 @@ struct fg_ctx {
     char err[512];
     int sm_count;
     int math = 0;        // 0: native fp32 MFMA; 6: fp32 emulated with six split-bf16 plane products (fg_set_math)
-    int fusion = FG_FUSE_ALL;   // fg_set_fusion: which optional kernel fusions / variants are on (default from the environment)
+    int fusion = FG_FUSE_DEFAULT;   // fg_set_fusion: which optional kernel fusions / variants are on (default from the environment)
     // optional per-launch HIP-event timing of the contraction kernels (bench.py roofline leg)
     bool prof = false;
     std::vector<FgProfRec> prof_recs;

@@ -50,8 +50,8 @@ int fg_set_math(fg_ctx* ctx, int mode);
 int fg_get_math(fg_ctx* ctx);
 
 /* Optional kernel fusions / variants (results equal to the un-fused path up to the summation order of a reduction; exposed so
- * the parity tests and the bench can run both ways).  Default: all on; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 / FG_DEFER_WFINISH=0 / FG_ADAM_PACK=0 in
- * the environment clear a bit at fg_ctx_create.  Replaces nothing in the reference. */
+ * the parity tests and the bench can run both ways).  Default: FG_FUSE_DEFAULT; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 / FG_DEFER_WFINISH=0 in the
+ * environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
 enum {
     FG_FUSE_PRELU = 1,      /* an nn.PReLU between two contraction layers (models_c2f.lua:118-130, 242-255) rides on their
                              * epilogues: forward copy behind the producing layer, backward (+ slope-gradient partials) in
@@ -63,8 +63,11 @@ enum {
                                 * order of additions, bit-identical gradients */
     FG_FUSE_ADAM_PACK = 8,  /* fg_step_D / fg_step_G / fg_gan_update with Adam: penalty + clamp + Adam + the re-pack of every
                              * layer's weights into the kernels' layouts in ONE launch (each pack job takes its weights from the
-                             * update of that element) instead of two; bit-identical parameters */
-    FG_FUSE_ALL = 15
+                             * update of that element) instead of two; bit-identical parameters.  OFF by default: the pack's
+                             * patch-wise access pattern slows the seven streams of the update down by more than the saved
+                             * pass over the weights (cfg2 4.31 vs 4.27 ms, c2f 38.8 vs 38.6 ms per step) */
+    FG_FUSE_ALL = 15,
+    FG_FUSE_DEFAULT = 7
 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);

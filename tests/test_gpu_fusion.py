@@ -15,7 +15,7 @@ from test_gpu_c2f import build, masks_for, dev_masks
 
 pytestmark = pytest.mark.gpu
 
-FG_FUSE_PRELU, FG_FUSE_THIN_SLAB, FG_FUSE_WFINISH_BATCH, FG_FUSE_ADAM_PACK, FG_FUSE_ALL = 1, 2, 4, 8, 15
+FG_FUSE_PRELU, FG_FUSE_THIN_SLAB, FG_FUSE_WFINISH_BATCH, FG_FUSE_ADAM_PACK, FG_FUSE_ALL, FG_FUSE_DEFAULT = 1, 2, 4, 8, 15, 7
 
 
 @pytest.fixture(scope="module")
@@ -23,7 +23,7 @@ def ctx():
     from face_generator_amd.runtime import get_context
     c = get_context(0)
     yield c
-    c.set_fusion(FG_FUSE_ALL)
+    c.set_fusion(FG_FUSE_DEFAULT)
 
 
 def test_fusion_flags_roundtrip_and_reject_unknown_bits(ctx):
@@ -32,8 +32,8 @@ def test_fusion_flags_roundtrip_and_reject_unknown_bits(ctx):
     assert ctx.get_fusion() == FG_FUSE_THIN_SLAB
     with pytest.raises(FgError):
         ctx.set_fusion(16)
-    ctx.set_fusion(FG_FUSE_ALL)
-    assert ctx.get_fusion() == FG_FUSE_ALL
+    ctx.set_fusion(FG_FUSE_DEFAULT)
+    assert ctx.get_fusion() == FG_FUSE_DEFAULT
 
 
 @pytest.mark.parametrize("S,B", [(16, 4), (64, 8)])
@@ -60,7 +60,7 @@ def test_prelu_in_epilogue_equals_separate_passes(ctx, S, B):
         gx = dnD.backward(dev(gyo, d), param_grads=True, input_grad=True).clone()
         gD = dnD.grads.clone()
         res[flags] = (y, gG, yd, gx, gD)
-    ctx.set_fusion(FG_FUSE_ALL)
+    ctx.set_fusion(FG_FUSE_DEFAULT)
     a, b = res[FG_FUSE_ALL], res[FG_FUSE_ALL & ~FG_FUSE_PRELU]
     assert torch.equal(a[0], b[0]), "G output"
     assert torch.equal(a[2], b[2]), "D output"
@@ -109,7 +109,7 @@ def test_thin_output_3x3_slab_kernel_equals_window_kernel_and_oracle(ctx, B, H, 
     for flags in (FG_FUSE_ALL, FG_FUSE_ALL & ~FG_FUSE_THIN_SLAB):
         ctx.set_fusion(flags)
         out[flags] = run()
-    ctx.set_fusion(FG_FUSE_ALL)
+    ctx.set_fusion(FG_FUSE_DEFAULT)
     tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
     close(out[FG_FUSE_ALL], ref, atol=tol, what="slab kernel vs oracle")
     close(out[FG_FUSE_ALL & ~FG_FUSE_THIN_SLAB], ref, atol=tol, what="window kernel vs oracle")
@@ -140,7 +140,7 @@ def test_cfg2_nets_fused_equal_unfused(ctx, B):
         yd = dnD.forward(nhwc(x, d), masks=masks).clone()
         gx = dnD.backward(dev(gyo, d), param_grads=True, input_grad=True).clone()
         res[flags] = (y, gG, yd, gx, dnD.grads.clone())
-    ctx.set_fusion(FG_FUSE_ALL)
+    ctx.set_fusion(FG_FUSE_DEFAULT)
     a, b = res[FG_FUSE_ALL], res[FG_FUSE_ALL & ~FG_FUSE_PRELU]
     assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     for name, net, ga, gb in (("G", st.G, a[1], b[1]), ("D", st.D, a[4], b[4])):
@@ -181,7 +181,7 @@ def test_batched_weight_gradient_sums_and_adam_in_the_repack_are_bit_identical(c
         y = G.device_net.forward(ctx.uniform((B, 100), -1.0, 1.0, seed=77)).clone()
         outs[flags] = dict(pG=G.getParameters()[0].clone(), pD=D.getParameters()[0].clone(), gG=G.getParameters()[1].clone(),
                            gD=D.getParameters()[1].clone(), d_loss=d_loss, g_loss=r2["loss"].clone(), samples=r2["samples"].clone(), y=y)
-    ctx.set_fusion(FG_FUSE_ALL)
+    ctx.set_fusion(FG_FUSE_DEFAULT)
     ref = outs[FG_FUSE_ALL]
     for flags, o in outs.items():
         for k in ref:
@@ -209,7 +209,7 @@ def test_c2f_batched_weight_gradient_sums_and_adam_in_the_repack_are_bit_identic
             r2 = tr.step_G(u((B, S, S, 1), -1, 1, 15 + it), u((B, S, S, 3), 0, 1, 16), masks)
         outs[flags] = dict(pG=G.getParameters()[0].clone(), pD=D.getParameters()[0].clone(), gG=G.getParameters()[1].clone(),
                            gD=D.getParameters()[1].clone(), samples=r2["samples"].clone(), g_out=r2["outputs"].clone())
-    ctx.set_fusion(FG_FUSE_ALL)
+    ctx.set_fusion(FG_FUSE_DEFAULT)
     ref = outs[FG_FUSE_ALL]
     for flags, o in outs.items():
         for k in ref:
