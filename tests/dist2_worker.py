@@ -58,14 +58,28 @@ def run(ctx, dist, rank, world, B, out_prefix, sync_bn=True):
 def main():
     rank, world, B, out_prefix = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     sync_bn = (sys.argv[6] != "0") if len(sys.argv) > 6 else True
+    # carrier (argv[7]): "gloo" = both ranks on device 0, torch.distributed over gloo (the one-GPU test box);
+    # "fg_comm" / "nccl" = one GPU per rank, the library's own RCCL communicator / torch.distributed over RCCL (>= 2 GPUs)
+    carrier = sys.argv[7] if len(sys.argv) > 7 else "gloo"
     from face_generator_amd.runtime import get_context
+    from face_generator_amd import distributed
     import torch.distributed as dist
-    ctx = get_context(0)
+    one_gpu_each = world > 1 and carrier in ("fg_comm", "nccl")
+    ctx = get_context(rank if one_gpu_each else 0)
+    carrier_obj = dist
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[5], RANK=str(rank), WORLD_SIZE=str(world))
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if one_gpu_each:
+            torch.cuda.set_device(rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+            carrier_obj = distributed.make_collective(ctx, dist, prefer="fg_comm" if carrier == "fg_comm" else "torch", strict=True)
+            assert not getattr(carrier_obj, "fallback", False)
+            if carrier == "fg_comm":
+                assert isinstance(carrier_obj, distributed.FgCollective), carrier_obj.describe()
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        run(ctx, dist, rank, world, B, out_prefix, sync_bn)
+        run(ctx, carrier_obj, rank, world, B, out_prefix, sync_bn)
     finally:
         if world > 1:
             dist.destroy_process_group()

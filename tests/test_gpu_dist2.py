@@ -72,3 +72,44 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     c = j["c2f"]                                                                     # configs[4]-style: B/2 per rank, D_it = 2
     assert "error" not in c, c
     assert c["value"] > 0 and c["config"]["batch_per_gpu"] == 8 and "D_it=2" in c["config"]["workload"]
+
+
+def _two_gpus():
+    import torch
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs (one rank per device: RCCL refuses two ranks on one)")
+@pytest.mark.parametrize("sync_bn", ["1", "0"])
+def test_library_bound_rccl_exchange_on_two_gpus_equals_torch_distributed(tmp_path, sync_bn):
+    """The path the 8-GPU bench takes and the one-GPU box cannot run: fg_step_D / fg_step_G with the gradient exchange issued BY THE
+    LIBRARY on its own communicator (fg_comm_*: RCCL bound through the C ABI, the exchange stream, the deferred D all-reduce, the
+    bucketed G all-reduce behind the backward stages, sync-BN's fp64 sums).  Two ranks on two devices: (a) the replicas stay
+    bit-identical, (b) the result equals bit for bit what torch.distributed (backend nccl = RCCL) gives as the carrier of the same
+    closures -- a two-operand sum has one order -- and (c) with sync-BN it matches the single-process run on the global batch."""
+    from gpu_util import close_after_first_adam_step
+    B = 16
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = {}
+    for carrier, port in (("fg_comm", "29583"), ("nccl", "29585")):
+        prefix = str(tmp_path / ("dp_" + carrier))
+        procs = [subprocess.Popen([sys.executable, WORKER, str(k), "2", str(B), prefix, port, sync_bn, carrier], stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True, env=env) for k in range(2)]
+        outs = [p.communicate(timeout=900) for p in procs]
+        for p, (so, se) in zip(procs, outs):
+            assert p.returncode == 0, se[-3000:]
+        res[carrier] = (np.load(prefix + "_0_of_2.npz"), np.load(prefix + "_1_of_2.npz"))
+        for k in ("pG", "pD", "gG", "gD"):
+            assert np.isfinite(res[carrier][0][k]).all() and np.array_equal(res[carrier][0][k], res[carrier][1][k]), \
+                "%s: replicas diverged in %s" % (carrier, k)
+    for k in ("pG", "pD", "gG", "gD"):
+        assert np.array_equal(res["fg_comm"][0][k], res["nccl"][0][k]), "fg_comm and torch.distributed(nccl) differ in %s" % k
+    if sync_bn == "1":
+        prefix = str(tmp_path / "one")
+        r = subprocess.run([sys.executable, WORKER, "0", "1", str(B), prefix], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        one, r0 = np.load(prefix + "_0_of_1.npz"), res["fg_comm"][0]
+        for net, rel in (("D", 1e-4), ("G", 1e-3)):
+            g_one, g_two = one["g" + net], 0.5 * r0["g" + net]
+            assert np.abs(g_two - g_one).max() <= rel * np.abs(g_one).max() + 1e-7, net
+            close_after_first_adam_step(r0["p" + net], one["p" + net], g_two, g_one, "%s parameters, 2 GPUs vs global batch" % net)
