@@ -295,3 +295,39 @@ def test_train_step_16px(ctx):
     got = tr.step_G(dev(nz2, ctx.device), [dev(m.reshape(-1), ctx.device) for m in masks])
     close(nchw(got["samples"]), ref["samples"], atol=1e-5, what="16px G-step samples")
     close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what="16px G-step D outputs")
+
+
+@pytest.mark.parametrize("C,H,W,nout", [(20, 5, 3, 10), (12, 4, 4, 33), (64, 3, 7, 8)])
+def test_linear_behind_a_view_with_ragged_feature_dims(ctx, C, H, W, nout):
+    """The re-pack of a Linear behind a View moves 16 x 16 x 16 bricks (out, channel, pixel) of the weight (pack mode 10): channel
+    counts, map sizes and output counts that are NOT multiples of 16 exercise every edge of the bricks and the zero padding of
+    both packs.  conv 3x3 -> View(C*H*W) -> Linear (models.lua:404-406 is this shape with C = 512, 4 x 4, 512 outputs)."""
+    from face_generator_amd import nn
+    B, cin = 6, 4
+    rng = np.random.default_rng(1200 + C + nout)
+    net = O.Sequential()
+    net.add(O.SpatialConvolution(cin, C, 3, 3, 1, 1, 1, rng=rng))
+    net.add(O.View(C * H * W))
+    net.add(O.Linear(C * H * W, nout, rng=rng))
+    pO, gO = net.getParameters()
+    dn = nn.Sequential()
+    dn.add(nn.SpatialConvolution(cin, C, 3, 3, 1, 1, 1))
+    dn.add(nn.View(C * H * W))
+    dn.add(nn.Linear(C * H * W, nout))
+    dn.cuda(ctx, max_batch=B)
+    p, g = dn.getParameters()
+    assert p.numel() == pO.size
+    for it in range(2):                                   # second round: weights changed -> the re-pack runs again
+        if it:
+            pO += rng.standard_normal(pO.shape).astype(np.float32) * 0.05
+        p.copy_(torch.tensor(pO)); dn.device_net.params_changed()
+        x = rng.uniform(-1, 1, (B, cin, H, W)).astype(np.float32)
+        out = net.forward(x)
+        gy = rng.standard_normal(out.shape).astype(np.float32)
+        gO[...] = 0
+        gin = net.backward(x, gy)
+        y = dn.device_net.forward(nhwc(x, ctx.device))
+        close(y.cpu().numpy(), out, atol=1e-5 * max(1.0, np.abs(out).max()), what="Linear behind a View: outputs")
+        gx = dn.device_net.backward(dev(gy, ctx.device), param_grads=True, input_grad=True)
+        close(nchw(gx), gin, atol=1e-5 * np.abs(gin).max() + 1e-7, what="Linear behind a View: input gradient")
+        close(g.cpu().numpy(), gO, atol=1e-5 * np.abs(gO).max() + 1e-7, what="Linear behind a View: parameter gradients")
