@@ -1119,9 +1119,27 @@ __global__ void sum_splits_kernel(const float* __restrict__ part, int splits, lo
     }
 }
 
+__global__ void sum_splits_scalar_kernel(const float* __restrict__ part, int splits, long long stride, const float* __restrict__ bias,
+                                         int N, float* __restrict__ out, long long count) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x) {
+        float s = part[i];
+        for (int k = 1; k < splits; ++k) s += part[k * stride + i];
+        if (bias) s += bias[(int)(i % N)];
+        out[i] = s;
+    }
+}
+
 int fg_launch_sum_splits(fg_ctx* ctx, const float* part, int splits, long long stride, const float* bias, int N,
                          float* out, long long count, const FgActFuse* act) {
-    if (count % 4 || N % 4 || stride % 4) return fg_set_err(ctx, FG_ERR_INVALID, "sum_splits: alignment");
+    if (count % 4 || N % 4 || stride % 4 || (((uintptr_t)part | (uintptr_t)out) & 15)) {
+        // ragged output widths (a Linear with 10 outputs, ...): one element per thread, same order of additions; the PReLU that
+        // follows is left to its own pass (act->applied = 0)
+        const int blocks = (int)min((long long)4096, (count + 255) / 256);
+        hipLaunchKernelGGL(sum_splits_scalar_kernel, dim3(blocks), dim3(256), 0, ctx->stream, part, splits, stride, bias, N, out, count);
+        if (act) act->applied = 0;
+        FG_CHECK_LAUNCH(ctx);
+        return FG_OK;
+    }
     long long c4 = count / 4;
     int blocks = (int)min((long long)2048, (c4 + 255) / 256);
     const bool fuse = act && act->y && act->slope && (!act->mask || ((uintptr_t)act->mask & 15) == 0);

@@ -314,6 +314,7 @@ def test_linear_behind_a_view_with_ragged_feature_dims(ctx, C, H, W, nout):
     dn.add(nn.SpatialConvolution(cin, C, 3, 3, 1, 1, 1))
     dn.add(nn.View(C * H * W))
     dn.add(nn.Linear(C * H * W, nout))
+    dn.input_dims = (cin, H, W)
     dn.cuda(ctx, max_batch=B)
     p, g = dn.getParameters()
     assert p.numel() == pO.size
