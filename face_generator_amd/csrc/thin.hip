@@ -1251,7 +1251,26 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // used exactly once, so there is nothing to stage), B = the <= 27 shifted thin values of the pair (a per-lane gather from
 // the tiny thin tensor, zero outside the image), columns 27..31 idle.  The VALU kernel above needs one LDS read per FMA
 // and ran 10x over the HBM time of its 33 MB stream.
-template <int K, int CS>
+// zero-bordered copy of the thin tensor: [B][H + 2 PAD][W + 2 PAD][CS]
+__global__ __launch_bounds__(256) void thin_pad_kernel(const float* __restrict__ thin, float* __restrict__ padded, int B, int H, int W,
+                                                       int CS, int PAD) {
+    const int Hp = H + 2 * PAD, Wp = W + 2 * PAD;
+    const long long n = (long long)B * Hp * Wp * CS;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int s = (int)(i % CS);
+        long long t = i / CS;
+        const int xp = (int)(t % Wp); t /= Wp;
+        const int yp = (int)(t % Hp);
+        const int b = (int)(t / Hp);
+        const int y = yp - PAD, x = xp - PAD;
+        padded[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? thin[((size_t)(b * H + y) * W + x) * CS + s] : 0.f;
+    }
+}
+// PADDED (5x5 / 7x7 layers, power-of-two maps): `thin` is the zero-bordered copy above, so a shifted value is ONE add (pixel base +
+// per-lane constant) and ONE load -- no bounds, no select (the 5 gathers of a 7x7x3 pixel pair cost ~50 VALU instructions per 10
+// MFMAs before, and every instruction issued beside an MFMA costs its pipe 6-9 cycles: DESIGN 4.7); columns >= NA read tap 0 and are
+// never stored.
+template <int K, int CS, int PADDED = 0>
 __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __restrict__ thin, const float* __restrict__ wide,
                                                               float* __restrict__ part, int B, int H, int W, int Cw, int sgn, int lgH, int lgW) {
     constexpr int PAD = (K - 1) / 2;
@@ -1272,6 +1291,10 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
         sch[ct] = jok[ct] ? jj - tap * CS : 0;
         oy[ct] = sgn * (tap / K - PAD); ox[ct] = sgn * (tap % K - PAD);
     }
+    const int Wp = W + 2 * PAD;
+    int poff[NCT];                                // PADDED: offset of this lane's (tap, s) from the pixel's own padded position
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) poff[ct] = (oy[ct] * Wp + ox[ct]) * CS + sch[ct];
     tw_f32x16 acc[NCT][2];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
@@ -1291,7 +1314,17 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
             a0[u] = 0.f; a1[u] = 0.f;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) bv[u][ct] = 0.f;
-            if (pp < npr && pix < npx) {
+            if (PADDED) {
+                const bool ok = pp < npr && pix < npx;
+                const int pc = ok ? pix : 0;
+                const float* wp = wide + (size_t)pc * Cw + cbase + j;
+                const float w0 = wp[0], w1 = wp[32];
+                a0[u] = ok ? w0 : 0.f; a1[u] = ok ? w1 : 0.f;
+                const int x = pc & (W - 1), row = pc >> lgW, b = row >> lgH;              // row = b * H + y
+                const int base = ((row + b * (2 * PAD) + PAD) * Wp + x + PAD) * CS;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) bv[u][ct] = thin[base + poff[ct]];
+            } else if (pp < npr && pix < npx) {
                 const float* wp = wide + (size_t)pix * Cw + cbase + j;
                 a0[u] = wp[0]; a1[u] = wp[32];
                 int x, y, t;
@@ -1331,6 +1364,12 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
 }
 
 int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);
+// A/B switch (round 3; default on): FG_THIN_WGRAD_PADDED=0 keeps the bounds-checked gathers
+static bool fg_thin_wgrad_padded_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FG_THIN_WGRAD_PADDED"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
 
 int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
                          int Cw, int k, int shift_thin, float* scratch) {
@@ -1343,6 +1382,29 @@ int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, floa
         int lgH = -1, lgW = -1;
         for (int q = 0; q < 15; ++q) { if ((1 << q) == H) lgH = q; if ((1 << q) == W) lgW = q; }
         const bool fits = (long long)B * H * W * Cw < (1LL << 31);
+        // 5x5 / 7x7 on power-of-two maps: gather from a zero-bordered copy of the thin tensor kept in the tail of the slab area
+        // (the layer's slabs are large: the copy displaces a few of the TW_BLOCKS blocks)
+        if (fits && k >= 5 && lgH >= 0 && lgW >= 0 && (Cs == 1 || Cs == 3) && fg_thin_wgrad_padded_on()) {
+            const int pad = (k - 1) / 2;
+            const long long slab = (long long)k * k * Cs * Cw, padf = (long long)B * (H + 2 * pad) * (W + 2 * pad) * Cs;
+            const long long take = (padf + slab - 1) / slab;
+            if (take <= TW_BLOCKS / 4 && padf < (1LL << 30)) {
+                const int nbp = nb < TW_BLOCKS - (int)take ? nb : TW_BLOCKS - (int)take;
+                float* padded = scratch + (long long)(TW_BLOCKS - take) * slab;
+                hipLaunchKernelGGL(thin_pad_kernel, dim3((unsigned)((padf + 255) / 256 < 4096 ? (padf + 255) / 256 : 4096)), dim3(256), 0, ctx->stream, thin, padded, B, H, W, Cs, pad);
+                FG_CHECK_LAUNCH(ctx);
+                dim3 gridp(nbp, Cw / 64);
+#define TWP(KK, CC)                                                                                                  \
+                if (k == KK && Cs == CC) {                                                                           \
+                    hipLaunchKernelGGL((thin_wgrad_mfma_kernel<KK, CC, 1>), gridp, dim3(256), 0, ctx->stream, padded, wide, scratch, B, \
+                                       H, W, Cw, shift_thin, lgH, lgW);                                              \
+                    FG_CHECK_LAUNCH(ctx);                                                                            \
+                    return fg_launch_colsum_final(ctx, scratch, nbp, KK * KK * CC * Cw, 0.f, gw_tsc);                \
+                }
+                TWP(5, 1) TWP(5, 3) TWP(7, 1) TWP(7, 3)
+#undef TWP
+            }
+        }
 #define TWM(KK, CC)                                                                                                  \
         if (fits && k == KK && Cs == CC) {                                                                           \
             hipLaunchKernelGGL((thin_wgrad_mfma_kernel<KK, CC>), grid, dim3(256), 0, ctx->stream, thin, wide, scratch, B, H, \
