@@ -310,7 +310,8 @@ int fg_launch_zero_insert2(fg_ctx*, const float* g, float* out, int B, int H, in
 // (data gradient of a thin-output layer) the layer, folded into the epilogue like IgemmArgs::act_*
 int fg_launch_thin_in_conv(fg_ctx*, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
                            int W, int Cs, int Cw, int k, int flip, const FgActFuse* actf = nullptr,
-                           const FgActBwd* actb = nullptr);
+                           const FgActBwd* actb = nullptr, float* padbuf = nullptr, long long padbuf_floats = 0)
+                           /* padbuf: >= B*(H+k-1)*(W+k-1)*Cs floats enables the zero-bordered 5x5 / 7x7 MFMA path */;
 // thin-out: out[pix][s<Cs] = act(bias[s] + sum_{tap, c<Cw} in[pix+off(tap)][c] * Wp[tap][s][c])
 int fg_launch_thin_out_conv(fg_ctx*, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
                             int W, int Cw, int Cs, int k, int flip, int sigmoid, float* rbuf = nullptr, long long rbuf_floats = 0)   /* rbuf: >= B*H*W*32 floats enables the two-pass 5x5/7x7 MFMA path */;

@@ -268,7 +268,7 @@ static int backward_run_stages(fg_net* n) {
                 }
                 if (!rc && need_gx) {
                     rc = fg_launch_thin_in_conv(ctx, gpre, s.wp_fwd, nullptr, gxb, B, s.ih, s.iw, s.oc, s.ic, k, 1, nullptr,
-                                                pf ? &actb : nullptr);
+                                                pf ? &actb : nullptr, scratch, n->scratch_floats);
                     prelu_folded = pf && !rc && actb.applied;
                 }
                 break;

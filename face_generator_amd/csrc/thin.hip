@@ -469,8 +469,121 @@ __global__ __launch_bounds__(256) void thin_in_mfma_lds_kernel(const float* __re
     if constexpr (EPI == 2) thin_epi_finish(epi, es, lane, wave);
 }
 
+// zero-bordered copy of a thin tensor: [B][H + 2 PAD][W + 2 PAD][CS] (shared with the thin weight gradient below)
+__global__ __launch_bounds__(256) void thin_pad_kernel(const float* __restrict__ thin, float* __restrict__ padded, int B, int H, int W,
+                                                       int CS, int PAD) {
+    const int Hp = H + 2 * PAD, Wp = W + 2 * PAD;
+    const long long n = (long long)B * Hp * Wp * CS;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int s = (int)(i % CS);
+        long long t = i / CS;
+        const int xp = (int)(t % Wp); t /= Wp;
+        const int yp = (int)(t % Hp);
+        const int b = (int)(t / Hp);
+        const int y = yp - PAD, x = xp - PAD;
+        padded[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? thin[((size_t)(b * H + y) * W + x) * CS + s] : 0.f;
+    }
+}
+static int fg_launch_thin_pad(fg_ctx* ctx, const float* thin, float* padded, int B, int H, int W, int Cs, int pad) {
+    const long long padf = (long long)B * (H + 2 * pad) * (W + 2 * pad) * Cs;
+    hipLaunchKernelGGL(thin_pad_kernel, dim3((unsigned)((padf + 255) / 256 < 4096 ? (padf + 255) / 256 : 4096)), dim3(256), 0, ctx->stream,
+                       thin, padded, B, H, W, Cs, pad);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
+// 5x5 / 7x7 thin-input convolution from a ZERO-BORDERED copy of the input (power-of-two maps; the data gradient of the c2f
+// generator head, models_c2f.lua:131 backward).  thin_in_mfma_lds_kernel spends ~10 VALU instructions per MFMA on its gather
+// (tap -> (dy, dx, s) divisions by constants that differ between the two lane halves, four bounds, the address, a select) and
+// every instruction issued beside an MFMA costs the pipe 6-9 cycles: 69 TFLOP/s.  Here the K axis is ordered so that
+// NO per-gather arithmetic is left: the K x K window is split into an upper and a lower half of RH = (K + 1) / 2 rows; the k-pair
+// q = (d, dx, s) of a v_mfma_f32_32x32x2_f32 multiplies tap (d, dx) in lanes 0-31 and tap (d + RH, dx) in lanes 32-63 (zero
+// weights for the row past the window), so a lane's address is (per-tile row base of row d, already including its half's RH rows)
+// + a COMPILE-TIME immediate (dx * CS + s) * 4: one raw buffer load per k-pair, nothing else.  (K + 1) / K more MFMAs (7x7: +14 %).
+template <int K, int CS, int EPI>
+__global__ __launch_bounds__(256) void thin_in_mfma_pad_kernel(const float* __restrict__ inp, const float* __restrict__ Wp,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               int npix, int B, int H, int W, int flip, int Cw, int lgH, int lgW,
+                                                               const ThinEpi epi) {
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int RH = (K + 1) / 2;
+    constexpr int NQ = RH * K * CS;                       // k-pairs
+    constexpr int TI_OOB = 0x7FFFFFF0;
+    __shared__ float wsh[2 * NQ][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cb = blockIdx.y * 64;
+    const int h = lane >> 5, j = lane & 31;
+    for (int e = threadIdx.x; e < 2 * NQ * 64; e += 256) {
+        const int kk = e >> 6, c = e & 63;
+        const int q = kk >> 1, hh = kk & 1;
+        const int d = q / (K * CS), rem = q - d * (K * CS), dx = rem / CS, sc = rem - dx * CS;
+        const int dy = d + hh * RH;
+        float v = 0.f;
+        if (dy < K) {
+            const int tap = dy * K + dx;
+            v = Wp[(size_t)((flip ? K * K - 1 - tap : tap) * CS + sc) * Cw + cb + c];
+        }
+        wsh[kk][c] = v;
+    }
+    __syncthreads();
+    const int Wpd = W + 2 * PAD;
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)inp, 0, B * (H + 2 * PAD) * Wpd * CS * 4, 0x00020000);
+    const float b0 = bias ? bias[cb + j] : 0.f, b1 = bias ? bias[cb + 32 + j] : 0.f;
+    const int ntiles = (npix + 31) / 32;
+    const float esl = EPI ? epi.slope[0] : 1.f;
+    float es = 0.f;
+    constexpr int GQ = K * CS;                            // one window row (both halves) per group: 21 loads, 42 MFMAs (7x7x3)
+    auto rowbase = [&](int tile, int d) -> int {          // byte offset of padded row (y + d + h RH), column x, of the lane's pixel
+        const int pix = tile * 32 + j;
+        if (pix >= npix) return TI_OOB;
+        const int x = pix & (W - 1), row = pix >> lgW, b = row >> lgH;      // row = b * H + y; padded row of (y + dy - PAD) = row + 2 PAD b + dy
+        return ((row + b * (2 * PAD) + d + h * RH) * Wpd + x) * (CS * 4);
+    };
+    auto gather = [&](int rb, float (&av)[GQ]) {
+#pragma unroll
+        for (int u = 0; u < GQ; ++u) av[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(irs, rb + u * 4, 0, 0));
+    };
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        tw_f32x16 acc0, acc1;
+        float px0[16], px1[16];
+        thin_epi_prefetch<EPI>(epi, tile, h, npix, Cw, cb + j, px0, px1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
+        // window rows d = 0 .. RH-1, software-pipelined: the loads of row d + 1 are in flight behind the MFMAs of row d
+        float avA[GQ], avB[GQ];
+        gather(rowbase(tile, 0), avA);
+#pragma unroll
+        for (int d = 0; d < RH; ++d) {
+            float (&cur)[GQ] = (d & 1) ? avB : avA;
+            float (&nxt)[GQ] = (d & 1) ? avA : avB;
+            if (d + 1 < RH) gather(rowbase(tile, d + 1), nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < GQ; ++u) {
+                const int kk = 2 * (d * GQ + u) + h;
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u], wsh[kk][j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[u], wsh[kk][32 + j], acc1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (p < npix) thin_epi_store<EPI>(epi, esl, out, (size_t)p * Cw + cb + j, acc0[r], acc1[r], px0[r], px1[r], es);
+        }
+    }
+    if constexpr (EPI == 2) thin_epi_finish(epi, es, lane, wave);
+}
+// A/B switch (round 3; default on): FG_THIN_PADDED=0 keeps the bounds-checked gathers of the 5x5 / 7x7 thin kernels
+static bool fg_thin_padded_on() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FG_THIN_PADDED"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
 int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
-                           int W, int Cs, int Cw, int k, int flip, const FgActFuse* actf, const FgActBwd* actb) {
+                           int W, int Cs, int Cw, int k, int flip, const FgActFuse* actf, const FgActBwd* actb,
+                           float* padbuf, long long padbuf_floats) {
     if (actf) actf->applied = 0;
     if (actb) actb->applied = 0;
     ThinEpi epi; memset(&epi, 0, sizeof(epi));
@@ -523,6 +636,25 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         dim3 mgrid(nb, Cw / 64);
         arm(mgrid);
         const int em = epi.x ? 2 : (epi.y ? 1 : 0);
+        {   // 5x5 / 7x7 on power-of-two maps with room for a zero-bordered copy of the input: no gather arithmetic at all
+            const int pad = (k - 1) / 2;
+            const long long padf = (long long)B * (H + 2 * pad) * (W + 2 * pad) * Cs;
+            if (k >= 5 && lgH >= 0 && lgW >= 0 && padbuf && padf <= padbuf_floats && padf < (1LL << 28) && fg_thin_padded_on()) {
+                const int rcp = fg_launch_thin_pad(ctx, in, padbuf, B, H, W, Cs, pad);
+                if (rcp) return rcp;
+#define TIP(KK, CC)                                                                                                  \
+                if (k == KK && Cs == CC) {                                                                           \
+                    if (em == 2) hipLaunchKernelGGL((thin_in_mfma_pad_kernel<KK, CC, 2>), mgrid, dim3(256), 0, ctx->stream, padbuf, Wp, bias, out, npix, B, H, W, flip, Cw, lgH, lgW, epi); \
+                    else if (em == 1) hipLaunchKernelGGL((thin_in_mfma_pad_kernel<KK, CC, 1>), mgrid, dim3(256), 0, ctx->stream, padbuf, Wp, bias, out, npix, B, H, W, flip, Cw, lgH, lgW, epi); \
+                    else hipLaunchKernelGGL((thin_in_mfma_pad_kernel<KK, CC, 0>), mgrid, dim3(256), 0, ctx->stream, padbuf, Wp, bias, out, npix, B, H, W, flip, Cw, lgH, lgW, epi); \
+                    FG_CHECK_LAUNCH(ctx);                                                                            \
+                    armed();                                                                                         \
+                    return FG_OK;                                                                                    \
+                }
+                TIP(5, 1) TIP(5, 3) TIP(7, 1) TIP(7, 3)
+#undef TIP
+            }
+        }
 #define TIL(KK, CC)                                                                                                  \
         if (k == KK && Cs == CC) {                                                                                   \
             if (em == 2) hipLaunchKernelGGL((thin_in_mfma_lds_kernel<KK, CC, 2>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW, epi); \
@@ -1251,21 +1383,6 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // used exactly once, so there is nothing to stage), B = the <= 27 shifted thin values of the pair (a per-lane gather from
 // the tiny thin tensor, zero outside the image), columns 27..31 idle.  The VALU kernel above needs one LDS read per FMA
 // and ran 10x over the HBM time of its 33 MB stream.
-// zero-bordered copy of the thin tensor: [B][H + 2 PAD][W + 2 PAD][CS]
-__global__ __launch_bounds__(256) void thin_pad_kernel(const float* __restrict__ thin, float* __restrict__ padded, int B, int H, int W,
-                                                       int CS, int PAD) {
-    const int Hp = H + 2 * PAD, Wp = W + 2 * PAD;
-    const long long n = (long long)B * Hp * Wp * CS;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int s = (int)(i % CS);
-        long long t = i / CS;
-        const int xp = (int)(t % Wp); t /= Wp;
-        const int yp = (int)(t % Hp);
-        const int b = (int)(t / Hp);
-        const int y = yp - PAD, x = xp - PAD;
-        padded[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? thin[((size_t)(b * H + y) * W + x) * CS + s] : 0.f;
-    }
-}
 // PADDED (5x5 / 7x7 layers, power-of-two maps): `thin` is the zero-bordered copy above, so a shifted value is ONE add (pixel base +
 // per-lane constant) and ONE load -- no bounds, no select (the 5 gathers of a 7x7x3 pixel pair cost ~50 VALU instructions per 10
 // MFMAs before, and every instruction issued beside an MFMA costs its pipe 6-9 cycles: DESIGN 4.7); columns >= NA read tap 0 and are
@@ -1305,6 +1422,51 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
     const int stride = gridDim.x * 4;
     const bool p2 = lgW >= 0 && lgH >= 0;
     constexpr int U = NCT <= 2 ? 2 : 1;           // independent pixel pairs in flight (register budget: NCT accumulators)
+    if constexpr (PADDED) {
+        // software-pipelined: the 2 + NCT loads of the NEXT pixel pair are issued before the 2 NCT MFMAs of the current one (with
+        // two waves per SIMD and ~2 000 cycles of load latency against 640 cycles of MFMAs per pair the plain loop was latency-bound)
+        // raw buffer loads: 32-bit byte offsets (no 64-bit address arithmetic), and a pair past the end gets an out-of-range
+        // offset -- the hardware returns zeros, no select behind the load
+        constexpr int TW_OOB = 0x7FFFFFF0;
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wide, 0, npx * Cw * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)thin, 0, B * (H + 2 * PAD) * Wp * CS * 4, 0x00020000);
+        const int wlane = (cbase + j) * 4, wrow = Cw * 4;
+        int poffB[NCT];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) poffB[ct] = poff[ct] * 4;
+        auto fetch = [&](int pp, float& a0, float& a1, float (&bv)[NCT]) {
+            const int pix = 2 * pp + k;
+            const bool ok = pp < npr && pix < npx;
+            const int wo = ok ? pix * wrow + wlane : TW_OOB;
+            a0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, wo, 0, 0));
+            a1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrs, wo + 128, 0, 0));
+            const int pc = ok ? pix : 0;
+            const int x = pc & (W - 1), row = pc >> lgW, b = row >> lgH;              // row = b * H + y
+            const int base = (((row + b * (2 * PAD) + PAD) * Wp + x + PAD) * CS) * 4;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bv[ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(trs, base + poffB[ct], 0, 0));
+        };
+        auto mul = [&](float a0, float a1, const float (&bv)[NCT]) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                acc[ct][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[ct], acc[ct][0], 0, 0, 0);
+                acc[ct][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[ct], acc[ct][1], 0, 0, 0);
+            }
+        };
+        float a0A, a1A, bA[NCT], a0B, a1B, bB[NCT];
+        int pp = blockIdx.x * 4 + wave;
+        fetch(pp, a0A, a1A, bA);
+        for (; pp < npr; pp += 2 * stride) {
+            fetch(pp + stride, a0B, a1B, bB);
+            __builtin_amdgcn_sched_barrier(0);          // keep the next pair's loads IN FRONT of this pair's MFMAs
+            mul(a0A, a1A, bA);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(pp + 2 * stride, a0A, a1A, bA);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(a0B, a1B, bB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
     for (int pp0 = blockIdx.x * 4 + wave; pp0 < npr; pp0 += U * stride) {
         float a0[U], a1[U], bv[U][NCT];
 #pragma unroll
@@ -1314,17 +1476,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
             a0[u] = 0.f; a1[u] = 0.f;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) bv[u][ct] = 0.f;
-            if (PADDED) {
-                const bool ok = pp < npr && pix < npx;
-                const int pc = ok ? pix : 0;
-                const float* wp = wide + (size_t)pc * Cw + cbase + j;
-                const float w0 = wp[0], w1 = wp[32];
-                a0[u] = ok ? w0 : 0.f; a1[u] = ok ? w1 : 0.f;
-                const int x = pc & (W - 1), row = pc >> lgW, b = row >> lgH;              // row = b * H + y
-                const int base = ((row + b * (2 * PAD) + PAD) * Wp + x + PAD) * CS;
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) bv[u][ct] = thin[base + poff[ct]];
-            } else if (pp < npr && pix < npx) {
+            if (pp < npr && pix < npx) {
                 const float* wp = wide + (size_t)pix * Cw + cbase + j;
                 a0[u] = wp[0]; a1[u] = wp[32];
                 int x, y, t;
@@ -1364,12 +1516,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
 }
 
 int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);
-// A/B switch (round 3; default on): FG_THIN_WGRAD_PADDED=0 keeps the bounds-checked gathers
-static bool fg_thin_wgrad_padded_on() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FG_THIN_WGRAD_PADDED"); v = e ? atoi(e) : 1; }
-    return v != 0;
-}
+static bool fg_thin_wgrad_padded_on() { return fg_thin_padded_on(); }
 
 int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
                          int Cw, int k, int shift_thin, float* scratch) {
@@ -1388,11 +1535,10 @@ int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, floa
             const int pad = (k - 1) / 2;
             const long long slab = (long long)k * k * Cs * Cw, padf = (long long)B * (H + 2 * pad) * (W + 2 * pad) * Cs;
             const long long take = (padf + slab - 1) / slab;
-            if (take <= TW_BLOCKS / 4 && padf < (1LL << 30)) {
+            if (take <= TW_BLOCKS / 4 && padf < (1LL << 28) && (long long)B * H * W * Cw * 4 < 0x7FFFFFF0LL) {
                 const int nbp = nb < TW_BLOCKS - (int)take ? nb : TW_BLOCKS - (int)take;
                 float* padded = scratch + (long long)(TW_BLOCKS - take) * slab;
-                hipLaunchKernelGGL(thin_pad_kernel, dim3((unsigned)((padf + 255) / 256 < 4096 ? (padf + 255) / 256 : 4096)), dim3(256), 0, ctx->stream, thin, padded, B, H, W, Cs, pad);
-                FG_CHECK_LAUNCH(ctx);
+{ const int rcp = fg_launch_thin_pad(ctx, thin, padded, B, H, W, Cs, pad); if (rcp) return rcp; }
                 dim3 gridp(nbp, Cw / 64);
 #define TWP(KK, CC)                                                                                                  \
                 if (k == KK && Cs == CC) {                                                                           \
