@@ -1733,10 +1733,44 @@ __device__ __forceinline__ void wgrad_finish_one(const WeightMap& wm, const floa
 // a job the blocks run (in-channel block, out-channel, tap) exactly as the grid of wgrad_finish_kernel does
 struct FgWFinishBatch { FgWFinishJob jobs[FG_DEFER_WMAX]; int n; };
 __global__ __launch_bounds__(128) void wgrad_finish_jobs_kernel(const FgWFinishBatch b) {
+    __shared__ float tl[32][33];
     int j = 0;
     while (j + 1 < b.n && (long long)blockIdx.x >= b.jobs[j + 1].blk0) ++j;
     const FgWFinishJob& jb = b.jobs[j];
     long long l = (long long)blockIdx.x - jb.blk0;
+    if (jb.ib < 0) {
+        // Linear behind a View (k = 1, in-features permuted: partial column pi = hw*C + c <-> reference column i = c*HW + hw): a block
+        // owns one out-feature and a 32 (c) x 32 (hw) patch -- partials read along c, the gradient written along hw, both in 128-byte
+        // runs through LDS (one thread per element wrote the 134 MB gradient of models_c2f.lua:262 one word per cache line)
+        const WeightMap& wm = jb.wm;
+        const int C = wm.i_c, HW = wm.i_hw, nct = (C + 31) / 32, nht = (HW + 31) / 32;
+        const int ht = (int)(l % nht); l /= nht;
+        const int ct = (int)(l % nct);
+        const int po = (int)(l / nct);
+        int o = po;
+        if (wm.o_hw > 1) { int hw = po / wm.o_c, c = po - hw * wm.o_c; o = c * wm.o_hw + hw; }
+        const size_t tile = (size_t)jb.Npad * jb.Cpad;
+        const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+        for (int r = ly; r < 32; r += 4) {                     // row r = hw, lanes = c
+            const int hw = ht * 32 + r, c = ct * 32 + lx;
+            float sum = 0.f;
+            if (hw < HW && c < C) {
+                const size_t e = (size_t)po * jb.Cpad + (size_t)hw * C + c;
+                for (int s = 0; s < jb.S; ++s) sum += jb.part[(size_t)s * tile + e];
+            }
+            tl[r][lx] = sum;
+        }
+        __syncthreads();
+        for (int r = ly; r < 32; r += 4) {                     // row r = c, lanes = hw
+            const int c = ct * 32 + r, hw = ht * 32 + lx;
+            if (hw < HW && c < C) {
+                float* gw = jb.gradW + (size_t)o * wm.I + (size_t)c * HW + hw;
+                const float sum = tl[lx][r];
+                *gw = (jb.beta == 0.f) ? sum : jb.beta * (*gw) + sum;
+            }
+        }
+        return;
+    }
     const int bx = (int)(l % jb.ib); l /= jb.ib;
     const int po = (int)(l % jb.wm.O), wi = (int)(l / jb.wm.O);
     wgrad_finish_one(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx * 128 + (int)threadIdx.x, po, wi);
@@ -1753,10 +1787,12 @@ int fg_launch_wgrad_finish_jobs(fg_ctx* ctx, const FgWFinishJob* jobs, int n, lo
 bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta, float* gradW) {
     FgDefer* d = ctx->defer;
     if (!d || !d->wjobs || d->wn >= FG_DEFER_WMAX) return false;
-    const long long nb = (long long)fg_cdiv(wm.I, 128) * wm.O * wm.k * wm.k;
+    const bool brick = wm.kind == 0 && wm.k == 1 && wm.i_hw > 1 && wm.i_c > 0;     // Linear behind a View: 32 x 32 patches (ib = -1)
+    const long long nb = brick ? (long long)wm.O * fg_cdiv(wm.i_c, 32) * fg_cdiv(wm.i_hw, 32)
+                               : (long long)fg_cdiv(wm.I, 128) * wm.O * wm.k * wm.k;
     if (d->wblocks + nb > 0x7fffffffLL) return false;
     FgWFinishJob& j = d->wjobs[d->wn++];
-    j.wm = wm; j.part = Part; j.gradW = gradW; j.S = S; j.Npad = Npad; j.Cpad = Cpad; j.ib = fg_cdiv(wm.I, 128); j.beta = beta;
+    j.wm = wm; j.part = Part; j.gradW = gradW; j.S = S; j.Npad = Npad; j.Cpad = Cpad; j.ib = brick ? -1 : fg_cdiv(wm.I, 128); j.beta = beta;
     j.blk0 = d->wblocks;
     d->wblocks += nb;
     return true;
