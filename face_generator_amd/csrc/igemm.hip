@@ -1321,16 +1321,23 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
         }                                                                                                   \
     }
 
-    f32x16 acc[MI][MI];
+    // BT == 64 (the 64-channel layers): intra-block split-K.  Each wave multiplies the WHOLE 64 x 64 tile over its own quarter of
+    // the K-step's pixels and the four partial tiles are summed through LDS at the end.  A lane reads TWO channels of a pixel with
+    // one ds_read_b64 -- lane (i, k) at [pixel 2 kp + k][channels 2 i, 2 i + 1] -- so register t of the read is an MFMA fragment
+    // whose 32 rows are the channels 2 i + t (the channel <-> accumulator-row assignment is free; undone in the epilogue): 2 LDS
+    // reads per 4 MFMAs instead of the 2 per MFMA of the one-32x32-tile-per-wave layout (4.9 instructions per MFMA, 113 TFLOP/s).
+    constexpr bool SK = (BT == 64 && BK == 64);
+    constexpr int AT = SK ? 2 : MI;
+    f32x16 acc[AT][AT];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < AT; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < MI; ++ni)
+        for (int ni = 0; ni < AT; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int d_lds = (lane >> 5) * BT + wm * (BT / 2) + (lane & 31);
-    const int x_lds = (lane >> 5) * BT + wn * (BT / 2) + (lane & 31);
+    const int d_lds = SK ? (16 * wid + (lane >> 5)) * BT + 2 * (lane & 31) : (lane >> 5) * BT + wm * (BT / 2) + (lane & 31);
+    const int x_lds = SK ? d_lds : (lane >> 5) * BT + wn * (BT / 2) + (lane & 31);
 
     if (KT > 0) {
         FG_WLOAD();
@@ -1341,7 +1348,24 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
     for (int kt = 0; kt < KT; ++kt) {
         const bool more = kt + 1 < KT;
         if (more) FG_WLOAD();
-        {
+        if constexpr (SK) {
+            const float* Db = Ds + cur * BK * BT + d_lds;
+            const float* Xb = Xs + cur * BK * BT + x_lds;
+            f32x2 af[2], bf[2];           // fragment double buffer
+            af[0] = *(const f32x2*)Db; bf[0] = *(const f32x2*)Xb;
+#pragma unroll
+            for (int kp = 0; kp < 8; ++kp) {
+                const int c = kp & 1;
+                if (kp + 1 < 8) {
+                    af[c ^ 1] = *(const f32x2*)(Db + (2 * kp + 2) * BT);
+                    bf[c ^ 1] = *(const f32x2*)(Xb + (2 * kp + 2) * BT);
+                }
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0], bf[c][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][0], bf[c][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][1], bf[c][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][1], bf[c][1], acc[1][1], 0, 0, 0);
+            }
+        } else {
             const float* Db = Ds + cur * BK * BT + d_lds;
             const float* Xb = Xs + cur * BK * BT + x_lds;
             float af[2][MI], bf[2][MI];   // fragment double buffer
@@ -1372,6 +1396,28 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
 #undef FG_WSTORE
 
     float* part = a.Part + ((size_t)pg * a.S + s) * a.Npad * a.Cpad;
+    if constexpr (SK) {
+        // the four waves' partial tiles -> LDS [wave][tile t,u][r][lane] (exactly the 64 KB of the two operand buffers; the K loop
+        // ended with a barrier), summed in a fixed order, stored with the channel permutation undone
+        float* red = smem;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wid * 4 + t * 2 + u) * 16 + r) * 64 + lane] = acc[t][u][r];
+        __syncthreads();
+        const int t = wid >> 1, u = wid & 1;                 // this wave finishes tile (t, u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = ((t * 2 + u) * 16 + r) * 64 + lane;
+            const float v = (red[e] + red[e + 4096]) + (red[e + 8192] + red[e + 12288]);
+            const int row = tn * BT + 2 * ((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) + t;
+            const int col = tc * BT + 2 * (lane & 31) + u;
+            part[(size_t)row * a.Cpad + col] = v;
+        }
+        if (want_bias) __syncthreads();                      // `red` is read; the bias sums below reuse the same LDS
+    } else
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
