@@ -139,6 +139,26 @@ static int choose_wgrad6(long long M, int Cout, int Cin, int G, int P, int* S, i
     return cfg;
 }
 
+// fp32 wave-specialised weight gradient: the tilings of choose_wgrad6, else (round 3) 128 dY x 64 X channels with the K-step split
+// over the MFMA waves (cfg 2: the 64 -> 128 layers of models_c2f.lua; 64-pixel K-steps, FG_WGRAD_WS64=0 switches it off)
+static int choose_wgrad_ws(long long M, int Cout, int Cin, int G, int P, int* S, int* mper) {
+    const int c = choose_wgrad6(M, Cout, Cin, G, P, S, mper);
+    if (c >= 0) return c;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FG_WGRAD_WS64"); on = e ? atoi(e) : 1; }
+    if (!on || Cout % 128 || Cin % 64) return -1;
+    const long long base = (long long)(Cout / 128) * (Cin / 64) * G * P;
+    long long s = (256 + base / 2) / base;
+    if (base * s > 256 && s > 1 && base * s - 256 < base / 2) s -= 1;
+    if (s < 1) s = 1;
+    const long long maxs = M / 512 > 0 ? M / 512 : 1;          // >= 8 sixty-four-pixel steps per block
+    if (s > maxs) s = maxs;
+    const int mp = fg_round_up((int)((M + s - 1) / s), 64);
+    *mper = mp;
+    *S = (int)((M + mp - 1) / mp);
+    return 2;
+}
+
 // A/B switch (round 3; default on): FG_WGRAD_WS=0 keeps the symmetric wgrad_kernel for the layers that tile 256 x 128 /
 // 128 x 256 channels instead of the wave-specialised wgrad_ws_kernel
 static bool fg_wgrad_ws_on() {
@@ -156,7 +176,7 @@ long long fg_conv_wgrad_part_floats(const ConvGeom& g) {
     int wt, S, mper, Np, Cp, S6, mper6;
     choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
     long long n = (long long)wm.P * wm.G * S * Np * Cp;
-    if (M >= 4096 && choose_wgrad6(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) >= 0) {
+    if (M >= 4096 && choose_wgrad_ws(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) >= 0) {
         const long long n6 = (long long)wm.P * wm.G * S6 * g.Cout * g.Cin;
         if (n6 > n) n = n6;
     }
@@ -446,11 +466,11 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         if ((rc = fg_launch_wgrad6(ctx, a, wm.P, cfg6))) return rc;
         if (gy6_out) *gy6_out = a.D6;
         if (used_out) *used_out = part + d6;
-    } else if (fg_wgrad_ws_on() && ctx->math != 6 && a.M >= 4096 && choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split) >= 0 &&
-               fg_wgrad_ws_shape_ok(a)) {
-        // wave-specialised fp32 weight gradient (256 x 128 / 128 x 256 channel tiles, one round of ~256 blocks); the bias gradient
-        // takes the separate column-sum pass at the end of this function
-        const int cfgw = choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split);
+    } else if (fg_wgrad_ws_on() && ctx->math != 6 && a.M >= 4096 && choose_wgrad_ws(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split) >= 0 &&
+               fg_wgrad_ws_shape_ok(a, choose_wgrad_ws(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split))) {
+        // wave-specialised fp32 weight gradient (256 x 128 / 128 x 256 channel tiles, or 128 x 64 with the K-step split over the
+        // MFMA waves; one round of ~256 blocks); the bias gradient takes the separate column-sum pass at the end of this function
+        const int cfgw = choose_wgrad_ws(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split);
         a.Npad = g.Cout; a.Cpad = g.Cin;
         const long long need = (long long)wm.P * wm.G * a.S * a.Npad * a.Cpad;
         if (need > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad (ws): scratch %lld > %lld", need, scratch_floats);

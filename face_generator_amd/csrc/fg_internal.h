@@ -170,7 +170,7 @@ struct WgradArgs {
 int fg_launch_wgrad(fg_ctx* ctx, const WgradArgs& a, int P, int tile);  // tile: 0 = 128x128, 2 = 64x64
 // wave-specialised fp32 weight gradient; cfg 0: block tile 256 dY-channels x 128 X-channels, cfg 1: 128 x 256
 int fg_launch_wgrad_ws(fg_ctx* ctx, const WgradArgs& a, int P, int cfg);
-bool fg_wgrad_ws_shape_ok(const WgradArgs& a);
+bool fg_wgrad_ws_shape_ok(const WgradArgs& a, int cfg);
 int fg_wgrad_ws_bias_rows(const WgradArgs& a, int cfg);      // bias_part rows per (parity, split): [P][S][rows][Nd]
 // bf16x6 weight-gradient contraction; cfg 0: block tile 256 dY-channels x 128 X-channels, cfg 1: 128 x 256
 int fg_launch_wgrad6(fg_ctx* ctx, const WgradArgs& a, int P, int cfg);

@@ -1870,10 +1870,16 @@ int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
 // Block tile RT (row operand) x QT (column operand) = 256 x 128 channels; SWAP = 0: rows = dY channels, columns = X channels;
 // SWAP = 1: rows = X channels, columns = dY channels (layers whose input has the 256).  Part stays [pg][s][dY ch][X ch].
 // ---------------------------------------------------------------------------------------------------------------
-template <int SWAP>
+// RT x QT = the block's channel tile, KS = pixels per K-step, WK = 1: the four MFMA waves split the TILE 2 x 2 (256 x 128, KS = 16);
+// WK = 4 (round 3, the 64-channel layers: RT x QT = 128 x 64, KS = 64): every MFMA wave multiplies the WHOLE tile (the same 4 x 2
+// accumulator tiles, the same b128 / b64 fragment reads) over its own quarter of the K-step's pixels, and the four partial tiles
+// are summed through LDS at the end in a fixed order -- a small tile without the two LDS reads per MFMA of wgrad_kernel<64>.
+template <int SWAP, int RT = 256, int QT = 128, int KS = 16, int WK = 1>
 __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
-    constexpr int RT = 256, QT = 128, MI = 4, NI = 2;
-    constexpr int STAGE = 16 * (RT + QT);                       // floats per ring stage
+    constexpr int MI = 4, NI = 2;
+    static_assert((WK == 1 && RT == 256 && QT == 128 && KS == 16) || (WK == 4 && RT == 128 && QT == 64 && KS == 64), "tile / wave split");
+    constexpr int LGKS = KS == 16 ? 4 : 6;
+    constexpr int STAGE = KS * (RT + QT);                       // floats per ring stage
     extern __shared__ __attribute__((aligned(16))) float smemw[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1887,7 +1893,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
     const int p = pg / a.G, g = pg - p * a.G;
     const int m0 = s * a.m_per_split;
     const int m1 = min(a.M, m0 + a.m_per_split);
-    const int KT = (m1 > m0) ? (m1 - m0) >> 4 : 0;         // whole 16-pixel steps only (see the launcher)
+    const int KT = (m1 > m0) ? (m1 - m0) >> LGKS : 0;      // whole KS-pixel steps only (see the launcher)
 
     if (wid >= 4) {
         // ------------------------------------------------------------------ loader waves (256 threads)
@@ -1897,12 +1903,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
         const int doy = a.doy[p], dox = a.dox[p], xoy = a.xoy[p][g], xox = a.xox[p][g];
         // dY tile: DT channels, X tile: XT channels; each loader lane owns one 16-byte chunk of 4 (resp. 2) pixel rows
         constexpr int DT = SWAP ? QT : RT, XT = SWAP ? RT : QT;
-        constexpr int ND = 16 * DT / 4 / 256, NX = 16 * XT / 4 / 256;       // chunks per lane and K-step
+        constexpr int ND = KS * DT / 4 / 256, NX = KS * XT / 4 / 256;       // chunks per lane and K-step
         constexpr int DPP = 256 / (DT / 4), XPP = 256 / (XT / 4);           // pixel rows covered by one pass of 256 lanes
         const int dpix = lt / (DT / 4), dch = (lt - dpix * (DT / 4)) * 4;
         const int xpix = lt / (XT / 4), xch = (lt - xpix * (XT / 4)) * 4;
-        const int d_lds0 = (SWAP ? 16 * RT : 0) + dpix * DT + dch;          // the row operand's image comes first
-        const int x_lds0 = (SWAP ? 0 : 16 * RT) + xpix * XT + xch;
+        const int d_lds0 = (SWAP ? KS * RT : 0) + dpix * DT + dch;          // the row operand's image comes first
+        const int x_lds0 = (SWAP ? 0 : KS * RT) + xpix * XT + xch;
         const int gD = (td * DT + dch) * 4, gX = (tx * XT + xch) * 4;
         const int dpixB = a.Nd * 4, xpixB = a.Cx * 4;
         // Address math (the launcher only selects this kernel when Hm, Wm are powers of two, 16 | Hm*Wm and 16 | m_per_split, so a
@@ -1951,7 +1957,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
                 const bool ok = (unsigned)(ybs + cyy[i]) < Hx && (unsigned)(xbs + cxx[i]) < Wx;          \
                 rx_[i] = fg_buffer_load4(xrsrc, ok ? bX + cX[i] : FG_OOB);                               \
             }                                                                                            \
-            mcur += 16;                                                                                  \
+            mcur += KS;                                                                                  \
         }
 #define WW_STORE(st, rd_, rx_)                                                                           \
         {                                                                                                \
@@ -1996,7 +2002,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
     }
 
     // ---------------------------------------------------------------------- MFMA waves (one per SIMD)
-    const int wm = wid >> 1, wn = wid & 1;                      // 2 x 2 waves: 128 row channels x 64 column channels each
+    const int wm = WK == 1 ? wid >> 1 : 0, wn = WK == 1 ? wid & 1 : 0;      // WK = 1: 2 x 2 waves, 128 row x 64 column channels each
+    const int wk = WK == 1 ? 0 : wid;                           // WK = 4: the wave's quarter of the K-step's pixels
     f32x16 acc[MI][NI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -2005,8 +2012,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     // lane (i = lane & 31, k = lane >> 5): rows = channels wm*128 + 4 i + j (j = register of the b128), columns = wn*64 + 2 n + j'
-    const int r_off = (lane >> 5) * RT + wm * 128 + (lane & 31) * 4;
-    const int q_off = 16 * RT + (lane >> 5) * QT + wn * 64 + (lane & 31) * 2;
+    const int r_off = (16 * wk + (lane >> 5)) * RT + wm * 128 + (lane & 31) * 4;
+    const int q_off = KS * RT + (16 * wk + (lane >> 5)) * QT + wn * 64 + (lane & 31) * 2;
     f32x4 af[8];
     f32x2 bf[8];
     __syncthreads();                                            // tiles 0 and 1 are in the ring
@@ -2037,6 +2044,35 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
     }
 
     float* part = a.Part + ((size_t)pg * a.S + s) * a.Npad * a.Cpad;
+    if constexpr (WK == 4) {
+        // four partial 128 x 64 tiles -> LDS [wave][mi][ni][r][lane] (128 KB of the ring; every wave is past the last barrier of the
+        // K loop, the loader waves are gone), summed (w0 + w1) + (w2 + w3); wave w finishes the row tiles mi = w
+        float* red = smemw;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((wid * MI + mi) * NI + ni) * 16 + r) * 64 + lane] = acc[mi][ni][r];
+        __syncthreads();
+        constexpr int WS = MI * NI * 16 * 64;                   // floats per wave
+        const int mi = wid;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int cq = 2 * (lane & 31) + ni;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = ((mi * NI + ni) * 16 + r) * 64 + lane;
+                const float v = (red[e] + red[e + WS]) + (red[e + 2 * WS] + red[e + 3 * WS]);
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int cr = 4 * i + mi;
+                const int o = SWAP ? td * QT + cq : td * RT + cr;  // dY channel
+                const int c = SWAP ? tx * RT + cr : tx * QT + cq;  // X channel
+                part[(size_t)o * a.Cpad + c] = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -2054,35 +2090,38 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
 }
 
 // the kernel's address math assumes whole 16-pixel steps inside one sample
-bool fg_wgrad_ws_shape_ok(const WgradArgs& a) {
-    return a.lgW >= 0 && a.lgH >= 0 && ((a.Hm * a.Wm) & 15) == 0 && (a.m_per_split & 15) == 0 && (a.M & 15) == 0;
+bool fg_wgrad_ws_shape_ok(const WgradArgs& a, int cfg) {
+    const int ks = cfg == 2 ? 63 : 15;
+    return a.lgW >= 0 && a.lgH >= 0 && ((a.Hm * a.Wm) & ks) == 0 && (a.m_per_split & ks) == 0 && (a.M & ks) == 0;
 }
 // partial rows per (parity, split) the kernel leaves in bias_part: (taps x X tiles) blocks x the pixel rows one pass of the 256
 // loader lanes covers
-int fg_wgrad_ws_bias_rows(const WgradArgs& a, int cfg) { return a.G * (a.Cpad / (cfg == 0 ? 128 : 256)) * (cfg == 0 ? 4 : 8); }
-// cfg 0: 256 dY channels x 128 X channels per block, cfg 1: 128 x 256
+int fg_wgrad_ws_bias_rows(const WgradArgs& a, int cfg) { return a.G * (a.Cpad / (cfg == 0 ? 128 : (cfg == 1 ? 256 : 64))) * (cfg == 0 ? 4 : 8); }
+// cfg 0: 256 dY channels x 128 X channels per block, cfg 1: 128 x 256, cfg 2: 128 x 64 with the K-step split over the MFMA waves
 int fg_launch_wgrad_ws(fg_ctx* ctx, const WgradArgs& a, int P, int cfg) {
-    const int RTd = cfg == 0 ? 256 : 128, QTx = cfg == 0 ? 128 : 256;
-    const size_t lds = (size_t)3 * 16 * (256 + 128) * sizeof(float);
-    static bool attr_set[2] = {false, false};
+    const int RTd = cfg == 0 ? 256 : 128, QTx = cfg == 0 ? 128 : (cfg == 1 ? 256 : 64);
+    const size_t lds = cfg == 2 ? (size_t)3 * 64 * (128 + 64) * sizeof(float) : (size_t)3 * 16 * (256 + 128) * sizeof(float);
+    static bool attr_set[3] = {false, false, false};
     if (!attr_set[cfg]) {
         if (cfg == 0) FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else if (cfg == 1) FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<0, 128, 64, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[cfg] = true;
     }
     if ((a.Nd % RTd) || (a.Cx % QTx) || a.Npad != a.Nd || a.Cpad != a.Cx)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: %d x %d channels do not tile %d x %d", a.Nd, a.Cx, RTd, QTx);
     if (a.d_bytes <= 0 || a.x_bytes <= 0 || a.d_bytes >= (long long)FG_OOB || a.x_bytes >= (long long)FG_OOB)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: operands must be < 2 GiB per launch");
-    if (!fg_wgrad_ws_shape_ok(a))
-        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: needs power-of-two Hm, Wm with 16 | Hm*Wm and 16 | m_per_split");
+    if (!fg_wgrad_ws_shape_ok(a, cfg))
+        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: needs power-of-two Hm, Wm and whole K-steps (16 / 64 pixels) per sample and split");
     dim3 grid((a.Npad / RTd) * (a.Cpad / QTx), a.S, a.G * P);
     const double exec = 2.0 * (double)a.Npad * a.Cpad * (double)P * a.G * (double)a.M;
     char label[96];
     snprintf(label, sizeof(label), "wgrad_ws_kernel<%d>/%s", cfg, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
     if (cfg == 0) hipLaunchKernelGGL(wgrad_ws_kernel<0>, grid, dim3(512), lds, ctx->stream, a);
-    else hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(512), lds, ctx->stream, a);
+    else if (cfg == 1) hipLaunchKernelGGL(wgrad_ws_kernel<1>, grid, dim3(512), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((wgrad_ws_kernel<0, 128, 64, 64, 4>), grid, dim3(512), lds, ctx->stream, a);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }

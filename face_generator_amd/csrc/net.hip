@@ -153,7 +153,7 @@ static void make_plan(fg_net* n, int B) {
         for (auto& s : n->st) {
             // (ST_CONV: the wave-specialised weight gradient leaves one bias partial row per (parity, split, tap, X tile, loader
             // pixel lane) -- up to ~1000 rows)
-            if (s.kind == ST_CONV) dn += 4LL * CR_ROWBLOCKS_MAX * s.oc + 64;
+            if (s.kind == ST_CONV) dn += 8LL * CR_ROWBLOCKS_MAX * s.oc + 64;
             // ... and its split-K / parity partials stay until the batched weight-gradient reduction at the end of the pass
             if (s.kind == ST_CONV && s.w_n > 0) { ConvGeom g = s.geom; g.B = B; dn += (fg_conv_wgrad_part_floats(g) + 63) / 64 * 64; }
             else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT || s.kind == ST_GEMV) dn += (long long)CR_ROWBLOCKS_MAX * s.oc + 64;
