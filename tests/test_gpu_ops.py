@@ -33,6 +33,12 @@ CONV_CASES = [
     (2, 16, 16, 1, 64, 3, 0),       # gray
     (2, 16, 16, 128, 1, 3, 0),
     (2, 8, 8, 64, 3, 3, 0),         # thin-out with Cw = 64
+    # M >= 4096 pixels: the wave-specialised weight gradients (the 256 x 128 tile, and the 128 x 64 tile whose 64-pixel K-step is
+    # split over the MFMA waves -- models_c2f.lua:120-121, 246: the 64 -> 128 layers at 64x64 and 32x32)
+    (2, 64, 64, 64, 128, 3, 0),
+    (5, 32, 32, 64, 128, 5, 0),
+    (2, 64, 32, 128, 256, 3, 0),
+    (8, 32, 32, 64, 128, 3, 1),     # folded: four parities x 2x2 taps through the 128 x 64 tile
 ]
 
 
