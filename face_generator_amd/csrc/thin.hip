@@ -528,6 +528,10 @@ __global__ __launch_bounds__(256) void thin_in_mfma_pad_kernel(const float* __re
     __syncthreads();
     const int Wpd = W + 2 * PAD;
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)inp, 0, B * (H + 2 * PAD) * Wpd * CS * 4, 0x00020000);
+    const int obytes = npix * Cw * 4;                      // (the launcher guarantees < 2 GiB)
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 2 ? epi.x : out), 0, obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 1 ? epi.y : out), 0, obytes, 0x00020000);
     const float b0 = bias ? bias[cb + j] : 0.f, b1 = bias ? bias[cb + 32 + j] : 0.f;
     const int ntiles = (npix + 31) / 32;
     const float esl = EPI ? epi.slope[0] : 1.f;
@@ -546,7 +550,20 @@ __global__ __launch_bounds__(256) void thin_in_mfma_pad_kernel(const float* __re
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         tw_f32x16 acc0, acc1;
         float px0[16], px1[16];
-        thin_epi_prefetch<EPI>(epi, tile, h, npix, Cw, cb + j, px0, px1);
+        // epilogue addressing without per-element arithmetic: element r of the tile sits at (lane part) + (wave-uniform part of r),
+        // so the 2 x 16 loads of x and the 2 x 16 (+ 2 x 16) stores take the lane part as voffset and the r part as SCALAR offset
+        // (64-bit pointer arithmetic per element was ~3 VALU instructions each: more issue slots than the tile's MFMAs)
+        const bool fullt = tile * 32 + 32 <= npix;                                    // wave-uniform
+        const int vlane = ((tile * 32 + 4 * h) * Cw + cb + j) * 4;
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = ((r & 3) + 8 * (r >> 2)) * Cw * 4;
+                const int vo = (fullt || tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < npix) ? vlane : TI_OOB;
+                px0[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, vo, so, 0));
+                px1[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, vo + 128, so, 0));
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
         // window rows d = 0 .. RH-1, software-pipelined: the loads of row d + 1 are in flight behind the MFMAs of row d
@@ -568,8 +585,23 @@ __global__ __launch_bounds__(256) void thin_in_mfma_pad_kernel(const float* __re
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int p = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (p < npix) thin_epi_store<EPI>(epi, esl, out, (size_t)p * Cw + cb + j, acc0[r], acc1[r], px0[r], px1[r], es);
+            const int so = ((r & 3) + 8 * (r >> 2)) * Cw * 4;
+            const int vo = (fullt || tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < npix) ? vlane : TI_OOB;
+            const float v0 = acc0[r], v1 = acc1[r];
+            if constexpr (EPI == 2) {
+                const float x0 = px0[r], x1 = px1[r];
+                es = fmaf(x0 > 0.f ? 0.f : x0, v0, es);                 // (an element past the end read x = 0 and v is finite)
+                es = fmaf(x1 > 0.f ? 0.f : x1, v1, es);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x0 > 0.f ? v0 : esl * v0), ors, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x1 > 0.f ? v1 : esl * v1), ors, vo + 128, so, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), ors, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), ors, vo + 128, so, 0);
+                if constexpr (EPI == 1) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0 > 0.f ? v0 : esl * v0), yrs, vo, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1 > 0.f ? v1 : esl * v1), yrs, vo + 128, so, 0);
+                }
+            }
         }
     }
     if constexpr (EPI == 2) thin_epi_finish(epi, es, lane, wave);
@@ -639,7 +671,8 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         {   // 5x5 / 7x7 on power-of-two maps with room for a zero-bordered copy of the input: no gather arithmetic at all
             const int pad = (k - 1) / 2;
             const long long padf = (long long)B * (H + 2 * pad) * (W + 2 * pad) * Cs;
-            if (k >= 5 && lgH >= 0 && lgW >= 0 && padbuf && padf <= padbuf_floats && padf < (1LL << 28) && fg_thin_padded_on()) {
+            if (k >= 5 && lgH >= 0 && lgW >= 0 && padbuf && padf <= padbuf_floats && padf < (1LL << 28) && (long long)npix * Cw * 4 < 0x7FFFFFF0LL &&
+                fg_thin_padded_on()) {
                 const int rcp = fg_launch_thin_pad(ctx, in, padbuf, B, H, W, Cs, pad);
                 if (rcp) return rcp;
 #define TIP(KK, CC)                                                                                                  \
