@@ -1944,12 +1944,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
         const int sXn = a.Hx * a.Wx * xpixB, sXy = a.xsy * a.Wx * xpixB, sXx = a.xsx * xpixB, sX0 = (xoy * a.Wx + xox) * xpixB;
         const int lgW = a.lgW, lgH = a.lgH, wmask = a.Wm - 1, hmask = a.Hm - 1, xsy = a.xsy, xsx = a.xsx;
         const unsigned Hx = (unsigned)a.Hx, Wx = (unsigned)a.Wx;
-        // rowx: the map is exactly KS pixels wide -- every K-step is one row (x0 = 0, yr = 0): 1 add per X load instead of 2 adds,
-        // 2 compares, an and and a select (out-of-range offsets, also the SUM of two of them, stay >= 2 GiB: zeros)
-        const bool rowx = a.Wm == KS;
-        int cXv[NX];
-#pragma unroll
-        for (int i = 0; i < NX; ++i) cXv[i] = (unsigned)cxx[i] < Wx ? cX[i] : FG_OOB;
         f32x4 xd[ND], xx[NX], yd[ND], yx[NX], zd[ND], zx[NX];
 #define WW_LOAD(rd_, rx_)                                                                                \
         {                                                                                                \
@@ -1959,14 +1953,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_ws_kernel(const WgradArgs a) {
             const int bX = nb * sXn + yb * sXy + x0 * sXx + sX0;                                         \
             const int ybs = yb * xsy, xbs = x0 * xsx;                                                    \
             _Pragma("unroll") for (int i = 0; i < ND; ++i) rd_[i] = fg_buffer_load4(drsrc, bD + cD[i]);  \
-            if (rowx) {   /* a K-step is ONE map row: the row's validity is scalar, a lane's x validity a constant (cXv) */ \
-                const int bXv = (unsigned)(ybs + xoy) < Hx ? bX : FG_OOB;                                \
-                _Pragma("unroll") for (int i = 0; i < NX; ++i) rx_[i] = fg_buffer_load4(xrsrc, (int)((unsigned)bXv + (unsigned)cXv[i])); \
-            } else {                                                                                     \
-                _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                         \
-                    const bool ok = (unsigned)(ybs + cyy[i]) < Hx && (unsigned)(xbs + cxx[i]) < Wx;      \
-                    rx_[i] = fg_buffer_load4(xrsrc, ok ? bX + cX[i] : FG_OOB);                           \
-                }                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < NX; ++i) {                                             \
+                const bool ok = (unsigned)(ybs + cyy[i]) < Hx && (unsigned)(xbs + cxx[i]) < Wx;          \
+                rx_[i] = fg_buffer_load4(xrsrc, ok ? bX + cX[i] : FG_OOB);                               \
             }                                                                                            \
             mcur += KS;                                                                                  \
         }

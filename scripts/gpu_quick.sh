@@ -1,9 +1,9 @@
 #!/bin/bash
 set -u
-OUT=gpurun_out; TAG=${1:-r3ar}
+OUT=gpurun_out; TAG=${1:-r3ap}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_c2f.py -x -q -m gpu 2>&1 | tail -6 | tee $OUT/${TAG}_tests.log
-for env in "" ""; do
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_net.py tests/test_gpu_c2f.py tests/test_gpu_modules.py tests/test_gpu_fusion.py -x -q -m gpu 2>&1 | tail -6 | tee $OUT/${TAG}_tests.log
+for env in "" "FG_WGRAD_WS64=0" "" "FG_WGRAD_WS64=0"; do
   env $env timeout 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-alt-math --no-clock-probe --no-live-traffic --c2f-steps 10 > $OUT/${TAG}_b.json 2>/dev/null
   python - <<P
 import json
