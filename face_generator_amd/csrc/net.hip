@@ -902,7 +902,6 @@ int fg_net_forward_to(fg_net* n, int B, const float* x, void* wsv, size_t ws_byt
     int rc;
     if ((rc = ensure_packed(n))) return rc;
     float* ws = (float*)wsv;
-    float* scratch = ws + n->scratch_off;
     n->mask_ptrs.assign(n->n_masks, nullptr);
     if (train) for (int i = 0; i < n->n_masks; ++i) n->mask_ptrs[i] = masks[i];
     n->last_train = train;
