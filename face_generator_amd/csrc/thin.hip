@@ -547,6 +547,12 @@ __global__ __launch_bounds__(256) void thin_in_mfma_pad_kernel(const float* __re
 #pragma unroll
         for (int u = 0; u < GQ; ++u) av[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(irs, rb + u * 4, 0, 0));
     };
+    // the window rows' gathers run one row ahead of the MFMAs -- ACROSS tiles when RH is even (the ping-pong parity then carries
+    // over): row 0 of the next tile is requested during the last row of this one, i.e. BEFORE this tile's 32 stores, so that its
+    // MFMAs do not wait behind them on the in-order vmcnt (575 -> 495 us came from the address-free gathers; this is the rest)
+    constexpr bool XTILE = (RH % 2) == 0;
+    float avA[GQ], avB[GQ];
+    if (XTILE) gather(rowbase(blockIdx.x * 4 + wave, 0), avA);
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         tw_f32x16 acc0, acc1;
         float px0[16], px1[16];
@@ -567,13 +573,13 @@ __global__ __launch_bounds__(256) void thin_in_mfma_pad_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc0[r] = b0; acc1[r] = b1; }
         // window rows d = 0 .. RH-1, software-pipelined: the loads of row d + 1 are in flight behind the MFMAs of row d
-        float avA[GQ], avB[GQ];
-        gather(rowbase(tile, 0), avA);
+        if (!XTILE) gather(rowbase(tile, 0), avA);
 #pragma unroll
         for (int d = 0; d < RH; ++d) {
             float (&cur)[GQ] = (d & 1) ? avB : avA;
             float (&nxt)[GQ] = (d & 1) ? avA : avB;
             if (d + 1 < RH) gather(rowbase(tile, d + 1), nxt);
+            else if (XTILE) gather(rowbase(tile + gridDim.x * 4, 0), nxt);     // (past the last tile: out-of-range offsets, zeros)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < GQ; ++u) {
