@@ -139,6 +139,16 @@ def test_dry_collective_schedule_eight_ranks_in_one_process():
     _check_schedule(_dry([sys.executable], 8), 8)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("env", [dict(FG_ADAM_PACK="1"), dict(FG_DEFER_WFINISH="0"), dict(FG_ADAM_PACK="1", FG_DEFER_WFINISH="0")])
+def test_dry_collective_schedule_does_not_depend_on_the_optimizer_fusions(env):
+    """fg_set_fusion bits 4 / 8 (batched weight-gradient sums, Adam inside the re-pack launch) change which kernels the host queues
+    around the exchange, never the exchange: the same schedule for every setting (and the host side of both paths -- the deferred
+    jobs, the update-only pack jobs -- runs without a GPU)."""
+    import sys
+    _check_schedule(_dry([sys.executable], 2, env=env), 2)
+
+
 def test_planning_only_context_excludes_device_contexts():
     """include/facegen_hip.h: a process holds either planning-only contexts or real ones; host 'device' buffers are plain memory."""
     import ctypes
