@@ -118,6 +118,25 @@ static void choose_wgrad(long long M, int Cout, int Cin, int G, int P, int* tile
 }
 
 
+// One block per CU and `base` blocks per pixel split: s splits fill base*s / (256 * rounds) of the chip -- 25 taps x 10 splits = 250
+// blocks leave 6 CUs idle for the whole launch (2.3 % of the 6.8 ms 5x5 weight gradient of models_c2f.lua:122).  When every block
+// would still run >= 512 K-steps, take the number of ROUNDS (<= 6) whose last round is fullest: 25 x 51 = 1275 blocks = 4.98 rounds.
+// More splits are more partial sums to write and add up, so a later round count must win by 1 % (FG_WGRAD_ROUNDS=0: one round).
+static long long fg_wgrad_rounds(long long base, long long s1, long long M, int kstep) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FG_WGRAD_ROUNDS"); on = e ? atoi(e) : 1; }
+    if (!on || base <= 0) return s1;
+    long long best = s1;
+    double beff = (double)(base * s1) / (double)(256 * ((base * s1 + 255) / 256));
+    for (int r = 2; r <= 6; ++r) {
+        const long long s = 256LL * r / base;
+        if (s <= best || M / s / kstep < 512) continue;
+        const double eff = (double)(base * s) / (256.0 * r);
+        if (eff > beff + 0.01) { beff = eff; best = s; }
+    }
+    return best;
+}
+
 // bf16x6 weight gradient: block tile (dY-channels x X-channels) 256x128 or 128x256; -1 = not tileable.
 // S pixel-splits so that one round of ~256 blocks fills the chip with >= 12 sixteen-pixel steps per block.
 static int choose_wgrad6(long long M, int Cout, int Cin, int G, int P, int* S, int* mper) {
@@ -133,6 +152,7 @@ static int choose_wgrad6(long long M, int Cout, int Cin, int G, int P, int* S, i
     if (s < 1) s = 1;
     const long long maxs = M / 192 > 0 ? M / 192 : 1;
     if (s > maxs) s = maxs;
+    s = fg_wgrad_rounds(base, s, M, 16);
     int mp = fg_round_up((int)((M + s - 1) / s), 16);
     *mper = mp;
     *S = (int)((M + mp - 1) / mp);
@@ -153,6 +173,7 @@ static int choose_wgrad_ws(long long M, int Cout, int Cin, int G, int P, int* S,
     if (s < 1) s = 1;
     const long long maxs = M / 512 > 0 ? M / 512 : 1;          // >= 8 sixty-four-pixel steps per block
     if (s > maxs) s = maxs;
+    s = fg_wgrad_rounds(base, s, M, 64);
     const int mp = fg_round_up((int)((M + s - 1) / s), 64);
     *mper = mp;
     *S = (int)((M + mp - 1) / mp);
