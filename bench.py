@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_MFMA_TFLOPS = 2516.6   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense, spec (16x the fp32 form)
 NOMINAL_CLOCK_GHZ = 2.4       # the clock the peaks below are quoted at (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, spec
+PEAK_HBM_TBS = 8.0               # MI355X_MICROARCH.md: HBM3E, spec
 # algorithmic FLOPs per image for cfg2/3: 7.962 GFLOP/img, 1019.19 GFLOP per B=128 iteration
 MG, MD, G1, D1 = 1052934144, 59703808, 819200, 1769472
 C2F_FLOP_PER_IMAGE = 37.220e9    # configs[3]: 4764.19 GFLOP per B=128 iteration
@@ -50,7 +51,7 @@ def parse_prof(text):
         if len(parts) != 6:
             continue
         name = parts[0].replace(" ", "")
-        rows[name] = dict(calls=int(parts[1]), ms=float(parts[2]), alg=float(parts[3]), exe=float(parts[4]))
+        rows[name] = dict(calls=int(parts[1]), ms=float(parts[2]), alg=float(parts[3]), exe=float(parts[4]), bytes=float(parts[5]))
     return rows
 
 
@@ -85,7 +86,7 @@ def cpu_baselines(workload, batch):
     if workload == "cfg2":
         from oracle import torch7_nn as O
         rng = np.random.default_rng(1)
-        G = O.create_G32((3, 32, 32), 100, rng)
+        G = O.create_G32((3, 32, 32), 100, rng, weight_init_=False)
         D = O.create_D32b((3, 32, 32), rng)
         O.initialize_weights(G, rng=rng)
         O.initialize_weights(D, rng=rng)
@@ -179,6 +180,14 @@ def load_traffic(kernel, live=True):
     return None
 
 
+STAGE = {"name": "start", "t0": time.time()}
+
+
+def stage(name):
+    """Where the run is (read by the watchdog of an N > 1 job: a partial JSON line names the stage that did not finish)."""
+    STAGE["name"], STAGE["t0"] = name, time.time()
+
+
 def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_iter, out, workload, steps, warmup, alt_math=True):
     """Timed region + roofline leg shared by both workloads.  Fills `out` in place."""
     def sync_all():
@@ -194,18 +203,28 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
             return float(t.item())
         return v
 
+    stage(workload + ": warm-up")
     for _ in range(warmup):
         iteration()
     tr.finish_pending()
     sync_all()
+    stage(workload + ": timed steps")
     t0 = time.perf_counter()
     for _ in range(steps):
         iteration()
     tr.finish_pending()          # N > 1: the last D update is deferred behind the next G forward -- complete it in-region
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0          # this rank's own clock, before the closing barrier: a straggler shows here
     sync_all()
     dt = max_over_ranks(time.perf_counter() - t0)
     ms = 1000.0 * dt / steps
     out.update(value=world * B * steps / dt, ms_per_step=ms)
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=ctx.device)
+        t[rank] = 1000.0 * dt_local / steps
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out["per_rank_ms_per_step"] = [round(v, 4) for v in t.tolist()]
+    stage(workload + ": roofline / baseline legs")
     # host cost of a step (outside the timed region): wall time to ENQUEUE a short burst of steps on an idle queue, no
     # sync inside -- short enough that the launch queue never back-pressures, so it is the pure host-side cost
     nb = min(4, steps)
@@ -255,10 +274,11 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
         sym = {}                                   # aggregate by kernel symbol (what rocprofv3 --stats reports)
         for name, r in rows.items():
             k = name.split("/")[0]
-            a = sym.setdefault(k, dict(calls=0, ms=0.0, alg=0.0, exe=0.0))
-            for f in ("calls", "ms", "alg", "exe"):
+            a = sym.setdefault(k, dict(calls=0, ms=0.0, alg=0.0, exe=0.0, bytes=0.0))
+            for f in ("calls", "ms", "alg", "exe", "bytes"):
                 a[f] += r[f]
         if sym:
+            sym = {k: v for k, v in sym.items() if v["exe"] > 0 or v["alg"] > 0} or sym     # contraction launches (the tail is reported apart)
             exe_iter = sum(v["exe"] for v in sym.values()) / args.prof_iters
             mfma_ms_iter = sum(v["ms"] for v in sym.values() if v["exe"] > 0) / args.prof_iters
             out["step_roofline"].update({
@@ -293,9 +313,22 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
             if "ws6" in dom:      # bf16x6 kernels issue 6 bf16 MFMA flops per fp32-equivalent flop: price against the bf16 pipe too
                 out["roofline"].update({"bf16_issued_tflops": 6.0 * exe, "bf16_dense_peak": PEAK_BF16_MFMA_TFLOPS,
                                         "bf16_issued_frac": 6.0 * exe / PEAK_BF16_MFMA_TFLOPS})
+            # the HBM-bound tail, separately -- algorithmic bytes (every operand once) of each
+            # pointwise / thin launch over its HIP-event time, against the 8 TB/s HBM peak
+            tail = [{"kernel": k, "launches_per_iter": v["calls"] / args.prof_iters,
+                     "bytes_per_launch": v["bytes"] / v["calls"], "us": 1e3 * v["ms"] / v["calls"],
+                     "ms_per_iter": v["ms"] / args.prof_iters,
+                     "tb_s": v["bytes"] / (v["ms"] * 1e-3) / 1e12, "frac_of_8TBs": v["bytes"] / (v["ms"] * 1e-3) / 1e12 / PEAK_HBM_TBS}
+                    for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]) if v["bytes"] > 0 and v["ms"] > 0]
+            if tail:
+                tb, tm = sum(t["bytes_per_launch"] * t["launches_per_iter"] for t in tail), sum(t["ms_per_iter"] for t in tail)
+                out["roofline"]["hbm_tail"] = tail
+                out["roofline"]["hbm_tail_total"] = {"ms_per_iter": tm, "gb_per_iter": tb / 1e9, "tb_s": tb / (tm * 1e-3) / 1e12,
+                                                     "frac_of_8TBs": tb / (tm * 1e-3) / 1e12 / PEAK_HBM_TBS, "bound": "hbm", "peak_tb_s": PEAK_HBM_TBS,
+                                                     "note": "launches shorter than ~8 us sit on the launch floor, not on HBM"}
             out["kernels"] = {k: {"calls_per_iter": v["calls"] / args.prof_iters, "ms_per_iter": v["ms"] / args.prof_iters,
                                   "executed_tflops": v["exe"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0}
-                              for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])}
+                              for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]) if v["exe"] > 0 or v["bytes"] == 0}
     # (the supplementary bf16x6 leg runs AFTER the roofline leg: it is power-bound and leaves the part at a lower clock for the
     # next few hundred ms -- measured right behind it the fp32 kernels read 6-8 % slow)
     alt = None
@@ -503,6 +536,11 @@ def main():
     ap.add_argument("--no-clock-probe", action="store_true", help="do not run the one-wave clock probe beside the roofline leg")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not spawn the two rocprofv3 PMC passes for roofline.traffic (a committed summary is used and labelled)")
+    ap.add_argument("--watchdog", type=float, default=360.0,
+                    help="N > 1: seconds the headline leg may take from process start (rendezvous, RCCL init, self-test, warm-up, timed "
+                         "steps); past it rank 0 prints a PARTIAL JSON line naming the stage that did not finish and every rank exits 4")
+    ap.add_argument("--no-dry-check", action="store_true",
+                    help="N > 1: do not walk the collective schedule of all N ranks on the CPU first (rank 0, a subprocess, ~5 s)")
     ap.add_argument("--dry-collective", action="store_true",
                     help="no GPU needed: walk the gradient-exchange path of a --gpus N job for every rank with planning-only contexts "
                          "and print the collective schedule (order, dtype, count, stream) every rank would issue; exit 3 on a mismatch")
@@ -525,7 +563,48 @@ def main():
     if test_gloo:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    out = {}
+    watchdog = None
+    dry = None
     if world > 1:
+        import threading
+
+        def bark():
+            # an N > 1 job that hangs (rendezvous, ncclCommInitRank, a collective no other rank joins) must not run to the
+            # driver's limit without a word: say where it stopped, with whatever was measured so far
+            if rank == 0:
+                part = dict(out)
+                part.update(error="stage '%s' did not finish: %.0f s in it, watchdog %.0f s from process start"
+                                  % (STAGE["name"], time.time() - STAGE["t0"], args.watchdog),
+                            stage=STAGE["name"], partial=True, n_gpus=world, dry_collective=dry)
+                part.setdefault("metric", "GAN train images/sec (G+D step) at 32x32x3 bs128")
+                part.setdefault("value", None)
+                print(json.dumps(part), flush=True)
+            os._exit(4)
+        watchdog = threading.Timer(args.watchdog, bark)
+        watchdog.daemon = True
+        watchdog.start()
+        if rank == 0 and not args.no_dry_check:
+            # the one thing that can hang an N-GPU run -- ranks issuing different collectives -- checked first, without a GPU:
+            # every rank's fg_step_D / fg_step_G walked by planning-only contexts in a CPU subprocess
+            stage("dry collective schedule (CPU)")
+            import hashlib
+            import subprocess
+            try:
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE",
+                                                                        "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                        "TORCHELASTIC_RUN_ID", "FG_BENCH_TEST_GLOO")}
+                env["HIP_VISIBLE_DEVICES"] = ""
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--dry-collective"], env=env,
+                                   capture_output=True, text=True, timeout=90)
+                dj = json.loads(r.stdout.strip().splitlines()[-1])
+                key = "gate=none sync_bn=%d overlap=1" % (1 if args.sync_bn else 0)
+                dry = {"ranks_agree": dj["ranks_agree"], "ranks_walked": len(dj["ranks_walked"]),
+                       "schedule_sha16": hashlib.sha256(json.dumps(dj["schedule"], sort_keys=True).encode()).hexdigest()[:16],
+                       "this_run": dj["schedule"].get(key), "combination": key}
+            except Exception as e:          # a diagnostic: never take the measurement down
+                dry = {"error": str(e)[:200]}
+        stage("torch.distributed rendezvous (init_process_group)")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if test_gloo:
             dist.init_process_group("gloo")
@@ -545,22 +624,25 @@ def main():
         B = args.batch
     coll = None
     if world > 1:
+        stage("fg_comm create + self-test (RCCL communicator of the library)")
         coll = distributed.make_collective(ctx, dist, prefer="torch" if (test_gloo or args.collective == "torch") else "fg_comm",
                                            strict=args.collective == "fg_comm")
     headline = "c2f" if args.workload == "c2f" else "cfg2"
-    out = {
+    out.update({
         "metric": "GAN train images/sec (G+D step) at 32x32x3 bs128" if headline == "cfg2"
                   else "GAN train images/sec (G+D step), c2f 64x64x3 bs128",
         "value": None, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "f32" if args.math == "f32" else "f32 (emulated: 6 exact bf16 split-plane products, fp32 accumulate)",
-    }
+    })
     if world > 1:
+        out["dry_collective"] = dry
         out["collective"] = coll.describe()
         # loud, top-level: the gradient exchange is NOT the library's own communicator (Trainer then drives the closures from
         # the host instead of fg_step_D / fg_step_G -- config.step_entry says so too)
         out["collective_fallback"] = bool(coll.fallback)
         out["rccl_ranks_seen"] = coll.ranks_seen
+    stage(headline + ": build nets")
     if headline == "c2f":
         w = build_c2f(args, ctx, torch, coll, world, rank, B, 1)
     else:
@@ -584,6 +666,8 @@ def main():
         torch.cuda.synchronize()
         out["host_input_images_per_sec"] = B * args.steps / (time.perf_counter() - th)
     out["reference_accounting_images_per_sec"] = out["value"] / 2   # adversarial.lua:305 counts B/2 per iteration
+    if watchdog is not None:
+        watchdog.cancel()          # the headline is measured; the c2f leg has its own timer below
 
     if args.workload == "both":
         # BASELINE configs[3] (one GPU: B = 128, D_it = 1) / configs[4] (N > 1: 64 per GPU, D_it = 2) in the same driver-timed run
@@ -616,6 +700,23 @@ def main():
             sub["error"] = str(e)[:300]
         done.set()
         out["c2f"] = sub
+        # the same numbers where a driver that keeps only `config` / `roofline` / `cpu_baseline` still sees them
+        if sub.get("value") is not None:
+            sr, rr = sub.get("step_roofline", {}), sub.get("roofline", {})
+            out["config"]["also"] = "%s -> roofline.c2f" % sub["config"]["workload"]
+            if isinstance(out.get("roofline"), dict):
+                out["roofline"]["c2f"] = {
+                    "workload": sub["config"]["workload"], "value": sub["value"], "unit": "images/sec", "ms_per_step": sub["ms_per_step"],
+                    "steps": sub["steps"], "warmup": sub["warmup"],
+                    "algorithmic_frac": sr.get("algorithmic_frac_of_f32_mfma_peak"), "executed_frac": sr.get("executed_frac"),
+                    "granted_clock_ghz": sr.get("granted_clock_ghz"),
+                    "target_80pct": {"images_per_sec": 0.8 * PEAK_F32_MFMA_TFLOPS * 1e12 / C2F_FLOP_PER_IMAGE if d_it == 1 else None,
+                                     "ms_per_step": (cB * C2F_FLOP_PER_IMAGE / (0.8 * PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3) if d_it == 1 else None},
+                    "dominant_kernel": {k: rr.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches_per_iter",
+                                                               "frac_at_granted_clock")},
+                    "hbm_tail_total": rr.get("hbm_tail_total")}
+            if isinstance(out.get("cpu_baseline"), dict) and isinstance(sub.get("cpu_baseline"), dict):
+                out["cpu_baseline"]["c2f"] = {k: sub["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind")}
     if world > 1:
         dist.barrier()
         if coll is not None:

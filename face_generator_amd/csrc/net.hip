@@ -525,7 +525,8 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
             }
             case FG_UPSAMPLE2X: {
                 if (i + 1 < nl && L[i + 1].type == FG_CONV && L[i + 1].a == c && L[i + 1].a > 4 && L[i + 1].b > 4 &&
-                    L[i + 1].c % 2 == 1 && L[i + 1].d == (L[i + 1].c - 1) / 2 && L[i + 1].a % 4 == 0) {
+                    L[i + 1].c % 2 == 1 && L[i + 1].d == (L[i + 1].c - 1) / 2 && L[i + 1].a % 4 == 0 &&
+                    !(L[i + 1].q > 1.f) && L[i + 1].p != 2.f) {     // a factor > 1 view or a stride-2 conv behind: not folded
                     const fg_layer_spec& cv = L[i + 1];
                     int T, rmin; fg_fold_window(cv.c, cv.d, &T, &rmin);
                     if (4 * T * T <= FG_MAX_GROUPS) {

@@ -450,8 +450,11 @@ int fg_launch_bn_forward(fg_ctx* ctx, const BnArgs& a) {
         FG_CHECK_LAUNCH(ctx);
     }
     const long long t4 = a.M * a.C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.y, t4, a.C,
-                       a.gamma, a.beta, a.slope, a.mean, a.invstd);
+    {
+        FgProfScope prof(ctx, fg_intern(ctx, "bn_apply_kernel"), 0.0, 0.0, 32.0 * (double)t4);      // read x, write y
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.y, t4, a.C,
+                           a.gamma, a.beta, a.slope, a.mean, a.invstd);
+    }
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
@@ -520,8 +523,11 @@ int fg_launch_bn_forward_sync2(fg_ctx* ctx, const BnArgs& a, const double* sync)
                        a.momentum, a.mean, a.invstd, a.running_mean, a.running_var);
     FG_CHECK_LAUNCH(ctx);
     const long long t4 = a.M * a.C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.y, t4, a.C,
-                       a.gamma, a.beta, a.slope, a.mean, a.invstd);
+    {
+        FgProfScope prof(ctx, fg_intern(ctx, "bn_apply_kernel"), 0.0, 0.0, 32.0 * (double)t4);      // read x, write y
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.y, t4, a.C,
+                           a.gamma, a.beta, a.slope, a.mean, a.invstd);
+    }
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
@@ -707,12 +713,15 @@ int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
     const int ncb = fg_cdiv(a.C, 64);
     float* part = a.scratch;
     float* coef = a.scratch + (size_t)3 * nrb * a.C;
-    if (cr4_ok(a.C))
-        hipLaunchKernelGGL(bn_bwd4_partial_kernel, dim3(nrb), dim3(CR4_NT), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
-                           a.beta, a.slope, a.mean, a.invstd, part);
-    else
-        hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb, ncb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
-                           a.beta, a.slope, a.mean, a.invstd, part);
+    {
+        FgProfScope prof(ctx, fg_intern(ctx, "bn_bwd_partial_kernel"), 0.0, 0.0, 8.0 * (double)a.M * a.C);     // read x, gy
+        if (cr4_ok(a.C))
+            hipLaunchKernelGGL(bn_bwd4_partial_kernel, dim3(nrb), dim3(CR4_NT), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
+                               a.beta, a.slope, a.mean, a.invstd, part);
+        else
+            hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb, ncb), dim3(256), 0, ctx->stream, a.x, a.gy, a.M, a.C, a.gamma,
+                               a.beta, a.slope, a.mean, a.invstd, part);
+    }
     FG_CHECK_LAUNCH(ctx);
     float* gs = (a.slope && a.gslope) ? a.gslope : nullptr;
     const int nfb = fg_cdiv(a.C, 16);
@@ -728,8 +737,11 @@ int fg_launch_bn_backward(fg_ctx* ctx, const BnBwdArgs& a) {
     }
     if (a.gx) {
         const long long t4 = a.M * a.C / 4;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.gy, a.gx, t4, a.C,
-                           a.gamma, a.beta, a.slope, a.mean, a.invstd, coef, 1);
+        {
+            FgProfScope prof(ctx, fg_intern(ctx, "bn_bwd_apply_kernel"), 0.0, 0.0, 48.0 * (double)t4);      // read x, gy; write gx
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_apply_blocks(t4, a.C)), dim3(256), 0, ctx->stream, a.x, a.gy, a.gx, t4, a.C,
+                               a.gamma, a.beta, a.slope, a.mean, a.invstd, coef, 1);
+        }
         FG_CHECK_LAUNCH(ctx);
     }
     return FG_OK;
@@ -845,8 +857,13 @@ int fg_launch_actpool_forward(fg_ctx* ctx, const float* x, const float* slope, c
     if (n == 0) return FG_OK;
     FgSplitParts none; memset(&none, 0, sizeof(none));
     if (sp && sp->splits && (!xout || sp->stride % 4 || sp->N != C)) return fg_set_err(ctx, FG_ERR_INVALID, "actpool: bad split partials");
-    hipLaunchKernelGGL(actpool_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, slope, mask, mscale, y, B, H,
-                       W, C, (sp && sp->splits) ? *sp : none, xout);
+    {
+        // read x (or `splits` partials, then also write x), write the pooled y
+        const double nx = 4.0 * B * H * W * C, sx = (sp && sp->splits) ? (double)sp->splits + 1.0 : 1.0;
+        FgProfScope prof(ctx, fg_intern(ctx, "actpool_fwd_kernel"), 0.0, 0.0, nx * sx + nx / 4);
+        hipLaunchKernelGGL(actpool_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, slope, mask, mscale, y, B, H,
+                           W, C, (sp && sp->splits) ? *sp : none, xout);
+    }
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
@@ -897,8 +914,13 @@ int fg_launch_actpool_backward(fg_ctx* ctx, const float* x, const float* gy, con
     if (grid.x > 1024) grid.x = 1024;
     float* dpart = (slope && gslope) ? fg_defer_alloc(ctx, grid.x) : nullptr;
     if (dpart) scratch = dpart;
-    hipLaunchKernelGGL(actpool_bwd_kernel, grid, dim3(256), 0, ctx->stream, x, gy, slope, mask, mscale, gx, scratch, B,
-                       H, W, C, spv);
+    {
+        // read x and the pooled gradient (or its `splits` partials), write gx
+        const double nx = 4.0 * B * H * W * C;
+        FgProfScope prof(ctx, fg_intern(ctx, "actpool_bwd_kernel"), 0.0, 0.0, nx * (gx ? 2.0 : 1.0) + nx / 4 * (spv.splits ? spv.splits : 1));
+        hipLaunchKernelGGL(actpool_bwd_kernel, grid, dim3(256), 0, ctx->stream, x, gy, slope, mask, mscale, gx, scratch, B,
+                           H, W, C, spv);
+    }
     FG_CHECK_LAUNCH(ctx);
     if (dpart) { fg_defer_push(ctx, dpart, (int)grid.x, 1, acc, gslope); return FG_OK; }
     if (slope && gslope) {
@@ -1431,7 +1453,10 @@ AdamScalars fg_adam_scalars(const AdamArgs& a) {
 }
 int fg_launch_adam(fg_ctx* ctx, const AdamArgs& a) {
     if (a.n == 0) return FG_OK;
-    hipLaunchKernelGGL(adam_kernel, FG_GRID(a.n, 256), dim3(256), 0, ctx->stream, a, fg_adam_scalars(a));
+    {
+        FgProfScope prof(ctx, fg_intern(ctx, "adam_kernel"), 0.0, 0.0, 28.0 * (double)a.n);   // read p, g, m, v; write p, m, v
+        hipLaunchKernelGGL(adam_kernel, FG_GRID(a.n, 256), dim3(256), 0, ctx->stream, a, fg_adam_scalars(a));
+    }
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }

@@ -624,6 +624,12 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
                            float* padbuf, long long padbuf_floats) {
     if (actf) actf->applied = 0;
     if (actb) actb->applied = 0;
+    // profile label "thin_in<k,Cs>": algorithmic bytes = the thin input read once + the wide output written once (a fused PReLU
+    // forward writes it twice, a fused PReLU backward also reads the PReLU's input)
+    char plabel[48] = "";
+    if (ctx->prof) snprintf(plabel, sizeof(plabel), "thin_in<%d,%d>", k, Cs);
+    FgProfScope prof(ctx, fg_intern(ctx, plabel), 0.0, 0.0,
+                     4.0 * B * H * W * ((double)Cs + (double)Cw * (1 + ((actf && actf->y) || (actb && actb->x) ? 1 : 0))));
     ThinEpi epi; memset(&epi, 0, sizeof(epi));
     // fold the neighbouring PReLU into the epilogue (MFMA variants): forward = plain PReLU only (no same-shape mask)
     const bool want_f = actf && actf->y && actf->slope && !actf->mask && fg_fuse_prelu(ctx);
@@ -1218,6 +1224,10 @@ int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const
     if (Cs > 4) return fg_set_err(ctx, FG_ERR_INVALID, "thin_out: Cs > 4");
     const int npix = B * H * W;
     if (npix == 0) return FG_OK;
+    // profile label "thin_out<k,Cs>": algorithmic bytes = the wide input read once + the thin output written once
+    char plabel[48] = "";
+    if (ctx->prof) snprintf(plabel, sizeof(plabel), "thin_out<%d,%d>", k, Cs);
+    FgProfScope prof(ctx, fg_intern(ctx, plabel), 0.0, 0.0, 4.0 * npix * ((double)Cw + Cs));
     if (rbuf && !flip && (k == 5 || k == 7) && (Cs == 1 || Cs == 3) && Cw % 32 == 0 && (long long)npix * 32 <= rbuf_floats) {
         dim3 grid(B * ((H + 3) / 4) * ((W + 31) / 32));
 #define TOR(KK, CC)                                                                                                  \
@@ -1560,6 +1570,10 @@ static bool fg_thin_wgrad_padded_on() { return fg_thin_padded_on(); }
 int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
                          int Cw, int k, int shift_thin, float* scratch) {
     if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_wgrad: Cw %% 64");
+    // profile label "thin_wgrad<k,Cs>": algorithmic bytes = both tensors read once (the per-block slabs are small)
+    char plabel[48] = "";
+    if (ctx->prof) snprintf(plabel, sizeof(plabel), "thin_wgrad<%d,%d>", k, Cs);
+    FgProfScope prof(ctx, fg_intern(ctx, plabel), 0.0, 0.0, 4.0 * B * H * W * ((double)Cw + Cs));
     {
         const long long npairs = ((long long)B * H * W + 1) / 2;
         int nb = (int)((npairs + 3) / 4 < TW_BLOCKS ? (npairs + 3) / 4 : TW_BLOCKS);

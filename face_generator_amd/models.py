@@ -5,9 +5,11 @@ Same public names as models.lua: `create_G(dimensions, noiseDim)` (models.lua:87
 (face_generator_amd.nn) whose modules mirror the Torch7 modules one for one.
 """
 from . import nn
+from .nn import cudnn
+from .weight_init import w_init
 
 
-def create_G_decoder_upsampling32(dimensions, noiseDim):
+def create_G_decoder_upsampling32(dimensions, noiseDim, gen=None):
     """models.lua:57-81."""
     model = nn.Sequential()
     model.add(nn.Linear(noiseDim, 128 * 8 * 8))
@@ -15,22 +17,23 @@ def create_G_decoder_upsampling32(dimensions, noiseDim):
     model.add(nn.PReLU())
 
     model.add(nn.SpatialUpSamplingNearest(2))
-    model.add(nn.SpatialConvolution(128, 256, 5, 5, 1, 1, (5 - 1) // 2, (5 - 1) // 2))
+    model.add(cudnn.SpatialConvolution(128, 256, 5, 5, 1, 1, (5 - 1) // 2, (5 - 1) // 2))
     model.add(nn.SpatialBatchNormalization(256))
     model.add(nn.PReLU())
 
     model.add(nn.SpatialUpSamplingNearest(2))
-    model.add(nn.SpatialConvolution(256, 128, 5, 5, 1, 1, (5 - 1) // 2, (5 - 1) // 2))
+    model.add(cudnn.SpatialConvolution(256, 128, 5, 5, 1, 1, (5 - 1) // 2, (5 - 1) // 2))
     model.add(nn.SpatialBatchNormalization(128))
     model.add(nn.PReLU())
 
-    model.add(nn.SpatialConvolution(128, dimensions[0], 3, 3, 1, 1, (3 - 1) // 2, (3 - 1) // 2))
+    model.add(cudnn.SpatialConvolution(128, dimensions[0], 3, 3, 1, 1, (3 - 1) // 2, (3 - 1) // 2))
     model.add(nn.Sigmoid())
     model.input_dims = (noiseDim, 1, 1)
+    model = w_init(model, 'heuristic', gen=gen)      # models.lua:48 / :78
     return model
 
 
-def create_G_decoder_upsampling16(dimensions, noiseDim):
+def create_G_decoder_upsampling16(dimensions, noiseDim, gen=None):
     """models.lua:27-51: the same decoder started from a 4x4 map (no new kernel class)."""
     model = nn.Sequential()
     model.add(nn.Linear(noiseDim, 128 * 4 * 4))
@@ -38,26 +41,27 @@ def create_G_decoder_upsampling16(dimensions, noiseDim):
     model.add(nn.PReLU())
 
     model.add(nn.SpatialUpSamplingNearest(2))
-    model.add(nn.SpatialConvolution(128, 256, 5, 5, 1, 1, (5 - 1) // 2, (5 - 1) // 2))
+    model.add(cudnn.SpatialConvolution(128, 256, 5, 5, 1, 1, (5 - 1) // 2, (5 - 1) // 2))
     model.add(nn.SpatialBatchNormalization(256))
     model.add(nn.PReLU())
 
     model.add(nn.SpatialUpSamplingNearest(2))
-    model.add(nn.SpatialConvolution(256, 128, 5, 5, 1, 1, (5 - 1) // 2, (5 - 1) // 2))
+    model.add(cudnn.SpatialConvolution(256, 128, 5, 5, 1, 1, (5 - 1) // 2, (5 - 1) // 2))
     model.add(nn.SpatialBatchNormalization(128))
     model.add(nn.PReLU())
 
-    model.add(nn.SpatialConvolution(128, dimensions[0], 3, 3, 1, 1, (3 - 1) // 2, (3 - 1) // 2))
+    model.add(cudnn.SpatialConvolution(128, dimensions[0], 3, 3, 1, 1, (3 - 1) // 2, (3 - 1) // 2))
     model.add(nn.Sigmoid())
     model.input_dims = (noiseDim, 1, 1)
+    model = w_init(model, 'heuristic', gen=gen)      # models.lua:48 / :78
     return model
 
 
-def create_G(dimensions, noiseDim):
+def create_G(dimensions, noiseDim, gen=None):
     """models.lua:87-93."""
     if dimensions[1] == 16:
-        return create_G_decoder_upsampling16(dimensions, noiseDim)
-    return create_G_decoder_upsampling32(dimensions, noiseDim)
+        return create_G_decoder_upsampling16(dimensions, noiseDim, gen=gen)
+    return create_G_decoder_upsampling32(dimensions, noiseDim, gen=gen)
 
 
 def create_D32b(dimensions):

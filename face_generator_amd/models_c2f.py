@@ -2,6 +2,7 @@
 `create_D(dimensions, cuda)` -> create_D_c (:237-278).  weight-init 'heuristic' (:138, :271) is a no-op on these nets
 (it does not recurse into the inner Sequential), so Torch's default reset() initialisation applies."""
 from . import nn
+from .weight_init import w_init
 
 
 def create_G_d(dimensions, cuda=False, max_batch=32, gen=None):
@@ -19,6 +20,7 @@ def create_G_d(dimensions, cuda=False, max_batch=32, gen=None):
     inner.add(nn.View(c, h, w))
     inner.input_dims = (c + 1, h, w)
     model_G = nn.TableSequential(nn.JoinTable(2, 2), inner)
+    model_G = w_init(model_G, 'heuristic')        # models_c2f.lua:138 -- top level only: no module matches, a no-op
     if cuda:
         model_G.cuda(max_batch=max_batch)
     return model_G
@@ -47,6 +49,7 @@ def create_D_c(dimensions, cuda=False, max_batch=32, gen=None):
     inner.add(nn.Sigmoid())
     inner.input_dims = (c, h, w)
     model_D = nn.TableSequential(nn.CAddTable(), inner)
+    model_D = w_init(model_D, 'heuristic')        # models_c2f.lua:271 -- a no-op for the same reason
     if cuda:
         model_D.cuda(max_batch=max_batch)
     return model_D

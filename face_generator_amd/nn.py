@@ -83,6 +83,14 @@ class Linear(Module):
         self.gradWeight = torch.zeros_like(self.weight)
         self.gradBias = torch.zeros_like(self.bias)
 
+    def reset(self, stdv=None, gen=None):
+        """Linear.lua reset(stdv): an explicit stdv is scaled by sqrt(3) (so that U(-s, s) has that standard deviation), the
+        default is 1 / sqrt(inputSize); weight and bias are both re-drawn from U(-s, s)."""
+        s = stdv * math.sqrt(3.0) if stdv else 1.0 / math.sqrt(self.weight.shape[1])
+        self.weight.copy_(_uniform(tuple(self.weight.shape), s, gen))
+        self.bias.copy_(_uniform(tuple(self.bias.shape), s, gen))
+        return self
+
     def spec(self):
         return ("LINEAR", self.weight.shape[1], self.weight.shape[0])
 
@@ -255,6 +263,13 @@ class SpatialConvolution(Module):
         self.gradWeight = torch.zeros_like(self.weight)
         self.gradBias = torch.zeros_like(self.bias)
 
+    def reset(self, stdv=None, gen=None):
+        """SpatialConvolution.lua reset(stdv): stdv * sqrt(3), default 1 / sqrt(kW * kH * nInputPlane); weight and bias ~ U(-s, s)."""
+        s = stdv * math.sqrt(3.0) if stdv else 1.0 / math.sqrt(self.kW * self.kW * self.nInputPlane)
+        self.weight.copy_(_uniform(tuple(self.weight.shape), s, gen))
+        self.bias.copy_(_uniform(tuple(self.bias.shape), s, gen))
+        return self
+
     def spec(self):
         return ("CONV", self.nInputPlane, self.nOutputPlane, self.kW, self.padW, float(getattr(self, "dW", 1)))
 
@@ -278,6 +293,15 @@ class SpatialConvolution(Module):
     def __repr__(self):
         return "%s(%d -> %d, %dx%d, 1,1, %d,%d)" % (self._typename, self.nInputPlane, self.nOutputPlane, self.kW,
                                                     self.kW, self.padW, self.padW)
+
+
+def CudnnSpatialConvolution(*args, **kw):
+    """cudnn.SpatialConvolution (models.lua:63, 68, 73): the same module under the cudnn rock's type name.  The name matters to
+    callers that dispatch on `__typename` -- weight-init.lua:56-71 resets `nn.SpatialConvolution` but NOT `cudnn.SpatialConvolution`
+    (it only zeroes its bias) -- and to the checkpoint writer (t7_checkpoint.py)."""
+    m = SpatialConvolution(*args, **kw)
+    m._typename = "cudnn.SpatialConvolution"
+    return m
 
 
 class SpatialBatchNormalization(Module):
@@ -975,3 +999,12 @@ class ConcatSequential(Sequential):
             lines.append("  (%d): %s" % (i + 1, repr(m).replace("\n", "\n  ")))
         lines.append("}")
         return "\n".join(lines)
+
+
+class _CudnnNamespace:
+    """`cudnn.*` as the reference scripts spell it (models.lua, models_c2f.lua, layers/cudnnSpatialConvolutionUpsample.lua)."""
+    SpatialConvolution = staticmethod(CudnnSpatialConvolution)
+    SpatialConvolutionUpsample = SpatialConvolutionUpsample
+
+
+cudnn = _CudnnNamespace

@@ -84,7 +84,7 @@ def module_to_t7(m, cudnn_convs=False):
         t = "cudnn.SpatialConvolutionUpsample"
     elif isinstance(m, nn.SpatialConvolution):
         _conv_fields(f, m)
-        if cudnn_convs:
+        if cudnn_convs or getattr(m, "_typename", "") == "cudnn.SpatialConvolution":
             f["groups"] = 1
             t = "cudnn.SpatialConvolution"
     elif isinstance(m, nn.SpatialBatchNormalization):
@@ -195,8 +195,8 @@ def module_from_t7(o):
         if t == "cudnn.SpatialConvolutionUpsample":
             m = nn.SpatialConvolutionUpsample(nI, nO, kW, int(f["kH"]), int(_num(o, "factor", 1)))
         else:
-            m = nn.SpatialConvolution(nI, nO, kW, int(f["kH"]), int(_num(o, "dW", 1)), int(_num(o, "dH", 1)), pad,
-                                      int(_num(o, "padH", pad)))
+            cls = nn.cudnn.SpatialConvolution if t == "cudnn.SpatialConvolution" else nn.SpatialConvolution
+            m = cls(nI, nO, kW, int(f["kH"]), int(_num(o, "dW", 1)), int(_num(o, "dH", 1)), pad, int(_num(o, "padH", pad)))
         setp(m, ("weight", "bias"))       # 2-D SpatialConvolutionMM weights reshape to [O][I][kH][kW] (same memory order)
         return m
     if t in ("nn.SpatialBatchNormalization", "nn.BatchNormalization", "cudnn.SpatialBatchNormalization"):

@@ -751,31 +751,61 @@ def interruptable_adagrad(opfunc, x, config, state=None):
 # ----------------------------------------------------------------------------------
 # models.lua (32x32 path)
 # ----------------------------------------------------------------------------------
-def create_G32(dimensions, noise_dim, rng=None):
-    """models.lua:57-81 create_G_decoder_upsampling32.  (weight-init 'heuristic' at :78 is
-    overridden by NN_UTILS.initializeWeights in train.lua:137-138 -- SURVEY F9.)"""
-    rng = rng or np.random.default_rng(1)
-    c = dimensions[0]
-    return Sequential(
-        Linear(noise_dim, 128 * 8 * 8, rng), View(128, 8, 8), PReLU(),
-        SpatialUpSamplingNearest(2), SpatialConvolution(128, 256, 5, 5, 1, 1, 2, 2, rng),
-        SpatialBatchNormalization(256, rng=rng), PReLU(),
-        SpatialUpSamplingNearest(2), SpatialConvolution(256, 128, 5, 5, 1, 1, 2, 2, rng),
-        SpatialBatchNormalization(128, rng=rng), PReLU(),
-        SpatialConvolution(128, c, 3, 3, 1, 1, 1, 1, rng), Sigmoid())
+def weight_init(net, arg='heuristic', rng=None):
+    """weight-init.lua:41-76 `require('weight-init')(model, 'heuristic')`: TOP-LEVEL modules only (no recursion, :52); modules
+    typed nn.SpatialConvolution / nn.SpatialConvolutionMM / nn.Linear get `m:reset(method(fan_in, fan_out))` -- Torch7's reset(stdv)
+    draws weight AND bias from U(-stdv*sqrt(3), stdv*sqrt(3)) -- and then every top-level module with a bias has it zeroed (:71-73).
+    cudnn.SpatialConvolution (`cudnn=True` on the oracle's module: G's convolutions, models.lua:63-73) is not in the list: only its
+    bias is zeroed.  With 'heuristic' = sqrt(1 / (3 fan_in)) the Linear's new range is 1/sqrt(fan_in), the default one."""
+    rng = rng or np.random.default_rng(5)
+    method = {'heuristic': lambda fi, fo: np.sqrt(1.0 / (3.0 * fi)), 'xavier': lambda fi, fo: np.sqrt(2.0 / (fi + fo)),
+              'xavier_caffe': lambda fi, fo: np.sqrt(1.0 / fi), 'kaiming': lambda fi, fo: np.sqrt(4.0 / (fi + fo))}[arg]
+    for m in getattr(net, 'modules', []):
+        std = None
+        if type(m) is SpatialConvolution and not getattr(m, 'cudnn', False):
+            o, i, kh, kw = m.weight.shape
+            std = method(i * kh * kw, o * kh * kw)
+        elif type(m) is Linear:
+            std = method(m.weight.shape[1], m.weight.shape[0])
+        if std is not None:
+            s = std * np.sqrt(3.0)
+            m.weight[...] = rng.uniform(-s, s, m.weight.shape).astype(m.weight.dtype)
+            m.bias[...] = rng.uniform(-s, s, m.bias.shape).astype(m.bias.dtype)
+        if getattr(m, 'bias', None) is not None:
+            m.bias[...] = 0
+    return net
 
 
-def create_G16(dimensions, noise_dim, rng=None):
-    """models.lua:27-51 create_G_decoder_upsampling16: the 32-px decoder started from a 4x4 map."""
+def _cudnn(conv):
+    conv.cudnn = True        # typed cudnn.SpatialConvolution in the reference (models.lua:63, 68, 73): weight_init skips its reset
+    return conv
+
+
+def create_G32(dimensions, noise_dim, rng=None, weight_init_=True):
+    """models.lua:57-81 create_G_decoder_upsampling32, including the weight-init 'heuristic' call of :78 (train.lua:137-138
+    overrides it with NN_UTILS.initializeWeights -- SURVEY F9; a caller of MODELS.create_G alone sees it).  `weight_init_=False`
+    leaves Torch7's default reset() state (non-zero biases): what the parity tests feed both sides."""
     rng = rng or np.random.default_rng(1)
     c = dimensions[0]
+    net = _create_G_decoder(8, c, noise_dim, rng)
+    return weight_init(net, 'heuristic', rng) if weight_init_ else net
+
+
+def create_G16(dimensions, noise_dim, rng=None, weight_init_=True):
+    """models.lua:27-51 create_G_decoder_upsampling16: the 32-px decoder started from a 4x4 map (weight-init at :48)."""
+    rng = rng or np.random.default_rng(1)
+    net = _create_G_decoder(4, dimensions[0], noise_dim, rng)
+    return weight_init(net, 'heuristic', rng) if weight_init_ else net
+
+
+def _create_G_decoder(s0, c, noise_dim, rng):
     return Sequential(
-        Linear(noise_dim, 128 * 4 * 4, rng), View(128, 4, 4), PReLU(),
-        SpatialUpSamplingNearest(2), SpatialConvolution(128, 256, 5, 5, 1, 1, 2, 2, rng),
+        Linear(noise_dim, 128 * s0 * s0, rng), View(128, s0, s0), PReLU(),
+        SpatialUpSamplingNearest(2), _cudnn(SpatialConvolution(128, 256, 5, 5, 1, 1, 2, 2, rng)),
         SpatialBatchNormalization(256, rng=rng), PReLU(),
-        SpatialUpSamplingNearest(2), SpatialConvolution(256, 128, 5, 5, 1, 1, 2, 2, rng),
+        SpatialUpSamplingNearest(2), _cudnn(SpatialConvolution(256, 128, 5, 5, 1, 1, 2, 2, rng)),
         SpatialBatchNormalization(128, rng=rng), PReLU(),
-        SpatialConvolution(128, c, 3, 3, 1, 1, 1, 1, rng), Sigmoid())
+        _cudnn(SpatialConvolution(128, c, 3, 3, 1, 1, 1, 1, rng)), Sigmoid())
 
 
 def create_D16_d(dimensions, rng=None):

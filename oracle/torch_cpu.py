@@ -186,7 +186,7 @@ def time_iterations(workload, batch, min_seconds=10.0, max_iters=50, threads=Non
             gan.step_D(diff[:h], [torch.rand(h, 1, S, S) * 2 - 1, coarse[h:]], cond=coarse)
             gan.step_G([torch.rand(batch, 1, S, S) * 2 - 1, coarse], cond=coarse)
     else:
-        G = O.create_G32((3, 32, 32), 100, rng)
+        G = O.create_G32((3, 32, 32), 100, rng, weight_init_=False)
         D = O.create_D32b((3, 32, 32), rng)
         O.initialize_weights(G, rng=rng); O.initialize_weights(D, rng=rng)
         gan = GanCPU(G, D)

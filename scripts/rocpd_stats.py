@@ -1,6 +1,8 @@
 """Summarise a rocprofv3 rocpd SQLite database (kernel trace) per kernel name: calls, total/avg ms, % of GPU time.
 usage: python scripts/rocpd_stats.py <results.db> [iters | auto]   -> markdown table on stdout
-(auto: iterations = rng_multi_kernel launches / 2 -- every closure of the training loop starts with one Philox launch)"""
+(auto: iterations = rng_multi_kernel launches / 2 -- every closure of the training loop starts with one Philox launch -- and every
+dispatch BEFORE the first such launch is dropped and listed apart: net construction (parameter uploads: `__amd_rocclr_copyBuffer`
+blits of up to 134 MB, fills, the first weight re-pack) is not per-iteration cost)"""
 import re
 import sqlite3
 import sys
@@ -18,7 +20,15 @@ def main():
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    rows = list(cur.execute("select %s, start, end from kernels" % namecol))
+    rows = sorted(cur.execute("select %s, start, end from kernels" % namecol), key=lambda r: r[1])
+    setup = {}
+    if iters == "auto":
+        first = next((i for i, r in enumerate(rows) if short(r[0]) == "rng_multi_kernel"), 0)
+        for name, s, e in rows[:first]:
+            a = setup.setdefault(short(name), [0, 0.0])
+            a[0] += 1
+            a[1] += (e - s) / 1e6
+        rows = rows[first:]
     agg = {}
     for name, s, e in rows:
         a = agg.setdefault(short(name), [0, 0.0])
@@ -38,6 +48,10 @@ def main():
     print("\ntotal kernel time %.3f ms over %d dispatches; first-to-last span %.3f ms" % (total, len(rows), span))
     if iters:
         print("%.1f iterations: %.3f ms of kernel time and %.1f dispatches per iteration" % (iters, total / iters, len(rows) / iters))
+    if setup:
+        print("\nbefore the first training closure (net construction; NOT in the table): %d dispatches, %.3f ms -- %s"
+              % (sum(v[0] for v in setup.values()), sum(v[1] for v in setup.values()),
+                 ", ".join("%s x%d %.3f ms" % (k, n, ms) for k, (n, ms) in sorted(setup.items(), key=lambda kv: -kv[1][1])[:6])))
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ from face_generator_amd.runtime import get_context
 ctx = get_context(0)
 B, C = 4, 3
 rng = np.random.default_rng(1)
-G = O.create_G32((C, 32, 32), 100, rng); D = O.create_D32b((C, 32, 32), rng)
+G = O.create_G32((C, 32, 32), 100, rng, weight_init_=False); D = O.create_D32b((C, 32, 32), rng)
 st = O.GanState(G, D)
 Gd = models.create_G((C, 32, 32), 100).cuda(ctx, max_batch=B)
 Dd = models.create_D((C, 32, 32)).cuda(ctx, max_batch=B)

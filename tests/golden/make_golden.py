@@ -21,7 +21,7 @@ def sample_idx(n, k, seed):
 
 def make_cfg(C, B, seed):
     rng = np.random.default_rng(seed)
-    G = O.create_G32((C, 32, 32), 100, rng)
+    G = O.create_G32((C, 32, 32), 100, rng, weight_init_=False)
     D = O.create_D32b((C, 32, 32), rng)
     for net in (G, D):
         for m in net.modules:

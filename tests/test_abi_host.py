@@ -63,7 +63,7 @@ def test_models_mirror_reference_structure_and_parameter_order():
     for C in (3, 1):
         G = models.create_G((C, 32, 32), 100)
         D = models.create_D((C, 32, 32))
-        oG = O.create_G32((C, 32, 32), 100)
+        oG = O.create_G32((C, 32, 32), 100, weight_init_=False)
         oD = O.create_D32b((C, 32, 32))
         for net, onet in ((G, oG), (D, oD)):
             assert [type(m).__name__ for m in net.modules] == [type(m).__name__ for m in onet.modules]
@@ -76,7 +76,7 @@ def test_models_mirror_reference_structure_and_parameter_order():
     assert nn_utils.getNumberOfParameters(D) == sum(
         m.weight.numel() for m in D.modules if getattr(m, "weight", None) is not None)  # biases excluded (nn_utils.lua:281)
     G16 = models.create_G((3, 16, 16), 100)                 # models.lua:27-51, same chain from a 4x4 map
-    assert [type(m).__name__ for m in G16.modules] == [type(m).__name__ for m in O.create_G16((3, 16, 16), 100).modules]
+    assert [type(m).__name__ for m in G16.modules] == [type(m).__name__ for m in O.create_G16((3, 16, 16), 100, weight_init_=False).modules]
     assert tuple(G16.modules[0].weight.shape) == (128 * 4 * 4, 100)
     D16 = models.create_D((3, 16, 16))                      # models.lua:279-316: ConcatTable{fine, dense} -> JoinTable -> Linear
     oD16 = O.create_D16_d((3, 16, 16))
@@ -95,7 +95,7 @@ def test_initialize_weights_semantics():
     bn = G.modules[5]
     assert abs(bn.weight.std().item() - 0.005) < 1.5e-3 and abs(bn.weight.mean().item()) < 2e-3   # gamma no longer U(0,1)
     assert abs(G.modules[2].weight.item()) < 0.05                                                 # PReLU slope re-drawn
-    assert isinstance(repr(G), str) and "nn.SpatialConvolution(128 -> 256, 5x5" in repr(G)       # print(MODEL_G), train.lua:155
+    assert isinstance(repr(G), str) and "cudnn.SpatialConvolution(128 -> 256, 5x5" in repr(G)       # print(MODEL_G), train.lua:155
 
 
 def test_layer_specs_cover_reference_constructors():
@@ -182,3 +182,53 @@ def test_trainer_optstate_comes_from_opt():
     from face_generator_amd import adversarial
     src = inspect.getsource(adversarial.Trainer.__init__)
     assert '"D_SGD_lr", 0.02' in src and '"G_SGD_momentum", 0' in src and '_adam_lr", -1' in src
+
+
+def test_weight_init_heuristic_in_create_G():
+    """models.lua:48, 78 -> weight-init.lua:41-76: top-level nn.Linear is re-drawn with reset(sqrt(1 / (3 fan_in))) (range
+    1 / sqrt(fan_in)), cudnn.SpatialConvolution is NOT reset (its type name is not in the list), every top-level bias is zero
+    (convolutions, Linear, BatchNorm beta); create_D32b has no such call; on the c2f nets the call is a no-op (no recursion)."""
+    from face_generator_amd import models, models_c2f, nn, weight_init
+    resets = []
+    orig_lin, orig_conv = nn.Linear.reset, nn.SpatialConvolution.reset
+    nn.Linear.reset = lambda self, stdv=None, gen=None: (resets.append((type(self).__name__, stdv)), orig_lin(self, stdv, gen))[1]
+    nn.SpatialConvolution.reset = lambda self, stdv=None, gen=None: (resets.append((type(self).__name__, stdv)), orig_conv(self, stdv, gen))[1]
+    try:
+        for dims, fan in (((3, 32, 32), 100), ((3, 16, 16), 100)):
+            resets.clear()
+            G = models.create_G(dims, fan, gen=torch.Generator().manual_seed(4))
+            assert [r[0] for r in resets] == ["Linear"] and abs(resets[0][1] - (1.0 / (3 * fan)) ** 0.5) < 1e-12
+            for m in G.modules:
+                if getattr(m, "bias", None) is not None:
+                    assert float(m.bias.abs().max()) == 0.0, type(m).__name__
+            lin = G.modules[0]
+            assert float(lin.weight.abs().max()) <= fan ** -0.5 and abs(lin.weight.std().item() - (1.0 / (3 * fan)) ** 0.5) < 2e-3
+            convs = [m for m in G.modules if isinstance(m, nn.SpatialConvolution)]
+            assert len(convs) == 3 and all(m._typename == "cudnn.SpatialConvolution" for m in convs)
+            assert all(float(m.weight.abs().max()) > 0 for m in convs)
+        resets.clear()
+        D = models.create_D((3, 32, 32))
+        assert not resets and any(float(m.bias.abs().max()) > 0 for m in D.modules if getattr(m, "bias", None) is not None)
+        Gc = models_c2f.create_G((3, 16, 16)); Dc = models_c2f.create_D((3, 16, 16))
+        assert not resets                                            # top level = {JoinTable | CAddTable, Sequential}: nothing matches
+        assert all(float(m.bias.abs().max()) > 0 for m in Gc.inner.modules + Dc.inner.modules if getattr(m, "bias", None) is not None)
+        # an nn.SpatialConvolution (not cudnn) at top level IS reset
+        net = nn.Sequential().add(nn.SpatialConvolution(8, 8, 3, 3, 1, 1, 1)).add(nn.SpatialBatchNormalization(8))
+        weight_init.w_init(net, "kaiming")
+        assert [r[0] for r in resets] == ["SpatialConvolution"] and abs(resets[0][1] - (4.0 / (72 + 72)) ** 0.5) < 1e-12
+        with pytest.raises(AssertionError):
+            weight_init.w_init(net, "nope")
+    finally:
+        nn.Linear.reset, nn.SpatialConvolution.reset = orig_lin, orig_conv
+    # the oracle's restatement has the same two properties and leaves the convolution weights as drawn
+    for mk in (O.create_G32, O.create_G16):
+        S0 = 32 if mk is O.create_G32 else 16
+        a = mk((3, S0, S0), 100, np.random.default_rng(9))
+        b = mk((3, S0, S0), 100, np.random.default_rng(9), weight_init_=False)
+        for ma, mb in zip(a.modules, b.modules):
+            if getattr(ma, "bias", None) is not None:
+                assert np.abs(ma.bias).max() == 0 and (type(ma).__name__ == "SpatialBatchNormalization" or np.abs(mb.bias).max() > 0)
+            if type(ma).__name__ == "SpatialConvolution":
+                assert np.array_equal(ma.weight, mb.weight)
+            if type(ma).__name__ == "Linear":
+                assert not np.array_equal(ma.weight, mb.weight) and np.abs(ma.weight).max() <= 0.1 + 1e-7

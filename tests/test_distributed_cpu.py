@@ -27,7 +27,7 @@ def _worker(rank, world, port, q):
     assert (r, w) == (rank, world)
     rng = np.random.default_rng(7)                       # identical replicas + the same GLOBAL batch on every rank
     Dn = O.create_D32b((1, 32, 32), rng)
-    Gn = O.create_G32((1, 32, 32), 100, rng)
+    Gn = O.create_G32((1, 32, 32), 100, rng, weight_init_=False)
     st = O.GanState(Gn, Dn)
     Bg = 8
     x = rng.uniform(0, 1, (Bg, 1, 32, 32)).astype(np.float32)

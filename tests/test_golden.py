@@ -45,7 +45,7 @@ def test_hip_path_matches_golden(fn):
     mg = rebuild(g)
     # initial parameters: regenerate from the seed (the fixture stores their checksum, not 21 MB of weights)
     rng = np.random.default_rng(seed)
-    G = O.create_G32((C, 32, 32), 100, rng); D = O.create_D32b((C, 32, 32), rng)
+    G = O.create_G32((C, 32, 32), 100, rng, weight_init_=False); D = O.create_D32b((C, 32, 32), rng)
     for net in (G, D):
         for m in net.modules:
             if isinstance(m, O.SpatialBatchNormalization):

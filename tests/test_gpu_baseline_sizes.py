@@ -183,6 +183,49 @@ def test_cfg2_full_step_at_batch_128(ctx, init):
     r64 = O.step_G(st64, nz2.astype(np.float64), masks2)
     close(gG, r64["grad"], atol=1e-4 * np.abs(r64["grad"]).max() + 1e-7, what="G-step flat gradient vs the float64 oracle")
     check_every_tensor("cfg2 B=128 G-step [%s]" % init, gG, st64.G, ref["grad"])
+    # Adam at t = 2 AT THE HEADLINE SIZE: a second D-step and G-step from the DEVICE's state -- parameters and
+    # both moment vectors are handed to the oracle (parity is per step), the closure is compared again, and the update arithmetic
+    # is pinned by an exact float64 Adam fed with the device's own gradient (adam_from: free of the gradient's rounding)
+    adopt_device_branches(ctx, dnD, st.D, clear=True, also=twinD)
+    adopt_device_branches(ctx, dnG, st.G, clear=True, also=twinG)
+    nD, nG = st.pD.size, st.pG.size
+
+    def hand_over():
+        for which, dn, p, ad, n in (("D", dnD, st.pD, st.adamD, nD), ("G", dnG, st.pG, st.adamG, nG)):
+            os_ = tr.gan.view("OPT_STATE_" + which)
+            p[...] = dn.params.cpu().numpy()
+            ad['m'][...] = os_[:n].cpu().numpy(); ad['v'][...] = os_[n:2 * n].cpu().numpy()
+        return (st.pD.copy(), st.adamD['m'].copy(), st.adamD['v'].copy()), (st.pG.copy(), st.adamG['m'].copy(), st.adamG['v'].copy())
+
+    (p0, m0, v0), _ = hand_over()
+    real = rng.uniform(0, 1, (B // 2, C, 32, 32)).astype(np.float32)
+    nz = rng.uniform(-1, 1, (B // 2, 100)).astype(np.float32)
+    masks = d_masks(rng, B)
+    got = tr.step_D(nhwc(real, d), dev(nz, d), [dev(m.reshape(-1), d) for m in masks], keep_grad=True)
+    assert tr.gan.steps(0) == 2
+    adopt_device_branches(ctx, dnD, st.D)
+    ref = O.step_D(st, real, nz, masks)
+    assert_flips_bounded("cfg2 B=128 second D-step [%s] D" % init, st.D)
+    gD = got["grad"].cpu().numpy()
+    close(got["outputs"].cpu().numpy().reshape(-1), ref["out"].reshape(-1), atol=1e-5, what="second D-step D outputs (B=128)")
+    close(gD, ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what="second D-step flat gradient (B=128)")
+    close(dnD.params.cpu().numpy(), adam_from(p0, gD, m0, v0, 1), atol=1e-6, what="D optimizer arithmetic at t = 2 (B=128)")
+    adopt_device_branches(ctx, dnD, st.D, clear=True)
+    t_D = st.adamD['t']
+    _, (p0, m0, v0) = hand_over()
+    assert t_D == 2 and st.adamG['t'] == 1
+    pG_before = dnG.params.clone()
+    nz2 = rng.uniform(-1, 1, (B, 100)).astype(np.float32)
+    masks2 = d_masks(rng, B)
+    got = tr.step_G(dev(nz2, d), [dev(m.reshape(-1), d) for m in masks2], keep_grad=True)
+    assert tr.gan.steps(1) == 2
+    adopt_device_branches(ctx, dnD, st.D)
+    adopt_device_branches(ctx, dnG, st.G, params=pG_before)
+    ref = O.step_G(st, nz2, masks2)
+    gG = got["grad"].cpu().numpy()
+    close(nchw(got["samples"]), ref["samples"], atol=1e-5, what="second G-step samples (B=128)")
+    close(gG, ref["grad"], atol=1e-4 * np.abs(ref["grad"]).max() + 1e-7, what="second G-step flat gradient (B=128)")
+    close(dnG.params.cpu().numpy(), adam_from(p0, gG, m0, v0, 1), atol=1e-6, what="G optimizer arithmetic at t = 2 (B=128)")
 
 
 def test_c2f_S64_forward_backward(ctx):

@@ -47,7 +47,7 @@ def test_c_host_runs_one_D_and_one_G_closure_without_torch(tmp_path):
     ctx = get_context(0)
     B, C = 4, 3
     rng = np.random.default_rng(9000)
-    G = O.create_G32((C, 32, 32), 100, rng)
+    G = O.create_G32((C, 32, 32), 100, rng, weight_init_=False)
     D = O.create_D32b((C, 32, 32), rng)
     st = O.GanState(G, D)
     pG0, pD0 = st.pG.copy(), st.pD.copy()

@@ -101,3 +101,35 @@ def test_compiled_plan_with_upsampling_convolutions(ctx):
     gx = dn.backward(nhwc(gy, ctx.device), param_grads=True, input_grad=True)
     close(nchw(gx), gx_ref, atol=1e-4 * np.abs(gx_ref).max() + 1e-8, what="plan gradInput")
     check_flat_grads(dn.grads.cpu().numpy(), onet, "upsampling decoder")
+
+
+def test_nearest_upsample_in_front_of_a_factor_2_convolution_is_not_folded(ctx):
+    """nn.SpatialUpSamplingNearest(2) followed by cudnn.SpatialConvolutionUpsample(.., factor = 2) -- the nearest-x2 tap
+    folding of the plan compiler must leave this pair alone (the folded stage has no view behind it): dims (nOut, 4 h, 4 w), values
+    and gradients against the oracle's un-folded modules."""
+    from face_generator_amd import nn
+    B, S = 3, 4
+    rng = np.random.default_rng(91)
+    onet = O.Sequential(O.SpatialUpSamplingNearest(2), O.SpatialConvolutionUpsample(8, 8, 3, 3, 2, rng), O.PReLU(),
+                        O.SpatialUpSamplingNearest(2), O.SpatialConvolutionUpsample(8, 8, 5, 5, 1, rng))
+    onet.modules[2].weight[0] = np.float32(0.3)
+    p_ref, g_ref = onet.getParameters()
+    net = nn.Sequential()
+    net.add(nn.SpatialUpSamplingNearest(2)).add(nn.SpatialConvolutionUpsample(8, 8, 3, 3, 2)).add(nn.PReLU())
+    net.add(nn.SpatialUpSamplingNearest(2)).add(nn.SpatialConvolutionUpsample(8, 8, 5, 5, 1))
+    net.input_dims = (8, S, S)
+    net.cuda(ctx, max_batch=B)
+    dn = net.device_net
+    assert dn.n_params == p_ref.size
+    dn.params.copy_(torch.tensor(p_ref)); dn.params_changed()
+    x, y_ref = draw_kink_safe(rng, lambda: rng.standard_normal((B, 8, S, S)).astype(np.float32), onet.forward, [onet])
+    gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    g_ref[...] = 0
+    gx_ref = onet.backward(x, gy)
+    y = dn.forward(nhwc(x, ctx.device), train=True)
+    assert tuple(y.shape) == (B, 8 * S, 8 * S, 8)
+    close(nchw(dn.layer_output(1)), onet.modules[1].output, atol=2e-5 * np.abs(onet.modules[1].output).max(), what="viewed conv output")
+    close(nchw(y), y_ref, atol=2e-5 * np.abs(y_ref).max(), what="plan output")
+    gx = dn.backward(nhwc(gy, ctx.device), param_grads=True, input_grad=True)
+    close(nchw(gx), gx_ref, atol=1e-4 * np.abs(gx_ref).max() + 1e-8, what="plan gradInput")
+    check_flat_grads(dn.grads.cpu().numpy(), onet, "upsample + factor-2 convolution")

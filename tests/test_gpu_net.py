@@ -20,7 +20,7 @@ def build(ctx, C, B, seed, init="default"):
     """oracle nets + device nets holding identical parameters."""
     from face_generator_amd import models
     rng = np.random.default_rng(seed)
-    G = O.create_G32((C, 32, 32), 100, rng)
+    G = O.create_G32((C, 32, 32), 100, rng, weight_init_=False)
     D = O.create_D32b((C, 32, 32), rng)
     if init == "reference":      # train.lua:137-138 -> N(0,0.005^2) / N(0,0.001^2), incl. BN gamma and PReLU slope
         O.initialize_weights(G, rng=rng); O.initialize_weights(D, rng=rng)
@@ -199,7 +199,7 @@ def test_G16_forward_backward(ctx):
     from face_generator_amd import models
     B, C = 6, 3
     rng = np.random.default_rng(950)
-    G = O.create_G16((C, 16, 16), 100, rng)
+    G = O.create_G16((C, 16, 16), 100, rng, weight_init_=False)
     for m in G.modules:
         if isinstance(m, O.SpatialBatchNormalization):
             m.bias[...] = rng.standard_normal(m.bias.shape).astype(np.float32) * 0.2
@@ -275,7 +275,7 @@ def test_train_step_16px(ctx):
     from face_generator_amd import models, adversarial
     B, C = 8, 3
     rng = np.random.default_rng(961)
-    G = O.create_G16((C, 16, 16), 100, rng); D = O.create_D16_d((C, 16, 16), rng)
+    G = O.create_G16((C, 16, 16), 100, rng, weight_init_=False); D = O.create_D16_d((C, 16, 16), rng)
     st = O.GanState(G, D)
     Gd = models.create_G((C, 16, 16), 100).cuda(ctx, max_batch=B)
     Dd = models.create_D((C, 16, 16)).cuda(ctx, max_batch=B)

@@ -37,7 +37,7 @@ def test_two_replicas_with_sync_bn_equal_global_batch():
     d = ctx.device
     B, C = 8, 3
     rng = np.random.default_rng(900)
-    G = O.create_G32((C, 32, 32), 100, rng)
+    G = O.create_G32((C, 32, 32), 100, rng, weight_init_=False)
     for m in G.modules:
         if isinstance(m, O.SpatialBatchNormalization):
             m.bias[...] = rng.standard_normal(m.bias.shape).astype(np.float32) * 0.2

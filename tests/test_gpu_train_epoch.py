@@ -127,7 +127,7 @@ def test_adversarial_train_epoch_config1_gray_batch16(ctx, tmp_path):
     from face_generator_amd.state import S
     B, C, N = 16, 1, 40
     rng = np.random.default_rng(2100)
-    G = O.create_G32((C, 32, 32), 100, rng)
+    G = O.create_G32((C, 32, 32), 100, rng, weight_init_=False)
     D = O.create_D32b((C, 32, 32), rng)
     st = O.GanState(G, D)
     S.reset()
@@ -349,7 +349,7 @@ def test_create_images_and_sort_by_prediction(ctx):
     from face_generator_amd.state import S
     C, N, bs = 3, 22, 8
     rng = np.random.default_rng(2300)
-    G = O.create_G32((C, 32, 32), 100, rng)
+    G = O.create_G32((C, 32, 32), 100, rng, weight_init_=False)
     D = O.create_D32b((C, 32, 32), rng)
     st = O.GanState(G, D)
     S.reset()

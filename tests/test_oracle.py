@@ -212,7 +212,7 @@ def _torch_net_from(seq, x, masks):
 def test_full_G_step_grads_match_torch_autograd():
     """fevalG_on_D (adversarial.lua:187-231) end to end vs autograd, float64, gray C=1, B=4."""
     rng = np.random.default_rng(5)
-    G = O.create_G32((1, 32, 32), 100, rng).astype(np.float64)
+    G = O.create_G32((1, 32, 32), 100, rng, weight_init_=False).astype(np.float64)
     D = O.create_D32b((1, 32, 32), rng).astype(np.float64)
     st = O.GanState(G, D, dict(G_L2=1e-3))
     B = 4
@@ -238,7 +238,7 @@ def test_full_G_step_grads_match_torch_autograd():
 
 def test_full_D_step_grads_match_torch_autograd():
     rng = np.random.default_rng(6)
-    G = O.create_G32((3, 32, 32), 100, rng).astype(np.float64)
+    G = O.create_G32((3, 32, 32), 100, rng, weight_init_=False).astype(np.float64)
     D = O.create_D32b((3, 32, 32), rng).astype(np.float64)
     st = O.GanState(G, D)
     B = 4
@@ -279,14 +279,14 @@ class D_with:
 
 
 def test_get_parameters_order_and_sizes():
-    G = O.create_G32((3, 32, 32), 100)
+    G = O.create_G32((3, 32, 32), 100, weight_init_=False)
     D = O.create_D32b((3, 32, 32))
     pG, gG = G.getParameters()
     pD, gD = D.getParameters()
     assert pG.size == 2470406 and pD.size == 2863239
     G.modules[0].weight[0, 0] = 7.0
     assert pG[0] == 7.0                                   # module fields are views
-    Gg = O.create_G32((1, 32, 32), 100)
+    Gg = O.create_G32((1, 32, 32), 100, weight_init_=False)
     assert Gg.getParameters()[0].size == 2468100
 
 
@@ -373,7 +373,7 @@ def test_torch_cpu_baseline_matches_the_numpy_oracle():
     from oracle import torch_cpu as TC
     rng = np.random.default_rng(77)
     B = 4
-    G = O.create_G32((3, 32, 32), 100, rng); D = O.create_D32b((3, 32, 32), rng)
+    G = O.create_G32((3, 32, 32), 100, rng, weight_init_=False); D = O.create_D32b((3, 32, 32), rng)
     st = O.GanState(G, D)
     gan = TC.GanCPU(G, D)
     real = rng.uniform(0, 1, (B // 2, 3, 32, 32)).astype(np.float32)
