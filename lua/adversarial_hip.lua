@@ -43,7 +43,11 @@ function adversarial.train(dataset, maxAccuracyD, accsInterval)
     local countTrainedD, countNotTrainedD = 0, 0
     local c, h, w = IMG_DIMENSIONS[1], IMG_DIMENSIONS[2], IMG_DIMENSIONS[3]
     local useGate = maxAccuracyD <= 1.0          -- D_maxAcc = 1.01 (train.lua:37) can never fire: the update stays inside the step
-    local pending, counts = {}, {0, 0, 0, 0}
+    local counts = {0, 0, 0, 0}
+    -- no gate: one device slot of 8 counts per D closure of the epoch, allocated ONCE here (hipMalloc is a blocking runtime call:
+    -- none inside the loop) and read once after it
+    local maxClosures = (math.floor((N_epoch - 1) / dataBatchSize) + 1) * OPT.D_iterations
+    local slots, nslots = (not useGate) and FG.DeviceTensor(8 * maxClosures) or nil, 0
 
     print(string.format("<trainer> Epoch #%d [batchSize = %d]", EPOCH, OPT.batchSize))
     for t = 1, N_epoch, dataBatchSize do
@@ -75,7 +79,7 @@ function adversarial.train(dataset, maxAccuracyD, accsInterval)
             else
                 -- no gate to decide: the counts stay on the device (no host sync inside the epoch) and are read after the loop,
                 -- exactly as face_generator_amd/adversarial.py defers them
-                pending[#pending + 1] = g:confusionDevice()
+                g:confusionInto(slots, nslots); nslots = nslots + 1
                 countTrainedD = countTrainedD + 1
             end
         end
@@ -86,8 +90,8 @@ function adversarial.train(dataset, maxAccuracyD, accsInterval)
         end
         xlua.progress(t + thisBatchSize, N_epoch)
     end
-    for _, t in ipairs(pending) do                            -- deferred: one host read per D closure, after the epoch's last launch
-        local conf = FG.readConfusion(t)
+    for s = 0, nslots - 1 do                                  -- deferred: one host read per D closure, after the epoch's last launch
+        local conf = FG.readConfusion(slots, s)
         for i = 1, 4 do counts[i] = counts[i] + conf[i] end
         adversarial.accs[#adversarial.accs + 1] = (conf[1] + conf[4]) / math.max(1, conf[1] + conf[2] + conf[3] + conf[4])
         if #adversarial.accs > accsInterval then table.remove(adversarial.accs, 1) end

@@ -574,9 +574,16 @@ function Gan:confusionDevice()
     check(C.fg_d2d(ctx, t.ptr, self.base + off[0], 32))
     return t
 end
-function M.readConfusion(t)
+-- ... or into slot `slot` (0-based) of ONE per-epoch DeviceTensor(8 * closures): no allocation inside the epoch loop
+function Gan:confusionInto(t, slot)
+    local off, cnt = ffi.new('long long[1]'), ffi.new('long long[1]')
+    check(C.fg_gan_buffer(self.h, C.FG_GAN_CONFUSION, off, cnt))
+    assert(8 * (slot + 1) <= t.n, 'confusionInto: slot out of range')
+    check(C.fg_d2d(ctx, t.ptr + 8 * slot, self.base + off[0], 32))
+end
+function M.readConfusion(t, slot)
     local host = ffi.new('int[8]')
-    check(C.fg_d2h(ctx, host, t.ptr, 32))
+    check(C.fg_d2h(ctx, host, t.ptr + 8 * (slot or 0), 32))
     return {host[0], host[1], host[2], host[3]}, {host[4], host[5], host[6], host[7]}
 end
 -- real / cond_*: DeviceTensor NHWC (cond_* only for the table nets); noise / masks nil: drawn by the library

@@ -104,21 +104,35 @@ def test_optimizers_mark_the_packed_weights_stale():
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only present in the build container")
 def test_patches_apply_to_the_reference_scripts(tmp_path):
     patches = sorted(glob.glob(os.path.join(ROOT, "lua", "patches", "*.patch")))
-    assert len(patches) >= 4
+    assert len(patches) >= 6 and {"train_c2f.lua.patch", "models_c2f.lua.patch"} <= {os.path.basename(p) for p in patches}
     for p in patches:
         r = subprocess.run(["patch", "-p1", "--dry-run", "-d", "/root/reference", "-i", p], capture_output=True, text=True)
         assert r.returncode == 0, "%s does not apply: %s" % (os.path.basename(p), r.stdout + r.stderr)
     # after patching, no CUDA rock is required on the training / sampling path
     import shutil
-    for rel in ("train.lua", "sample.lua", "utils/nn_utils.lua", "layers/cudnnSpatialConvolutionUpsample.lua"):
+    RELS = ("train.lua", "sample.lua", "utils/nn_utils.lua", "layers/cudnnSpatialConvolutionUpsample.lua", "train_c2f.lua", "models_c2f.lua")
+    for rel in RELS:
         os.makedirs(os.path.dirname(os.path.join(str(tmp_path), rel)), exist_ok=True)
         shutil.copy(os.path.join("/root/reference", rel), os.path.join(str(tmp_path), rel))
     for p in patches:
         subprocess.run(["patch", "-p1", "-s", "-d", str(tmp_path), "-i", p], check=True)
-    for rel in ("train.lua", "sample.lua", "utils/nn_utils.lua", "layers/cudnnSpatialConvolutionUpsample.lua"):
+    for rel in RELS:
         code = strip_lua_comments(open(os.path.join(str(tmp_path), rel)).read())
         assert not re.search(r"require\s+'(cutorch|cunn|cudnn)'", code), "%s still requires a CUDA rock" % rel
         assert "cutorch." not in code and ":cuda()" not in code, "%s still calls into cutorch" % rel
+        assert "CudaTensor" not in code, "%s still names torch.CudaTensor" % rel
+    # configs 4-5: every create_G_* / create_D_* variant of models_c2f.lua keeps its {first, Copy, inner, Copy}
+    # shape and hands the inner Sequential to FG.attach with the dimensions its first layer takes; train_c2f.lua binds the library,
+    # selects the re-hosted loop and re-attaches a reloaded checkpoint
+    mc = strip_lua_comments(open(os.path.join(str(tmp_path), "models_c2f.lua")).read())
+    assert mc.count("FG.attach(model_G:get(3), {dimensions[1]+1, dimensions[2], dimensions[3]}, OPT.batchSize)") == 4
+    assert mc.count("FG.attach(model_D:get(3), {dimensions[1], dimensions[2], dimensions[3]}, OPT.batchSize)") == 3
+    assert mc.count("nn.Copy('torch.FloatTensor', 'torch.FloatTensor')") == 14 and mc.count("nn.JoinTable(2, 2)") == 4
+    tc = strip_lua_comments(open(os.path.join(str(tmp_path), "train_c2f.lua")).read())
+    assert "ADVERSARIAL = require 'adversarial_c2f_hip'" in tc and "FG = require 'facegen_hip'" in tc
+    assert tc.index("FG = require 'facegen_hip'") < tc.index("FG.setDevice(OPT.gpu + 1)") < tc.index("FG.manualSeed(OPT.seed)") \
+        < tc.index("MODELS.create_D(IMG_DIMENSIONS, OPT.gpu ~= false)")
+    assert "FG.attach(MODEL_G:get(3), {IMG_DIMENSIONS[1] + 1, IMG_DIMENSIONS[2], IMG_DIMENSIONS[3]}, OPT.batchSize)" in tc
 
 
 def _fn_body(code, header):
@@ -163,6 +177,50 @@ def test_nothing_unserialisable_is_on_a_module_during_save_or_clone():
 def test_the_two_mirrors_of_adversarial_train_defer_the_confusion_counts_alike():
     """without a gate neither mirror reads the counts inside the epoch; with one both read per D closure."""
     adv = lua_code(os.path.join(ROOT, "lua", "adversarial_hip.lua"))
-    assert "pending[#pending + 1] = g:confusionDevice()" in adv and "FG.readConfusion(t)" in adv
+    # one per-epoch slot buffer instead of a hipMalloc per closure (ADVICE r3): nothing is allocated or read inside the loop
+    assert "g:confusionInto(slots, nslots); nslots = nslots + 1" in adv and "FG.readConfusion(slots, s)" in adv
+    loop = adv[adv.index("for t = 1, N_epoch, dataBatchSize do"):adv.index("for s = 0, nslots - 1 do")]
+    assert "FG.DeviceTensor(" not in loop and "readConfusion" not in loop
+    assert adv.index("FG.DeviceTensor(8 * maxClosures)") < adv.index("for t = 1, N_epoch, dataBatchSize do")
     py = open(os.path.join(ROOT, "face_generator_amd", "adversarial.py")).read()
     assert "pending.append(r[\"confusion\"].clone())" in py and "if not use_gate:" in py
+
+
+def test_c2f_rehost_follows_adversarial_c2f_lua():
+    """lua/adversarial_c2f_hip.lua against adversarial_c2f.lua:10-223, 305-344 and its executed Python mirror: table-mode step
+    object, the reference's pick order (real .diff / .coarse from ONE pick, then new .coarse picks for the fake half, then
+    thisBatchSize .coarse picks for the G closure), counts deferred without allocations, both checkpoint names, the parzen distance
+    on the device, and the hand-over to the reference's own file when the nets carry no device plan."""
+    adv = lua_code(os.path.join(ROOT, "lua", "adversarial_c2f_hip.lua"))
+    assert "FG.Gan(inner_of(MODEL_G).fg, inner_of(MODEL_D).fg, true, OPT.batchSize)" in adv       # table_inputs = true
+    assert "model.modules[3]" in adv                                                             # {first, Copy, inner, Copy}
+    train = adv[adv.index("function adversarial.train(trainData)"):adv.index("function adversarial.save(")]
+    assert "return reference_impl().train(trainData)" in train and "require 'adversarial_c2f'" in adv
+    d_it = train[train.index("for k = 1, OPT.D_iterations do"):train.index("for k = 1, OPT.G_iterations do")]
+    one_pick = d_it.index("local ex = trainData[math.random(trainData:size())]")
+    assert one_pick < d_it.index("diff[i] = ex.diff; condR[i] = ex.coarse") < d_it.index("pick(trainData, half, 'coarse'") \
+        < d_it.index("g:stepD(thisBatchSize, FG.to_device_nhwc(diff), FG.to_device_nhwc(condR), FG.to_device_nhwc(condF), false)")
+    assert d_it.count("math.random") == 1 and "FG.DeviceTensor(" not in d_it                      # the second pick is pick()'s
+    g_it = train[train.index("for k = 1, OPT.G_iterations do"):train.index("xlua.progress(")]
+    assert g_it.index("pick(trainData, thisBatchSize, 'coarse'") < g_it.index("g:stepG(thisBatchSize, FG.to_device_nhwc(cond), false)")
+    for must in ("thisBatchSize < 4", "thisBatchSize - thisBatchSize % 2", "g:configure('D', OPT, OPTSTATE)", "g:configure('G', OPT, OPTSTATE)",
+                 "g:finishPending()", "CONFUSION:updateValids()", "EPOCH % OPT.saveFreq == 0", "'adversarial_c2f_%d_to_%d.net'",
+                 "EPOCH = EPOCH + 1"):
+        assert must in train, must
+    save = adv[adv.index("function adversarial.save("):adv.index("function adversarial.approxParzen(")]
+    assert save.index("FG.detach(innerD)") < save.index("pcall(torch.save, filename, tab)") < save.index("FG.reattach(innerD, savedD)")
+    assert save.index("fg:download(false)") < save.index("FG.detach(innerD)")
+    pz = adv[adv.index("function adversarial.approxParzen("):]
+    for must in ("best_dist = best_dist or 1e10", "ds[math.random(ds:size())]", "C.fg_rng_uniform(", "C.fg_concat_channels(",
+                 "dnG:forward(joined, nneighbors)", "C.fg_parzen_min_dist(", "min_dev.ptr + (n - 1)", "distances:mean() < best_dist",
+                 "'adversarial_c2f_%d_to_%d.bestnet'", "return distances"):
+        assert must in pz, must
+    # the executed mirror makes the same calls in the same order
+    py = open(os.path.join(ROOT, "face_generator_amd", "adversarial_c2f.py")).read()
+    tr = py[py.index("def train(trainData):"):py.index("def approxParzen(")]
+    assert tr.index("trainData[i].diff") < tr.index("trainData[i].coarse") < tr.index('pick(half, "coarse")') < tr.index("tr.step_D(diff, cond_r, nz, cond_f)")
+    assert tr.index('pick(thisBatchSize, "coarse")') < tr.index("tr.step_G(nz, cond)")
+    assert "fg_parzen_min_dist" in py[py.index("def approxParzen("):]
+    binding = lua_code(os.path.join(ROOT, "lua", "facegen_hip.lua"))
+    into = _fn_body(binding, "function Gan:confusionInto(t, slot)")
+    assert "C.fg_d2d(ctx, t.ptr + 8 * slot" in into and "fg_malloc" not in into
