@@ -214,7 +214,8 @@ struct PackJob {
     int rows2, cols2;     // its padded dims (rows = in-channels, cols = out-channels)
     int npo, npi;         // patches along the out / in channel axis (over the padded extents)
 };
-int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params);
+// prof_bytes: algorithmic bytes of the launch for the profile (every parameter read once, every packed element written once)
+int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params, double prof_bytes);
 void fg_fold_window(int k, int pad, int* T, int* rmin);
 static inline int fg_fold_r(int parity, int d, int pad) {  // floor((parity + d - pad)/2)
     int v = parity + d - pad;
@@ -299,6 +300,8 @@ int fg_launch_add_halves(fg_ctx*, const float* a0, const float* b0, const float*
 // deferred finals: partial buffer of `floats` floats (nullptr = not deferring / arena full -> caller uses its scratch and an
 // immediate final); registration of one final job; flush = run all registered jobs in one launch
 int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);   // out[c] = beta*out[c] + sum_r part[r][c]
+// the same over C1 + C2 columns: the first C1 sums go to out1, the other C2 to out2 (beta = 0)
+int fg_launch_colsum_final2(fg_ctx* ctx, const float* part, int nrb, int C1, float* out1, int C2, float* out2);
 float* fg_defer_alloc(fg_ctx* ctx, long long floats);
 void fg_defer_push(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);
 int fg_defer_flush(fg_ctx* ctx);
@@ -316,8 +319,10 @@ int fg_launch_thin_in_conv(fg_ctx*, const float* in, const float* Wp, const floa
 int fg_launch_thin_out_conv(fg_ctx*, const float* in, const float* Wp, const float* bias, float* out, int B, int H,
                             int W, int Cw, int Cs, int k, int flip, int sigmoid, float* rbuf = nullptr, long long rbuf_floats = 0)   /* rbuf: >= B*H*W*32 floats enables the two-pass 5x5/7x7 MFMA path */;
 // thin wgrad: gw[tap][s][c] (partials reduced) = sum_pix thin[pix + sgn*off(tap)][s] * wide[pix][c]
+// wide_colsum / colsum_done (optional, both or neither): sum_pix wide[pix][c] from the ones column of the matrix-pipe kernels
+// (*colsum_done = 1 when produced); the slabs then have k*k*Cs + 1 rows -- scratch >= (FG_THIN_WGRAD_BLOCKS + 1) * (k*k*Cs + 1) * Cw
 int fg_launch_thin_wgrad(fg_ctx*, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
-                         int Cw, int k, int shift_thin, float* scratch);
+                         int Cw, int k, int shift_thin, float* scratch, float* wide_colsum = nullptr, int* colsum_done = nullptr);
 // repack between reference [O][I][k][k] and thin layouts
 // mode 0: Wp[tap][s=I][c=O] (thin-in fwd, I small)      mode 1: Wp[tap][s=O][c=I] (thin-out fwd, O small)
 int fg_launch_thin_pack(fg_ctx*, const float* W, float* Wp, int O, int I, int k, int mode);

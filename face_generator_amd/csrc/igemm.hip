@@ -1732,11 +1732,11 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         jb.dst[loc] = pk_load<ADAM>(params, ad, ak, w0 + (long long)c * wm.o_hw + hw);
     }
 }
-int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params) {
+int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params, double prof_bytes) {
     if (total == 0 || njobs == 0) return FG_OK;
     AdamArgs none = AdamArgs();
     {
-        FgProfScope prof(ctx, fg_intern(ctx, "pack_jobs_kernel"), 0.0, 0.0, 8.0 * (double)total);   // every packed element: one read, one write
+        FgProfScope prof(ctx, fg_intern(ctx, "pack_jobs_kernel"), 0.0, 0.0, prof_bytes);
         hipLaunchKernelGGL(pack_jobs_kernel<false>, dim3(fg_cdiv(total, 256)), dim3(256), 0, ctx->stream, jobs_dev, njobs, total, params,
                            none, AdamScalars{0.f, 0.f, 0.f});
     }

@@ -120,7 +120,7 @@ static long long stage_scratch(const Stage& s, int B) {
         case ST_THIN_IN: case ST_THIN_OUT: {
             const int cw = s.kind == ST_THIN_IN ? s.oc : s.ic, cs = s.kind == ST_THIN_IN ? s.ic : s.oc;
             const long long na = (long long)s.geom.k * s.geom.k * cs;
-            need = (FG_THIN_WGRAD_BLOCKS + 1) * na * cw + (long long)CR_ROWBLOCKS_MAX * (s.oc > 64 ? s.oc : 64) + 64;
+            need = (FG_THIN_WGRAD_BLOCKS + 1) * (na + 1) * cw + (long long)CR_ROWBLOCKS_MAX * (s.oc > 64 ? s.oc : 64) + 64;   // na + 1: the bias row
             const long long nr = (long long)B * s.ih * s.iw * 32 + 64;      // R of the two-pass 5x5 / 7x7 thin-output forward
             if (s.kind == ST_THIN_OUT && s.geom.k >= 5 && nr > need) need = nr;
             break;
@@ -244,10 +244,12 @@ static int backward_run_stages(fg_net* n) {
             case ST_THIN_IN: {
                 const int k = s.geom.k;
                 if (want_p) {
-                    float* gw = scratch + (long long)FG_THIN_WGRAD_BLOCKS * k * k * s.ic * s.oc;
-                    rc = fg_launch_thin_wgrad(ctx, xin, gcur, gw, B, s.ih, s.iw, s.ic, s.oc, k, +1, scratch);
+                    // slabs of k*k*Cin + 1 rows: the extra row is the bias gradient (the ones column of the matrix-pipe kernel)
+                    float* gw = scratch + (long long)FG_THIN_WGRAD_BLOCKS * (k * k * s.ic + 1) * s.oc;
+                    int bias_done = 0;
+                    rc = fg_launch_thin_wgrad(ctx, xin, gcur, gw, B, s.ih, s.iw, s.ic, s.oc, k, +1, scratch, Gp + s.b_off, &bias_done);
                     if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 0, 0.f);
-                    if (!rc) rc = fg_launch_colsum(ctx, gcur, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
+                    if (!rc && !bias_done) rc = fg_launch_colsum(ctx, gcur, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
                 }
                 if (!rc && need_gx)
                     rc = fg_launch_thin_out_conv(ctx, gcur, s.wp_fwd, nullptr, gxb, B, s.ih, s.iw, s.oc, s.ic, k, 1, 0);
@@ -862,7 +864,7 @@ static int build_pack_jobs(fg_net* n) {
 }
 
 static int pack_all(fg_net* n) {
-    int rc = fg_launch_pack_jobs(n->ctx, n->jobs_dev, n->n_jobs, n->jobs_total, n->params);
+    int rc = fg_launch_pack_jobs(n->ctx, n->jobs_dev, n->n_jobs, n->jobs_total, n->params, 4.0 * ((double)n->n_params + (double)n->packed_total));
     if (rc) return rc;
     n->dirty = false;
     n->planes_valid = false;

@@ -170,8 +170,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     colreduce_body<1>(M, C, part, [&](long long r, int c, float* acc) { acc[0] += x[r * C + c]; });
 }
 // final stage of every column reduction: block = 64 columns x 16 partial lanes, fp64 accumulate
+// (columns >= C1 go to out2[c - C1] when out2 is given: one launch finishes two results that share their partial rows)
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nrb, int C, float beta,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int C1 = 0, float* __restrict__ out2 = nullptr) {
     __shared__ double sh[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
         double t = 0.0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += sh[i][tx];
-        out[c] = (beta == 0.f) ? (float)t : beta * out[c] + (float)t;
+        float* o = (out2 && c >= C1) ? out2 + (c - C1) : out + c;
+        *o = (beta == 0.f) ? (float)t : beta * (*o) + (float)t;
     }
 }
 // ---- deferred finals (see FgDefer): all jobs of a backward pass in one launch; block -> job by a scan over <= 48 entries
@@ -209,16 +211,29 @@ __global__ __launch_bounds__(1024) void multi_final_kernel(const FgFinalBatch b)
         }
         return;
     }
-    const int c = ((int)blockIdx.x - jb.blk0) * 64 + tx;
+    // round 4: 16 columns x 64 row lanes per block (was 64 x 16: a bias-gradient job of the wave-specialised weight gradient has up
+    // to 2 048 partial rows and 128 columns -- two blocks walked 128 rows each, one dependent-latency chain per lane: 42 us of a
+    // 4.3 ms step for 1 MB of partials; as the BatchNorm finals of round 2b).  fp64 sums of <= 2 048 fp32 values are exact up to
+    // 1e-16, so the result does not depend on the association.
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = ((int)blockIdx.x - jb.blk0) * 16 + cx;
     double s = 0.0;
-    if (c < jb.C)
-        for (int r = ty; r < jb.nrb; r += 16) s += (double)jb.part[(size_t)r * jb.C + c];
-    sh[ty][tx] = s;
+    if (c < jb.C) {
+        int r = ry;
+        for (; r + 192 < jb.nrb; r += 256) {       // four independent loads in flight
+            const float v0 = jb.part[(size_t)r * jb.C + c], v1 = jb.part[(size_t)(r + 64) * jb.C + c];
+            const float v2 = jb.part[(size_t)(r + 128) * jb.C + c], v3 = jb.part[(size_t)(r + 192) * jb.C + c];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; r < jb.nrb; r += 64) s += (double)jb.part[(size_t)r * jb.C + c];
+    }
+    double* shf = &sh[0][0];                        // [64 row lanes][16 columns]
+    shf[ry * 16 + cx] = s;
     __syncthreads();
-    if (ty == 0 && c < jb.C) {
+    if (ry == 0 && c < jb.C) {
         double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t += sh[i][tx];
+        for (int i = 0; i < 64; ++i) t += shf[i * 16 + cx];
         jb.out[c] = (jb.beta == 0.f) ? (float)t : jb.beta * jb.out[c] + (float)t;
     }
 }
@@ -235,7 +250,7 @@ void fg_defer_push(fg_ctx* ctx, const float* part, int nrb, int C, float beta, f
     FgDefer* d = ctx->defer;
     FgFinalJob& j = d->jobs[d->n++];
     j.part = part; j.out = out; j.nrb = nrb; j.C = C; j.beta = beta; j.blk0 = d->blocks;
-    d->blocks += fg_cdiv(C, 64);
+    d->blocks += fg_cdiv(C, 16);
 }
 int fg_defer_flush(fg_ctx* ctx) {
     FgDefer* d = ctx->defer;
@@ -254,7 +269,12 @@ int fg_defer_flush(fg_ctx* ctx) {
     return FG_OK;
 }
 int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out) {
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(C, 64)), dim3(1024), 0, ctx->stream, part, nrb, C, beta, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(C, 64)), dim3(1024), 0, ctx->stream, part, nrb, C, beta, out, 0, (float*)nullptr);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_colsum_final2(fg_ctx* ctx, const float* part, int nrb, int C1, float* out1, int C2, float* out2) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(C1 + C2, 64)), dim3(1024), 0, ctx->stream, part, nrb, C1 + C2, 0.f, out1, C1, out2);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }

@@ -300,7 +300,7 @@ template <int CS, int EPI>
 __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restrict__ in, const float* __restrict__ Wp,
                                                            const float* __restrict__ bias, float* __restrict__ out,
                                                            int npix, int H, int W, int flip, int Cw, int lgH, int lgW,
-                                                           const ThinEpi epi) {
+                                                           const ThinEpi epi, int nt_store) {
     constexpr int NA = 9 * CS;
     constexpr int KS = (NA + 1) / 2;
     constexpr int TS_LD = 68;            // floats per staged pixel row (64 channels + 4: 16-byte aligned rows)
@@ -378,7 +378,11 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
                 const int pl = i * 4 + (lane >> 4), c4 = (lane & 15) * 4;
                 const tw_f32x4 v = *(const tw_f32x4*)(ts + pl * TS_LD + c4);
                 const int p = tile * 32 + pl;
-                if (p < npix) *(tw_f32x4*)(out + (size_t)p * Cw + cb + c4) = v;
+                if (p < npix) {
+                    // measurement switch (FG_THIN_NT=1): streaming stores that do not allocate in L2
+                    if (nt_store) __builtin_nontemporal_store(v, (tw_f32x4*)(out + (size_t)p * Cw + cb + c4));
+                    else *(tw_f32x4*)(out + (size_t)p * Cw + cb + c4) = v;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         } else {
@@ -657,14 +661,18 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         for (int q = 0; q < 15; ++q) { if ((1 << q) == H) lgH = q; if ((1 << q) == W) lgW = q; }
         // tiles per wave: every wave first fetches its 2 x 14 weight fragments, so one tile per wave is all set-up latency
         // (1 -> 4 tiles per wave with the next tile's gather in flight: 17.6 -> 15.5 us for the 33 / 67 MB outputs)
-        const int tpw = 4;
+        static int tpw_env = -1, nt_env = -1;
+        if (tpw_env < 0) { const char* e = getenv("FG_THIN_TPW"); tpw_env = e ? atoi(e) : 0; }
+        if (nt_env < 0) { const char* e = getenv("FG_THIN_NT"); nt_env = e ? atoi(e) : 0; }
+        const int tpw = tpw_env > 0 ? tpw_env : 4;
+        const int nt_store = nt_env;
         int nb = fg_cdiv(fg_cdiv(npix, 32), 4 * tpw);
         if (nb > 2048) nb = 2048;
         if (nb < 1) nb = 1;
         dim3 mgrid(nb, Cw / 64);
         arm(mgrid);
         const int em = epi.x ? 2 : (epi.y ? 1 : 0);
-#define TIM(CC, EE) hipLaunchKernelGGL((thin_in_mfma_kernel<CC, EE>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW, epi)
+#define TIM(CC, EE) hipLaunchKernelGGL((thin_in_mfma_kernel<CC, EE>), mgrid, dim3(256), 0, ctx->stream, in, Wp, bias, out, npix, H, W, flip, Cw, lgH, lgW, epi, nt_store)
         if (Cs == 3) { if (em == 2) TIM(3, 2); else if (em == 1) TIM(3, 1); else TIM(3, 0); }
         else { if (em == 2) TIM(1, 2); else if (em == 1) TIM(1, 1); else TIM(1, 0); }
 #undef TIM
@@ -1436,17 +1444,25 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // per-lane constant) and ONE load -- no bounds, no select (the 5 gathers of a 7x7x3 pixel pair cost ~50 VALU instructions per 10
 // MFMAs before, and every instruction issued beside an MFMA costs its pipe 6-9 cycles: DESIGN 4.7); columns >= NA read tap 0 and are
 // never stored.
+// ONES (round 4): column NA of the (tap, s) axis -- idle in every instance, NA is never a multiple of 32 -- multiplies the constant
+// 1, so row NA of the slab is sum_pix wide[pix][c]: with wide = the output gradient of a thin-INPUT convolution that is its bias
+// gradient, from the pass that streams the tensor anyway (the separate column-sum pass re-read all of it: 134 MB per layer in c2f).
 template <int K, int CS, int PADDED = 0>
 __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __restrict__ thin, const float* __restrict__ wide,
-                                                              float* __restrict__ part, int B, int H, int W, int Cw, int sgn, int lgH, int lgW) {
+                                                              float* __restrict__ part, int B, int H, int W, int Cw, int sgn, int lgH, int lgW,
+                                                              int ones) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int NA = K * K * CS;
     constexpr int NCT = (NA + 31) / 32;          // 32-column tiles of the (tap, s) axis: 1 (3x3) ... 5 (7x7x3)
+    static_assert(NA % 32 != 0, "the ones column needs an idle column");
+    constexpr int CTO = NA / 32;                  // the tile that holds column NA
     __shared__ float red[4][2][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cbase = blockIdx.y * 64;
     const long long npix = (long long)B * H * W, npairs = (npix + 1) / 2;
     const int j = lane & 31, k = lane >> 5;
+    const bool ones_lane = ones && (CTO * 32 + j == NA);
+    const int NR = NA + (ones ? 1 : 0);           // slab rows
     int oy[NCT], ox[NCT], sch[NCT];
     bool jok[NCT];
 #pragma unroll
@@ -1494,6 +1510,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
             const int base = (((row + b * (2 * PAD) + PAD) * Wp + x + PAD) * CS) * 4;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) bv[ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(trs, base + poffB[ct], 0, 0));
+            if (ones_lane) bv[CTO] = 1.f;           // (a pair past the end multiplies zeros of the wide tensor)
         };
         auto mul = [&](float a0, float a1, const float (&bv)[NCT]) {
 #pragma unroll
@@ -1537,6 +1554,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
                     if (jok[ct] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
                         bv[u][ct] = thin[(size_t)((t - y + yy) * W + xx) * CS + sch[ct]];
                 }
+                if (ones_lane) bv[u][CTO] = 1.f;
             }
         }
 #pragma unroll
@@ -1548,7 +1566,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
             }
     }
     // block reduce (fixed wave order) -> one slab [NA][Cw] per block, like thin_wgrad_kernel
-    float* dst = part + (size_t)blockIdx.x * NA * Cw;
+    float* dst = part + (size_t)blockIdx.x * NR * Cw;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         if (ct) __syncthreads();
@@ -1558,18 +1576,28 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
         for (int e = threadIdx.x; e < 2 * 16 * 64; e += 256) {
             const int tile = e >> 10, r = (e >> 6) & 15, l = e & 63;
             const int col = ct * 32 + (l & 31), row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-            if (col < NA)
+            if (col < NR)
                 dst[(size_t)col * Cw + cbase + tile * 32 + row] = (red[0][tile][r][l] + red[1][tile][r][l]) + (red[2][tile][r][l] + red[3][tile][r][l]);
         }
     }
 }
 
-int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);
 static bool fg_thin_wgrad_padded_on() { return fg_thin_padded_on(); }
 
+// wide_colsum (optional): receives sum_pix wide[pix][c] (beta = 0) from the ones column of the matrix-pipe kernels; *colsum_done
+// tells the caller whether it was produced (the VALU fallback kernels do not).  With it the slabs have k*k*Cs + 1 rows: `scratch`
+// holds FG_THIN_WGRAD_BLOCKS * (k*k*Cs + 1) * Cw floats for them.
 int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
-                         int Cw, int k, int shift_thin, float* scratch) {
+                         int Cw, int k, int shift_thin, float* scratch, float* wide_colsum, int* colsum_done) {
+    if (colsum_done) *colsum_done = 0;
     if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_wgrad: Cw %% 64");
+    const int ones = (wide_colsum && colsum_done && (ctx->fusion & FG_FUSE_THIN_BIAS)) ? 1 : 0;      // fg_set_fusion
+    const int NR = k * k * Cs + ones;
+    auto finish = [&](int nblocks) -> int {       // fp64 sum of the slabs; row k*k*Cs (the ones column) goes to wide_colsum
+        if (!ones) return fg_launch_colsum_final(ctx, scratch, nblocks, NR * Cw, 0.f, gw_tsc);
+        *colsum_done = 1;
+        return fg_launch_colsum_final2(ctx, scratch, nblocks, (NR - 1) * Cw, gw_tsc, Cw, wide_colsum);
+    };
     // profile label "thin_wgrad<k,Cs>": algorithmic bytes = both tensors read once (the per-block slabs are small)
     char plabel[48] = "";
     if (ctx->prof) snprintf(plabel, sizeof(plabel), "thin_wgrad<%d,%d>", k, Cs);
@@ -1586,7 +1614,7 @@ int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, floa
         // (the layer's slabs are large: the copy displaces a few of the TW_BLOCKS blocks)
         if (fits && k >= 5 && lgH >= 0 && lgW >= 0 && (Cs == 1 || Cs == 3) && fg_thin_wgrad_padded_on()) {
             const int pad = (k - 1) / 2;
-            const long long slab = (long long)k * k * Cs * Cw, padf = (long long)B * (H + 2 * pad) * (W + 2 * pad) * Cs;
+            const long long slab = (long long)NR * Cw, padf = (long long)B * (H + 2 * pad) * (W + 2 * pad) * Cs;
             const long long take = (padf + slab - 1) / slab;
             if (take <= TW_BLOCKS / 4 && padf < (1LL << 28) && (long long)B * H * W * Cw * 4 < 0x7FFFFFF0LL) {
                 const int nbp = nb < TW_BLOCKS - (int)take ? nb : TW_BLOCKS - (int)take;
@@ -1596,9 +1624,9 @@ int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, floa
 #define TWP(KK, CC)                                                                                                  \
                 if (k == KK && Cs == CC) {                                                                           \
                     hipLaunchKernelGGL((thin_wgrad_mfma_kernel<KK, CC, 1>), gridp, dim3(256), 0, ctx->stream, padded, wide, scratch, B, \
-                                       H, W, Cw, shift_thin, lgH, lgW);                                              \
+                                       H, W, Cw, shift_thin, lgH, lgW, ones);                                        \
                     FG_CHECK_LAUNCH(ctx);                                                                            \
-                    return fg_launch_colsum_final(ctx, scratch, nbp, KK * KK * CC * Cw, 0.f, gw_tsc);                \
+                    return finish(nbp);                                                                              \
                 }
                 TWP(5, 1) TWP(5, 3) TWP(7, 1) TWP(7, 3)
 #undef TWP
@@ -1607,9 +1635,9 @@ int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, floa
 #define TWM(KK, CC)                                                                                                  \
         if (fits && k == KK && Cs == CC) {                                                                           \
             hipLaunchKernelGGL((thin_wgrad_mfma_kernel<KK, CC>), grid, dim3(256), 0, ctx->stream, thin, wide, scratch, B, H, \
-                               W, Cw, shift_thin, lgH, lgW);                                                         \
+                               W, Cw, shift_thin, lgH, lgW, ones);                                                   \
             FG_CHECK_LAUNCH(ctx);                                                                                    \
-            return fg_launch_colsum_final(ctx, scratch, nb, KK * KK * CC * Cw, 0.f, gw_tsc);                         \
+            return finish(nb);                                                                                       \
         }
         TWM(3, 1) TWM(3, 3) TWM(3, 4) TWM(5, 1) TWM(5, 3) TWM(7, 1) TWM(7, 3)
 #undef TWM

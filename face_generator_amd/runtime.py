@@ -61,7 +61,8 @@ class Context:
     def set_fusion(self, flags):
         """Optional kernel fusions (include/facegen_hip.h FG_FUSE_*): 1 = PReLU in the neighbouring contraction's epilogue,
         2 = one-pass matrix-pipe 3x3 thin-output convolution, 4 = all weight-gradient split-K sums of a backward pass in one launch,
-        8 = Adam + the re-pack of every layer in one launch (measured slower: off by default); default 7."""
+        8 = Adam + the re-pack of every layer in one launch (measured slower: off by default), 16 = the bias gradient of a thin-input
+        convolution from its weight-gradient kernel (no separate column-sum pass); default 23."""
         self.check(self.lib.fg_set_fusion(self.h, int(flags)))
 
     def get_fusion(self):

@@ -50,8 +50,8 @@ int fg_set_math(fg_ctx* ctx, int mode);
 int fg_get_math(fg_ctx* ctx);
 
 /* Optional kernel fusions / variants (results equal to the un-fused path up to the summation order of a reduction; exposed so
- * the parity tests and the bench can run both ways).  Default: FG_FUSE_DEFAULT; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 / FG_DEFER_WFINISH=0 in the
- * environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
+ * the parity tests and the bench can run both ways).  Default: FG_FUSE_DEFAULT; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 / FG_DEFER_WFINISH=0 /
+ * FG_THIN_BIAS=0 in the environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
 enum {
     FG_FUSE_PRELU = 1,      /* an nn.PReLU between two contraction layers (models_c2f.lua:118-130, 242-255) rides on their
                              * epilogues: forward copy behind the producing layer, backward (+ slope-gradient partials) in
@@ -66,8 +66,13 @@ enum {
                              * update of that element) instead of two; bit-identical parameters.  OFF by default: the pack's
                              * patch-wise access pattern slows the seven streams of the update down by more than the saved
                              * pass over the weights (cfg2 4.31 vs 4.27 ms, c2f 38.8 vs 38.6 ms per step) */
-    FG_FUSE_ALL = 15,
-    FG_FUSE_DEFAULT = 7
+    FG_FUSE_THIN_BIAS = 16, /* the bias gradient of a convolution with <= 4 input channels (models.lua:385; models_c2f.lua:123, 244)
+                             * from the weight-gradient kernel itself: one idle column of its (tap, channel) axis multiplies the
+                             * constant 1, so the pass that streams the output gradient anyway also leaves its per-channel sums;
+                             * off: a separate column-sum pass re-reads the tensor (134 MB per layer at 64x64, B = 128).  Same
+                             * fp64 final reduction; the fp32 partial sums are formed in a different order (FG_THIN_BIAS=0 clears it) */
+    FG_FUSE_ALL = 31,
+    FG_FUSE_DEFAULT = 23
 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);

@@ -15,7 +15,7 @@ from test_gpu_c2f import build, masks_for, dev_masks
 
 pytestmark = pytest.mark.gpu
 
-FG_FUSE_PRELU, FG_FUSE_THIN_SLAB, FG_FUSE_WFINISH_BATCH, FG_FUSE_ADAM_PACK, FG_FUSE_ALL, FG_FUSE_DEFAULT = 1, 2, 4, 8, 15, 7
+FG_FUSE_PRELU, FG_FUSE_THIN_SLAB, FG_FUSE_WFINISH_BATCH, FG_FUSE_ADAM_PACK, FG_FUSE_THIN_BIAS, FG_FUSE_ALL, FG_FUSE_DEFAULT = 1, 2, 4, 8, 16, 31, 23
 
 
 @pytest.fixture(scope="module")
@@ -31,7 +31,7 @@ def test_fusion_flags_roundtrip_and_reject_unknown_bits(ctx):
     ctx.set_fusion(FG_FUSE_THIN_SLAB)
     assert ctx.get_fusion() == FG_FUSE_THIN_SLAB
     with pytest.raises(FgError):
-        ctx.set_fusion(16)
+        ctx.set_fusion(32)
     ctx.set_fusion(FG_FUSE_DEFAULT)
     assert ctx.get_fusion() == FG_FUSE_DEFAULT
 
@@ -214,3 +214,48 @@ def test_c2f_batched_weight_gradient_sums_and_adam_in_the_repack_are_bit_identic
     for flags, o in outs.items():
         for k in ref:
             assert torch.equal(ref[k], o[k]), "fusion flags %d: %s differs from the all-on run (c2f)" % (flags, k)
+
+
+@pytest.mark.parametrize("which,S,B", [("cfg2", 32, 16), ("cfg2", 32, 128), ("c2f", 64, 8)])
+def test_bias_gradient_from_the_thin_weight_gradient_kernel(ctx, which, S, B):
+    """FG_FUSE_THIN_BIAS (round 4): the bias gradient of a convolution with <= 4 input channels (D's first layer, models.lua:385;
+    both first layers of the c2f nets, models_c2f.lua:123, 244) is row k*k*Cin of the weight-gradient slabs -- the idle column of
+    the (tap, channel) axis multiplied by 1 -- instead of a separate column-sum pass over the output gradient.  Every other entry of
+    the flat gradient is bit-identical either way; the bias gradient agrees to fp32 summation-order rounding (both ways end in the
+    same fp64 final) and with the oracle at the plain bar (the full-size parity tests run with the bit on)."""
+    outs = {}
+    for flags in (FG_FUSE_ALL, FG_FUSE_ALL & ~FG_FUSE_THIN_BIAS):
+        ctx.set_fusion(flags)
+        if which == "cfg2":
+            from test_gpu_step_abi import make32, masks32
+            tr, G, D = make32(ctx, B, dict(D_L1=0.0, D_L2=0.0), True, seed=21)
+            real = ctx.uniform((B // 2, 32, 32, 3), 0.0, 1.0, seed=9)
+            r = tr.step_D(real, ctx.uniform((B // 2, 100), -1.0, 1.0, seed=10), masks32(ctx, B, 20), keep_grad=True)
+            nets = [D]
+        else:
+            from face_generator_amd import models_c2f, adversarial_c2f
+            gen = torch.Generator().manual_seed(5)
+            G = models_c2f.create_G((3, S, S), gen=gen).cuda(ctx, max_batch=B)
+            D = models_c2f.create_D((3, S, S), gen=gen).cuda(ctx, max_batch=B)
+            tr = adversarial_c2f.TrainerC2F(ctx, G, D, dict(batchSize=B))
+            u = lambda shape, lo, hi, seed: ctx.uniform(shape, lo, hi, seed=seed)
+            masks = [ctx.bernoulli((B * 256 * (S // 4) ** 2,), 0.5, 7), ctx.bernoulli((B * 512,), 0.5, 8)]
+            tr.step_D(u((B // 2, S, S, 3), -1, 1, 11), u((B // 2, S, S, 3), 0, 1, 12), u((B // 2, S, S, 1), -1, 1, 13),
+                      u((B // 2, S, S, 3), 0, 1, 14), masks, keep_grad=True)
+            tr.step_G(u((B, S, S, 1), -1, 1, 15), u((B, S, S, 3), 0, 1, 16), masks, keep_grad=True)
+            nets = [D, G]
+        outs[flags] = [n.getParameters()[1].clone() for n in nets] + [nets]
+    ctx.set_fusion(FG_FUSE_DEFAULT)
+    on, off = outs[FG_FUSE_ALL], outs[FG_FUSE_ALL & ~FG_FUSE_THIN_BIAS]
+    for g_on, g_off, net in zip(on[:-1], off[:-1], on[-1]):
+        inner = getattr(net, "inner", net)
+        first = inner.modules[0]
+        dn = inner.device_net
+        wo, wn, bo, bn = dn.param_offsets(0)
+        assert bn == first.bias.numel() and first.nInputPlane <= 4
+        same = torch.ones_like(g_on, dtype=torch.bool)
+        same[bo:bo + bn] = False
+        assert torch.equal(g_on[same], g_off[same]), "a gradient entry outside the first layer's bias moved"
+        b_on, b_off = g_on[bo:bo + bn].double(), g_off[bo:bo + bn].double()
+        scale = float(b_off.abs().max())
+        assert scale > 0 and float((b_on - b_off).abs().max()) <= 2e-6 * scale + 1e-12, (float((b_on - b_off).abs().max()), scale)
