@@ -3,6 +3,10 @@
 #include "fg_internal.h"
 
 #define CR_ROWBLOCKS_MAX 256
+// most bias-gradient partial rows a wave-specialised weight gradient may leave (parities x splits x taps x X tiles x loader pixel
+// lanes): 25 taps x 51 splits x 4 = 5 100 for the 5x5 128 -> 256 layer of models_c2f.lua:126 since the multi-round split counts of
+// round 3 -- with the old bound of 2 048 that layer silently took the separate column-sum pass over its 537 MB output gradient
+#define FG_WS_BIAS_ROWS_MAX (32 * CR_ROWBLOCKS_MAX)
 
 struct ConvGeom {
     int B;          // batch

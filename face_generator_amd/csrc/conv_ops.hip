@@ -204,6 +204,26 @@ long long fg_conv_wgrad_part_floats(const ConvGeom& g) {
     return n + 64;
 }
 
+// floats of bias-gradient partial rows the fp32 weight gradient of this layer leaves for the deferred final (0: it takes the
+// separate column-sum pass) -- the same decisions as fg_conv_wgrad_run, for the arena of a net's workspace
+long long fg_conv_wgrad_bias_part_floats(const ConvGeom& g) {
+    WeightMap wm; fg_geom_weightmap(g, &wm);
+    const int st = g.stride == 2 ? 2 : 1;
+    const long long M = (long long)g.B * (g.H / st) * (g.W / st);
+    int wt, S, mper, Np, Cp;
+    choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
+    long long rows = (long long)wm.P * S;
+    int S6, mper6;
+    const int cfg = M >= 4096 ? choose_wgrad_ws(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) : -1;
+    if (cfg >= 0) {
+        WgradArgs a; memset(&a, 0, sizeof(a));
+        a.G = wm.G; a.Cpad = g.Cin;
+        const long long r = (long long)wm.P * S6 * fg_wgrad_ws_bias_rows(a, cfg);
+        if (r <= FG_WS_BIAS_ROWS_MAX && r > rows) rows = r;
+    }
+    return rows * g.Cout + 64;
+}
+
 static long long scratch_for_math(const ConvGeom& g, int math) {
     WeightMap wm; fg_geom_weightmap(g, &wm);
     const long long M = (long long)g.B * g.H * g.W;  // source-resolution M-space
@@ -236,6 +256,13 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
             // Part + planes of gy and x, then (shared-plane backward) the data-gradient's split-K partials + weight planes
             n3 = (long long)wm.P * wm.G * S6 * g.Cout * g.Cin + 4 + ((outM * g.Cout + M * g.Cin) * 3 + 1) / 2 + 64 +
                  256LL * 256 * 128 + 64 + ((long long)wm.P * wm.G * rb * cb * 3 + 1) / 2 + 64;
+    }
+    if (math != 6) {
+        // the default fp32 path runs wgrad_ws_kernel where it tiles (choose_wgrad_ws: its own split counts, up to 6 rounds of blocks):
+        // partials + the bias-gradient rows its loader waves leave (<= FG_WS_BIAS_ROWS_MAX rows) -- sized here explicitly, not by
+        // the accident that fg_conv_scratch_floats takes the maximum with the bf16x6 bound
+        const long long nws = fg_conv_wgrad_part_floats(g) + fg_conv_wgrad_bias_part_floats(g);
+        if (nws > n3) n3 = nws;
     }
     if (n3 > need) need = n3;
     long long n4 = (long long)(CR_ROWBLOCKS_MAX + 2) * g.Cout;
@@ -499,7 +526,7 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         const int nrb = wm.P * a.S * fg_wgrad_ws_bias_rows(a, cfgw);
         const long long nb = (long long)nrb * g.Cout;
         bool deferred = false;
-        if (gradb && nrb <= 8 * CR_ROWBLOCKS_MAX) {
+        if (gradb && nrb <= FG_WS_BIAS_ROWS_MAX) {
             float* dp = fg_defer_alloc(ctx, nb);          // inside fg_net backward: final batched at the end
             if (dp) { a.bias_part = dp; deferred = true; }
             else if (need + nb <= scratch_floats) a.bias_part = scratch + need;

@@ -196,6 +196,7 @@ int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
 #define FG_DEFER_WMAX 16
 struct FgWFinishJob { WeightMap wm; const float* part; float* gradW; int S, Npad, Cpad, ib; float beta; long long blk0; };
 long long fg_conv_wgrad_part_floats(const struct ConvGeom& g);
+long long fg_conv_wgrad_bias_part_floats(const struct ConvGeom& g);   // its bias-gradient partial rows (deferred final)
 bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta, float* gradW);
 int fg_launch_wgrad_finish_jobs(fg_ctx* ctx, const FgWFinishJob* jobs, int n, long long blocks);
 // One launch re-packs every layer of a net after an optimizer step.

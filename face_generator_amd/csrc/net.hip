@@ -108,6 +108,7 @@ struct fg_net {
     int n_jobs_all = 0;               // ... + the update-only jobs of the fused optimizer launch
     long long jobs_total_all = 0;
     bool adam_fusable = false;
+    bool park_w = true;               // FG_FUSE_WFINISH_BATCH at creation: the workspace reserves room for parked weight-gradient partials
 };
 
 static inline long long align64(long long v) { return (v + 63) / 64 * 64; }
@@ -150,12 +151,21 @@ static void make_plan(fg_net* n, int B) {
     }
     {   // arena for the deferred finals: [row blocks][C] partials of every bias-gradient / slope-gradient reduction
         long long dn = 0;
+        //  the weight-gradient partials are only parked here while FG_FUSE_WFINISH_BATCH is on, and only the first
+        // FG_DEFER_WMAX layers of a pass can defer their reduction: nothing is reserved beyond that (134 MB for the 65536 -> 512
+        // Linear of models_c2f.lua:262 alone).  Decided ONCE, when the net is created (fg_net::park_w), so that the workspace size a
+        // host queried stays valid whatever fg_set_fusion does later: a bit switched on afterwards finds no arena and falls back to
+        // the per-layer reduction (fg_defer_alloc returns null), it never overruns and never asks for more.
+        const bool park_w = n->park_w;
+        int parked = 0;
         for (auto& s : n->st) {
             // (ST_CONV: the wave-specialised weight gradient leaves one bias partial row per (parity, split, tap, X tile, loader
-            // pixel lane) -- up to ~1000 rows)
-            if (s.kind == ST_CONV) dn += 8LL * CR_ROWBLOCKS_MAX * s.oc + 64;
+            // pixel lane) -- up to FG_WS_BIAS_ROWS_MAX rows; sized exactly)
+            if (s.kind == ST_CONV) { ConvGeom g = s.geom; g.B = B; dn += (fg_conv_wgrad_bias_part_floats(g) + 63) / 64 * 64; }
             // ... and its split-K / parity partials stay until the batched weight-gradient reduction at the end of the pass
-            if (s.kind == ST_CONV && s.w_n > 0) { ConvGeom g = s.geom; g.B = B; dn += (fg_conv_wgrad_part_floats(g) + 63) / 64 * 64; }
+            if (s.kind == ST_CONV && s.w_n > 0 && park_w && parked < FG_DEFER_WMAX) {
+                ConvGeom g = s.geom; g.B = B; dn += (fg_conv_wgrad_part_floats(g) + 63) / 64 * 64; ++parked;
+            }
             else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT || s.kind == ST_GEMV) dn += (long long)CR_ROWBLOCKS_MAX * s.oc + 64;
             if (s.has_prelu || s.kind == ST_PRELU || s.kind == ST_ACTPOOL) dn += 1024 + 64;
             // a PReLU whose backward rides on the epilogue of the neighbouring contraction leaves 4 partials per block
@@ -472,6 +482,7 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
     if (!ctx || !L || !out || nl <= 0) return fg_set_err(ctx, FG_ERR_INVALID, "fg_net_create: null/empty");
     fg_net* n = new fg_net();
     n->ctx = ctx; n->in_c = in_c; n->in_h = in_h; n->in_w = in_w;
+    n->park_w = (ctx->fusion & FG_FUSE_WFINISH_BATCH) != 0;
     n->layers.resize(nl);
     int c = in_c, h = in_h, w = in_w;
     int perm_c = 0, perm_hw = 0;  // pending NCHW-flatten permutation for the next Linear

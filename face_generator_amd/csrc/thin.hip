@@ -1447,10 +1447,11 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* __restrict
 // ONES (round 4): column NA of the (tap, s) axis -- idle in every instance, NA is never a multiple of 32 -- multiplies the constant
 // 1, so row NA of the slab is sum_pix wide[pix][c]: with wide = the output gradient of a thin-INPUT convolution that is its bias
 // gradient, from the pass that streams the tensor anyway (the separate column-sum pass re-read all of it: 134 MB per layer in c2f).
-template <int K, int CS, int PADDED = 0>
+// (a template parameter: as a run-time flag it cost the 7x7 instance -- 160 accumulator registers, a hand-scheduled load / MFMA
+// pipeline -- 417 -> 507 us although that instance never uses it)
+template <int K, int CS, int PADDED = 0, int ONES = 0>
 __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __restrict__ thin, const float* __restrict__ wide,
-                                                              float* __restrict__ part, int B, int H, int W, int Cw, int sgn, int lgH, int lgW,
-                                                              int ones) {
+                                                              float* __restrict__ part, int B, int H, int W, int Cw, int sgn, int lgH, int lgW) {
     constexpr int PAD = (K - 1) / 2;
     constexpr int NA = K * K * CS;
     constexpr int NCT = (NA + 31) / 32;          // 32-column tiles of the (tap, s) axis: 1 (3x3) ... 5 (7x7x3)
@@ -1461,8 +1462,8 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
     const int cbase = blockIdx.y * 64;
     const long long npix = (long long)B * H * W, npairs = (npix + 1) / 2;
     const int j = lane & 31, k = lane >> 5;
-    const bool ones_lane = ones && (CTO * 32 + j == NA);
-    const int NR = NA + (ones ? 1 : 0);           // slab rows
+    const bool ones_lane = ONES && (CTO * 32 + j == NA);
+    constexpr int NR = NA + ONES;                 // slab rows
     int oy[NCT], ox[NCT], sch[NCT];
     bool jok[NCT];
 #pragma unroll
@@ -1510,7 +1511,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
             const int base = (((row + b * (2 * PAD) + PAD) * Wp + x + PAD) * CS) * 4;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) bv[ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(trs, base + poffB[ct], 0, 0));
-            if (ones_lane) bv[CTO] = 1.f;           // (a pair past the end multiplies zeros of the wide tensor)
+            if constexpr (ONES) { if (ones_lane) bv[CTO] = 1.f; }      // (a pair past the end multiplies zeros of the wide tensor)
         };
         auto mul = [&](float a0, float a1, const float (&bv)[NCT]) {
 #pragma unroll
@@ -1554,7 +1555,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(const float* __res
                     if (jok[ct] && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
                         bv[u][ct] = thin[(size_t)((t - y + yy) * W + xx) * CS + sch[ct]];
                 }
-                if (ones_lane) bv[u][CTO] = 1.f;
+                if constexpr (ONES) { if (ones_lane) bv[u][CTO] = 1.f; }
             }
         }
 #pragma unroll
@@ -1591,7 +1592,8 @@ int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, floa
                          int Cw, int k, int shift_thin, float* scratch, float* wide_colsum, int* colsum_done) {
     if (colsum_done) *colsum_done = 0;
     if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_wgrad: Cw %% 64");
-    const int ones = (wide_colsum && colsum_done && (ctx->fusion & FG_FUSE_THIN_BIAS)) ? 1 : 0;      // fg_set_fusion
+    // (3x3 layers only: the thin-INPUT convolutions of models.lua:385 / models_c2f.lua:123, 244)
+    const int ones = (wide_colsum && colsum_done && k == 3 && (ctx->fusion & FG_FUSE_THIN_BIAS)) ? 1 : 0;      // fg_set_fusion
     const int NR = k * k * Cs + ones;
     auto finish = [&](int nblocks) -> int {       // fp64 sum of the slabs; row k*k*Cs (the ones column) goes to wide_colsum
         if (!ones) return fg_launch_colsum_final(ctx, scratch, nblocks, NR * Cw, 0.f, gw_tsc);
@@ -1624,7 +1626,7 @@ int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, floa
 #define TWP(KK, CC)                                                                                                  \
                 if (k == KK && Cs == CC) {                                                                           \
                     hipLaunchKernelGGL((thin_wgrad_mfma_kernel<KK, CC, 1>), gridp, dim3(256), 0, ctx->stream, padded, wide, scratch, B, \
-                                       H, W, Cw, shift_thin, lgH, lgW, ones);                                        \
+                                       H, W, Cw, shift_thin, lgH, lgW);                                              \
                     FG_CHECK_LAUNCH(ctx);                                                                            \
                     return finish(nbp);                                                                              \
                 }
@@ -1634,8 +1636,12 @@ int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, floa
         }
 #define TWM(KK, CC)                                                                                                  \
         if (fits && k == KK && Cs == CC) {                                                                           \
-            hipLaunchKernelGGL((thin_wgrad_mfma_kernel<KK, CC>), grid, dim3(256), 0, ctx->stream, thin, wide, scratch, B, H, \
-                               W, Cw, shift_thin, lgH, lgW, ones);                                                   \
+            if (KK == 3 && ones)                                                                                     \
+                hipLaunchKernelGGL((thin_wgrad_mfma_kernel<KK, CC, 0, (KK == 3 ? 1 : 0)>), grid, dim3(256), 0, ctx->stream, thin, wide, \
+                                   scratch, B, H, W, Cw, shift_thin, lgH, lgW);                                      \
+            else                                                                                                     \
+                hipLaunchKernelGGL((thin_wgrad_mfma_kernel<KK, CC>), grid, dim3(256), 0, ctx->stream, thin, wide, scratch, B, H, \
+                                   W, Cw, shift_thin, lgH, lgW);                                                     \
             FG_CHECK_LAUNCH(ctx);                                                                                    \
             return finish(nb);                                                                                       \
         }

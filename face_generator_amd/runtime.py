@@ -138,6 +138,7 @@ def make_specs(layers):
 class DeviceNet:
     """An nn.Sequential compiled by fg_net_create, with its flat parameter / gradient vectors
     (== Module:getParameters(), train.lua:151-152), BN running stats and workspace as torch device tensors."""
+    _count = 0          # nets built by this process (salt of the default dropout-mask key)
 
     def __init__(self, ctx, layers, in_dims, max_batch, params=None, grads=None):
         """params / grads: optional slices of a larger flat vector shared by several nets (nn.ConcatSequential)."""
@@ -167,10 +168,12 @@ class DeviceNet:
         ctx.check(self.lib.fg_net_bind(h, self.params.data_ptr(), self.grads.data_ptr(), self.buffers.data_ptr()))
         self.train = True
         self.sync_buf, self._sync_reduce = None, None
-        # Philox streams are keyed by (seed, counter) only: the dropout masks must not share the noise stream's key (S.noise_seed
-        # defaults to 1), and two different nets should not share one either -- 1000 (like the Lua binding's 1000 + seed) plus a
-        # salt taken from the net itself, so that the same program draws the same masks on every run
-        self.mask_seed, self.mask_offset = 1000 + self.n_params % 9973, 0
+        # Philox streams are keyed by (seed, counter) only: the dropout masks must not share the noise stream's key (S.noise_seed:
+        # small integers, seed + rank), and two nets must not share one either -- not even two with the same parameter count
+        # (two identical D's, the branches of a CompositeDeviceNet).  Key = a tag in the upper 32 bits (a namespace no
+        # noise seed reaches) + the number of nets this process has built so far: the same program draws the same masks every run.
+        DeviceNet._count += 1
+        self.mask_seed, self.mask_offset = (0x4D41534B << 32) + DeviceNet._count, 0
         self._masks = None
         self._batch = 0
         self._x = None

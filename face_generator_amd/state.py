@@ -53,7 +53,8 @@ class _State:
             if dn is not None:
                 for d in ([dn] if not hasattr(dn, "_nets") else dn._nets()):
                     k += 1
-                    d.mask_seed = 1000 * (seed + rank) + k         # one key per net and rank, none shared with the noise stream
+                    # one key per net and rank, in a namespace (upper 32 bits) no noise seed and no default net key reaches
+                    d.mask_seed = (0x4D41534C << 32) + 1000 * (seed + rank) + k
 
 
 S = _State()

@@ -69,6 +69,12 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32 and j["value"] > 0 and j["scaling"] == "weak"
     assert "alt_math" in j and "error" not in j["alt_math"] and "roofline" in j and "cpu_baseline" not in j
     assert j["collective_fallback"] is False and j["rccl_ranks_seen"] == 2          # (gloo was ASKED for here: not a fallback)
+    # round 4: the run diagnoses itself -- every rank's own step time (a straggler shows), and the collective schedule of all N
+    # ranks walked on the CPU before the rendezvous (rank 0, planning-only contexts), with its hash in the line
+    assert len(j["per_rank_ms_per_step"]) == 2 and all(0 < v <= j["ms_per_step"] * 1.001 + 0.05 for v in j["per_rank_ms_per_step"])
+    d = j["dry_collective"]
+    assert d["ranks_agree"] is True and d["ranks_walked"] == 2 and len(d["schedule_sha16"]) == 16 and d["this_run"], d
+    assert any(" allreduce f32 2863239 " in l for l in d["this_run"])                  # D's flat gradient, models.lua:382-416
     c = j["c2f"]                                                                     # configs[4]-style: B/2 per rank, D_it = 2
     assert "error" not in c, c
     assert c["value"] > 0 and c["config"]["batch_per_gpu"] == 8 and "D_it=2" in c["config"]["workload"]
