@@ -173,18 +173,28 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 // (columns >= C1 go to out2[c - C1] when out2 is given: one launch finishes two results that share their partial rows)
 __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nrb, int C, float beta,
                                                             float* __restrict__ out, int C1 = 0, float* __restrict__ out2 = nullptr) {
-    __shared__ double sh[16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    // round 4: block = 16 columns x 64 partial lanes (was 64 x 16: the 512 slabs of a thin weight gradient were walked 32 rows per
+    // lane, one dependent-latency chain each: 17.7 us for 3.5 MB); fp64 sums of <= a few thousand fp32 values are exact to 1e-16,
+    // so the association does not show in the rounded result
+    __shared__ double sh[64][16];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     double s = 0.0;
-    if (c < C)
-        for (int b = ty; b < nrb; b += 16) s += (double)part[(size_t)b * C + c];
-    sh[ty][tx] = s;
+    if (c < C) {
+        int b = ry;
+        for (; b + 192 < nrb; b += 256) {
+            const float v0 = part[(size_t)b * C + c], v1 = part[(size_t)(b + 64) * C + c];
+            const float v2 = part[(size_t)(b + 128) * C + c], v3 = part[(size_t)(b + 192) * C + c];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; b < nrb; b += 64) s += (double)part[(size_t)b * C + c];
+    }
+    sh[ry][cx] = s;
     __syncthreads();
-    if (ty == 0 && c < C) {
+    if (ry == 0 && c < C) {
         double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t += sh[i][tx];
+        for (int i = 0; i < 64; ++i) t += sh[i][cx];
         float* o = (out2 && c >= C1) ? out2 + (c - C1) : out + c;
         *o = (beta == 0.f) ? (float)t : beta * (*o) + (float)t;
     }
@@ -269,12 +279,12 @@ int fg_defer_flush(fg_ctx* ctx) {
     return FG_OK;
 }
 int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out) {
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(C, 64)), dim3(1024), 0, ctx->stream, part, nrb, C, beta, out, 0, (float*)nullptr);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(C, 16)), dim3(1024), 0, ctx->stream, part, nrb, C, beta, out, 0, (float*)nullptr);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
 int fg_launch_colsum_final2(fg_ctx* ctx, const float* part, int nrb, int C1, float* out1, int C2, float* out2) {
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(C1 + C2, 64)), dim3(1024), 0, ctx->stream, part, nrb, C1 + C2, 0.f, out1, C1, out2);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(C1 + C2, 16)), dim3(1024), 0, ctx->stream, part, nrb, C1 + C2, 0.f, out1, C1, out2);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
@@ -319,7 +329,7 @@ int fg_launch_colsum(fg_ctx* ctx, const float* x, long long M, int N, float beta
         hipLaunchKernelGGL(colsum_partial_kernel, dim3(nrb, fg_cdiv(N, 64)), dim3(256), 0, ctx->stream, x, M, N, scratch);
     FG_CHECK_LAUNCH(ctx);
     if (dpart) { fg_defer_push(ctx, dpart, nrb, N, beta, out); return FG_OK; }
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(N, 64)), dim3(1024), 0, ctx->stream, scratch, nrb, N, beta, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(N, 16)), dim3(1024), 0, ctx->stream, scratch, nrb, N, beta, out);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }

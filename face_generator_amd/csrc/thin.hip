@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
             const int d = kdesc[ks];
             const int yy = y + (d & 3) - 1, xx = x + ((d >> 2) & 3) - 1;
             float a = 0.f;
-            if (ok && (d >> 8) && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+            if (ok && (d >> 8) && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W && !(nt_store & 4))
                 a = in[(size_t)((t - y + yy) * W + xx) * CS + ((d >> 4) & 15)];
             av[ks] = a;
         }
@@ -378,9 +378,10 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
                 const int pl = i * 4 + (lane >> 4), c4 = (lane & 15) * 4;
                 const tw_f32x4 v = *(const tw_f32x4*)(ts + pl * TS_LD + c4);
                 const int p = tile * 32 + pl;
-                if (p < npix) {
-                    // measurement switch (FG_THIN_NT=1): streaming stores that do not allocate in L2
-                    if (nt_store) __builtin_nontemporal_store(v, (tw_f32x4*)(out + (size_t)p * Cw + cb + c4));
+                if (p < npix && !(nt_store & 2)) {
+                    // measurement switches: FG_THIN_NT=1 streaming stores that do not allocate in L2; FG_THIN_DBG bit 0 drops the
+                    // stores, bit 1 the gathers (what is left of the kernel without them)
+                    if (nt_store & 1) __builtin_nontemporal_store(v, (tw_f32x4*)(out + (size_t)p * Cw + cb + c4));
                     else *(tw_f32x4*)(out + (size_t)p * Cw + cb + c4) = v;
                 }
             }
@@ -663,7 +664,10 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         // (1 -> 4 tiles per wave with the next tile's gather in flight: 17.6 -> 15.5 us for the 33 / 67 MB outputs)
         static int tpw_env = -1, nt_env = -1;
         if (tpw_env < 0) { const char* e = getenv("FG_THIN_TPW"); tpw_env = e ? atoi(e) : 0; }
-        if (nt_env < 0) { const char* e = getenv("FG_THIN_NT"); nt_env = e ? atoi(e) : 0; }
+        if (nt_env < 0) {
+            const char* e = getenv("FG_THIN_NT"); nt_env = e ? (atoi(e) & 1) : 0;
+            const char* dbg = getenv("FG_THIN_DBG"); if (dbg) nt_env |= (atoi(dbg) & 3) << 1;      // measurement only: results are wrong
+        }
         const int tpw = tpw_env > 0 ? tpw_env : 4;
         const int nt_store = nt_env;
         int nb = fg_cdiv(fg_cdiv(npix, 32), 4 * tpw);

@@ -86,6 +86,10 @@ def test_library_drawn_noise_and_masks(ctx):
     runs = []
     for rep in range(2):
         tr, G, D = make32(ctx, B)
+        # the default dropout-mask key is unique per net of the process (runtime.DeviceNet: tag + construction count), so that no two
+        # nets ever share a stream; "the same seeds" means the same keys handed to fg_gan_set_seeds
+        from face_generator_amd.state import S
+        tr.gan.set_seeds(S.noise_seed, S.noise_offset, 777, 0)
         real = ctx.uniform((B // 2, 32, 32, 3), 0.0, 1.0, seed=9)
         r = tr.step_D(real, None)
         nz1 = r["noise"].clone(); m1 = [m.clone() for m in r["masks"]]
