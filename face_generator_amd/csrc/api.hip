@@ -82,7 +82,6 @@ int fg_ctx_create(int device, fg_ctx** out) {
     if (const char* m = getenv("FG_THIN_SLAB")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_THIN_SLAB;
     if (const char* m = getenv("FG_DEFER_WFINISH")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WFINISH_BATCH;
     if (const char* m = getenv("FG_THIN_BIAS")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_THIN_BIAS;
-    if (const char* m = getenv("FG_G_LOOKAHEAD")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_G_LOOKAHEAD;
     c->fusion &= ~FG_FUSE_ADAM_PACK;        // measured slower than the two launches: opt-in
     if (const char* m = getenv("FG_ADAM_PACK")) if (atoi(m) != 0) c->fusion |= FG_FUSE_ADAM_PACK;
     ++g_real_ctx;

@@ -293,14 +293,6 @@ struct fg_gan {
     std::vector<GBucket> buckets;
     bool sync_bn = false;
     int overlap = 1;                   // 2 (test hook): take the N > 1 exchange path even on a one-rank communicator
-    // generator lookahead (FG_FUSE_G_LOOKAHEAD, round 4): the G closure's generator forward depends on nothing the D closure does
-    // after ITS generator forward, so it runs on a side stream beside D's forward / backward / optimizer pass -- D's mid-size
-    // convolutions are single-round launches that leave a third of the chip idle.  Two events per iteration.
-    hipStream_t la_stream = nullptr;
-    hipEvent_t la_e1 = nullptr, la_e2 = nullptr;   // e1: the D closure's generator forward is done; e2: the lookahead forward is done
-    bool la_valid = false;             // e1 was recorded by the D closure that precedes this G closure
-    long long o_dinput2 = 0;           // the lookahead writes its samples here (the D closure's batch is still being read)
-    long long o_dinput_cur = 0;        // what FG_GAN_D_INPUT names: the batch of the last closure
 };
 
 static inline long long al64(long long v) { return (v + 63) / 64 * 64; }
@@ -310,8 +302,6 @@ static void gan_layout(fg_gan* g) {
     long long off = 0;
     auto take = [&](long long n) { const long long o = off; off += al64(n); return o; };
     g->o_dinput = take(B * g->img);
-    g->o_dinput2 = g->table ? g->o_dinput : take(B * g->img);
-    g->o_dinput_cur = g->o_dinput;
     g->o_ginput = take(B * g->gin);
     g->o_noise = take(B * g->nz_elems);
     g->o_dsum = g->table ? take(B * g->img) : 0;
@@ -446,13 +436,10 @@ static int gan_targets(fg_gan* g, int w, int B) {
 }
 
 // noise batch (when the caller passes none) + every dropout mask (ditto) of one closure in a single Philox launch
-// (parts: 1 = the noise, 2 = the masks, 3 = both in one launch; the two Philox streams have their own counters, so two launches
-// draw the same values as one)
 static int gan_draw(fg_gan* g, int n_noise_rows, const float* noise_in, int B, const float* const* masks_in,
-                    const float** noise_out, std::vector<const float*>& dmasks, int parts = 3) {
+                    const float** noise_out, std::vector<const float*>& dmasks) {
     RngMulti m; memset(&m, 0, sizeof(m));
-    if (!(parts & 1)) {}
-    else if (noise_in) *noise_out = noise_in;
+    if (noise_in) *noise_out = noise_in;
     else {
         RngSeg& s = m.seg[m.n++];
         s.out = g->ws + g->o_noise; s.n = (long long)n_noise_rows * g->nz_elems; s.seed = g->noise_seed; s.offset = g->noise_off;
@@ -460,8 +447,8 @@ static int gan_draw(fg_gan* g, int n_noise_rows, const float* noise_in, int B, c
         g->noise_off += (uint64_t)((s.n + 3) / 4);
         *noise_out = s.out;
     }
-    const int nm = (parts & 2) ? fg_net_num_masks(g->D) : 0;
-    if (parts & 2) dmasks.assign(nm, nullptr);
+    const int nm = fg_net_num_masks(g->D);
+    dmasks.assign(nm, nullptr);
     for (int i = 0; i < nm; ++i) {
         if (masks_in) { dmasks[i] = masks_in[i]; continue; }
         if (m.n >= FG_RNG_MAX_SEGS) return fg_set_err(g->ctx, FG_ERR_UNSUPPORTED, "fg_gan: more than %d random segments per step", FG_RNG_MAX_SEGS);
@@ -471,11 +458,7 @@ static int gan_draw(fg_gan* g, int n_noise_rows, const float* noise_in, int B, c
         g->mask_off += (uint64_t)((s.n + 3) / 4);
         dmasks[i] = s.out;
     }
-    if (m.n == 0) return FG_OK;
     return fg_launch_rng_multi(g->ctx, m);
-}
-static bool gan_lookahead_on(const fg_gan* g) {
-    return !g_fg_dry && g->la_stream && !g->table && !gan_exchange(g) && !g->sync_bn && (g->ctx->fusion & FG_FUSE_G_LOOKAHEAD);
 }
 
 extern "C" {
@@ -517,26 +500,13 @@ int fg_gan_create(fg_ctx* ctx, fg_net* G, fg_net* D, int table_inputs, int max_b
     }
     if (!rc && !g_fg_dry && hipMemsetAsync(g->ws + g->o_opt[0], 0, (size_t)(2 * g->nP[0]) * 4, ctx->stream) != hipSuccess) rc = fg_set_err(ctx, FG_ERR_HIP, "fg_gan_create: memset");
     if (!rc && !g_fg_dry && hipMemsetAsync(g->ws + g->o_opt[1], 0, (size_t)(2 * g->nP[1]) * 4, ctx->stream) != hipSuccess) rc = fg_set_err(ctx, FG_ERR_HIP, "fg_gan_create: memset");
-    if (!rc && !g_fg_dry && !g->table) {
-        if (hipStreamCreateWithFlags(&g->la_stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&g->la_e1, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&g->la_e2, hipEventDisableTiming) != hipSuccess)
-            rc = fg_set_err(ctx, FG_ERR_HIP, "fg_gan_create: lookahead stream / events");
-    }
-    if (rc) { fg_gan_destroy(g); return rc; }
+    if (rc) { delete g; return rc; }
     gan_buckets(g, 900000);
     *out = g;
     return FG_OK;
 }
 
-int fg_gan_destroy(fg_gan* g) {
-    if (!g) return FG_OK;
-    if (g->la_stream) { (void)hipStreamSynchronize(g->la_stream); (void)hipStreamDestroy(g->la_stream); }
-    if (g->la_e1) (void)hipEventDestroy(g->la_e1);
-    if (g->la_e2) (void)hipEventDestroy(g->la_e2);
-    delete g;
-    return FG_OK;
-}
+int fg_gan_destroy(fg_gan* g) { delete g; return FG_OK; }
 
 /* the nets' own workspaces (fg_net_workspace_bytes(net, max_batch)); re-bind whenever the caller re-allocates them */
 int fg_gan_bind_workspaces(fg_gan* g, void* wsG, size_t wsG_bytes, void* wsD, size_t wsD_bytes) {
@@ -594,7 +564,7 @@ int fg_gan_buffer(const fg_gan* g, int what, long long* offset_floats, long long
     if (!g) return FG_ERR_INVALID;
     long long o = -1, c = 0;
     switch (what) {
-        case FG_GAN_D_INPUT: o = g->o_dinput_cur; c = g->maxB * g->img; break;      // the batch of the LAST closure
+        case FG_GAN_D_INPUT: o = g->o_dinput; c = g->maxB * g->img; break;
         case FG_GAN_NOISE: o = g->o_noise; c = g->maxB * g->nz_elems; break;
         case FG_GAN_D_GRAD_INPUT: o = g->o_gx; c = g->maxB * g->img; break;
         case FG_GAN_LOSS: o = g->o_loss; c = 2; break;
@@ -645,12 +615,6 @@ int fg_step_D(fg_gan* g, int B, const float* real, const float* cond_real, const
     // C5: the fakes come from G in TRAIN mode (BatchNorm batch statistics over B/2; running statistics move)
     rc = fg_net_forward_to(g->G, h, gin, g->wsG, g->wsG_bytes, 1, nullptr, 0, &off, dinput + (long long)h * g->img);
     if ((rc = gan_drain(g, g->G, rc, true))) return rc;
-    g->o_dinput_cur = g->o_dinput;
-    g->la_valid = false;
-    if (gan_lookahead_on(g)) {           // from here on nothing of this closure touches G, its workspace or the noise buffer
-        FG_HIP(ctx, hipEventRecord(g->la_e1, ctx->stream));
-        g->la_valid = true;
-    }
     const float* din = dinput;
     if (g->table) {                      // nn.CAddTable{x, cond} (models_c2f.lua:240) over [real | fake] x [cond_real | cond_fake]
         if ((rc = fg_launch_add_halves(ctx, real, cond_real, dinput + (long long)h * g->img, cond_fake, g->ws + g->o_dsum,
@@ -683,36 +647,16 @@ int fg_step_G(fg_gan* g, int B, const float* cond, const float* noise, const flo
     if (g->table && !cond) return fg_set_err(ctx, FG_ERR_INVALID, "fg_step_G: null input");
     const float* nz = nullptr;
     std::vector<const float*> dm;
-    const bool la = g->la_valid && gan_lookahead_on(g);
-    g->la_valid = false;
-    float* dinput = g->ws + (la ? g->o_dinput2 : g->o_dinput);          // `samples` (adversarial.lua:202): G's output IS D's batch
-    g->o_dinput_cur = la ? g->o_dinput2 : g->o_dinput;
-    long long off = 0;
-    if (la) {
-        // the noise and the generator forward go to the side stream, behind the D closure's own generator forward (e1) and beside
-        // whatever of that closure is still running; the masks of D (still read by its backward) are drawn on the main stream
-        hipStream_t main_stream = ctx->stream;
-        FG_HIP(ctx, hipStreamWaitEvent(g->la_stream, g->la_e1, 0));
-        ctx->stream = g->la_stream;
-        rc = gan_draw(g, B, noise, B, masks, &nz, dm, 1);
-        if (!rc) rc = fg_net_forward_to(g->G, B, nz, g->wsG, g->wsG_bytes, 1, nullptr, 0, &off, dinput);
-        hipError_t he = hipSuccess;
-        if (!rc) he = hipEventRecord(g->la_e2, g->la_stream);
-        ctx->stream = main_stream;
-        if (rc) return rc;
-        if (he != hipSuccess) return fg_set_err(ctx, FG_ERR_HIP, "fg_step_G: hipEventRecord: %s", hipGetErrorString(he));
-        FG_HIP(ctx, hipStreamWaitEvent(main_stream, g->la_e2, 0));
-        if ((rc = gan_draw(g, B, noise, B, masks, &nz, dm, 2))) return rc;
-    } else if ((rc = gan_draw(g, B, noise, B, masks, &nz, dm))) return rc;
+    if ((rc = gan_draw(g, B, noise, B, masks, &nz, dm))) return rc;
+    float* dinput = g->ws + g->o_dinput;          // `samples` (adversarial.lua:202): G's output IS D's batch
     const float* gin = nz;
     if (g->table) {
         if ((rc = fg_launch_concat(ctx, nz, cond, g->ws + g->o_ginput, (long long)B * g->gh * g->gw, 1, g->ic))) return rc;
         gin = g->ws + g->o_ginput;
     }
-    if (!la) {
-        rc = fg_net_forward_to(g->G, B, gin, g->wsG, g->wsG_bytes, 1, nullptr, 0, &off, dinput);
-        if ((rc = gan_drain(g, g->G, rc, true))) return rc;
-    }
+    long long off = 0;
+    rc = fg_net_forward_to(g->G, B, gin, g->wsG, g->wsG_bytes, 1, nullptr, 0, &off, dinput);
+    if ((rc = gan_drain(g, g->G, rc, true))) return rc;
     if ((rc = gan_finish_pending(g))) return rc;   // D's deferred update must land before D is evaluated
     const float* din = dinput;
     if (g->table) {

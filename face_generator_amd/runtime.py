@@ -62,8 +62,7 @@ class Context:
         """Optional kernel fusions (include/facegen_hip.h FG_FUSE_*): 1 = PReLU in the neighbouring contraction's epilogue,
         2 = one-pass matrix-pipe 3x3 thin-output convolution, 4 = all weight-gradient split-K sums of a backward pass in one launch,
         8 = Adam + the re-pack of every layer in one launch (measured slower: off by default), 16 = the bias gradient of a thin-input
-        convolution from its weight-gradient kernel (no separate column-sum pass), 32 = the G closure's generator forward on a side
-        stream beside the D closure's backward; default 55."""
+        convolution from its weight-gradient kernel (no separate column-sum pass); default 23."""
         self.check(self.lib.fg_set_fusion(self.h, int(flags)))
 
     def get_fusion(self):

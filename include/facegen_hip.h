@@ -51,7 +51,7 @@ int fg_get_math(fg_ctx* ctx);
 
 /* Optional kernel fusions / variants (results equal to the un-fused path up to the summation order of a reduction; exposed so
  * the parity tests and the bench can run both ways).  Default: FG_FUSE_DEFAULT; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 / FG_DEFER_WFINISH=0 /
- * FG_THIN_BIAS=0 / FG_G_LOOKAHEAD=0 in the environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
+ * FG_THIN_BIAS=0 in the environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
 enum {
     FG_FUSE_PRELU = 1,      /* an nn.PReLU between two contraction layers (models_c2f.lua:118-130, 242-255) rides on their
                              * epilogues: forward copy behind the producing layer, backward (+ slope-gradient partials) in
@@ -71,13 +71,8 @@ enum {
                              * constant 1, so the pass that streams the output gradient anyway also leaves its per-channel sums;
                              * off: a separate column-sum pass re-reads the tensor (134 MB per layer at 64x64, B = 128).  Same
                              * fp64 final reduction; the fp32 partial sums are formed in a different order (FG_THIN_BIAS=0 clears it) */
-    FG_FUSE_G_LOOKAHEAD = 32, /* fg_step_G right behind an fg_step_D (one GPU, plain nets): the generator forward of the G closure
-                             * (adversarial.lua:200-202) depends on nothing the D closure does after ITS generator forward, so it is
-                             * enqueued on a side stream beside D's forward / backward / optimizer pass and joined (one event) in
-                             * front of D's evaluation of the samples; same kernels, same inputs, bit-identical results.  The step
-                             * workspace holds a second sample batch for it.  FG_G_LOOKAHEAD=0 clears it */
-    FG_FUSE_ALL = 63,
-    FG_FUSE_DEFAULT = 55
+    FG_FUSE_ALL = 31,
+    FG_FUSE_DEFAULT = 23
 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);
@@ -277,8 +272,7 @@ int fg_comm_schedule(fg_comm* comm, char* buf, size_t len, int reset);
  *      overlapped, 2 = overlapped even on a one-rank communicator (exercises the N > 1 path on one GPU). ---- */
 enum { FG_STEP_NO_UPDATE = 1 };
 enum fg_gan_buffer_id {
-    FG_GAN_D_INPUT = 0,       /* D's batch of the LAST closure, NHWC [B][H][W][C]: real || fake (D-step), G's samples (G-step);
-                               * query the offset after the closure (the G-step may use a second batch buffer: FG_FUSE_G_LOOKAHEAD) */
+    FG_GAN_D_INPUT = 0,       /* D's batch, NHWC [B][H][W][C]: real || fake (D-step), G's samples (G-step)            */
     FG_GAN_NOISE = 1,         /* the noise the last closure used when the library drew it                              */
     FG_GAN_D_GRAD_INPUT = 2,  /* G-step: d loss / d samples                                                           */
     FG_GAN_LOSS = 3,          /* float[2]: BCE of the last D-step, of the last G-step                                  */
