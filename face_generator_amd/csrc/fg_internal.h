@@ -216,7 +216,10 @@ struct PackJob {
     int npo, npi;         // patches along the out / in channel axis (over the padded extents)
 };
 // prof_bytes: algorithmic bytes of the launch for the profile (every parameter read once, every packed element written once)
-int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params, double prof_bytes);
+// lds_floats: dynamic shared memory of the launch = max over the jobs of fg_pack_lds_floats(mode, k)
+int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params, double prof_bytes,
+                        long long lds_floats);
+long long fg_pack_lds_floats(int mode, int k);
 void fg_fold_window(int k, int pad, int* T, int* rmin);
 static inline int fg_fold_r(int parity, int d, int pad) {  // floor((parity + d - pad)/2)
     int v = parity + d - pad;
@@ -390,7 +393,7 @@ __device__ __forceinline__ float fg_adam_elem(const AdamArgs& a, const AdamScala
 // parameter is read by exactly one job; mode 9 jobs update the parameters no pack reads)
 struct fg_net;
 int fg_net_adam_step(fg_net* n, const AdamArgs& a);
-int fg_launch_adam_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const AdamArgs& a);
+int fg_launch_adam_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const AdamArgs& a, long long lds_floats);
 int fg_launch_sgd(fg_ctx*, float* p, const float* g, float* mom, long long n, float gscale, float l1mul, float l2,
                   float clamp, float lr, float momentum, float dampening, float wd, int nesterov, int first);
 int fg_launch_adagrad(fg_ctx*, float* p, const float* g, float* var, long long n, float gscale, float l1mul, float l2,

@@ -1565,7 +1565,16 @@ __device__ __forceinline__ float packed_from_taps(const WeightMap& wm, const flo
     return s;
 }
 
-#define PK_ROW (16 * 49 + 1)    // LDS row of one out-channel: 16 in-channels x up to 7x7 taps, +1 so rows fall on distinct banks
+// LDS row of one out-channel in a mode-7 job: 16 in-channels x k*k taps, +1 so rows fall on distinct banks.  Round 4: the staging
+// area is DYNAMIC shared memory sized for the largest job of the net (fg_pack_lds_floats) -- as a static 16 x (16 x 49 + 1) array it
+// took 50 KB in every block, three blocks per CU, whatever the net's kernels were (3x3 needs 9 KB, the 16^3 brick of mode 10 17 KB)
+#define PK_ROW_OF(kk) (16 * (kk) + 1)
+long long fg_pack_lds_floats(int mode, int k) {
+    if (mode == 7) return 16LL * PK_ROW_OF(k * k);
+    if (mode == 8) return 32 * 33;
+    if (mode == 10) return 16 * 273;
+    return 0;
+}
 // ADAM = true: the fused optimizer + re-pack launch.  Every weight a job reads is the freshly UPDATED value of that element
 // (fg_adam_elem: penalty, clamp, Adam; parameter and moments written back) -- each parameter is read by exactly one thread of
 // exactly one job, so the update happens once.  `params` is the flat parameter vector (ADAM: == ad.p).
@@ -1577,7 +1586,7 @@ __device__ __forceinline__ float pk_load(const float* __restrict__ params, const
 template <bool ADAM>
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, int njobs, long long total,
                                                         const float* __restrict__ params, const AdamArgs ad, const AdamScalars ak) {
-    __shared__ float taps[16 * PK_ROW];
+    extern __shared__ float taps[];
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     int j = 0;
     {   // block-uniform job lookup (every job's count is a multiple of 256)
@@ -1595,6 +1604,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         // 16 coalesced runs into LDS; every thread then forms the (tap-folded) values of its pair from LDS and writes them
         // with the in-channel fastest (forward pack) and, in a second role, with the out-channel fastest (data-gradient pack).
         const int kk = wm.k * wm.k, run = 16 * kk;
+        const int PK_ROW = PK_ROW_OF(kk);
         const int patch = (int)(loc >> 8), t = (int)(loc & 255);
         const int po0 = (patch / jb.npi) * 16, pi0 = (patch % jb.npi) * 16;
         for (int e = t; e < 16 * run; e += 256) {
@@ -1732,20 +1742,21 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         jb.dst[loc] = pk_load<ADAM>(params, ad, ak, w0 + (long long)c * wm.o_hw + hw);
     }
 }
-int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params, double prof_bytes) {
+int fg_launch_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const float* params, double prof_bytes,
+                        long long lds_floats) {
     if (total == 0 || njobs == 0) return FG_OK;
     AdamArgs none = AdamArgs();
     {
         FgProfScope prof(ctx, fg_intern(ctx, "pack_jobs_kernel"), 0.0, 0.0, prof_bytes);
-        hipLaunchKernelGGL(pack_jobs_kernel<false>, dim3(fg_cdiv(total, 256)), dim3(256), 0, ctx->stream, jobs_dev, njobs, total, params,
-                           none, AdamScalars{0.f, 0.f, 0.f});
+        hipLaunchKernelGGL(pack_jobs_kernel<false>, dim3(fg_cdiv(total, 256)), dim3(256), (size_t)lds_floats * sizeof(float), ctx->stream,
+                           jobs_dev, njobs, total, params, none, AdamScalars{0.f, 0.f, 0.f});
     }
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
-int fg_launch_adam_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const AdamArgs& a) {
+int fg_launch_adam_pack_jobs(fg_ctx* ctx, const PackJob* jobs_dev, int njobs, long long total, const AdamArgs& a, long long lds_floats) {
     if (total == 0 || njobs == 0) return FG_OK;
-    hipLaunchKernelGGL(pack_jobs_kernel<true>, dim3(fg_cdiv(total, 256)), dim3(256), 0, ctx->stream, jobs_dev, njobs, total,
+    hipLaunchKernelGGL(pack_jobs_kernel<true>, dim3(fg_cdiv(total, 256)), dim3(256), (size_t)lds_floats * sizeof(float), ctx->stream, jobs_dev, njobs, total,
                        (const float*)a.p, a, fg_adam_scalars(a));
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;

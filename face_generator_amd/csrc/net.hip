@@ -108,6 +108,7 @@ struct fg_net {
     int n_jobs_all = 0;               // ... + the update-only jobs of the fused optimizer launch
     long long jobs_total_all = 0;
     bool adam_fusable = false;
+    long long pack_lds_floats = 64;   // dynamic shared memory of the re-pack launch: the largest staging area any of its jobs needs
     bool park_w = true;               // FG_FUSE_WFINISH_BATCH at creation: the workspace reserves room for parked weight-gradient partials
 };
 
@@ -768,7 +769,7 @@ extern "C++" int fg_net_adam_step(fg_net* n, const AdamArgs& a) {
         n->dirty = true;
         return rc;
     }
-    const int rc = fg_launch_adam_pack_jobs(n->ctx, n->jobs_dev, n->n_jobs_all, n->jobs_total_all, a);
+    const int rc = fg_launch_adam_pack_jobs(n->ctx, n->jobs_dev, n->n_jobs_all, n->jobs_total_all, a, n->pack_lds_floats);
     if (rc) { n->dirty = true; return rc; }
     n->dirty = false;
     n->planes_valid = false;
@@ -844,6 +845,8 @@ static int build_pack_jobs(fg_net* n) {
     }
     n->n_jobs = (int)jobs.size();
     n->jobs_total = start;
+    n->pack_lds_floats = 64;
+    for (auto& j : jobs) { const long long f = fg_pack_lds_floats(j.mode, j.wm.k); if (f > n->pack_lds_floats) n->pack_lds_floats = f; }
     // the fused optimizer + re-pack launch (fg_net_adam_step): possible when every pack job reads each of its weights once
     // (all but the generic modes 0 / 1); the parameters NO job reads get update-only jobs (mode 9) behind the pack jobs
     n->adam_fusable = true;
@@ -875,7 +878,8 @@ static int build_pack_jobs(fg_net* n) {
 }
 
 static int pack_all(fg_net* n) {
-    int rc = fg_launch_pack_jobs(n->ctx, n->jobs_dev, n->n_jobs, n->jobs_total, n->params, 4.0 * ((double)n->n_params + (double)n->packed_total));
+    int rc = fg_launch_pack_jobs(n->ctx, n->jobs_dev, n->n_jobs, n->jobs_total, n->params, 4.0 * ((double)n->n_params + (double)n->packed_total),
+                                 n->pack_lds_floats);
     if (rc) return rc;
     n->dirty = false;
     n->planes_valid = false;
