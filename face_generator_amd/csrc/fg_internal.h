@@ -214,7 +214,6 @@ struct PackJob {
     float* dst2;          // data-gradient pack
     int rows2, cols2;     // its padded dims (rows = in-channels, cols = out-channels)
     int npo, npi;         // patches along the out / in channel axis (over the padded extents)
-    int split;            // mode 7: blocks per patch, each forming its share of the (parity, tap) groups (0 / 1: one block)
 };
 // prof_bytes: algorithmic bytes of the launch for the profile (every parameter read once, every packed element written once)
 // lds_floats: dynamic shared memory of the launch = max over the jobs of fg_pack_lds_floats(mode, k)

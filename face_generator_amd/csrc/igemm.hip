@@ -1605,12 +1605,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         // with the in-channel fastest (forward pack) and, in a second role, with the out-channel fastest (data-gradient pack).
         const int kk = wm.k * wm.k, run = 16 * kk;
         const int PK_ROW = PK_ROW_OF(kk);
-        // (round 4) a patch of a tap-folded layer is 2 x 36 stores per thread behind one another, and the generator has only 256 such
-        // patches: `split` blocks share a patch's (parity, tap) groups (each stages the patch itself: 16 x 16 x k*k floats)
-        const int nsplit = jb.split > 1 ? jb.split : 1;
-        const int blk = (int)(loc >> 8), t = (int)(loc & 255);
-        const int patch = blk / nsplit, part = blk - patch * nsplit;
-        if (ADAM && part) return;      // the fused optimizer launch reads (= updates) every weight once: one block per patch does it all
+        const int patch = (int)(loc >> 8), t = (int)(loc & 255);
         const int po0 = (patch / jb.npi) * 16, pi0 = (patch % jb.npi) * 16;
         for (int e = t; e < 16 * run; e += 256) {
             const int a = e / run, off = e - a * run;
@@ -1619,14 +1614,13 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         }
         __syncthreads();
         const int ng = wm.P * wm.G;
-        const int pg0 = ADAM ? 0 : part * ng / nsplit, pg1 = ADAM ? ng : (part + 1) * ng / nsplit;
         {   // forward pack [p][g][O_pad][I_pad]: lanes run over the in-channel
             const int a = t >> 4, b = t & 15, po = po0 + a, pi = pi0 + b;
             if (po < jb.rows && pi < jb.cols) {
                 const float* w = taps + a * PK_ROW + b * kk;
                 float* d = jb.dst + (size_t)po * jb.cols + pi;
                 const size_t tile = (size_t)jb.rows * jb.cols;
-                for (int pg = pg0; pg < pg1; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
+                for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
             }
         }
         {   // data-gradient pack [p][g][I_pad][O_pad]: lanes run over the out-channel
@@ -1635,7 +1629,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                 const float* w = taps + a * PK_ROW + b * kk;
                 float* d = jb.dst2 + (size_t)pi * jb.cols2 + po;
                 const size_t tile = (size_t)jb.rows2 * jb.cols2;
-                for (int pg = pg0; pg < pg1; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
+                for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
             }
         }
         return;

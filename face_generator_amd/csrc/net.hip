@@ -810,20 +810,7 @@ static int build_pack_jobs(fg_net* n) {
                 j.dst2 = s.wp_bwd; j.rows2 = rb; j.cols2 = cb;
                 const int opad = rf > cb ? rf : cb, ipad = cf > rb ? cf : rb;
                 j.npo = (opad + 15) / 16; j.npi = (ipad + 15) / 16;
-                // blocks per patch: enough that a layer's patches fill the chip twice, never more than its (parity, tap) groups;
-                // (in the fused optimizer launch, FG_FUSE_ADAM_PACK, one block per patch does it all: every weight is read -- and updated
-                // -- exactly once)
-                {
-                    static int env = -2;
-                    if (env == -2) { const char* e = getenv("FG_PACK_SPLIT"); env = e ? atoi(e) : -1; if (env == 0) env = -1; }
-                    const long long patches = (long long)j.npo * j.npi, ng = (long long)wm.P * wm.G;
-                    long long sp = env >= 0 ? env : (512 + patches - 1) / patches;
-                    if (sp > ng) sp = ng;
-                    if (sp > 12) sp = 12;
-                    if (sp < 1) sp = 1;
-                    j.split = (int)sp;
-                }
-                j.start = start; j.count = (long long)j.npo * j.npi * j.split * 256;
+                j.start = start; j.count = (long long)j.npo * j.npi * 256;
                 jobs.push_back(j);
                 start += j.count;
             } else if (wm.k == 1 && wm.i_hw > 1 && wm.i_c > 0) {   // Linear behind a View: 16 x 16 x 16 bricks (mode 10)
