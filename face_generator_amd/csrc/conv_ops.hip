@@ -94,6 +94,13 @@ static void choose_igemm(long long M, int Npad, int ksteps, int P, int math, int
 }
 static void choose_wgrad(long long M, int Cout, int Cin, int G, int P, int* tile, int* S, int* mper, int* Npad, int* Cpad) {
     int bt = (Cout >= 128 && Cin >= 128) ? 128 : 64;
+    {   // a Linear layer reduces over the B samples only (M = 128): with 128 x 128 tiles Linear(2048, 512) is 64 blocks of 8 K-steps
+        // on a quarter of the chip, all prologue and epilogue (24 us for 0.27 GFLOP); 64 x 64 tiles give 256 blocks (round 4;
+        // FG_LINEAR_WGRAD64=0 switches back)
+        static int on = -1;
+        if (on < 0) { const char* e = getenv("FG_LINEAR_WGRAD64"); on = e ? atoi(e) : 1; }
+        if (on && G == 1 && P == 1 && M <= 256 && (long long)Cout * Cin <= (1LL << 21)) bt = 64;     // (not the 65536 x 512 layer of models_c2f.lua:262: 8.6 GFLOP)
+    }
     *tile = bt == 128 ? 0 : 2;
     *Npad = fg_round_up(Cout, bt);
     *Cpad = fg_round_up(Cin, bt);
