@@ -167,7 +167,7 @@ def load_traffic(kernel, live=True):
         tj = live_traffic(kernel)
         if tj is not None:
             return tj
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:

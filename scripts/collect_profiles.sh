@@ -3,7 +3,7 @@
 # workloads, PMC passes on the dominant kernels.  usage (through gpurun): bash scripts/collect_profiles.sh <tag>
 #   -> gpurun_out/<tag>_*; copy what is to be judged into profiles/
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $OUT

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-end GPU call: the whole -m gpu suite, smoke(), then the evidence set (scripts/collect_profiles.sh)
 set -u
-OUT=gpurun_out; TAG=${1:-r03}
+OUT=gpurun_out; TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; mkdir -p $OUT
 T0=$(date +%s)
 timeout 1500 python -m pytest tests -m gpu -q --durations=8 > $OUT/${TAG}_gpu_tests.log 2>&1
