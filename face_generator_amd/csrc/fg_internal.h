@@ -293,8 +293,12 @@ int fg_launch_maxpool_forward(fg_ctx*, const float* x, float* y, int B, int H, i
 int fg_launch_maxpool_backward(fg_ctx*, const float* x, const float* gy, float* gx, int B, int H, int W, int C);
 // SpatialMaxPooling backward + the backward of the nn.PReLU in front of it in one pass: xpre = the PReLU's input (the
 // pooled tensor prelu(xpre) is re-evaluated, bit-identical to the forward), gx = gradient wrt xpre
+// mask / mscale (optional): the nn.Dropout behind the pool -- gy is multiplied by mask[i] * mscale first
 int fg_launch_maxpool_prelu_backward(fg_ctx*, const float* xpre, const float* gy, const float* slope, float* gx,
-                                     float* gslope, int B, int H, int W, int C, float* scratch);
+                                     float* gslope, int B, int H, int W, int C, float* scratch, const float* mask = nullptr, float mscale = 1.f);
+// PReLU -> SpatialMaxPooling(2, 2) [-> Dropout] forward from the pre-activation in one pass (mask: on the pooled tensor)
+int fg_launch_actmaxpool_forward(fg_ctx*, const float* x, const float* slope, const float* mask, float mscale, float* y, int B, int H,
+                                 int W, int C);
 int fg_launch_mul_mask(fg_ctx*, const float* x, const float* mask, float scale, float* y, long long n);
 int fg_launch_concat(fg_ctx*, const float* a, const float* b, float* out, long long npix, int ca, int cb);
 int fg_launch_split(fg_ctx*, const float* g, float* ga, float* gb, long long npix, int ca, int cb);

@@ -21,6 +21,7 @@ enum StageKind {
     ST_BNPRELU,       // SpatialBatchNormalization [+PReLU]
     ST_PRELU,         // PReLU [+Dropout]
     ST_ACTPOOL,       // PReLU + SpatialDropout + AvgPool2
+    ST_ACTMAXPOOL,    // PReLU + SpatialMaxPooling(2, 2) [+ Dropout] (models_c2f.lua:245-246, 251-253): one pass forward, one backward
     ST_SIGMOID,
     ST_LEAKYRELU,
     ST_UPSAMPLE,
@@ -331,6 +332,11 @@ static int backward_run_stages(fg_net* n) {
             case ST_REVIEW: if (need_gx) rc = fg_launch_nchw_review(ctx, gcur, gxb, B, s.ih, s.iw, s.ic, s.factor, 1); break;
             case ST_AVGPOOL: if (need_gx) rc = fg_launch_avgpool_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
             case ST_SDROPOUT: if (need_gx) rc = fg_launch_scale_mask_nc(ctx, gcur, mask, 1.f, gxb, B, s.ih * s.iw, s.ic); break;
+            case ST_ACTMAXPOOL:
+                if (need_gx)
+                    rc = fg_launch_maxpool_prelu_backward(ctx, xin, gcur, P + s.slope_off, gxb, want_p ? Gp + s.slope_off : nullptr, B, s.ih,
+                                                          s.iw, s.ic, scratch, mask, s.mask_kind ? 1.f / (1.f - s.p) : 1.f);
+                break;
             case ST_MAXPOOL:
                 if (need_gx && pf && !actb.mask) {     // pooled tensor = prelu(actb.x): both backward passes in one
                     rc = fg_launch_maxpool_prelu_backward(ctx, actb.x, gcur, actb.slope, gxb, actb.gslope, B, s.ih, s.iw, s.ic, scratch);
@@ -461,6 +467,11 @@ static int forward_run(fg_net* n, long long* out_offset) {
                 rc = fg_launch_scale_mask_nc(ctx, cur, train ? mask : nullptr, train ? 1.f : 1.f - s.p, y, B, s.ih * s.iw, s.ic);
                 break;
             case ST_MAXPOOL: rc = fg_launch_maxpool_forward(ctx, cur, y, B, s.ih, s.iw, s.ic); break;
+            case ST_ACTMAXPOOL: {
+                const float* m = (s.mask_kind && n->run_train) ? n->mask_ptrs[s.mask_idx] : nullptr;     // evaluate(): Dropout is the identity
+                rc = fg_launch_actmaxpool_forward(ctx, cur, P + s.slope_off, m, s.mask_kind ? 1.f / (1.f - s.p) : 1.f, y, B, s.ih, s.iw, s.ic);
+                break;
+            }
             case ST_DROPOUT:
                 rc = fg_launch_mul_mask(ctx, cur, train ? mask : nullptr, train ? 1.f / (1.f - s.p) : 1.f, y,
                                         (long long)B * s.ic * s.ih * s.iw);
@@ -602,9 +613,16 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
                 s.slope_off = poff; poff += 1;
                 n->layers[i].w_off = s.slope_off; n->layers[i].w_n = 1;
                 s.has_prelu = 1; s.oc = c; s.oh = h; s.ow = w;
+                static int amp_on = -1;      // A/B switch (round 4; default on): FG_ACTMAXPOOL=0 keeps PReLU / MaxPool / Dropout apart
+                if (amp_on < 0) { const char* e = getenv("FG_ACTMAXPOOL"); amp_on = e ? atoi(e) : 1; }
                 if (i + 2 < nl && L[i + 1].type == FG_SPATIAL_DROPOUT && L[i + 2].type == FG_AVGPOOL2 && c % 4 == 0 &&
                     h % 2 == 0 && w % 2 == 0) {
                     s.kind = ST_ACTPOOL; s.p = L[i + 1].p; s.mask_kind = 1; s.oh = h / 2; s.ow = w / 2; consumed = 3;
+                } else if (amp_on && i + 1 < nl && L[i + 1].type == FG_MAXPOOL2 && c % 4 == 0 && h % 2 == 0 && w % 2 == 0 && i > 0) {
+                    // PReLU -> MaxPool [-> Dropout]: the pooled (and masked) tensor is all the next layer reads, prelu(x) at full
+                    // resolution is never materialised (the producing layer stores x alone); backward re-evaluates it from x
+                    s.kind = ST_ACTMAXPOOL; s.oh = h / 2; s.ow = w / 2; consumed = 2;
+                    if (i + 2 < nl && L[i + 2].type == FG_DROPOUT) { s.p = L[i + 2].p; s.mask_kind = 2; consumed = 3; }
                 } else if (i + 1 < nl && L[i + 1].type == FG_DROPOUT) {
                     s.kind = ST_PRELU; s.p = L[i + 1].p; s.mask_kind = 2; consumed = 2;
                 } else s.kind = ST_PRELU;
@@ -726,6 +744,7 @@ int fg_net_num_masks(const fg_net* n) { return n ? n->n_masks : 0; }
 long long fg_net_mask_elems(const fg_net* n, int mi, int batch) {
     if (!n || mi < 0 || mi >= n->n_masks) return -1;
     const Stage& s = n->st[n->mask_stage[mi]];
+    if (s.kind == ST_ACTMAXPOOL) return (long long)batch * s.oc * s.oh * s.ow;       // the Dropout acts on the POOLED tensor
     return s.mask_kind == 1 ? (long long)batch * s.ic : (long long)batch * s.ic * s.ih * s.iw;
 }
 float fg_net_mask_keep(const fg_net* n, int mi) {

@@ -1197,9 +1197,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 }
 // maxpool backward + the backward of the PReLU in front of it: the pooled tensor was prelu(xpre) (re-evaluated with
 // prelu_fwd_kernel's expression, so the argmax is the forward's), gx = gradient wrt xpre, slope-gradient partials per block
+// (mask / mscale: the nn.Dropout BEHIND the pool, on the pooled tensor: its backward is one multiply of the incoming gradient)
 __global__ __launch_bounds__(256) void maxpool_prelu_bwd_kernel(const float* __restrict__ xpre, const float* __restrict__ gy,
                                                                 const float* __restrict__ slope, float* __restrict__ gx,
-                                                                float* __restrict__ part, int B, int H, int W, int C) {
+                                                                float* __restrict__ part, int B, int H, int W, int C,
+                                                                const float* __restrict__ mask, float mscale) {
     __shared__ float sh[4];
     const float a = slope[0];
     const int H2 = H >> 1, W2 = W >> 1;
@@ -1221,7 +1223,7 @@ __global__ __launch_bounds__(256) void maxpool_prelu_bwd_kernel(const float* __r
         float m = xv[0] > 0.f ? xv[0] : a * xv[0];
 #pragma unroll
         for (int k = 1; k < 4; ++k) { const float v = xv[k] > 0.f ? xv[k] : a * xv[k]; if (v > m) { m = v; am = k; } }
-        const float g = gy[i];
+        const float g = mask ? gy[i] * (mask[i] * mscale) : gy[i];           // mul_mask_kernel's expression
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool pos = xv[k] > 0.f;
@@ -1234,7 +1236,7 @@ __global__ __launch_bounds__(256) void maxpool_prelu_bwd_kernel(const float* __r
     if (threadIdx.x == 0 && part) part[blockIdx.x] = s;
 }
 int fg_launch_maxpool_prelu_backward(fg_ctx* ctx, const float* xpre, const float* gy, const float* slope, float* gx,
-                                     float* gslope, int B, int H, int W, int C, float* scratch) {
+                                     float* gslope, int B, int H, int W, int C, float* scratch, const float* mask, float mscale) {
     if (H % 2 || W % 2) return fg_set_err(ctx, FG_ERR_INVALID, "maxpool: even H/W");
     long long n = (long long)B * (H / 2) * (W / 2) * C;
     if (n == 0) return FG_OK;
@@ -1242,13 +1244,56 @@ int fg_launch_maxpool_prelu_backward(fg_ctx* ctx, const float* xpre, const float
     if (grid.x > 1024) grid.x = 1024;
     float* dpart = gslope ? fg_defer_alloc(ctx, grid.x) : nullptr;
     float* part = dpart ? dpart : (gslope ? scratch : nullptr);
-    hipLaunchKernelGGL(maxpool_prelu_bwd_kernel, grid, dim3(256), 0, ctx->stream, xpre, gy, slope, gx, part, B, H, W, C);
+    hipLaunchKernelGGL(maxpool_prelu_bwd_kernel, grid, dim3(256), 0, ctx->stream, xpre, gy, slope, gx, part, B, H, W, C, mask, mscale);
     FG_CHECK_LAUNCH(ctx);
     if (dpart) { fg_defer_push(ctx, dpart, (int)grid.x, 1, 0.f, gslope); return FG_OK; }
     if (gslope) {
         hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(1024), 0, ctx->stream, part, (int)grid.x, gslope, 0.f);
         FG_CHECK_LAUNCH(ctx);
     }
+    return FG_OK;
+}
+// PReLU -> SpatialMaxPooling(2, 2) [-> Dropout] forward in one pass over the pre-activation: y = max over the window of
+// prelu_fwd_kernel's expression (the same one maxpool_prelu_bwd_kernel re-evaluates for its argmax), times mul_mask_kernel's
+// mask[i] * mscale.  Replaces a second full-resolution store in the producing layer's epilogue + maxpool_fwd + mul_mask.
+__global__ __launch_bounds__(256) void actmaxpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope,
+                                                             const float* __restrict__ mask, float mscale, float* __restrict__ y,
+                                                             int B, int H, int W, int C) {
+    const float a = slope[0];
+    const int H2 = H >> 1, W2 = W >> 1, C4 = C >> 2;
+    const long long total = (long long)B * H2 * W2 * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long t = i / C4;
+        const int w2 = (int)(t % W2); t /= W2;
+        const int h2 = (int)(t % H2);
+        const int b = (int)(t / H2);
+        const float4* px = (const float4*)(x + (((size_t)b * H + 2 * h2) * W + 2 * w2) * C) + c4;
+        const float4 v0 = px[0], v1 = px[C4], v2 = px[(size_t)W * C4], v3 = px[(size_t)W * C4 + C4];
+        auto act = [a](float v) { return v > 0.f ? v : a * v; };
+        float4 m;
+        m.x = fmaxf(fmaxf(act(v0.x), act(v1.x)), fmaxf(act(v2.x), act(v3.x)));
+        m.y = fmaxf(fmaxf(act(v0.y), act(v1.y)), fmaxf(act(v2.y), act(v3.y)));
+        m.z = fmaxf(fmaxf(act(v0.z), act(v1.z)), fmaxf(act(v2.z), act(v3.z)));
+        m.w = fmaxf(fmaxf(act(v0.w), act(v1.w)), fmaxf(act(v2.w), act(v3.w)));
+        if (mask) {
+            const float4 k = ((const float4*)mask)[i];
+            m.x = m.x * (k.x * mscale); m.y = m.y * (k.y * mscale); m.z = m.z * (k.z * mscale); m.w = m.w * (k.w * mscale);
+        }
+        ((float4*)y)[i] = m;
+    }
+}
+int fg_launch_actmaxpool_forward(fg_ctx* ctx, const float* x, const float* slope, const float* mask, float mscale, float* y, int B,
+                                 int H, int W, int C) {
+    if (C % 4 || H % 2 || W % 2) return fg_set_err(ctx, FG_ERR_INVALID, "actmaxpool: C%%4, even H/W");
+    const long long n = (long long)B * (H / 2) * (W / 2) * (C / 4);
+    if (n == 0) return FG_OK;
+    {
+        const double nx = 4.0 * B * H * W * C;
+        FgProfScope prof(ctx, fg_intern(ctx, "actmaxpool_fwd_kernel"), 0.0, 0.0, nx + nx / 4 * (mask ? 2.0 : 1.0));
+        hipLaunchKernelGGL(actmaxpool_fwd_kernel, FG_GRID(n, 256), dim3(256), 0, ctx->stream, x, slope, mask, mscale, y, B, H, W, C);
+    }
+    FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
 int fg_launch_maxpool_forward(fg_ctx* ctx, const float* x, float* y, int B, int H, int W, int C) {

@@ -70,7 +70,16 @@ def adopt_device_branches(ctx, dn, onet, clear=False, params=None, also=()):
                 for mm in [m] + [t[i] for t in twins]:
                     mm.indices_override = None
                 continue
-            x = _nchw(dn.layer_output(i - 1))
+            try:
+                x = _nchw(dn.layer_output(i - 1))
+            except Exception:
+                # PReLU + MaxPool [+ Dropout] is ONE stage of the device plan (round 4): prelu(x) is not materialised -- re-evaluate
+                # it in float32 from the stage's input and the slope, prelu_fwd_kernel's expression (what the device's pool saw)
+                assert isinstance(mods[i - 1], O.PReLU)
+                xpre = _nchw(dn.layer_output(i - 2)).astype(np.float32)
+                wo, wn, bo, bn = dn.param_offsets(i - 1)
+                a = np.float32(P[wo:wo + 1].cpu().numpy()[0])
+                x = np.where(xpre > 0, xpre, (a * xpre).astype(np.float32)).astype(np.float32)
             n, c, h, w = x.shape
             blk = x.reshape(n, c, h // 2, 2, w // 2, 2).transpose(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
             idx = blk.argmax(axis=-1)                           # first max in scan order, like the kernel
