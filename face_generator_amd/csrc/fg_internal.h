@@ -309,7 +309,12 @@ int fg_launch_add_halves(fg_ctx*, const float* a0, const float* b0, const float*
 // immediate final); registration of one final job; flush = run all registered jobs in one launch
 int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);   // out[c] = beta*out[c] + sum_r part[r][c]
 // the same over C1 + C2 columns: the first C1 sums go to out1, the other C2 to out2 (beta = 0)
+// out[c * o_hw + hw] = sum_r x[r][hw * o_c + c]: the bias gradient of a Linear behind a View, reference order, one launch (M small)
+int fg_launch_colsum_perm(fg_ctx* ctx, const float* x, int M, int C, int o_c, int o_hw, float* out);
 int fg_launch_colsum_final2(fg_ctx* ctx, const float* part, int nrb, int C1, float* out1, int C2, float* out2);
+// the slabs of a thin weight gradient ([tap][s][c] columns) summed straight into gradW[O][I][k][k] (mode: fg_launch_thin_unpack_grad's);
+// C2 further columns (the bias row) go to out2
+int fg_launch_colsum_final_thin(fg_ctx* ctx, const float* part, int nrb, float* gradW, int O, int I, int k, int mode, int C2, float* out2);
 float* fg_defer_alloc(fg_ctx* ctx, long long floats);
 void fg_defer_push(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);
 int fg_defer_flush(fg_ctx* ctx);
@@ -330,7 +335,8 @@ int fg_launch_thin_out_conv(fg_ctx*, const float* in, const float* Wp, const flo
 // wide_colsum / colsum_done (optional, both or neither): sum_pix wide[pix][c] from the ones column of the matrix-pipe kernels
 // (*colsum_done = 1 when produced); the slabs then have k*k*Cs + 1 rows -- scratch >= (FG_THIN_WGRAD_BLOCKS + 1) * (k*k*Cs + 1) * Cw
 int fg_launch_thin_wgrad(fg_ctx*, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
-                         int Cw, int k, int shift_thin, float* scratch, float* wide_colsum = nullptr, int* colsum_done = nullptr);
+                         int Cw, int k, int shift_thin, float* scratch, float* wide_colsum = nullptr, int* colsum_done = nullptr,
+                         float* gradW_ref = nullptr, int unpack_mode = 0, int* unpacked = nullptr);
 // repack between reference [O][I][k][k] and thin layouts
 // mode 0: Wp[tap][s=I][c=O] (thin-in fwd, I small)      mode 1: Wp[tap][s=O][c=I] (thin-out fwd, O small)
 int fg_launch_thin_pack(fg_ctx*, const float* W, float* Wp, int O, int I, int k, int mode);

@@ -233,11 +233,14 @@ static int backward_run_stages(fg_net* n) {
                                            scratch, n->scratch_floats, s.x6_valid ? (const void*)(ws + s.x6_off) : nullptr,
                                            &gy6, &gy6_used);
                     if (!rc && s.bias_packed) {  // bias grad in NHWC feature order -> reference order
-                        float* tb = scratch + (long long)CR_ROWBLOCKS_MAX * g.Cout;
-                        FgDefer* dsv = ctx->defer; ctx->defer = nullptr;      // `tb` is consumed right away: no deferral
-                        rc = fg_launch_colsum(ctx, gcur, (long long)B, g.Cout, 0.f, tb, scratch);
-                        ctx->defer = dsv;
-                        if (!rc) rc = fg_launch_nhwc_to_nchw(ctx, tb, Gp + s.b_off, 1, g.o_c, g.o_hw, 1);
+                        if (B <= 1024) rc = fg_launch_colsum_perm(ctx, gcur, B, g.Cout, g.o_c, g.o_hw, Gp + s.b_off);
+                        else {
+                            float* tb = scratch + (long long)CR_ROWBLOCKS_MAX * g.Cout;
+                            FgDefer* dsv = ctx->defer; ctx->defer = nullptr;      // `tb` is consumed right away: no deferral
+                            rc = fg_launch_colsum(ctx, gcur, (long long)B, g.Cout, 0.f, tb, scratch);
+                            ctx->defer = dsv;
+                            if (!rc) rc = fg_launch_nhwc_to_nchw(ctx, tb, Gp + s.b_off, 1, g.o_c, g.o_hw, 1);
+                        }
                     }
                 }
                 // the fused PReLU + SpatialDropout + AvgPool backward in front of this layer sums split-K partials itself
@@ -258,9 +261,10 @@ static int backward_run_stages(fg_net* n) {
                 if (want_p) {
                     // slabs of k*k*Cin + 1 rows: the extra row is the bias gradient (the ones column of the matrix-pipe kernel)
                     float* gw = scratch + (long long)FG_THIN_WGRAD_BLOCKS * (k * k * s.ic + 1) * s.oc;
-                    int bias_done = 0;
-                    rc = fg_launch_thin_wgrad(ctx, xin, gcur, gw, B, s.ih, s.iw, s.ic, s.oc, k, +1, scratch, Gp + s.b_off, &bias_done);
-                    if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 0, 0.f);
+                    int bias_done = 0, unpacked = 0;
+                    rc = fg_launch_thin_wgrad(ctx, xin, gcur, gw, B, s.ih, s.iw, s.ic, s.oc, k, +1, scratch, Gp + s.b_off, &bias_done,
+                                              Gp + s.w_off, 0, &unpacked);
+                    if (!rc && !unpacked) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 0, 0.f);
                     if (!rc && !bias_done) rc = fg_launch_colsum(ctx, gcur, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
                 }
                 if (!rc && need_gx)
@@ -276,8 +280,10 @@ static int backward_run_stages(fg_net* n) {
                 }
                 if (!rc && want_p) {
                     float* gw = scratch + (long long)FG_THIN_WGRAD_BLOCKS * k * k * s.oc * s.ic;
-                    rc = fg_launch_thin_wgrad(ctx, gpre, xin, gw, B, s.ih, s.iw, s.oc, s.ic, k, -1, scratch);
-                    if (!rc) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 1, 0.f);
+                    int unpacked = 0;
+                    rc = fg_launch_thin_wgrad(ctx, gpre, xin, gw, B, s.ih, s.iw, s.oc, s.ic, k, -1, scratch, nullptr, nullptr,
+                                              Gp + s.w_off, 1, &unpacked);
+                    if (!rc && !unpacked) rc = fg_launch_thin_unpack_grad(ctx, gw, Gp + s.w_off, s.geom.Cout, s.geom.Cin, k, 1, 0.f);
                     if (!rc) rc = fg_launch_colsum(ctx, gpre, (long long)B * s.oh * s.ow, s.oc, 0.f, Gp + s.b_off, scratch);
                 }
                 if (!rc && need_gx) {

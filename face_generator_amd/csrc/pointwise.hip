@@ -170,12 +170,11 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     colreduce_body<1>(M, C, part, [&](long long r, int c, float* acc) { acc[0] += x[r * C + c]; });
 }
 // final stage of every column reduction: block = 64 columns x 16 partial lanes, fp64 accumulate
-// (columns >= C1 go to out2[c - C1] when out2 is given: one launch finishes two results that share their partial rows)
-__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nrb, int C, float beta,
-                                                            float* __restrict__ out, int C1 = 0, float* __restrict__ out2 = nullptr) {
-    // round 4: block = 16 columns x 64 partial lanes (was 64 x 16: the 512 slabs of a thin weight gradient were walked 32 rows per
-    // lane, one dependent-latency chain each: 17.7 us for 3.5 MB); fp64 sums of <= a few thousand fp32 values are exact to 1e-16,
-    // so the association does not show in the rounded result
+// block = 16 columns x 64 partial lanes (round 4; was 64 x 16: the 512 slabs of a thin weight gradient were walked 32 rows per lane, one
+// dependent-latency chain each: 17.7 us for 3.5 MB); fp64 sums of <= a few thousand fp32 values are exact to 1e-16, so the association
+// does not show in the rounded result.  store(c, t) writes column c's sum.
+template <class Store>
+__device__ __forceinline__ void colsum_final_body(const float* __restrict__ part, int nrb, int C, Store store) {
     __shared__ double sh[64][16];
     const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cx;
@@ -195,9 +194,29 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
         double t = 0.0;
 #pragma unroll
         for (int i = 0; i < 64; ++i) t += sh[i][cx];
-        float* o = (out2 && c >= C1) ? out2 + (c - C1) : out + c;
-        *o = (beta == 0.f) ? (float)t : beta * (*o) + (float)t;
+        store(c, (float)t);
     }
+}
+// (columns >= C1 go to out2[c - C1] when out2 is given: one launch finishes two results that share their partial rows)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, int nrb, int C, float beta,
+                                                            float* __restrict__ out, int C1 = 0, float* __restrict__ out2 = nullptr) {
+    colsum_final_body(part, nrb, C, [&](int c, float t) {
+        float* o = (out2 && c >= C1) ? out2 + (c - C1) : out + c;
+        *o = (beta == 0.f) ? t : beta * (*o) + t;
+    });
+}
+// the slabs of a thin weight gradient, [tap][s][c] columns, finished straight into the reference layout gradW[O][I][k][k]
+// (thin_unpack_grad_kernel's index map: mode 0 = thin-input layer, s = I, c = O; mode 1 = thin-output layer, s = O, c = I), beta = 0;
+// columns >= C1 (the ones-column row: a bias gradient) go to out2
+__global__ __launch_bounds__(1024) void colsum_final_thin_kernel(const float* __restrict__ part, int nrb, int C, float* __restrict__ gradW,
+                                                                 int O, int I, int kk, int mode, int C1, float* __restrict__ out2) {
+    colsum_final_body(part, nrb, C, [&](int col, float t) {
+        if (col >= C1) { out2[col - C1] = t; return; }
+        const int Cs = mode == 0 ? I : O, Cw = mode == 0 ? O : I;
+        const int c = col % Cw, ts = col / Cw, s = ts % Cs, tap = ts / Cs;
+        const int o = mode == 0 ? c : s, i = mode == 0 ? s : c;
+        gradW[((size_t)o * I + i) * kk + tap] = t;
+    });
 }
 // ---- deferred finals (see FgDefer): all jobs of a backward pass in one launch; block -> job by a scan over <= 48 entries
 struct FgFinalBatch { FgFinalJob jobs[FG_DEFER_MAX]; int n; };
@@ -280,6 +299,36 @@ int fg_defer_flush(fg_ctx* ctx) {
 }
 int fg_launch_colsum_final(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out) {
     hipLaunchKernelGGL(colsum_final_kernel, dim3(fg_cdiv(C, 16)), dim3(1024), 0, ctx->stream, part, nrb, C, beta, out, 0, (float*)nullptr);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+// bias gradient of a Linear whose output is viewed as [o_c][o_hw] (models.lua:58-59): column sums of gy [M][C] in the device's NHWC
+// feature order j = hw * o_c + c, written in the reference's order c * o_hw + hw -- one launch for a few-hundred-row reduction
+// (was: partial sums, final, transposition: three launches for 8 192 floats).  fp64 accumulation in row order.
+__global__ __launch_bounds__(256) void colsum_perm_kernel(const float* __restrict__ x, int M, int C, int o_c, int o_hw, float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= C) return;
+    double s = 0.0;
+    int r = 0;
+    for (; r + 4 <= M; r += 4) {
+        const float v0 = x[(size_t)r * C + j], v1 = x[(size_t)(r + 1) * C + j], v2 = x[(size_t)(r + 2) * C + j], v3 = x[(size_t)(r + 3) * C + j];
+        s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+    }
+    for (; r < M; ++r) s += (double)x[(size_t)r * C + j];
+    const int hw = j / o_c, c = j - hw * o_c;
+    out[(size_t)c * o_hw + hw] = (float)s;
+}
+int fg_launch_colsum_perm(fg_ctx* ctx, const float* x, int M, int C, int o_c, int o_hw, float* out) {
+    if (C == 0) return FG_OK;
+    if ((long long)o_c * o_hw != C) return fg_set_err(ctx, FG_ERR_INVALID, "colsum_perm: %d x %d != %d", o_c, o_hw, C);
+    hipLaunchKernelGGL(colsum_perm_kernel, dim3(fg_cdiv(C, 256)), dim3(256), 0, ctx->stream, x, M, C, o_c, o_hw, out);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+int fg_launch_colsum_final_thin(fg_ctx* ctx, const float* part, int nrb, float* gradW, int O, int I, int k, int mode, int C2, float* out2) {
+    const int C1 = O * I * k * k;
+    hipLaunchKernelGGL(colsum_final_thin_kernel, dim3(fg_cdiv(C1 + C2, 16)), dim3(1024), 0, ctx->stream, part, nrb, C1 + C2, gradW, O, I,
+                       k * k, mode, C1, out2);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }

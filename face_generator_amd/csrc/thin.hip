@@ -1592,14 +1592,24 @@ static bool fg_thin_wgrad_padded_on() { return fg_thin_padded_on(); }
 // wide_colsum (optional): receives sum_pix wide[pix][c] (beta = 0) from the ones column of the matrix-pipe kernels; *colsum_done
 // tells the caller whether it was produced (the VALU fallback kernels do not).  With it the slabs have k*k*Cs + 1 rows: `scratch`
 // holds FG_THIN_WGRAD_BLOCKS * (k*k*Cs + 1) * Cw floats for them.
+// gradW_ref / unpack_mode (optional, matrix-pipe kernels only; *unpacked = 1 when used): the final sum writes the reference layout
+// gradW[O][I][k][k] itself (beta = 0) instead of gw_tsc -- no thin_unpack_grad launch behind it
 int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, float* gw_tsc, int B, int H, int W, int Cs,
-                         int Cw, int k, int shift_thin, float* scratch, float* wide_colsum, int* colsum_done) {
+                         int Cw, int k, int shift_thin, float* scratch, float* wide_colsum, int* colsum_done, float* gradW_ref,
+                         int unpack_mode, int* unpacked) {
     if (colsum_done) *colsum_done = 0;
+    if (unpacked) *unpacked = 0;
     if (Cw % 64) return fg_set_err(ctx, FG_ERR_INVALID, "thin_wgrad: Cw %% 64");
     // (3x3 layers only: the thin-INPUT convolutions of models.lua:385 / models_c2f.lua:123, 244)
     const int ones = (wide_colsum && colsum_done && k == 3 && (ctx->fusion & FG_FUSE_THIN_BIAS)) ? 1 : 0;      // fg_set_fusion
     const int NR = k * k * Cs + ones;
     auto finish = [&](int nblocks) -> int {       // fp64 sum of the slabs; row k*k*Cs (the ones column) goes to wide_colsum
+        if (gradW_ref && unpacked) {
+            *unpacked = 1;
+            if (ones) *colsum_done = 1;
+            const int O = unpack_mode == 0 ? Cw : Cs, I = unpack_mode == 0 ? Cs : Cw;
+            return fg_launch_colsum_final_thin(ctx, scratch, nblocks, gradW_ref, O, I, k, unpack_mode, ones ? Cw : 0, wide_colsum);
+        }
         if (!ones) return fg_launch_colsum_final(ctx, scratch, nblocks, NR * Cw, 0.f, gw_tsc);
         *colsum_done = 1;
         return fg_launch_colsum_final2(ctx, scratch, nblocks, (NR - 1) * Cw, gw_tsc, Cw, wide_colsum);
