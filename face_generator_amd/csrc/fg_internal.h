@@ -352,13 +352,6 @@ int fg_launch_gemv_backward(fg_ctx*, const float* x, const float* w, const float
 
 // BCECriterion forward+backward fused: loss (device scalar), grad[B], confusion[4] = [pred][target] counts
 int fg_launch_bce(fg_ctx*, const float* prob, const float* target, float* loss, float* grad, int* confusion, int B);
-// Linear(K -> 1) + Sigmoid + BCECriterion in one launch: fg_launch_gemv_forward(sigmoid = 1) followed by fg_launch_bce, bit for bit
-int fg_launch_gemv_bce(fg_ctx*, const float* x, const float* w, const float* b, float* y, int B, int K, const float* target,
-                       float* loss, float* grad, int* confusion);
-// the criterion of the step object rides on a net's LAST stage when that is Linear(K -> 1) + Sigmoid: arm before fg_net_forward,
-// ask afterwards whether it ran (fg_net_bce_done clears the request either way)
-void fg_net_arm_bce(struct fg_net* n, const float* target, float* loss, float* grad, int* confusion);
-bool fg_net_bce_done(struct fg_net* n);
 
 // fused penalty + clamp + Torch7-Adam over a flat vector
 struct AdamArgs {

@@ -109,21 +109,11 @@ struct fg_net {
     int n_jobs_all = 0;               // ... + the update-only jobs of the fused optimizer launch
     long long jobs_total_all = 0;
     bool adam_fusable = false;
-    // BCECriterion armed by the step object for the next forward (fg_net_arm_bce): fused into a closing Linear(K -> 1) + Sigmoid stage
-    const float* bce_target = nullptr; float* bce_loss = nullptr; float* bce_grad = nullptr; int* bce_conf = nullptr;
-    bool bce_armed = false, bce_done = false;
     long long pack_lds_floats = 64;   // dynamic shared memory of the re-pack launch: the largest staging area any of its jobs needs
     bool park_w = true;               // FG_FUSE_WFINISH_BATCH at creation: the workspace reserves room for parked weight-gradient partials
 };
 
 static inline long long align64(long long v) { return (v + 63) / 64 * 64; }
-void fg_net_arm_bce(fg_net* n, const float* target, float* loss, float* grad, int* confusion) {
-    static int on = -1;      // A/B switch (round 4; default on): FG_GEMV_BCE=0 keeps the criterion a launch of its own
-    if (on < 0) { const char* e = getenv("FG_GEMV_BCE"); on = e ? atoi(e) : 1; }
-    n->bce_target = target; n->bce_loss = loss; n->bce_grad = grad; n->bce_conf = confusion;
-    n->bce_armed = on != 0; n->bce_done = false;
-}
-bool fg_net_bce_done(fg_net* n) { const bool d = n->bce_done; n->bce_armed = false; n->bce_done = false; return d; }
 
 static long long stage_scratch(const Stage& s, int B) {
     long long need = 4096;
@@ -413,10 +403,7 @@ static int forward_run(fg_net* n, long long* out_offset) {
                 break;
             }
             case ST_GEMV:
-                if (n->bce_armed && s.has_sigmoid && si + 1 == (int)n->st.size() && B <= 4096) {
-                    rc = fg_launch_gemv_bce(ctx, cur, P + s.w_off, P + s.b_off, y, B, s.ic, n->bce_target, n->bce_loss, n->bce_grad, n->bce_conf);
-                    n->bce_done = !rc;
-                } else rc = fg_launch_gemv_forward(ctx, cur, P + s.w_off, P + s.b_off, y, B, s.ic, s.has_sigmoid);
+                rc = fg_launch_gemv_forward(ctx, cur, P + s.w_off, P + s.b_off, y, B, s.ic, s.has_sigmoid);
                 break;
             case ST_THIN_IN: {
                 // a plain PReLU directly behind rides on the MFMA kernel's epilogue

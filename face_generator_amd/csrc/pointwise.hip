@@ -1560,48 +1560,6 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ prob
     if (threadIdx.x == 0 && loss) loss[0] = (float)(-(shd[0] + shd[1] + shd[2] + shd[3]) / (double)B);
     if (threadIdx.x < 4 && conf) conf[threadIdx.x] = shc[threadIdx.x];
 }
-// Linear(K -> 1) + Sigmoid + BCECriterion in ONE launch (round 4: the net's last stage and the criterion were two ~5 us launches in
-// every closure).  One block: wave w computes rows w, w + 16, ... with gemv_fwd_kernel's arithmetic (64 lanes over k, wave_sum, bias,
-// sigmoid), then the first 256 threads run bce_kernel's body -- the same expressions in the same order, bit-identical results.
-__global__ __launch_bounds__(1024) void gemv_bce_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ b, float* __restrict__ y, int B, int K,
-                                                        const float* __restrict__ target, float* __restrict__ loss,
-                                                        float* __restrict__ grad, int* __restrict__ conf) {
-    __shared__ double shd[4];
-    __shared__ int shc[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = wave; row < B; row += 16) {
-        float s = 0.f;
-        for (int k = lane; k < K; k += 64) s = fmaf(x[(size_t)row * K + k], w[k], s);
-        s = wave_sum(s);
-        if (lane == 0) { s += b[0]; y[row] = 1.f / (1.f + expf(-s)); }
-    }
-    if (threadIdx.x < 4) shc[threadIdx.x] = 0;
-    __syncthreads();                                   // the block's own global writes of y are visible behind it
-    if (threadIdx.x >= 256) return;
-    const float eps = 1e-12f;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < B; i += 256) {
-        const float p = y[i], t = target[i];
-        s += (double)(t * logf(p + eps) + (1.f - t) * logf((1.f - p) + eps));
-        if (grad) grad[i] = -(t - p) / (((1.f - p) + eps) * (p + eps)) / (float)B;
-        if (conf) atomicAdd(&shc[(p > 0.5f ? 2 : 0) + (t > 0.5f ? 1 : 0)], 1);
-    }
-    s = wave_sum_d(s);
-    if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
-    // (the four waves that take part synchronise among themselves: a named barrier is not available, so spin-free: all 256 threads
-    // reach this point together because the rest of the block has already left -- a retired wave does not count in s_barrier)
-    __syncthreads();
-    if (threadIdx.x == 0 && loss) loss[0] = (float)(-(shd[0] + shd[1] + shd[2] + shd[3]) / (double)B);
-    if (threadIdx.x < 4 && conf) conf[threadIdx.x] = shc[threadIdx.x];
-}
-int fg_launch_gemv_bce(fg_ctx* ctx, const float* x, const float* w, const float* b, float* y, int B, int K, const float* target,
-                       float* loss, float* grad, int* confusion) {
-    if (B == 0) return FG_OK;
-    hipLaunchKernelGGL(gemv_bce_kernel, dim3(1), dim3(1024), 0, ctx->stream, x, w, b, y, B, K, target, loss, grad, confusion);
-    FG_CHECK_LAUNCH(ctx);
-    return FG_OK;
-}
 int fg_launch_bce(fg_ctx* ctx, const float* prob, const float* target, float* loss, float* grad, int* confusion,
                   int B) {
     hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(256), 0, ctx->stream, prob, target, loss, grad, confusion, B);

@@ -622,14 +622,11 @@ int fg_step_D(fg_gan* g, int B, const float* real, const float* cond_real, const
         din = g->ws + g->o_dsum;
     } else if ((rc = fg_launch_copy(ctx, real, dinput, (long long)h * g->img))) return rc;
     if ((rc = gan_targets(g, 0, B))) return rc;
-    int* conf = (int*)(g->ws + g->o_conf);
-    fg_net_arm_bce(g->D, g->ws + g->o_targets, g->ws + g->o_loss, g->ws + g->o_dprob, conf);      // rides on D's closing Linear + Sigmoid
     rc = fg_net_forward(g->D, B, din, g->wsD, g->wsD_bytes, 1, dm.empty() ? nullptr : dm.data(), (int)dm.size(), &off);
-    rc = gan_drain(g, g->D, rc, true);
-    const bool bce_d = fg_net_bce_done(g->D);
-    if (rc) return rc;
+    if ((rc = gan_drain(g, g->D, rc, true))) return rc;
     g->d_out_off = off; g->last_B[0] = B;
-    if (!bce_d && (rc = fg_launch_bce(ctx, g->wsD + off, g->ws + g->o_targets, g->ws + g->o_loss, g->ws + g->o_dprob, conf, B))) return rc;
+    int* conf = (int*)(g->ws + g->o_conf);
+    if ((rc = fg_launch_bce(ctx, g->wsD + off, g->ws + g->o_targets, g->ws + g->o_loss, g->ws + g->o_dprob, conf, B))) return rc;
     rc = fg_net_backward(g->D, B, din, g->ws + g->o_dprob, g->wsD, g->wsD_bytes, FG_BWD_PARAM_GRADS, nullptr);
     if ((rc = gan_drain(g, g->D, rc, false))) return rc;
     if (flags & FG_STEP_NO_UPDATE) {
@@ -667,13 +664,10 @@ int fg_step_G(fg_gan* g, int B, const float* cond, const float* noise, const flo
         din = g->ws + g->o_dsum;
     }
     if ((rc = gan_targets(g, 1, B))) return rc;
-    fg_net_arm_bce(g->D, g->ws + g->o_targets + g->maxB, g->ws + g->o_loss + 1, g->ws + g->o_dprob, nullptr);
     rc = fg_net_forward(g->D, B, din, g->wsD, g->wsD_bytes, 1, dm.empty() ? nullptr : dm.data(), (int)dm.size(), &off);
-    rc = gan_drain(g, g->D, rc, true);
-    const bool bce_g = fg_net_bce_done(g->D);
-    if (rc) return rc;
+    if ((rc = gan_drain(g, g->D, rc, true))) return rc;
     g->d_out_off = off; g->last_B[1] = B;
-    if (!bce_g && (rc = fg_launch_bce(ctx, g->wsD + off, g->ws + g->o_targets + g->maxB, g->ws + g->o_loss + 1, g->ws + g->o_dprob, nullptr, B))) return rc;
+    if ((rc = fg_launch_bce(ctx, g->wsD + off, g->ws + g->o_targets + g->maxB, g->ws + g->o_loss + 1, g->ws + g->o_dprob, nullptr, B))) return rc;
     // MODEL_D.modules[1].gradInput (adversarial.lua:210); D's weight gradients are not formed (quirk C6)
     float* gx = g->ws + g->o_gx;
     rc = fg_net_backward(g->D, B, din, g->ws + g->o_dprob, g->wsD, g->wsD_bytes, FG_BWD_INPUT_GRAD, gx);
