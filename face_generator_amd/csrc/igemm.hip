@@ -312,6 +312,10 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a) {
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) bf[(c + 1) & 1][ni] = *(const f32x4*)(Bb + ni * 32 * LDK + (c + 1) * 8);
                 }
+                // (round 4) keep the NEXT chunk's fragment reads in front of THIS chunk's MFMAs: without the fence the compiler folds
+                // the two-deep buffer into read -> lgkmcnt(0) -> MFMAs on one register set, and a wave with a single accumulator
+                // (the 64 x 64 tile: one wave per SIMD in a one-round launch) leaves the matrix pipe idle for every LDS round trip
+                if constexpr (MI * NI == 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -320,6 +324,7 @@ __device__ __forceinline__ void igemm_body(const IgemmArgs& a) {
                         for (int ni = 0; ni < NI; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][mi][j], bf[c & 1][ni][j],
                                                                                acc[mi][ni], 0, 0, 0);
+                if constexpr (MI * NI == 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (more) FG_STORE_TILE(cur ^ 1);
