@@ -80,6 +80,23 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert c["value"] > 0 and c["config"]["batch_per_gpu"] == 8 and "D_it=2" in c["config"]["workload"]
 
 
+def test_bench_watchdog_prints_a_partial_line_naming_the_stage():
+    """A multi-GPU bench run that stops making progress (rendezvous, ncclCommInitRank, a collective one rank never joins) must not run
+    silently into the driver's limit: past --watchdog rank 0 prints ONE partial JSON line (error, stage, whatever was measured) and
+    every rank exits 4.  Forced here with a watchdog far shorter than the run."""
+    import json
+    env = dict(os.environ, FG_BENCH_TEST_GLOO="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29587", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "16", "--c2f-steps", "1", "--watchdog", "0.3", "--no-dry-check"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    j = json.loads(lines[0])
+    assert j["partial"] is True and j["n_gpus"] == 2 and j["stage"] and "did not finish" in j["error"] and j["value"] is None
+
+
 def _two_gpus():
     import torch
     return torch.cuda.is_available() and torch.cuda.device_count() >= 2
