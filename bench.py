@@ -574,7 +574,7 @@ def main():
             # driver's limit without a word: say where it stopped, with whatever was measured so far
             if rank == 0:
                 part = dict(out)
-                part.update(error="stage '%s' did not finish: %.0f s in it, watchdog %.0f s from process start"
+                part.update(error="stage '%s' did not finish: %.1f s in it, watchdog %.1f s from process start"
                                   % (STAGE["name"], time.time() - STAGE["t0"], args.watchdog),
                             stage=STAGE["name"], partial=True, n_gpus=world, dry_collective=dry)
                 part.setdefault("metric", "GAN train images/sec (G+D step) at 32x32x3 bs128")

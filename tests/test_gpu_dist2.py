@@ -94,7 +94,8 @@ def test_bench_watchdog_prints_a_partial_line_naming_the_stage():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     j = json.loads(lines[0])
-    assert j["partial"] is True and j["n_gpus"] == 2 and j["stage"] and "did not finish" in j["error"] and j["value"] is None
+    assert j["partial"] is True and j["n_gpus"] == 2 and j["stage"] and "did not finish" in j["error"] and j["stage"] in j["error"]
+    assert "metric" in j and "value" in j                      # whatever was measured by then (None before the timed steps)
 
 
 def _two_gpus():
