@@ -224,3 +224,23 @@ def test_c2f_rehost_follows_adversarial_c2f_lua():
     binding = lua_code(os.path.join(ROOT, "lua", "facegen_hip.lua"))
     into = _fn_body(binding, "function Gan:confusionInto(t, slot)")
     assert "C.fg_d2d(ctx, t.ptr + 8 * slot" in into and "fg_malloc" not in into
+
+
+def test_lua_files_are_block_balanced():
+    """No Lua interpreter in the image: the least a syntax error could hide behind is checked mechanically -- every block opener
+    (function / if / do / repeat) has its end / until, every bracket its partner (comments and string literals stripped)."""
+    def strip(src):
+        src = re.sub(r"--\[\[.*?\]\]", "", src, flags=re.S)
+        src = re.sub(r"\[\[.*?\]\]", "''", src, flags=re.S)
+        src = re.sub(r"--[^\n]*", "", src)
+        src = re.sub(r"'(?:\\.|[^'\\\n])*'", "''", src)
+        return re.sub(r'"(?:\\.|[^"\\\n])*"', '""', src)
+    for path in LUA:
+        src = strip(open(path).read())
+        depth = 0
+        for t in re.findall(r"\b(function|if|do|repeat|until|end)\b", src):
+            depth += 1 if t in ("function", "if", "do", "repeat") else -1
+            assert depth >= 0, "%s: an `end` without an opener" % os.path.basename(path)
+        assert depth == 0, "%s: %d unclosed block(s)" % (os.path.basename(path), depth)
+        for a, b in ("()", "{}", "[]"):
+            assert src.count(a) == src.count(b), "%s: unbalanced %s%s" % (os.path.basename(path), a, b)
