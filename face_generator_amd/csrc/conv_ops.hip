@@ -189,6 +189,12 @@ static int choose_wgrad_ws(long long M, int Cout, int Cin, int G, int P, int* S,
 
 // A/B switch (round 3; default on): FG_WGRAD_WS=0 keeps the symmetric wgrad_kernel for the layers that tile 256 x 128 /
 // 128 x 256 channels instead of the wave-specialised wgrad_ws_kernel
+// smallest pixel count the wave-specialised weight gradient takes (measurement knob: FG_WGRAD_WS_MINM; default 4096)
+static long long fg_wgrad_ws_minm() {
+    static long long v = -1;
+    if (v < 0) { const char* e = getenv("FG_WGRAD_WS_MINM"); v = e ? atoll(e) : 4096; if (v < 256) v = 256; }
+    return v;
+}
 static bool fg_wgrad_ws_on() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("FG_WGRAD_WS"); v = e ? atoi(e) : 1; }
@@ -204,7 +210,7 @@ long long fg_conv_wgrad_part_floats(const ConvGeom& g) {
     int wt, S, mper, Np, Cp, S6, mper6;
     choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
     long long n = (long long)wm.P * wm.G * S * Np * Cp;
-    if (M >= 4096 && choose_wgrad_ws(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) >= 0) {
+    if (M >= fg_wgrad_ws_minm() && choose_wgrad_ws(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) >= 0) {
         const long long n6 = (long long)wm.P * wm.G * S6 * g.Cout * g.Cin;
         if (n6 > n) n = n6;
     }
@@ -221,7 +227,7 @@ long long fg_conv_wgrad_bias_part_floats(const ConvGeom& g) {
     choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
     long long rows = (long long)wm.P * S;
     int S6, mper6;
-    const int cfg = M >= 4096 ? choose_wgrad_ws(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) : -1;
+    const int cfg = M >= fg_wgrad_ws_minm() ? choose_wgrad_ws(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) : -1;
     if (cfg >= 0) {
         WgradArgs a; memset(&a, 0, sizeof(a));
         a.G = wm.G; a.Cpad = g.Cin;
@@ -521,7 +527,7 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         if ((rc = fg_launch_wgrad6(ctx, a, wm.P, cfg6))) return rc;
         if (gy6_out) *gy6_out = a.D6;
         if (used_out) *used_out = part + d6;
-    } else if (fg_wgrad_ws_on() && ctx->math != 6 && a.M >= 4096 && choose_wgrad_ws(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split) >= 0 &&
+    } else if (fg_wgrad_ws_on() && ctx->math != 6 && a.M >= fg_wgrad_ws_minm() && choose_wgrad_ws(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split) >= 0 &&
                fg_wgrad_ws_shape_ok(a, choose_wgrad_ws(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split))) {
         // wave-specialised fp32 weight gradient (256 x 128 / 128 x 256 channel tiles, or 128 x 64 with the K-step split over the
         // MFMA waves; one round of ~256 blocks); the bias gradient takes the separate column-sum pass at the end of this function
