@@ -315,10 +315,11 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
                                         "bf16_issued_frac": 6.0 * exe / PEAK_BF16_MFMA_TFLOPS})
             # the HBM-bound tail, separately -- algorithmic bytes (every operand once) of each
             # pointwise / thin launch over its HIP-event time, against the 8 TB/s HBM peak
-            tail = [{"kernel": k, "launches_per_iter": v["calls"] / args.prof_iters,
-                     "bytes_per_launch": v["bytes"] / v["calls"], "us": 1e3 * v["ms"] / v["calls"],
-                     "ms_per_iter": v["ms"] / args.prof_iters,
-                     "tb_s": v["bytes"] / (v["ms"] * 1e-3) / 1e12, "frac_of_8TBs": v["bytes"] / (v["ms"] * 1e-3) / 1e12 / PEAK_HBM_TBS}
+            tail = [{"kernel": k, "launches_per_iter": round(v["calls"] / args.prof_iters, 2),
+                     "bytes_per_launch": round(v["bytes"] / v["calls"]), "us": round(1e3 * v["ms"] / v["calls"], 2),
+                     "ms_per_iter": round(v["ms"] / args.prof_iters, 4),
+                     "tb_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e12, 3),
+                     "frac_of_8TBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}
                     for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]) if v["bytes"] > 0 and v["ms"] > 0]
             if tail:
                 tb, tm = sum(t["bytes_per_launch"] * t["launches_per_iter"] for t in tail), sum(t["ms_per_iter"] for t in tail)
