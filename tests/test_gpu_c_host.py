@@ -37,8 +37,11 @@ def test_c_host_compiles_against_the_public_header(tmp_path):
 
 
 @pytest.mark.gpu
-def test_c_host_runs_one_D_and_one_G_closure_without_torch(tmp_path):
-    """The flow of __graft_entry__.smoke() twice on identical inputs: once through the Python host inside this (torch) process
+@pytest.mark.parametrize("B", [4, 128])
+def test_c_host_runs_one_D_and_one_G_closure_without_torch(tmp_path, B):
+    """(B = 128: the headline batch -- the wave-specialised kernels, the production split counts and the deferred finals, driven by
+    a process that has no torch in it.)
+    The flow of __graft_entry__.smoke() twice on identical inputs: once through the Python host inside this (torch) process
     -- the oracle adopts that run's PReLU branch decisions (oracle/device_branches.py) -- and once through the C host in its
     own torch-free process.  The C host's results must meet the smoke bars against the oracle AND equal the in-process run
     bit for bit (the kernels are deterministic: the same library on the same inputs, whoever allocated the memory)."""
@@ -47,7 +50,7 @@ def test_c_host_runs_one_D_and_one_G_closure_without_torch(tmp_path):
     from face_generator_amd import models, adversarial
     from face_generator_amd.runtime import get_context
     ctx = get_context(0)
-    B, C = 4, 3
+    C = 3
     rng = np.random.default_rng(9000)
     G = O.create_G32((C, 32, 32), 100, rng, weight_init_=False)
     D = O.create_D32b((C, 32, 32), rng)
