@@ -55,7 +55,50 @@ def make_cfg(C, B, seed):
     return out
 
 
+def make_c2f(S, B, seed):
+    """BASELINE configs 4-5 at a size the oracle finishes in seconds: create_G_d / create_D_c (models_c2f.lua:113-145, 237-278) at
+    S x S, one D closure and one G closure of adversarial_c2f.lua with train_c2f.lua's penalties (C2F_OPT)."""
+    rng = np.random.default_rng(seed)
+    G = O.create_G_d((3, S, S), rng)
+    D = O.create_D_c((3, S, S), rng)
+    for net in (G, D):
+        for m in net.modules:
+            if isinstance(m, O.PReLU):
+                m.weight[0] = np.float32(rng.uniform(0.1, 0.4))
+    st = O.GanState(G, D, O.C2F_OPT)
+    pG0, pD0 = st.pG.copy(), st.pD.copy()
+    h = B // 2
+    u = lambda lo, hi, shape: rng.uniform(lo, hi, shape).astype(np.float32)
+    diff_r, cond_r, cond_f, nzD = u(-1, 1, (h, 3, S, S)), u(0, 1, (h, 3, S, S)), u(0, 1, (h, 3, S, S)), u(-1, 1, (h, 1, S, S))
+    cond_g, nzG = u(0, 1, (B, 3, S, S)), u(-1, 1, (B, 1, S, S))
+    mk = lambda: [(rng.random((B, 256, S // 4, S // 4)) < 0.5).astype(np.float32), (rng.random((B, 512)) < 0.5).astype(np.float32)]
+    masksD, masksG = mk(), mk()
+    rd = O.step_D_c2f(st, diff_r, cond_r, nzD, cond_f, masksD)
+    rg = O.step_G_c2f(st, nzG, cond_g, masksG)
+    iG, iD = sample_idx(st.pG.size, 4096, seed + 1), sample_idx(st.pD.size, 4096, seed + 2)
+    out = dict(S=S, B=B, seed=seed, pG0=pG0, pD0=pD0, diff_r=diff_r, cond_r=cond_r, cond_f=cond_f, nzD=nzD, cond_g=cond_g, nzG=nzG,
+               D_out=rd["out"], D_f_bce=np.float64(rd["f_bce"]), D_conf=rd["conf"], D_grad_idx=iD, D_grad_val=rd["grad"][iD],
+               D_grad_l2=np.float64(np.sqrt((rd["grad"].astype(np.float64) ** 2).sum())), pD1_val=st.pD[iD],
+               G_samples=rg["samples"], G_out=rg["out"], G_f_bce=np.float64(rg["f_bce"]), G_grad_idx=iG, G_grad_val=rg["grad"][iG],
+               G_grad_l2=np.float64(np.sqrt((rg["grad"].astype(np.float64) ** 2).sum())), pG1_val=st.pG[iG])
+    for i, m in enumerate(masksD):
+        out["maskD%d" % i] = m
+    for i, m in enumerate(masksG):
+        out["maskG%d" % i] = m
+    return out
+
+
 if __name__ == "__main__":
+    for (S, B, seed) in [(16, 4, 9105)]:
+        d = make_c2f(S, B, seed)
+        chk = dict(pG0_sum=np.float64(d["pG0"].astype(np.float64).sum()), pD0_sum=np.float64(d["pD0"].astype(np.float64).sum()))
+        del d["pG0"], d["pD0"]
+        d.update(chk)
+        fn = os.path.join(HERE, "c2f_s%d_b%d.npz" % (S, B))
+        np.savez_compressed(fn, **d)
+        print(fn, os.path.getsize(fn) // 1024, "KiB")
+    if "--c2f-only" in sys.argv:
+        sys.exit(0)
     for (C, B, seed) in [(3, 4, 9001), (1, 4, 9002)]:
         d = make_cfg(C, B, seed)
         # parameters are regenerated from the seed by the tests; do not store the 21 MB vectors
