@@ -393,7 +393,7 @@ def build_cfg2(args, ctx, torch, coll, world, rank, B):
             tr.step_G(S.next_noise(ctx, B, 100))
     return dict(tr=tr, iteration=iteration, flops=alg_flops_per_iter(B), real=real,
                 data="synthetic (U[0,1) images, U(-1,1) noise, reference init N(0,.005^2)/N(0,.001^2))",
-                config={"workload": "configs[1]: 32x32 color, noiseDim=100, batch 128 per GPU, Adam, D_it=G_it=1"
+                config={"workload": "configs[1]: 32x32 color, noiseDim=100, batch %d per GPU, Adam, D_it=G_it=1" % B
                                     + ("" if world == 1 else "; configs[2]-style %s scaling, RCCL grad all-reduce"
                                        % ("strong" if args.strong else "weak")),
                         "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world,
