@@ -80,6 +80,19 @@ static void choose_igemm(long long M, int Npad, int ksteps, int P, int math, int
     }
     if (b0 >= target) { *tile = 0; return; }
     if (b1 >= target) { *tile = 1; return; }
+    {   // a Linear over very many input features and few samples (65536 -> 512 at M = 128, models_c2f.lua:262: 8.6 GFLOP): 128 x 128
+        // tiles split over K until one round of 256 blocks fills the chip, instead of 64 x 64 tiles capped at 16 splits (round 4;
+        // FG_LINEAR_FWD128=0 switches back)
+        static int on = -1;
+        if (on < 0) { const char* e = getenv("FG_LINEAR_FWD128"); on = e ? atoi(e) : 1; }
+        if (on && math != 6 && b0 > 0 && b0 <= 16 && ksteps >= 1024) {
+            int s = (int)(256 / b0);
+            if (s > ksteps / 16) s = ksteps / 16;
+            const int per = (ksteps + s - 1) / s;
+            *tile = 0; *splits = (ksteps + per - 1) / per;
+            return;
+        }
+    }
     *tile = 2;
     // (a contraction of <= 4 K-steps over >= 128 tiles -- G's first Linear, 100 -> 8192 -- is shorter than the extra pass that
     // would sum its partials)
