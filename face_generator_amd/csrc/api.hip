@@ -82,6 +82,7 @@ int fg_ctx_create(int device, fg_ctx** out) {
     if (const char* m = getenv("FG_THIN_SLAB")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_THIN_SLAB;
     if (const char* m = getenv("FG_DEFER_WFINISH")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WFINISH_BATCH;
     if (const char* m = getenv("FG_THIN_BIAS")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_THIN_BIAS;
+    if (const char* m = getenv("FG_WINO")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WINOGRAD;
     c->fusion &= ~FG_FUSE_ADAM_PACK;        // measured slower than the two launches: opt-in
     if (const char* m = getenv("FG_ADAM_PACK")) if (atoi(m) != 0) c->fusion |= FG_FUSE_ADAM_PACK;
     ++g_real_ctx;
@@ -264,9 +265,10 @@ int fg_norms(fg_ctx* ctx, const float* p, long long n, float* out2, float* scrat
 // ---------------------------------------------------------------- module-level conv / linear
 static bool thin_in(int cin, int cout) { return cin <= 4 && cout % 64 == 0; }
 static bool thin_out(int cin, int cout) { return cout <= 4 && cin % 64 == 0; }
-static ConvGeom mk_geom(int b, int h, int w, int cin, int cout, int k, int pad, int up) {
+static ConvGeom mk_geom(int b, int h, int w, int cin, int cout, int k, int pad, int up, int fusion = 0) {
     ConvGeom g; memset(&g, 0, sizeof(g));
     g.B = b; g.H = h; g.W = w; g.Cin = cin; g.Cout = cout; g.k = k; g.pad = pad; g.fold = up;
+    fg_geom_set_wino(g, fusion);  // 3x3 layers: Winograd F(2x2, 3x3) forward / data gradient (fg_set_fusion bit FG_FUSE_WINOGRAD)
     return g;
 }
 static inline long long a64(long long v) { return (v + 63) / 64 * 64; }
@@ -276,9 +278,16 @@ size_t fg_conv2d_workspace_bytes(int batch, int h, int w, int cin, int cout, int
         const long long na = (long long)k * k * (cin <= 4 ? cin : cout), cw = cin <= 4 ? cout : cin;
         return (size_t)(a64((long long)cin * cout * k * k) + (FG_THIN_WGRAD_BLOCKS + 1) * na * cw + 258LL * (cout > 64 ? cout : 64) + 256) * 4;
     }
-    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, (k - 1) / 2, up);
-    long long pf = fg_geom_pack_floats(g, 0), pb = fg_geom_pack_floats(g, 1);
-    return (size_t)(a64(pf > pb ? pf : pb) + fg_conv_scratch_floats(g) + 64) * sizeof(float);
+    // (no context here: the bound covers both settings of FG_FUSE_WINOGRAD)
+    size_t need = 0;
+    for (int wn = 0; wn < 2; ++wn) {
+        ConvGeom g = mk_geom(batch, h, w, cin, cout, k, (k - 1) / 2, up, wn ? FG_FUSE_WINOGRAD : 0);
+        if (wn && !g.wino) break;
+        long long pf = fg_geom_pack_floats(g, 0), pb = fg_geom_pack_floats(g, 1);
+        const size_t n = (size_t)(a64(pf > pb ? pf : pb) + fg_conv_scratch_floats(g) + 64) * sizeof(float);
+        if (n > need) need = n;
+    }
+    return need;
 }
 static int conv_check(fg_ctx* ctx, int cin, int cout, int k, int pad, int up) {
     if (k % 2 != 1 || pad != (k - 1) / 2) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: only odd-k 'same' stride-1");
@@ -310,7 +319,7 @@ int fg_conv2d_forward(fg_ctx* ctx, const float* x, const float* wt, const float*
         if ((rc = fg_launch_thin_pack(ctx, wt, ws, cout, cin, k, 1))) return rc;
         return fg_launch_thin_out_conv(ctx, x, ws, bias, y, batch, h, w, cin, cout, k, 0, 0);
     }
-    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, pad, up);
+    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, pad, up, ctx->fusion);
     const long long pf = a64(fg_geom_pack_floats(g, 0));
     if ((rc = fg_conv_pack(ctx, g, wt, ws, nullptr))) return rc;
     return fg_conv_forward_run(ctx, g, x, ws, bias, y, ws + pf, (long long)(ws_bytes / 4) - pf);
@@ -330,7 +339,7 @@ int fg_conv2d_backward_data(fg_ctx* ctx, const float* gy, const float* wt, float
         if ((rc = fg_launch_thin_pack(ctx, wt, ws, cout, cin, k, 1))) return rc;
         return fg_launch_thin_in_conv(ctx, gy, ws, nullptr, gx, batch, h, w, cout, cin, k, 1);
     }
-    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, pad, up);
+    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, pad, up, ctx->fusion);
     const long long pb = a64(fg_geom_pack_floats(g, 1));
     if ((rc = fg_conv_pack(ctx, g, wt, nullptr, ws))) return rc;
     return fg_conv_dgrad_run(ctx, g, gy, ws, gx, ws + pb, (long long)(ws_bytes / 4) - pb);

@@ -15,11 +15,18 @@ struct ConvGeom {
     int k, pad;     // odd k, "same" pad = (k-1)/2. Linear: 1, 0
     int fold;       // 1: an nn.SpatialUpSamplingNearest(2) in front of the conv is folded into its taps
     int stride;     // 0 / 1: stride 1; 2: stride 2 (output (H/2) x (W/2); models.lua:289-291 create_D16_d), never with fold
+    int wino;       // 1: forward and data gradient run as Winograd F(2x2, 3x3) (wino.hip); the packs hold U = G g G^T (fg_geom_set_wino)
     // Linear next to an nn.View: NCHW-flatten <-> NHWC-memory feature permutation (0 = none)
     int o_c, o_hw, i_c, i_hw;
 };
 
 void fg_geom_weightmap(const ConvGeom& g, WeightMap* wm);
+// the map the PACKS of the layer are built with: fg_geom_weightmap, or kind 2 (16 Winograd positions) for a g.wino layer.
+// (The weight gradient always uses fg_geom_weightmap: it is computed tap by tap whatever the forward algorithm.)
+void fg_geom_packmap(const ConvGeom& g, WeightMap* wm);
+// decides g.wino from the geometry (3x3, pad 1, stride 1, no folded upsample, even H / W, channel counts % 8 == 0 and > 4)
+// and the context's fg_set_fusion bit FG_FUSE_WINOGRAD (default on; off keeps the implicit GEMM: the A/B and parity switch)
+void fg_geom_set_wino(ConvGeom& g, int fusion);
 void fg_geom_pack_dims(const ConvGeom& g, int* rows_f, int* cols_f, int* rows_b, int* cols_b);
 long long fg_geom_pack_floats(const ConvGeom& g, int bwd);
 long long fg_conv_scratch_floats(const ConvGeom& g);

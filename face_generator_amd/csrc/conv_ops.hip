@@ -29,20 +29,35 @@ void fg_geom_weightmap(const ConvGeom& g, WeightMap* wm) {
     }
 }
 
+void fg_geom_packmap(const ConvGeom& g, WeightMap* wm) {
+    fg_geom_weightmap(g, wm);
+    if (g.wino) { wm->kind = 2; wm->G = 16; wm->P = 1; }
+}
+void fg_geom_set_wino(ConvGeom& g, int fusion) {
+    const bool on = (fusion & FG_FUSE_WINOGRAD) != 0;
+    g.wino = (on && g.k == 3 && g.pad == 1 && !g.fold && g.stride != 2 && g.H >= 2 && g.W >= 2 && (g.H & 1) == 0 && (g.W & 1) == 0 &&
+              g.Cin % 8 == 0 && g.Cout % 8 == 0 && g.Cin > 4 && g.Cout > 4) ? 1 : 0;
+}
+
 static inline int pad_rows(int n) { return n < 128 ? fg_round_up(n, 64) : fg_round_up(n, 128); }
 
 void fg_geom_pack_dims(const ConvGeom& g, int* rows_f, int* cols_f, int* rows_b, int* cols_b) {
+    if (g.wino) {        // 64 output channels per block, K chunks of 8 channels (wino.hip)
+        *rows_f = fg_round_up(g.Cout, 64); *cols_f = fg_round_up(g.Cin, 8);
+        *rows_b = fg_round_up(g.Cin, 64);  *cols_b = fg_round_up(g.Cout, 8);
+        return;
+    }
     *rows_f = pad_rows(g.Cout); *cols_f = fg_round_up(g.Cin, 32);
     *rows_b = pad_rows(g.Cin);  *cols_b = fg_round_up(g.Cout, 32);
 }
 long long fg_geom_pack_floats(const ConvGeom& g, int bwd) {
-    WeightMap wm; fg_geom_weightmap(g, &wm);
+    WeightMap wm; fg_geom_packmap(g, &wm);
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
     return (long long)wm.P * wm.G * (bwd ? (long long)rb * cb : (long long)rf * cf);
 }
 
 int fg_conv_pack(fg_ctx* ctx, const ConvGeom& g, const float* W, float* wp_fwd, float* wp_bwd) {
-    WeightMap wm; fg_geom_weightmap(g, &wm);
+    WeightMap wm; fg_geom_packmap(g, &wm);
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
     int rc;
     if (wp_fwd && (rc = fg_launch_pack_weights(ctx, wm, 0, W, wp_fwd, rf, cf))) return rc;
@@ -104,6 +119,18 @@ static void choose_igemm(long long M, int Npad, int ksteps, int P, int math, int
         s = (ksteps + per - 1) / per;   // every split non-empty
         *splits = s < 1 ? 1 : s;
     }
+}
+// Winograd launch: blocks of 64 tiles x 64 output channels; when they do not fill the chip the K chunks (8 channels each) are
+// split over gridDim.y, >= 4 chunks per split (the partials are summed by the pass behind the layer, like every split-K launch)
+static int choose_wino_splits(long long T, int Npad, int C) {
+    const long long blocks = ((T + 63) / 64) * (Npad / 64);
+    const int nch = C / 8;
+    if (blocks >= 192 || nch < 8) return 1;
+    int s = (int)(256 / blocks);
+    if (s > nch / 4) s = nch / 4;
+    if (s < 1) s = 1;
+    const int per = (nch + s - 1) / s;
+    return (nch + per - 1) / per;          // every split non-empty
 }
 static void choose_wgrad(long long M, int Cout, int Cin, int G, int P, int* tile, int* S, int* mper, int* Npad, int* Cpad) {
     int bt = (Cout >= 128 && Cin >= 128) ? 128 : 64;
@@ -257,6 +284,14 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
     const long long outM = g.fold ? M * 4 : M;
     int tile, splits;
+    if (g.wino) {
+        // forward / data gradient run the Winograd kernel in every math mode: their split partials; the weight gradient below
+        // (a smaller run-time batch may split further: splits x tiles is bounded by one round of 256 blocks of 64 tiles)
+        const int sf = choose_wino_splits(M / 4, rf, g.Cin), sb = choose_wino_splits(M / 4, rb, g.Cout);
+        const long long nf = sf > 1 ? (long long)sf * M * g.Cout : 0, nb = sb > 1 ? (long long)sb * M * g.Cin : 0;
+        need = nf > nb ? nf : nb;
+        if (need < 256LL * 64 * 4 * 64 + 64) need = 256LL * 64 * 4 * 64 + 64;
+    } else {
     choose_igemm(M, rf, wm.G * (cf / 32), wm.P, math, &tile, &splits);
     {
         long long n = splits > 1 ? (long long)splits * outM * g.Cout : 0;
@@ -272,6 +307,7 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
         if (math == 6 && rb % 64 == 0 && n < 256LL * 256 * 128 + 64) n = 256LL * 256 * 128 + 64;
         if (math == 6 && rb % 64 == 0) n += ((outM * g.Cout + (long long)wm.P * wm.G * rb * cb) * 3 + 1) / 2 + 64;
         if (n > need) need = n;
+    }
     }
     int wt, S, mper, Np, Cp;
     choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
@@ -324,6 +360,14 @@ static void fill_mspace(IgemmArgs& a, int B, int H, int W) {
 }
 
 
+static void fill_wino(WinoArgs& w, const ConvGeom& g, int C, int N, int Npad) {
+    w.B = g.B; w.H = g.H; w.W = g.W; w.C = C; w.N = N; w.Npad = Npad;
+    w.TH = g.H / 2; w.TW = g.W / 2; w.T = g.B * w.TH * w.TW;
+    w.lgTH = ilog2_exact(w.TH); w.lgTW = ilog2_exact(w.TW);
+    if (w.lgTH < 0 || w.lgTW < 0) w.lgTH = w.lgTW = -1;
+    w.x_bytes = (long long)g.B * g.H * g.W * C * 4;
+}
+
 // bf16x6 math mode (fg_set_math): the wave-specialised kernel reads both operands as split-bf16 planes; build them in
 // the (otherwise unused: tile 4 never splits K) scratch.  Weight planes are rebuilt per call -- a few MB, ~5 us.
 static int maybe_split_operands(fg_ctx* ctx, IgemmArgs& a, int tile, long long packed_floats, float* scratch,
@@ -362,6 +406,31 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
     IgemmArgs a; memset(&a, 0, sizeof(a));
     const int st = g.stride == 2 ? 2 : 1;
     if (st == 2 && (g.fold || (g.H & 1) || (g.W & 1))) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "stride-2 conv: even H/W, no folded upsample");
+    if (g.wino) {
+        // Winograd F(2x2, 3x3) (wino.hip): un-split launches take the bias and the PReLU behind the layer in their epilogue, split
+        // ones leave partials for the same passes as the implicit GEMM's
+        WinoArgs w; memset(&w, 0, sizeof(w));
+        fill_wino(w, g, g.Cin, g.Cout, rf);
+        w.X = x; w.U = wp_fwd; w.bias = bias; w.Out = y;
+        w.alg_flops = alg_flops(g); w.tag = tag_of(g, 0);
+        const int splits = choose_wino_splits(w.T, rf, g.Cin);
+        const long long out_count = (long long)g.B * g.H * g.W * g.Cout;
+        w.splits = splits;
+        if (splits > 1) {
+            if ((long long)splits * out_count > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv fwd (winograd): scratch");
+            w.Out = scratch; w.split_stride = out_count;
+        }
+        if (act && splits == 1 && act->y && act->slope && !act->mask && fg_fuse_prelu(ctx)) { w.act_y = act->y; w.act_slope = act->slope; }
+        int rc = fg_launch_wino(ctx, w);
+        if (rc) return rc;
+        if (w.act_y) act->applied = 1;
+        if (splits > 1 && leave && !act && out_count % 4 == 0 && g.Cout % 4 == 0) {
+            leave->part = scratch; leave->splits = splits; leave->stride = out_count; leave->bias = bias; leave->N = g.Cout;
+            return FG_OK;
+        }
+        if (splits > 1) return fg_launch_sum_splits(ctx, scratch, splits, out_count, bias, g.Cout, y, out_count, act);
+        return FG_OK;
+    }
     fill_mspace(a, g.B, g.H / st, g.W / st);                 // M-space = output pixels
     a.A = x; a.Bp = wp_fwd; a.bias = bias; a.Out = y;
     a.alg_flops = alg_flops(g); a.tag = tag_of(g, 0);
@@ -432,6 +501,42 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
     }
     WeightMap wm; fg_geom_weightmap(g, &wm);
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
+    if (g.wino) {
+        // the data gradient of a 3x3 / pad 1 / stride 1 layer is the same convolution with flipped, transposed taps: the same
+        // Winograd kernel on the data-gradient pack (U of the flipped taps = U with positions 0 <-> 3 exchanged on both axes)
+        WinoArgs w; memset(&w, 0, sizeof(w));
+        fill_wino(w, g, g.Cout, g.Cin, rb);
+        w.X = gy; w.U = wp_bwd; w.bias = nullptr; w.Out = gx;
+        w.alg_flops = alg_flops(g); w.tag = tag_of(g, 1);
+        const int splits = choose_wino_splits(w.T, rb, g.Cout);
+        const long long out_count = (long long)g.B * g.H * g.W * g.Cin;
+        w.splits = splits;
+        if (splits > 1) {
+            if ((long long)splits * out_count > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv dgrad (winograd): scratch");
+            w.Out = scratch; w.split_stride = out_count;
+        }
+        long long nparts = 0;
+        if (actb && actb->x && actb->slope && !actb->mask && splits == 1 && fg_fuse_prelu(ctx)) {
+            nparts = 4 * fg_wino_blocks(w);
+            float* dp = actb->gslope ? fg_defer_alloc(ctx, nparts) : nullptr;
+            if (!actb->gslope || dp) { w.act_x = actb->x; w.act_slope = actb->slope; w.act_part = dp; }
+        }
+        int rc = fg_launch_wino(ctx, w);
+        if (rc) return rc;
+        if (w.act_x) {
+            actb->applied = 1;
+            if (w.act_part) fg_defer_push(ctx, w.act_part, (int)nparts, 1, 0.f, actb->gslope);
+        }
+        if (splits > 1 && leave && !actb && out_count % 4 == 0 && g.Cin % 4 == 0) {
+            leave->part = scratch; leave->splits = splits; leave->stride = out_count; leave->bias = nullptr; leave->N = g.Cin;
+            return FG_OK;
+        }
+        if (splits > 1) {
+            if (actb && g.Cin % 4 == 0) return fg_launch_sum_splits_actbwd(ctx, scratch, splits, out_count, gx, out_count, actb);
+            return fg_launch_sum_splits(ctx, scratch, splits, out_count, nullptr, g.Cin, gx, out_count);
+        }
+        return FG_OK;
+    }
     IgemmArgs a; memset(&a, 0, sizeof(a));
     fill_mspace(a, g.B, g.H, g.W);
     a.A = gy; a.Bp = wp_bwd; a.bias = nullptr; a.Out = gx;

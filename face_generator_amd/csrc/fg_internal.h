@@ -147,6 +147,39 @@ int fg_launch_sum_splits_actbwd(fg_ctx* ctx, const float* part, int splits, long
                                 const FgActBwd* actb);
 
 // ---------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) convolution (wino.hip): 3x3 / pad 1 / stride 1 layers, forward and data gradient.
+//   Out[b][y][x][n] = bias[n] + sum_{c, dy, dx} X[b][y + dy - 1][x + dx - 1][c] * g[n][c][dy][dx]   (g: the layer's taps for the
+//   forward pass, the flipped + transposed taps for the data gradient), evaluated as 16 position-wise contractions over the
+//   2x2-output tiles; U = G g G^T comes pre-transformed from the re-pack launch (WeightMap kind 2)
+// ---------------------------------------------------------------------------------
+struct WinoArgs {
+    const float* X;      // NHWC [B][H][W][C]
+    const float* U;      // packed [Npad / 64][C / 8][pos 16][k half 2][64][4]  (fg_wino_pack_index)
+    const float* bias;   // [N] or nullptr (added only when splits == 1)
+    float* Out;          // NHWC [B][H][W][N]  (or [splits][...] partials)
+    int B, H, W, C, N, Npad;
+    int TH, TW, T;       // 2x2 tiles per column / row / in the batch (T = B * TH * TW)
+    int lgTH, lgTW;      // log2 if both are powers of two, else -1
+    int splits;          // split over the K chunks (gridDim.y); partials at Out + s * split_stride
+    long long split_stride;
+    long long x_bytes;   // size of X in bytes (< 2 GiB: raw-buffer addressing)
+    // an nn.PReLU folded into the epilogue (splits == 1), same meaning as IgemmArgs::act_*
+    const float* act_slope;
+    float* act_y;
+    const float* act_x;
+    float* act_part;     // 4 floats per block (fg_wino_blocks)
+    double alg_flops;    // host-side bookkeeping: reference-formulation FLOPs of this launch
+    const char* tag;
+    unsigned long long* dbg_trace;   // measurement only (FG_WINO_TRACE=1): s_memtime rows of wino_trace_kernel
+};
+int fg_launch_wino(fg_ctx* ctx, const WinoArgs& a);
+long long fg_wino_blocks(const WinoArgs& a);
+// packed position of U[pos][n][k] (n: output channel of the contraction, k: its reduction channel; Kpad % 8 == 0)
+__host__ __device__ static inline size_t fg_wino_pack_index(int pos, int n, int k, int Kpad) {
+    return ((((size_t)(n >> 6) * (Kpad >> 3) + (k >> 3)) * 16 + pos) * 2 + ((k >> 2) & 1)) * 256 + (n & 63) * 4 + (k & 3);
+}
+
+// ---------------------------------------------------------------------------------
 // Weight-gradient contraction: Part[pg][s][n][c] = sum_{m in split s} dY[pixd(m,p)][n] * X[pixx(m,pg)][c]
 // ---------------------------------------------------------------------------------
 struct WgradArgs {

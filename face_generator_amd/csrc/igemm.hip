@@ -1506,12 +1506,31 @@ __device__ __forceinline__ int dev_fold_r(int parity, int d, int pad) {
     return (v >= 0) ? (v >> 1) : -((-v + 1) >> 1);
 }
 
+// Winograd F(2x2, 3x3) weight transform (WeightMap kind 2, wino.hip): U[i][j] = (G g G^T)[i][j] of one (out, in) pair's nine taps,
+// G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].  The taps of the data gradient are the flipped ones, and G J = P G with P the
+// exchange of rows 0 <-> 3, so its transform is U[perm(i)][perm(j)]: fg_wino_bwd_pos.
+__device__ __forceinline__ float fg_wino_u(const float* w, int i, int j) {
+    float r[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float w0 = w[a * 3], w1 = w[a * 3 + 1], w2 = w[a * 3 + 2];
+        r[a] = j == 0 ? w0 : (j == 3 ? w2 : 0.5f * ((w0 + w2) + (j == 1 ? w1 : -w1)));
+    }
+    return i == 0 ? r[0] : (i == 3 ? r[2] : 0.5f * ((r[0] + r[2]) + (i == 1 ? r[1] : -r[1])));
+}
+__device__ __forceinline__ int fg_wino_bwd_pos(int pos) {
+    const int i = pos >> 2, j = pos & 3;
+    const int pi = i == 0 ? 3 : (i == 3 ? 0 : i), pj = j == 0 ? 3 : (j == 3 ? 0 : j);
+    return pi * 4 + pj;
+}
+
 // value of the (possibly tap-folded) weight for parity p, group g, reference out-channel o, in-channel i
 __device__ __forceinline__ float packed_weight_value(const WeightMap& wm, const float* __restrict__ W, int p, int g,
                                                      int o, int i) {
     const int kk = wm.k * wm.k;
     const float* w = W + ((size_t)o * wm.I + i) * kk;
     if (wm.kind == 0) return w[g];
+    if (wm.kind == 2) return fg_wino_u(w, g >> 2, g & 3);
     const int py = p >> 1, px = p & 1, ty = g / wm.T, tx = g - ty * wm.T;
     // source offset r = t + rmin collects the taps d with floor((parity + d - pad)/2) == r, i.e. d in {2r-parity+pad, +1}
     const int dy0 = 2 * (ty + wm.rmin) - py + wm.pad, dx0 = 2 * (tx + wm.rmin) - px + wm.pad;
@@ -1545,9 +1564,10 @@ __global__ void pack_weights_kernel(const WeightMap wm, int mode, const float* _
         int o = po, i = pi;
         if (wm.o_hw > 1) { int hw = po / wm.o_c, c = po - hw * wm.o_c; o = c * wm.o_hw + hw; }
         if (wm.i_hw > 1) { int hw = pi / wm.i_c, c = pi - hw * wm.i_c; i = c * wm.i_hw + hw; }
-        v = packed_weight_value(wm, W, p, g, o, i);
+        v = packed_weight_value(wm, W, p, (wm.kind == 2 && mode == 1) ? fg_wino_bwd_pos(g) : g, o, i);
     }
-    Bp[idx] = v;
+    if (wm.kind == 2) Bp[fg_wino_pack_index(g, row, col, cols_pad)] = v;      // the order wino_kernel's LDS stage wants
+    else Bp[idx] = v;
 }
 
 int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const float* W, float* Bp, int rows_pad,
@@ -1562,6 +1582,7 @@ int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const flo
 // packed value from a pair's k*k taps held in LDS (same arithmetic and summation order as packed_weight_value)
 __device__ __forceinline__ float packed_from_taps(const WeightMap& wm, const float* w, int p, int g) {
     if (wm.kind == 0) return w[g];
+    if (wm.kind == 2) return fg_wino_u(w, g >> 2, g & 3);
     const int py = p >> 1, px = p & 1, ty = g / wm.T, tx = g - ty * wm.T;
     const int dy0 = 2 * (ty + wm.rmin) - py + wm.pad, dx0 = 2 * (tx + wm.rmin) - px + wm.pad;
     float s = 0.f;
@@ -1633,6 +1654,9 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                 const float* w = taps + a * PK_ROW + b * kk;
                 float* d = jb.dst + (size_t)po * jb.cols + pi;
                 const size_t tile = (size_t)jb.rows * jb.cols;
+                if (wm.kind == 2) {      // Winograd: U[pos][out][in] in the order of wino_kernel's LDS stage
+                    for (int pg = 0; pg < 16; ++pg) jb.dst[fg_wino_pack_index(pg, po, pi, jb.cols)] = fg_wino_u(w, pg >> 2, pg & 3);
+                } else
                 for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
             }
         }
@@ -1642,6 +1666,12 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                 const float* w = taps + a * PK_ROW + b * kk;
                 float* d = jb.dst2 + (size_t)pi * jb.cols2 + po;
                 const size_t tile = (size_t)jb.rows2 * jb.cols2;
+                if (wm.kind == 2) {      // data gradient: roles of out / in exchanged, taps flipped
+                    for (int pg = 0; pg < 16; ++pg) {
+                        const int fp = fg_wino_bwd_pos(pg);
+                        jb.dst2[fg_wino_pack_index(pg, pi, po, jb.cols2)] = fg_wino_u(w, fp >> 2, fp & 3);
+                    }
+                } else
                 for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
             }
         }

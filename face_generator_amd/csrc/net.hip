@@ -597,7 +597,7 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
                 else if (l.b <= 4 && l.a % 64 == 0) {
                     s.kind = ST_THIN_OUT;
                     if (i + 1 < nl && L[i + 1].type == FG_SIGMOID && !(l.q > 1.f)) { s.has_sigmoid = 1; consumed = 2; }
-                } else if (l.a % 4 == 0 && l.c * l.c <= FG_MAX_GROUPS) s.kind = ST_CONV;
+                } else if (l.a % 4 == 0 && l.c * l.c <= FG_MAX_GROUPS) { s.kind = ST_CONV; fg_geom_set_wino(g, ctx->fusion); }   // 3x3: Winograd F(2x2, 3x3)
                 else fail(FG_ERR_UNSUPPORTED, "conv channel counts not supported", i);
                 break;
             }
@@ -827,7 +827,7 @@ static int build_pack_jobs(fg_net* n) {
     for (auto& s : n->st) {
         if (s.kind == ST_CONV) {
             ConvGeom g = s.geom; g.B = 1;
-            WeightMap wm; fg_geom_weightmap(g, &wm);
+            WeightMap wm; fg_geom_packmap(g, &wm);
             int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
             if (wm.k > 1 && wm.k <= 7 && wm.o_hw <= 1 && wm.i_hw <= 1) {   // convolutions: one LDS-staged job makes both packs
                 PackJob j; memset(&j, 0, sizeof(j));

@@ -1,0 +1,415 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix pipe of gfx950 (MI355X): forward and data gradient of the 3x3 / pad 1 /
+// stride 1 layers of D (models.lua:390-400) and of the coarse-to-fine nets (models_c2f.lua:124, 247-254), which the reference
+// hands to cuDNN v3 / THNN SpatialConvolutionMM.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      d: 4x4 input patch of a 2x2 output tile, g: the 3x3 taps, (.) summed over the
+//                                              input channels = 16 independent [tiles x Cin] x [Cin x Cout] contractions
+//   16 multiplies per 4 outputs and channel pair instead of 36: 2.25 x fewer MFMAs than the 9-tap implicit GEMM.
+//
+// Why it fits THIS part.  v_mfma_f32_32x32x2_f32 occupies a SIMD's matrix pipe for 64 cycles -- ~13 issue slots in which the
+// same wave can issue VALU / LDS / VMEM work for free.  So the kernel is ONE wave per SIMD (4 waves per CU) and every wave does
+// everything: a wave owns 32 tiles x 32 output channels for ALL 16 Winograd positions = 16 accumulator tiles = 256 accumulator
+// registers of the unified 512-entry file, which makes the output transform A^T m A lane-local (a lane holds the 16 positions
+// of its (tile, channel) pairs: no LDS round trip, no second kernel, no [16][T][Cout] intermediate in HBM), and the input
+// transform B^T d B runs in the issue shadow of the MFMAs (64 VALU per 64 MFMAs and wave).  The transformed weights
+// U = G g G^T come from the re-pack launch that runs once per optimizer step (pack kind 2), stored in exactly the order the
+// LDS stage wants them, so a K chunk of U is one contiguous 32 KB run.
+//
+// Block = 256 threads, tile 64 tiles x 64 output channels, K chunk = 8 input channels, two LDS stages of 64 KB:
+//   V[pos 16][k half 2][tile 64][4]   U[pos 16][k half 2][channel 64][4]        (floats; k = 4 * half + j)
+// Lane l of an MFMA supplies A[i = l & 31][k = l >> 5]; with lanes < 32 reading half 0 and lanes >= 32 half 1 of a row, one
+// ds_read_b128 per operand feeds the four MFMAs j = 0..3 of a position, and every 16-lane group of such a read touches 64
+// consecutive banks (conflict-free without padding).  The bias enters as the initial value of position (1, 1): A^T e11 A is the
+// all-ones 2x2 block.
+#include "fg_internal.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define FG_OOB 0x7FFFFFF0   // voffset marker: beyond any buffer (< 2 GiB) -> loads return zeros, stores are dropped
+
+#define WN_STAGE 16384      // floats per LDS stage: V 8192 + U 8192
+
+__device__ __forceinline__ f32x2 wn_load2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 wn_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void wn_decode(int t, const WinoArgs& a, int& b, int& ty, int& tx) {
+    if (a.lgTW >= 0) {
+        tx = t & (a.TW - 1);
+        ty = (t >> a.lgTW) & (a.TH - 1);
+        b = t >> (a.lgTW + a.lgTH);
+    } else {
+        tx = t % a.TW;
+        const int q = t / a.TW;
+        ty = q % a.TH;
+        b = q / a.TH;
+    }
+}
+
+// EPI: 0 = store (+ bias), 1 = store + the nn.PReLU behind the layer (act_y), 2 = the backward of the nn.PReLU in front of the
+// layer (act_x; data gradient) -- the same three epilogues as the implicit-GEMM kernels (igemm.hip fg_epilogue)
+// TRACE (measurement kernel only, FG_WINO_TRACE=1): s_memtime of wave 0 at entry, after the prologue's barrier, after every K chunk
+// and after the epilogue -> dbg_trace[block][0 .. NC + 2]; same row format as igemm_ws_trace_kernel (scripts/ws_trace_report.py)
+template <int EPI, int TRACE = 0>
+__device__ __forceinline__ void wino_body(const WinoArgs& a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* rowoff = (int*)(smem + 2 * WN_STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    // XCD-aware block -> (tile block, channel block): the channel blocks of one tile block re-read the same input patches and
+    // should share an L2 (the dispatcher deals block b to XCD b % 8; speed only, never relied on)
+    const int ntn = a.Npad >> 6;
+    const int nmt = (a.T + 63) >> 6;
+    int lin = blockIdx.x;
+    if ((nmt & 7) == 0) {
+        const int xcd = lin & 7, loc = lin >> 3;
+        lin = (xcd * (nmt >> 3) + loc / ntn) * ntn + loc % ntn;
+    }
+    const int tile_m = lin / ntn, tile_n = lin - tile_m * ntn;
+    const int nch = a.C >> 3;
+    const int per = (nch + a.splits - 1) / a.splits;
+    const int c0 = blockIdx.y * per;
+    const int NC = max(0, min(nch, c0 + per) - c0);
+
+    if (tid < 64) {
+        const int t = tile_m * 64 + tid;
+        int off = -1;
+        if (t < a.T) {
+            int b, ty, tx;
+            wn_decode(t, a, b, ty, tx);
+            off = ((b * a.H + 2 * ty) * a.W + 2 * tx) * a.N;
+        }
+        rowoff[tid] = off;
+    }
+
+    // ---- this thread's share of the loads: (tile tl, channel pair q) of the input patch, 8 float4 of the U chunk
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, FG_OOB, 0x00020000);
+    int voff[16];
+    {
+        const int tl = tid >> 2, q = tid & 3;
+        const int t = tile_m * 64 + tl;
+        int b, ty, tx;
+        wn_decode(t < a.T ? t : 0, a, b, ty, tx);
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int y = y0 + (p >> 2), x = x0 + (p & 3);
+            const bool ok = t < a.T && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            voff[p] = ok ? (((b * a.H + y) * a.W + x) * a.C + 2 * q) * 4 : FG_OOB;
+        }
+    }
+    const int vw = ((tid & 3) >> 1) * 256 + (tid >> 2) * 4 + (tid & 1) * 2;      // V store: [pos][half][tile][4], pos = immediate
+    const int uo = tid * 4;                                                      // U: float4 number tid + 256 i of the chunk image
+    const int ubase = tile_n * nch;                                              // chunk images of this channel block
+    const int a_rd = (lane >> 5) * 256 + (wm * 32 + (lane & 31)) * 4;
+    const int b_rd = 8192 + (lane >> 5) * 256 + (wn * 32 + (lane & 31)) * 4;
+
+    f32x2 rv[16];
+    f32x4 ru[8];
+#define WN_LOAD(c)                                                                                         \
+    {                                                                                                      \
+        const int sx = (c) * 32, su = (ubase + (c)) * 32768;                                               \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) ru[i] = wn_load4(ursrc, (uo + i * 1024) * 4, su);     \
+        _Pragma("unroll") for (int p = 0; p < 16; ++p) rv[p] = wn_load2(xrsrc, voff[p], sx);               \
+    }
+    // input transform B^T d B of this thread's patch (two channels at a time) and the stores of a whole chunk, not interleaved
+    // with anything: the prologue
+#define WN_XFORM_STORE(S, rv, ru)                                                                          \
+    {                                                                                                      \
+        float* Vs = (S) + vw;                                                                              \
+        float* Us = (S) + 8192 + uo;                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) *(f32x4*)(Us + i * 1024) = ru[i];                    \
+        f32x2 w_[16];                                                                                      \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                    \
+            w_[0 + x] = rv[0 + x] - rv[8 + x];                                                             \
+            w_[4 + x] = rv[4 + x] + rv[8 + x];                                                             \
+            w_[8 + x] = rv[8 + x] - rv[4 + x];                                                             \
+            w_[12 + x] = rv[4 + x] - rv[12 + x];                                                           \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+            *(f32x2*)(Vs + (i * 4 + 0) * 512) = w_[i * 4 + 0] - w_[i * 4 + 2];                             \
+            *(f32x2*)(Vs + (i * 4 + 1) * 512) = w_[i * 4 + 1] + w_[i * 4 + 2];                             \
+            *(f32x2*)(Vs + (i * 4 + 2) * 512) = w_[i * 4 + 2] - w_[i * 4 + 1];                             \
+            *(f32x2*)(Vs + (i * 4 + 3) * 512) = w_[i * 4 + 1] - w_[i * 4 + 3];                             \
+        }                                                                                                  \
+    }
+
+    f32x16 acc[16];
+    {
+        const int col = tile_n * 64 + wn * 32 + (lane & 31);
+        float bv = (a.bias != nullptr && a.splits == 1 && col < a.N) ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][r] = (p == 5) ? bv : 0.f;
+    }
+
+    f32x4 fa[2][2], fb[2][2];       // fragment double buffer: [set][position of the pair]
+    unsigned long long* trc = nullptr;
+    if (TRACE) {
+        if (wid == 0 && a.dbg_trace) trc = a.dbg_trace + (size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 128;
+        if (trc && lane == 0) trc[0] = __builtin_amdgcn_s_memtime();
+    }
+    if (NC > 0) {
+        // chunk 0 AND chunk 1 requested before anything waits: the second set of loads lands while the first is transformed
+        f32x2 rv0[16];
+        f32x4 ru0[8];
+        {
+            const int sx = c0 * 32, su = (ubase + c0) * 32768;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ru0[i] = wn_load4(ursrc, (uo + i * 1024) * 4, su);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) rv0[p] = wn_load2(xrsrc, voff[p], sx);
+        }
+        if (NC > 1) WN_LOAD(c0 + 1);
+        WN_XFORM_STORE(smem, rv0, ru0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (TRACE && trc && lane == 0) trc[1] = __builtin_amdgcn_s_memtime();
+    if (NC > 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fa[0][h] = *(const f32x4*)(smem + a_rd + h * 512);
+            fb[0][h] = *(const f32x4*)(smem + b_rd + h * 512);
+        }
+    }
+
+    // One K chunk = 64 MFMA slots (8 position pairs x 2 positions x 4 k-steps).  Every slot is one MFMA followed by a small,
+    // fixed slice of the other work, pinned in program order (sched_barrier) so that it issues in the MFMA's shadow:
+    //   slots 8p .. 8p+3   the four fragment reads of the NEXT pair (pair 7: pair 0 of the next chunk, behind the barrier)
+    //   HAS1 (a next chunk exists; its raw loads were issued one chunk ago):
+    //     slots 0..7    U stores          slots 8..23  column pass of B^T d B       slots 24..40 row pass + V stores
+    //     end of slot 55: lgkmcnt(0) + barrier (stage s^1 complete, every wave is done reading stage s except its last pair,
+    //     whose fragments are already in registers)
+    //   HAS2 (a chunk after that exists): its loads -- U in slots 8..15 (registers free after the U stores), the patch in
+    //     slots 24..39 (free after the column pass)
+#define WN_CHUNK(HAS1, HAS2, cnext2)                                                                       \
+    {                                                                                                      \
+        const float* Sc = smem + s * WN_STAGE;                                                             \
+        float* Sn = smem + (s ^ 1) * WN_STAGE;                                                             \
+        float* Vs = Sn + vw;                                                                               \
+        float* Us = Sn + 8192 + uo;                                                                        \
+        const int sx2 = (cnext2) * 32, su2 = (ubase + (cnext2)) * 32768;                                   \
+        f32x2 w_[16];                                                                                      \
+        _Pragma("unroll") for (int pr = 0; pr < 8; ++pr) {                                                 \
+            _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                                \
+                const int sl = pr * 8 + m, h = m & 1, j = m >> 1, pos = 2 * pr + h;                        \
+                acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pr & 1][h][j], fb[pr & 1][h][j], acc[pos], 0, 0, 0); \
+                if (m < 4 && pr < 7) {                                                                     \
+                    const int np = 2 * (pr + 1) + (m >> 1);                                                \
+                    if ((m & 1) == 0) fa[(pr + 1) & 1][m >> 1] = *(const f32x4*)(Sc + a_rd + np * 512);    \
+                    else fb[(pr + 1) & 1][m >> 1] = *(const f32x4*)(Sc + b_rd + np * 512);                 \
+                }                                                                                          \
+                if (HAS1) {                                                                                \
+                    if (m < 4 && pr == 7) {                                                                \
+                        if ((m & 1) == 0) fa[0][m >> 1] = *(const f32x4*)(Sn + a_rd + (m >> 1) * 512);     \
+                        else fb[0][m >> 1] = *(const f32x4*)(Sn + b_rd + (m >> 1) * 512);                  \
+                    }                                                                                      \
+                    if (sl < 8) *(f32x4*)(Us + sl * 1024) = ru[sl];                                        \
+                    if (sl >= 8 && sl < 24) {                                                              \
+                        const int k = sl - 8, x = k >> 2, o = k & 3;                                       \
+                        if (o == 0) w_[0 + x] = rv[0 + x] - rv[8 + x];                                     \
+                        if (o == 1) w_[4 + x] = rv[4 + x] + rv[8 + x];                                     \
+                        if (o == 2) w_[8 + x] = rv[8 + x] - rv[4 + x];                                     \
+                        if (o == 3) w_[12 + x] = rv[4 + x] - rv[12 + x];                                   \
+                    }                                                                                      \
+                    if (sl >= 24 && sl < 40) {                                                             \
+                        const int k = sl - 24, i = k >> 2, o = k & 3;                                      \
+                        f32x2 v_;                                                                          \
+                        if (o == 0) v_ = w_[i * 4 + 0] - w_[i * 4 + 2];                                    \
+                        if (o == 1) v_ = w_[i * 4 + 1] + w_[i * 4 + 2];                                    \
+                        if (o == 2) v_ = w_[i * 4 + 2] - w_[i * 4 + 1];                                    \
+                        if (o == 3) v_ = w_[i * 4 + 1] - w_[i * 4 + 3];                                    \
+                        *(f32x2*)(Vs + k * 512) = v_;                                                      \
+                    }                                                                                      \
+                    if (HAS2) {                                                                            \
+                        if (sl >= 8 && sl < 16) ru[sl - 8] = wn_load4(ursrc, (uo + (sl - 8) * 1024) * 4, su2); \
+                        if (sl >= 24 && sl < 40) rv[sl - 24] = wn_load2(xrsrc, voff[sl - 24], sx2);        \
+                    }                                                                                      \
+                    if (sl == 55) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          \
+                }                                                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+
+    int s = 0;
+    int ci = 0;
+#define WN_STAMP() if (TRACE && trc && lane == 0) trc[2 + (ci < 119 ? ci : 119)] = __builtin_amdgcn_s_memtime();
+    for (; ci + 2 < NC; ++ci) {
+        WN_CHUNK(true, true, c0 + ci + 2);
+        s ^= 1;
+        WN_STAMP();
+    }
+    if (ci + 1 < NC) {
+        WN_CHUNK(true, false, 0);
+        s ^= 1;
+        WN_STAMP();
+        ++ci;
+    }
+    if (ci < NC) { WN_CHUNK(false, false, 0); WN_STAMP(); }
+#undef WN_STAMP
+#undef WN_LOAD
+#undef WN_XFORM_STORE
+#undef WN_CHUNK
+
+    // ---- output transform A^T m A, lane-local, and the stores.  Lane l holds column (l & 31) and rows (r & 3) + 8 (r >> 2)
+    // + 4 (l >> 5) of each 32 x 32 accumulator tile; the 2 x 2 outputs of a tile are 0, N, W N, (W + 1) N floats from rowoff.
+    float* outp = a.Out + (size_t)blockIdx.y * a.split_stride;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
+    const int col = tile_n * 64 + wn * 32 + (lane & 31);
+    const bool colok = col < a.N;
+    const int oN = a.N * 4, oW = a.W * a.N * 4;
+    float sl_ = 0.f, ssum = 0.f;
+    if (EPI != 0) sl_ = a.act_slope[0];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int4 ro4 = *(const int4*)(rowoff + wm * 32 + 8 * r4 + 4 * (lane >> 5));
+        const int ros[4] = {ro4.x, ro4.y, ro4.z, ro4.w};
+        float xv[4][4];
+        if (EPI == 2) {
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.act_x, 0, FG_OOB, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int vo = (ros[q] >= 0 && colok) ? (ros[q] + col) * 4 : FG_OOB;
+                xv[q][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, vo, 0, 0));
+                xv[q][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, vo, oN, 0));
+                xv[q][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, vo, oW, 0));
+                xv[q][3] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xr, vo, oW + oN, 0));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            __builtin_amdgcn_sched_barrier(0);       // one accumulator row at a time: 16 reads of the accumulator file, 24 sums, 4 stores
+            const int r = r4 * 4 + q;
+            float t0[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t0[j] = (acc[0 + j][r] + acc[4 + j][r]) + acc[8 + j][r];
+                t1[j] = (acc[4 + j][r] - acc[8 + j][r]) - acc[12 + j][r];
+            }
+            float y[4];
+            y[0] = (t0[0] + t0[1]) + t0[2];
+            y[1] = (t0[1] - t0[2]) - t0[3];
+            y[2] = (t1[0] + t1[1]) + t1[2];
+            y[3] = (t1[1] - t1[2]) - t1[3];
+            const int vo = (ros[q] >= 0 && colok) ? (ros[q] + col) * 4 : FG_OOB;
+            const int so[4] = {0, oN, oW, oW + oN};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (EPI == 2) {
+                    const float x = xv[q][e];
+                    const bool pos = x > 0.f;
+                    ssum = fmaf(pos ? 0.f : x, y[e], ssum);      // masked elements read x = 0: they add 0 * g
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pos ? y[e] : sl_ * y[e]), orsrc, vo, so[e], 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[e]), orsrc, vo, so[e], 0);
+                    if (EPI == 1) {
+                        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)a.act_y, 0, FG_OOB, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[e] > 0.f ? y[e] : sl_ * y[e]), yr, vo, so[e], 0);
+                    }
+                }
+            }
+        }
+    }
+    if (EPI == 2 && a.act_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, 64);
+        if (lane == 0) a.act_part[blockIdx.x * 4 + wid] = ssum;
+    }
+    if (TRACE && trc && lane == 0) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // the stores have left the wave
+        trc[(NC < 120 ? NC : 120) + 2] = __builtin_amdgcn_s_memtime();
+        trc[127] = (unsigned long long)__builtin_amdgcn_s_getreg(((3 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)NC << 32);   // XCC_ID, NC
+        trc[126] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);                                    // HW_ID
+    }
+}
+template <int EPI>
+__global__ __launch_bounds__(256) void wino_kernel(const WinoArgs a) { wino_body<EPI, 0>(a); }
+__global__ __launch_bounds__(256) void wino_trace_kernel(const WinoArgs a) { wino_body<0, 1>(a); }
+
+// FG_WINO_TRACE=1 (measurement only): EPI-0 launches run the trace kernel four times (three to settle the clocks); the per-block
+// s_memtime rows of the fourth are appended to FG_WS_TRACE_FILE in igemm_ws_trace_kernel's row format
+static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, size_t lds) {
+    WinoArgs a = a_in;
+    const size_t nblk = (size_t)grid.x * grid.y;
+    unsigned long long* dvc = nullptr;
+    if (hipMalloc((void**)&dvc, nblk * 128 * 8) != hipSuccess) return fg_set_err(ctx, FG_ERR_NOMEM, "trace buffer");
+    (void)hipMemset(dvc, 0, nblk * 128 * 8);
+    a.dbg_trace = dvc;
+    FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_trace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int rep = 0; rep < 4; ++rep) {
+        (void)hipEventRecord(e0, ctx->stream);
+        hipLaunchKernelGGL(wino_trace_kernel, grid, dim3(256), lds, ctx->stream, a);
+        (void)hipEventRecord(e1, ctx->stream);
+    }
+    FG_CHECK_LAUNCH(ctx);
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float wall_ms = 0.f;
+    (void)hipEventElapsedTime(&wall_ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    std::vector<unsigned long long> host(nblk * 128);
+    FG_HIP(ctx, hipMemcpy(host.data(), dvc, nblk * 128 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dvc);
+    const char* path = getenv("FG_WS_TRACE_FILE");
+    FILE* f = fopen(path ? path : "/tmp/fg_ws_trace.txt", "a");
+    if (f) {
+        // (BN=128: scripts/ws_trace_report.py prices a step at 64 MFMAs x 64 cycles per wave -- one K chunk of this kernel)
+        fprintf(f, "# launch wino/%s BN=128 blocks=%zu T=%d Npad=%d C=%d splits=%d wall_us=%.1f\n", a.tag ? a.tag : "?", nblk, a.T, a.Npad, a.C, a.splits, wall_ms * 1e3);
+        for (size_t b = 0; b < nblk; ++b) {
+            const unsigned long long* r = host.data() + b * 128;
+            const int kt = (int)(r[127] >> 32), xcc = (int)(r[127] & 0xffffffff);
+            fprintf(f, "%zu %d %d %llu", b, xcc, kt, r[126]);
+            for (int i = 0; i < (kt < 120 ? kt : 120) + 3; ++i) fprintf(f, " %llu", r[i]);
+            fprintf(f, "\n");
+        }
+        fclose(f);
+    }
+    return FG_OK;
+}
+
+long long fg_wino_blocks(const WinoArgs& a) { return (long long)fg_cdiv(a.T, 64) * (a.Npad / 64); }
+
+int fg_launch_wino(fg_ctx* ctx, const WinoArgs& a) {
+    if (a.C % 8 || a.Npad % 64 || a.H % 2 || a.W % 2 || a.splits < 1) return fg_set_err(ctx, FG_ERR_INVALID, "winograd: C %% 8 / Npad %% 64 / even H, W");
+    if ((a.act_y || a.act_x) && (a.splits != 1 || !a.act_slope || (a.act_y && a.act_x)))
+        return fg_set_err(ctx, FG_ERR_INVALID, "winograd: a fused PReLU needs splits == 1 and its slope");
+    if (a.x_bytes <= 0 || a.x_bytes >= (long long)FG_OOB || (long long)a.B * a.H * a.W * a.N * 4 >= (long long)FG_OOB)
+        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "winograd: operands must be < 2 GiB per launch");
+    const size_t lds = (size_t)(2 * WN_STAGE + 64) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)fg_wino_blocks(a), a.splits, 1);
+    const double exec = 2.0 * (double)grid.x * 64 * 64 * 16.0 * a.C;       // MFMA FLOPs issued: 16 positions, every tile padded to 64 x 64
+    const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
+    {
+        static int tr = -1;
+        if (tr < 0) { const char* e = getenv("FG_WINO_TRACE"); tr = e ? atoi(e) : 0; }
+        if (tr && epi == 0) return fg_wino_trace_launch(ctx, a, grid, lds);
+    }
+    char label[96];
+    snprintf(label, sizeof(label), "wino_kernel<%d>/%s", epi, a.tag ? a.tag : "?");
+    FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
+    if (epi == 2) hipLaunchKernelGGL(wino_kernel<2>, grid, dim3(256), lds, ctx->stream, a);
+    else if (epi == 1) hipLaunchKernelGGL(wino_kernel<1>, grid, dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL(wino_kernel<0>, grid, dim3(256), lds, ctx->stream, a);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}

@@ -62,7 +62,8 @@ class Context:
         """Optional kernel fusions (include/facegen_hip.h FG_FUSE_*): 1 = PReLU in the neighbouring contraction's epilogue,
         2 = one-pass matrix-pipe 3x3 thin-output convolution, 4 = all weight-gradient split-K sums of a backward pass in one launch,
         8 = Adam + the re-pack of every layer in one launch (measured slower: off by default), 16 = the bias gradient of a thin-input
-        convolution from its weight-gradient kernel (no separate column-sum pass); default 23."""
+        convolution from its weight-gradient kernel (no separate column-sum pass), 32 = 3x3 convolutions as Winograd F(2x2, 3x3)
+        (read when a net is created); default 55."""
         self.check(self.lib.fg_set_fusion(self.h, int(flags)))
 
     def get_fusion(self):

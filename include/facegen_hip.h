@@ -51,7 +51,7 @@ int fg_get_math(fg_ctx* ctx);
 
 /* Optional kernel fusions / variants (results equal to the un-fused path up to the summation order of a reduction; exposed so
  * the parity tests and the bench can run both ways).  Default: FG_FUSE_DEFAULT; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 / FG_DEFER_WFINISH=0 /
- * FG_THIN_BIAS=0 in the environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
+ * FG_THIN_BIAS=0 / FG_WINO=0 in the environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
 enum {
     FG_FUSE_PRELU = 1,      /* an nn.PReLU between two contraction layers (models_c2f.lua:118-130, 242-255) rides on their
                              * epilogues: forward copy behind the producing layer, backward (+ slope-gradient partials) in
@@ -71,8 +71,14 @@ enum {
                              * constant 1, so the pass that streams the output gradient anyway also leaves its per-channel sums;
                              * off: a separate column-sum pass re-reads the tensor (134 MB per layer at 64x64, B = 128).  Same
                              * fp64 final reduction; the fp32 partial sums are formed in a different order (FG_THIN_BIAS=0 clears it) */
-    FG_FUSE_ALL = 31,
-    FG_FUSE_DEFAULT = 23
+    FG_FUSE_WINOGRAD = 32,  /* 3x3 / pad 1 / stride 1 convolutions with channel counts % 8 == 0 on even-sized maps (models.lua:390-400,
+                             * models_c2f.lua:124, 247-254): forward and data gradient as Winograd F(2x2, 3x3) on the fp32 matrix pipe
+                             * (16 multiplies per 2x2 outputs instead of 36; transforms in fp32, results equal to the direct
+                             * convolution to a few fp32 roundings) instead of the 9-tap implicit GEMM.  Read when a net is created
+                             * (fg_net_create: its packed weights hold the transformed taps) and per call by the module-level
+                             * fg_conv2d_* entries; FG_WINO=0 clears it.  The weight gradient is not affected */
+    FG_FUSE_ALL = 63,
+    FG_FUSE_DEFAULT = 55
 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);

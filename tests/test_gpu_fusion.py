@@ -15,7 +15,7 @@ from test_gpu_c2f import build, masks_for, dev_masks
 
 pytestmark = pytest.mark.gpu
 
-FG_FUSE_PRELU, FG_FUSE_THIN_SLAB, FG_FUSE_WFINISH_BATCH, FG_FUSE_ADAM_PACK, FG_FUSE_THIN_BIAS, FG_FUSE_ALL, FG_FUSE_DEFAULT = 1, 2, 4, 8, 16, 31, 23
+FG_FUSE_PRELU, FG_FUSE_THIN_SLAB, FG_FUSE_WFINISH_BATCH, FG_FUSE_ADAM_PACK, FG_FUSE_THIN_BIAS, FG_FUSE_WINOGRAD, FG_FUSE_ALL, FG_FUSE_DEFAULT = 1, 2, 4, 8, 16, 32, 63, 55
 
 
 @pytest.fixture(scope="module")

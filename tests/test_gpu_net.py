@@ -257,13 +257,17 @@ def test_D16_d_forward_backward(ctx):
     gx = Dd.device_net.backward(dev(gy, ctx.device), param_grads=True, input_grad=True)
     close(nchw(gx), gin, atol=1e-4 * np.abs(gin).max() + 1e-7, what="D16_d input gradient")
     got, ref = g.cpu().numpy(), gD
-    # per parameter tensor, in flat order
-    off = 0
+    # per parameter tensor, in flat order.  Floor of 2e-6 of the net's largest gradient entry (the bar of the BASELINE-size tests,
+    # tests/test_gpu_baseline_sizes.py::check_every_tensor): a tensor whose own gradient is small inherits the rounding noise of the
+    # signal propagated to it -- here the first layer's weight gradient (max 3e-3) behind the 128 -> 128 3x3 layer, whose data
+    # gradient is a Winograd F(2x2, 3x3) contraction (1.7 x the direct convolution's fp32 rounding error, tests/test_gpu_wino.py)
+    off, gmax = 0, np.abs(ref).max()
     for (m, pn, gn) in D.parameters():
         r = getattr(m, gn).reshape(-1)
         e = np.abs(got[off:off + r.size] - r).max()
         tol = 1e-4 * np.abs(r).max() + 1e-7 + (32 * 6e-8 * getattr(m, "gw_cond", 0.0) if isinstance(m, O.PReLU) else 0.0)
-        assert e <= tol, "D16_d %s.%s: err %.3e tol %.3e" % (type(m).__name__, pn, e, tol)
+        tol = max(tol, 2e-6 * gmax)
+        assert e <= tol, "D16_d %s.%s: err %.3e tol %.3e (max|g_tensor| %.3e, max|g_net| %.3e)" % (type(m).__name__, pn, e, tol, np.abs(r).max(), gmax)
         off += r.size
     # evaluate mode: dropout off / SpatialDropout scaling
     D.evaluate(); Dd.evaluate()

@@ -1,0 +1,86 @@
+"""Winograd F(2x2, 3x3) (csrc/wino.hip; fg_set_fusion bit FG_FUSE_WINOGRAD): forward and data gradient of the 3x3 / pad 1 /
+stride 1 layers (models.lua:390-400, models_c2f.lua:124, 247-254) against the oracle's direct convolution and against the
+library's own 9-tap implicit GEMM (the bit cleared), on the same seeded inputs.
+
+Tolerance: the transforms run in fp32 (B^T d B: two additions per value; G g G^T: halves and sums; A^T m A: sums of up to nine
+products of transformed values), so a result differs from the direct convolution's by a few fp32 roundings of the LARGEST partial
+sum, not of the result: the bar is 3e-5 * max|y| (the implicit GEMM meets 2e-5), stated per check below."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch7_nn as O
+from gpu_util import nhwc, nchw, dev, close
+
+pytestmark = pytest.mark.gpu
+
+FG_FUSE_WINOGRAD, FG_FUSE_DEFAULT = 32, 55
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from face_generator_amd.runtime import get_context
+    c = get_context(0)
+    yield c
+    c.set_fusion(FG_FUSE_DEFAULT)
+
+
+CASES = [
+    # B, H, W, Cin, Cout
+    (3, 8, 8, 64, 128),      # 48 tiles: one ragged block
+    (2, 4, 4, 256, 512),     # D's deepest conv (models.lua:400): 8 tiles, 32 K chunks split over gridDim.y
+    (5, 16, 16, 64, 128),    # 320 tiles = 5 blocks x 2 channel blocks
+    (2, 6, 10, 16, 24),      # tile grid 3 x 5 (no power of two), 24 of 64 output channels live, two K chunks
+    (1, 2, 2, 8, 8),         # a single tile, a single chunk
+    (2, 64, 64, 64, 64),     # models_c2f.lua:124 / :247 at 64x64: 2048 tiles, un-split
+    (9, 32, 32, 128, 256),   # models_c2f.lua:251: 2304 tiles = 36 blocks (no XCD remap: 36 % 8 != 0) x 4 channel blocks
+    (16, 8, 8, 128, 256),    # D's d9 (models.lua:395): 256 tiles, split in two
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", CASES)
+def test_winograd_forward_and_data_gradient(ctx, B, H, W, Cin, Cout):
+    from face_generator_amd import ops
+    rng = np.random.default_rng(B * 1000 + H * 100 + Cin + Cout)
+    conv = O.SpatialConvolution(Cin, Cout, 3, 3, 1, 1, 1, 1, rng)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    y = conv.forward(x)
+    gy = rng.standard_normal(y.shape).astype(np.float32)
+    gx = conv.backward(x, gy)
+    d = ctx.device
+    w_d, b_d = dev(conv.weight, d), dev(conv.bias, d)
+    got = {}
+    for flags in (FG_FUSE_DEFAULT, FG_FUSE_DEFAULT & ~FG_FUSE_WINOGRAD):
+        ctx.set_fusion(flags)
+        got[flags] = (nchw(ops.conv2d_forward(nhwc(x, d), w_d, b_d)), nchw(ops.conv2d_backward_data(nhwc(gy, d), w_d, (H, W))))
+    ctx.set_fusion(FG_FUSE_DEFAULT)
+    yw, gw = got[FG_FUSE_DEFAULT]
+    yi, gi = got[FG_FUSE_DEFAULT & ~FG_FUSE_WINOGRAD]
+    sy, sg = max(np.abs(y).max(), 1.0), max(np.abs(gx).max(), 1.0)
+    close(yw, y, atol=3e-5 * sy, what="winograd forward vs oracle")
+    close(gw, gx, atol=3e-5 * sg, what="winograd data gradient vs oracle")
+    close(yi, y, atol=2e-5 * sy, what="implicit GEMM forward vs oracle")
+    close(yw, yi, atol=3e-5 * sy, what="winograd vs implicit GEMM forward")
+    close(gw, gi, atol=3e-5 * sg, what="winograd vs implicit GEMM data gradient")
+    assert not np.array_equal(yw, yi), "both settings of FG_FUSE_WINOGRAD gave identical bits: the switch selected nothing"
+
+
+def test_winograd_is_exact_on_small_integers(ctx):
+    """Every intermediate of F(2x2, 3x3) on small-integer data with taps that are multiples of 4 is an integer below 2^24: the
+    transforms, the 16 contractions and the output transform are then exact in fp32, so the result must equal the direct
+    convolution BIT FOR BIT (pins the index maps -- tile decode, halo, position order, the 0 <-> 3 exchange of the flipped taps)."""
+    from face_generator_amd import ops
+    rng = np.random.default_rng(7)
+    B, H, W, Cin, Cout = 3, 12, 8, 24, 40
+    conv = O.SpatialConvolution(Cin, Cout, 3, 3, 1, 1, 1, 1, rng)
+    conv.weight[...] = (4 * rng.integers(-2, 3, conv.weight.shape)).astype(np.float32)
+    conv.bias[...] = rng.integers(-8, 9, conv.bias.shape).astype(np.float32)
+    x = rng.integers(-3, 4, (B, Cin, H, W)).astype(np.float32)
+    y = conv.forward(x)
+    gy = rng.integers(-3, 4, y.shape).astype(np.float32)
+    gx = conv.backward(x, gy)
+    d = ctx.device
+    ctx.set_fusion(FG_FUSE_DEFAULT)
+    w_d, b_d = dev(conv.weight, d), dev(conv.bias, d)
+    assert np.array_equal(nchw(ops.conv2d_forward(nhwc(x, d), w_d, b_d)), y)
+    assert np.array_equal(nchw(ops.conv2d_backward_data(nhwc(gy, d), w_d, (H, W))), gx)

@@ -244,3 +244,125 @@ def test_lua_files_are_block_balanced():
         assert depth == 0, "%s: %d unclosed block(s)" % (os.path.basename(path), depth)
         for a, b in ("()", "{}", "[]"):
             assert src.count(a) == src.count(b), "%s: unbalanced %s%s" % (os.path.basename(path), a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# no Lua in the image, so the shipped Lua is syntax-checked by a Lua 5.1 parser written for the purpose
+# (tests/lua_parser.py: the whole grammar, not a block counter) and its free names are resolved against what the host script defines.
+# ---------------------------------------------------------------------------------------------------------------------------
+from lua_parser import parse as lua_parse, LuaSyntaxError, tokenize as lua_tokenize      # noqa: E402
+
+LUA_STDLIB = {"assert", "collectgarbage", "dofile", "error", "getfenv", "getmetatable", "ipairs", "load", "loadfile", "loadstring",
+              "module", "next", "pairs", "pcall", "print", "rawequal", "rawget", "rawset", "require", "select", "setfenv",
+              "setmetatable", "tonumber", "tostring", "type", "unpack", "xpcall", "_G", "_VERSION", "coroutine", "debug", "io", "math",
+              "os", "package", "string", "table", "bit", "jit", "arg"}
+
+
+def test_the_parser_knows_lua():
+    """The checker itself: accepts the constructs of the 5.1 manual, rejects the classic slips, resolves scopes."""
+    ok = r'''
+        local a, b = 1, 0x1F; local s = 'x\'y' .. "z" .. [[long
+        string]] .. [==[ with ]] inside ]==]
+        --[[ long
+        comment ]] --[==[ another ]==]
+        local function f(x, ...) local t = {...}; return x and #t or -x ^ 2 ^ 3, select('#', ...) end
+        function M.sub.name:method(p) self.v = p; return self end
+        for i = 1, 10, 2 do if i % 2 == 0 then break elseif i > 5 then g = i else h = {i, [i] = 2, k = 3; 4,} end end
+        for k, v in pairs(t) do repeat local z = k until z ~= nil end
+        while not done do done = f(a)(b){c}'d':m(1, 2):n "s" [1].x end
+        do local x <const_is_not_5_1 = 1 end
+    '''
+    with pytest.raises(LuaSyntaxError):
+        lua_parse(ok)                                # `<attrib>` is 5.4, not 5.1: rejected
+    c = lua_parse(ok.replace(" <const_is_not_5_1", ""))
+    assert {"M", "pairs", "t", "done", "select"} <= set(c.globals_read) | set(c.globals_written)
+    assert "a" not in c.globals_read and "f" not in c.globals_read                     # locals (incl. `local function`) are not free
+    assert {"g", "h", "done"} <= set(c.globals_written) and "z" not in c.globals_read and "self" not in c.globals_read
+    assert ("M.sub.name:method", 1, False) in [(q, n, v) for (_, q, n, v) in c.functions]
+    for bad in ("if x then y = 1", "if x y = 1 end", "f(1,,2)", "x = = 1", "local function end", "for i = 1 do end", "x = {1 2}",
+                "return 1 x = 2", "break", "f() = 1", "a.b:c = 1", "x = 1 +", "function f(a,) end", "local t = {[1] 2}",
+                "repeat x = 1 end", "y = 'unfinished", "z = [[unfinished", "x = 3e", "local function f() return ... end",
+                "goto done", "x = a ? b : c", "end"):
+        with pytest.raises(LuaSyntaxError):
+            lua_parse(bad)
+    assert lua_parse("local x = 1ULL + 0x10LL + 2i").n_statements == 1                    # LuaJIT number suffixes (the FFI binding uses them)
+
+
+def test_shipped_lua_parses():
+    assert len(LUA) >= 3
+    for path in LUA:
+        c = lua_parse(open(path).read())
+        assert c.n_statements > 50 and c.functions, os.path.basename(path)
+
+
+def _mutations(src):
+    """Three deliberate slips per file: a dropped `end`, a dropped `then`, a doubled comma in an argument list."""
+    toks = lua_tokenize(src)
+    lines = src.split("\n")
+
+    def drop(word, which):
+        hits = [t for t in toks if t.kind == "keyword" and t.val == word]
+        t = hits[which % len(hits)]
+        ln = lines[t.line - 1]
+        i = [m.start() for m in re.finditer(r"\b%s\b" % word, ln)]
+        # the token stream has no columns: take the line's last occurrence that is not inside a comment
+        code = ln.split("--")[0]
+        i = [k for k in i if k < len(code)]
+        assert i, (word, t.line, ln)
+        out = list(lines)
+        out[t.line - 1] = ln[:i[-1]] + " " * len(word) + ln[i[-1] + len(word):]
+        return "\n".join(out)
+    yield "a dropped `end`", drop("end", -1)
+    yield "a dropped `end` mid-file", drop("end", len([t for t in toks if t.val == "end"]) // 2)
+    yield "a dropped `then`", drop("then", 1)
+    blank = lambda mm: re.sub(r"[^\n]", " ", mm.group(0))                  # comments blanked in place: offsets stay valid
+    code = re.sub(r"--[^\n]*", blank, re.sub(r"--\[(=*)\[.*?\]\1\]", blank, src, flags=re.S))
+    code = re.sub(r"\[(=*)\[.*?\]\1\]", blank, code, flags=re.S)             # long strings too (the cdef block is C, not Lua)
+    m = re.search(r"\w\(([^()\n'\"]*?), ", code)
+    yield "a doubled comma", src[:m.end() - 1] + ", " + src[m.end() - 1:]
+
+
+def test_a_broken_end_then_or_comma_is_caught_in_every_file():
+    for path in LUA:
+        src = open(path).read()
+        lua_parse(src)
+        for what, bad in _mutations(src):
+            assert bad != src
+            with pytest.raises(LuaSyntaxError):
+                lua_parse(bad)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is only present in the build container")
+def test_patched_reference_scripts_parse_and_define_what_the_rehosted_files_read(tmp_path):
+    """Every reference script, untouched and after lua/patches/*.patch, is valid Lua 5.1; and every free name the re-hosted loops
+    read is a Lua / LuaJIT library name, a global the (patched) host script assigns before it calls the loop, or a name the
+    reference's own version of that file reads as well (train.lua:71-94 sets OPT, MODEL_G, NN_UTILS, CONFUSION, ...)."""
+    import shutil
+    ref = "/root/reference"
+    scripts = sorted(glob.glob(os.path.join(ref, "*.lua")) + glob.glob(os.path.join(ref, "*", "*.lua")))
+    assert len(scripts) >= 15
+    for s in scripts:
+        lua_parse(open(s).read())                                                   # the checker accepts all of upstream's Lua
+        rel = os.path.relpath(s, ref)
+        os.makedirs(os.path.dirname(os.path.join(str(tmp_path), rel)) or str(tmp_path), exist_ok=True)
+        shutil.copy(s, os.path.join(str(tmp_path), rel))
+    for p in sorted(glob.glob(os.path.join(ROOT, "lua", "patches", "*.patch"))):
+        subprocess.run(["patch", "-p1", "-s", "-d", str(tmp_path), "-i", p], check=True)
+    parsed = {}
+    for s in scripts:
+        rel = os.path.relpath(s, ref)
+        parsed[rel] = lua_parse(open(os.path.join(str(tmp_path), rel)).read())      # ... and all of it after the patches
+    mine = {os.path.basename(p): lua_parse(open(p).read()) for p in LUA}
+    binding = mine["facegen_hip.lua"]
+    extra = set(binding.globals_read) - LUA_STDLIB - {"torch", "IMG_DIMENSIONS"}
+    assert not extra, "lua/facegen_hip.lua reads undefined globals: %s" % sorted(extra)
+    for host, loop, upstream in (("train.lua", "adversarial_hip.lua", "adversarial.lua"),
+                                 ("train_c2f.lua", "adversarial_c2f_hip.lua", "adversarial_c2f.lua")):
+        defined = set(parsed[host].globals_written) | set(mine[loop].globals_written)
+        theirs = set(lua_parse(open(os.path.join(ref, upstream)).read()).globals_read)
+        unknown = set(mine[loop].globals_read) - LUA_STDLIB - defined - theirs
+        assert not unknown, "%s reads %s, which %s never assigns and %s never reads" % (loop, sorted(unknown), host, upstream)
+        # the patched host still assigns everything the loop reads from it, and binds the library before building the nets
+        for name in ("OPT", "MODEL_G", "MODEL_D", "NN_UTILS", "CONFUSION", "OPTSTATE", "EPOCH", "IMG_DIMENSIONS", "ADVERSARIAL"):
+            assert name in parsed[host].globals_written, "%s (patched) no longer assigns %s" % (host, name)
+        assert "FG" in parsed[host].globals_written, "%s (patched) does not bind the library (FG = require 'facegen_hip')" % host
