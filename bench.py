@@ -23,6 +23,7 @@ Roofline keys (dominant kernel, HIP events on the launch stream, live in this ru
   step_roofline.*               the whole iteration: algorithmic and executed FLOPs over the measured step time
 """
 import argparse
+import re
 import json
 import os
 import sys
@@ -114,10 +115,20 @@ KERNEL_SOURCE = os.path.join(ROOT, "face_generator_amd", "csrc", "igemm.hip")
 # the dominant launch of the dominant kernel: nearest-x2 + 5x5 conv 256 -> 128 forward at B = 128 (models.lua:68-69):
 # reads the 33.5 MB input + 4.7 MB of folded weights, writes the 67.1 MB output
 DOMINANT_LAUNCH = dict(kernel="igemm_ws_kernel<128>", launch="nearest-x2 + 5x5 conv 256->128 forward, B=128 (models.lua:68-69)",
-                       algorithmic_bytes_per_launch=128 * 16 * 16 * 256 * 4 + 4 * 9 * 256 * 128 * 4 + 128 * 32 * 32 * 128 * 4 + 128 * 4)
+                       algorithmic_bytes_per_launch=128 * 16 * 16 * 256 * 4 + 4 * 9 * 256 * 128 * 4 + 128 * 32 * 32 * 128 * 4 + 128 * 4,
+                       bench_one=["fwd", "4"], trace_prefix="igemm_ws_kernel<128>")
+# configs[3]: the 5x5 conv 128 -> 256 at 64x64 (models_c2f.lua:126) -- in the step it runs as igemm_ws_act_kernel<128,1> (the PReLU
+# behind it in the epilogue: the pre-activation AND prelu(x) are stored); the module-level launch measured here is the same loop with
+# the plain epilogue (one store of the output), so both byte counts are given
+DOMINANT_LAUNCH_C2F = dict(kernel="igemm_ws_act_kernel<128,1>", launch="5x5 conv 128->256 forward at 64x64, B=128 (models_c2f.lua:126), "
+                           "measured on the plain-epilogue instantiation igemm_ws_kernel<128> of the same loop (module-level launch); the "
+                           "step's launch also stores prelu(x): + 536.9 MB of writes",
+                           algorithmic_bytes_per_launch=128 * 64 * 64 * 128 * 4 + 25 * 128 * 256 * 4 + 128 * 64 * 64 * 256 * 4 + 256 * 4,
+                           algorithmic_bytes_with_fused_prelu_store=128 * 64 * 64 * 128 * 4 + 25 * 128 * 256 * 4 + 2 * 128 * 64 * 64 * 256 * 4 + 256 * 4,
+                           bench_one=["fwd", "3", "0", "128", "64", "64", "128", "256", "5", "0"], trace_prefix="igemm_ws_kernel<128>")
 
 
-def live_traffic(kernel, timeout=150):
+def live_traffic(kernel, timeout=150, spec=None):
     """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 PMC passes (FETCH_SIZE, then WRITE_SIZE -- they do
     not fit one pass; --kernel-trace only, as MI355X_MICROARCH.md prescribes) over scripts/bench_one.py, which launches exactly the
     dominant launch.  FETCH_SIZE is doubled (gfx950: 128-byte requests tallied at 64 bytes for 16-byte-per-lane loads); both are KiB.
@@ -127,7 +138,8 @@ def live_traffic(kernel, timeout=150):
     import shutil
     import subprocess
     import tempfile
-    if kernel != DOMINANT_LAUNCH["kernel"] or shutil.which("rocprofv3") is None:
+    spec = spec or DOMINANT_LAUNCH
+    if kernel != spec["kernel"] or shutil.which("rocprofv3") is None:
         return None
     vals = {}
     for pmc in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -135,12 +147,12 @@ def live_traffic(kernel, timeout=150):
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(["rocprofv3", "--pmc", pmc, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                            sys.executable, os.path.join(ROOT, "scripts", "bench_one.py"), "fwd", "4"],
+                            sys.executable, os.path.join(ROOT, "scripts", "bench_one.py")] + spec["bench_one"],
                            cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
             tot, launches = 0.0, set()
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r["Kernel_Name"].startswith("void igemm_ws_kernel<128>") or r["Kernel_Name"].startswith("igemm_ws_kernel<128>"):
+                    if r["Kernel_Name"].startswith("void " + spec["trace_prefix"]) or r["Kernel_Name"].startswith(spec["trace_prefix"]):
                         if r["Counter_Name"] == pmc:
                             tot += float(r["Counter_Value"])
                             launches.add(r["Dispatch_Id"])
@@ -151,7 +163,7 @@ def live_traffic(kernel, timeout=150):
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    tj = dict(DOMINANT_LAUNCH)
+    tj = {k: v for k, v in spec.items() if k not in ("bench_one", "trace_prefix")}
     tj.update(fetch_size_kb_raw=vals["FETCH_SIZE"], fetch_correction=2.0, write_size_kb=vals["WRITE_SIZE"],
               hbm_bytes_per_launch=2.0 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024,
               kernel_source_sha16=_sha16(KERNEL_SOURCE), freshness="live",
@@ -160,14 +172,16 @@ def live_traffic(kernel, timeout=150):
     return tj
 
 
-def load_traffic(kernel, live=True):
+def load_traffic(kernel, live=True, spec=None):
     """HBM bytes per launch of the dominant kernel: measured by this run (live_traffic) when rocprofv3 is there, otherwise the newest
     committed PMC summary, labelled `stale` unless it was taken from the kernel source this run executes (sha of igemm.hip)."""
     if live:
-        tj = live_traffic(kernel)
+        tj = live_traffic(kernel, spec=spec)
         if tj is not None:
             return tj
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    if spec is not None and spec is not DOMINANT_LAUNCH:
+        return None
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -278,7 +292,7 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
             for f in ("calls", "ms", "alg", "exe", "bytes"):
                 a[f] += r[f]
         if sym:
-            sym = {k: v for k, v in sym.items() if v["exe"] > 0 or v["alg"] > 0} or sym     # contraction launches (the tail is reported apart)
+            sym = {k: v for k, v in sym.items() if v["exe"] > 0} or sym     # contraction launches (the tail is reported apart)
             exe_iter = sum(v["exe"] for v in sym.values()) / args.prof_iters
             mfma_ms_iter = sum(v["ms"] for v in sym.values() if v["exe"] > 0) / args.prof_iters
             out["step_roofline"].update({
@@ -292,7 +306,9 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
             a = sym[dom]
             alg = a["alg"] / (a["ms"] * 1e-3) / 1e12
             exe = a["exe"] / (a["ms"] * 1e-3) / 1e12
-            tj = load_traffic(dom, live=not args.no_live_traffic) if (workload == "cfg2" and world == 1) else None
+            tj = None
+            if world == 1:
+                tj = load_traffic(dom, live=not args.no_live_traffic, spec=DOMINANT_LAUNCH if workload == "cfg2" else DOMINANT_LAUNCH_C2F)
             out["roofline"] = {"bound": "mfma", "achieved": exe, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": exe / PEAK_F32_MFMA_TFLOPS,
                                "traffic": tj["hbm_bytes_per_launch"] if tj else None,
@@ -300,6 +316,7 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
                                "traffic_over_algorithmic": (tj["hbm_bytes_per_launch"] / tj["algorithmic_bytes_per_launch"])
                                if tj and tj.get("algorithmic_bytes_per_launch") else None,
                                "traffic_note": (tj["launch"] + "; " + tj["source"]) if tj else None,
+                               "algorithmic_bytes_with_fused_prelu_store": tj.get("algorithmic_bytes_with_fused_prelu_store") if tj else None,
                                "traffic_freshness": tj.get("freshness") if tj else None,
                                "granted_clock_ghz": out["step_roofline"].get("granted_clock_ghz"),
                                "frac_at_granted_clock": (exe / (PEAK_F32_MFMA_TFLOPS * out["step_roofline"]["granted_clock_ghz"] / NOMINAL_CLOCK_GHZ))
@@ -315,12 +332,24 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
                                         "bf16_issued_frac": 6.0 * exe / PEAK_BF16_MFMA_TFLOPS})
             # the HBM-bound tail, separately -- algorithmic bytes (every operand once) of each
             # pointwise / thin launch over its HIP-event time, against the 8 TB/s HBM peak
+            def padded(k):       # thin_in<7,3> / thin_out<5,3> / thin_wgrad<7,4>: the 5x5 / 7x7 layers with <= 4 channels on one side
+                m = re.match(r"thin_(?:in|out|wgrad)<(\d+),", k)
+                return bool(m) and int(m.group(1)) >= 5
+            pad = [{"kernel": k, "launches_per_iter": round(v["calls"] / args.prof_iters, 2), "us": round(1e3 * v["ms"] / v["calls"], 2),
+                    "ms_per_iter": round(v["ms"] / args.prof_iters, 4), "useful_gflop_per_launch": round(v["alg"] / v["calls"] / 1e9, 3),
+                    "useful_tflops": round(v["alg"] / (v["ms"] * 1e-3) / 1e12, 2),
+                    "useful_frac_of_f32_mfma_peak": round(v["alg"] / (v["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                   for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]) if padded(k) and v["ms"] > 0]
+            if pad:
+                out["roofline"]["mfma_padded"] = pad
+                out["roofline"]["mfma_padded_note"] = ("bound: the fp32 matrix pipe on tiles padded to the MFMA shape (a 7x7x3 window = 147 of 160 "
+                                                       "K columns, 21 of 32 N columns live): priced by useful FLOPs / time / 157.3, not in TB/s")
             tail = [{"kernel": k, "launches_per_iter": round(v["calls"] / args.prof_iters, 2),
                      "bytes_per_launch": round(v["bytes"] / v["calls"]), "us": round(1e3 * v["ms"] / v["calls"], 2),
                      "ms_per_iter": round(v["ms"] / args.prof_iters, 4),
                      "tb_s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e12, 3),
                      "frac_of_8TBs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)}
-                    for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]) if v["bytes"] > 0 and v["ms"] > 0]
+                    for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]) if v["bytes"] > 0 and v["ms"] > 0 and not padded(k)]
             if tail:
                 tb, tm = sum(t["bytes_per_launch"] * t["launches_per_iter"] for t in tail), sum(t["ms_per_iter"] for t in tail)
                 out["roofline"]["hbm_tail"] = tail
@@ -360,6 +389,83 @@ def measure(args, ctx, tr, iteration, torch, dist, world, rank, B, flops_per_ite
         out["alt_math"] = alt
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out.update(cpu_baselines(workload, B))
+
+
+def timed_leg(ctx, torch, dist, world, rank, tr, iteration, steps, warmup):
+    """`steps` iterations bracketed like the headline (barrier + synchronize on both sides, MAX over ranks) plus every rank's own
+    step time; no roofline leg.  Returns (ms_per_step, [per-rank ms])."""
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for _ in range(warmup):
+        iteration()
+    tr.finish_pending()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        iteration()
+    tr.finish_pending()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    sync_all()
+    dt = time.perf_counter() - t0
+    per = [1000.0 * dt_local / steps]
+    if world > 1:
+        t = torch.zeros(world + 1, dtype=torch.float64, device=ctx.device)
+        t[rank] = 1000.0 * dt_local / steps
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        m = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        dt = float(m.item())
+        per = [round(v, 4) for v in t.tolist()[:world]]
+    return 1000.0 * dt / steps, per
+
+
+def multi_gpu_extras(args, ctx, torch, dist, coll, world, rank, B, out):
+    """N > 1 only: what a first SCALE record needs to be decisive, in the same driver-timed run --
+      * `compute_only`: the SAME per-rank iteration with no communicator attached (no exchange, no deferred update): every rank's
+        N = 1-equivalent compute time; compute_over_step = max over ranks / the headline's ms_per_step is the scaling efficiency
+        the exchange leaves, independent of any N = 1 run on another box;
+      * `sync_bn` (or `per_gpu_bn` when the headline ran --sync-bn): the other BatchNorm mode -- per-GPU statistics are the
+        throughput mode, sync-BN is the reference's B_global semantics (SURVEY 8(e)); both numbers in one line;
+      * `strong`: BASELINE configs[1]'s global batch of 128 split over the ranks (the weak line is the headline).
+    Each leg builds its own nets and is bracketed like the headline; a failure is recorded, never raised."""
+    ex = {}
+    steps, warm = max(3, min(args.steps, 20)), max(1, min(args.warmup, 3))
+
+    def leg(name, build, with_coll, note):
+        stage("multi-GPU extra: " + name)
+        try:
+            w = build(coll if with_coll else None)
+            ms, per = timed_leg(ctx, torch, dist, world, rank, w["tr"], w["iteration"], steps, warm)
+            bpg = w["config"]["batch_per_gpu"]
+            ex[name] = {"value": world * bpg * 1000.0 / ms, "unit": "images/sec", "ms_per_step": ms, "per_rank_ms_per_step": per,
+                        "batch_per_gpu": bpg, "steps": steps, "warmup": warm, "note": note}
+            del w
+            torch.cuda.empty_cache()
+        except Exception as e:
+            ex[name] = {"error": str(e)[:300]}
+
+    class A(object):       # args with one field changed
+        def __init__(self, **kw):
+            self.__dict__.update(vars(args)); self.__dict__.update(kw)
+    leg("compute_only", lambda c: build_cfg2(args, ctx, torch, None, 1, rank, B), False,
+        "no communicator: each rank's own iteration at its per-GPU batch (replicas diverge -- timing only); `value` is the "
+        "no-exchange aggregate N x B / max-rank time")
+    if "ms_per_step" in ex.get("compute_only", {}) and out.get("ms_per_step"):
+        c = ex["compute_only"]
+        out["per_rank_compute_ms"] = c["per_rank_ms_per_step"]
+        out["compute_over_step"] = max(c["per_rank_ms_per_step"]) / out["ms_per_step"]
+        out["exchange_exposed_ms_per_step"] = out["ms_per_step"] - max(c["per_rank_ms_per_step"])
+    other = "per_gpu_bn" if args.sync_bn else "sync_bn"
+    leg(other, lambda c: build_cfg2(A(sync_bn=not args.sync_bn), ctx, torch, c, world, rank, B), True,
+        "the other BatchNorm mode of the same weak-scaling workload (headline: %s)" % ("sync-BN" if args.sync_bn else "per-GPU statistics"))
+    if not args.strong and 128 % (2 * world) == 0:
+        leg("strong", lambda c: build_cfg2(A(strong=True), ctx, torch, c, world, rank, 128 // world), True,
+            "strong scaling: the global batch of 128 (BASELINE configs[1]) split over the ranks, %d per GPU" % (128 // world))
+    out["multi_gpu"] = ex
 
 
 C2F_D2_FLOP_PER_IMAGE = 45.130e9   # configs[4] (SURVEY 8(d)): D_iterations = 2 -> 2888.30 GFLOP per B=64 iteration
@@ -540,6 +646,9 @@ def main():
     ap.add_argument("--watchdog", type=float, default=360.0,
                     help="N > 1: seconds the headline leg may take from process start (rendezvous, RCCL init, self-test, warm-up, timed "
                          "steps); past it rank 0 prints a PARTIAL JSON line naming the stage that did not finish and every rank exits 4")
+    ap.add_argument("--no-multi-gpu-extras", action="store_true",
+                    help="N > 1: skip the compute-only / other-BatchNorm-mode / strong-scaling legs behind the headline (multi_gpu record)")
+    ap.add_argument("--extras-timeout", type=float, default=240.0, help="N > 1: seconds the multi_gpu legs may take in total")
     ap.add_argument("--no-dry-check", action="store_true",
                     help="N > 1: do not walk the collective schedule of all N ranks on the CPU first (rank 0, a subprocess, ~5 s)")
     ap.add_argument("--dry-collective", action="store_true",
@@ -668,7 +777,26 @@ def main():
         out["host_input_images_per_sec"] = B * args.steps / (time.perf_counter() - th)
     out["reference_accounting_images_per_sec"] = out["value"] / 2   # adversarial.lua:305 counts B/2 per iteration
     if watchdog is not None:
-        watchdog.cancel()          # the headline is measured; the c2f leg has its own timer below
+        watchdog.cancel()          # the headline is measured; the supplementary legs have their own timers below
+    if world > 1 and headline == "cfg2" and not args.no_multi_gpu_extras:
+        import threading
+        ex_done = threading.Event()
+
+        def ex_bail():             # a stalled extra leg must not cost the headline: print what exists and leave (every rank)
+            if not ex_done.is_set():
+                if rank == 0:
+                    out.setdefault("multi_gpu", {})["error"] = "stage '%s' did not finish within %.0f s" % (STAGE["name"], args.extras_timeout)
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        ex_timer = threading.Timer(args.extras_timeout, ex_bail)
+        ex_timer.daemon = True
+        ex_timer.start()
+        del w, tr
+        torch.cuda.empty_cache()
+        multi_gpu_extras(args, ctx, torch, dist, coll, world, rank, B, out)
+        ex_done.set()
+        ex_timer.cancel()
+        w = tr = None
 
     if args.workload == "both":
         # BASELINE configs[3] (one GPU: B = 128, D_it = 1) / configs[4] (N > 1: 64 per GPU, D_it = 2) in the same driver-timed run
@@ -687,7 +815,7 @@ def main():
             timer.start()
         sub = {}
         try:
-            del w, tr
+            w = tr = None
             torch.cuda.empty_cache()
             cB, d_it = (B, 1) if world == 1 else (max(2, B // 2), 2)
             cw = build_c2f(args, ctx, torch, coll, world, rank, cB, d_it)
@@ -697,6 +825,15 @@ def main():
             sub["config"]["step_entry"] = step_entry(cw["tr"])
             measure(args, ctx, cw["tr"], cw["iteration"], torch, dist, world, rank, cB, cw["flops"], sub, "c2f", args.c2f_steps, 3,
                     alt_math=False)
+            if world > 1 and not args.no_multi_gpu_extras:
+                del cw
+                torch.cuda.empty_cache()
+                stage("c2f: compute-only leg")
+                cl = build_c2f(args, ctx, torch, None, 1, rank, cB, d_it)
+                _, per = timed_leg(ctx, torch, dist, world, rank, cl["tr"], cl["iteration"], max(1, min(args.c2f_steps, 5)), 1)
+                sub["per_rank_compute_ms"] = per
+                sub["compute_over_step"] = max(per) / sub["ms_per_step"]
+                sub["exchange_exposed_ms_per_step"] = sub["ms_per_step"] - max(per)
         except Exception as e:          # supplementary: never let it take the headline measurement down
             sub["error"] = str(e)[:300]
         done.set()
@@ -715,6 +852,12 @@ def main():
                                      "ms_per_step": (cB * C2F_FLOP_PER_IMAGE / (0.8 * PEAK_F32_MFMA_TFLOPS * 1e12) * 1e3) if d_it == 1 else None},
                     "dominant_kernel": {k: rr.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_ms", "launches_per_iter",
                                                                "frac_at_granted_clock")},
+                    # HBM bytes of the dominant launch from this run's own PMC passes
+                    "traffic": rr.get("traffic"), "algorithmic_bytes": rr.get("algorithmic_bytes"),
+                    "algorithmic_bytes_with_fused_prelu_store": rr.get("algorithmic_bytes_with_fused_prelu_store"),
+                    "traffic_over_algorithmic": rr.get("traffic_over_algorithmic"), "traffic_freshness": rr.get("traffic_freshness"),
+                    "traffic_note": rr.get("traffic_note"),
+                    "mfma_padded": rr.get("mfma_padded"), "mfma_padded_note": rr.get("mfma_padded_note"),
                     "hbm_tail_total": rr.get("hbm_tail_total")}
             if isinstance(out.get("cpu_baseline"), dict) and isinstance(sub.get("cpu_baseline"), dict):
                 out["cpu_baseline"]["c2f"] = {k: sub["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind")}

@@ -295,7 +295,7 @@ static int conv_check(fg_ctx* ctx, int cin, int cout, int k, int pad, int up) {
         if (up) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: upsample fold on a thin conv");
         return FG_OK;
     }
-    if (cin % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv2d: nInputPlane %% 4 != 0");
+    // (any channel count: a ragged one -- nInputPlane / nOutputPlane % 4 != 0 -- takes a zero-padded copy of the operand, conv_ops.hip)
     if (up) {
         int T, rmin;
         fg_fold_window(k, pad, &T, &rmin);
@@ -374,7 +374,6 @@ size_t fg_linear_workspace_bytes(int batch, int in_f, int out_f) {
 int fg_linear_forward(fg_ctx* ctx, const float* x, const float* wt, const float* bias, float* y, int batch, int in_f,
                       int out_f, void* wsv, size_t ws_bytes) {
     NEED(ctx, ctx && x && wt && y && wsv, "null argument");
-    if (in_f % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "linear: in_features %% 4 != 0");
     if (ws_bytes < fg_linear_workspace_bytes(batch, in_f, out_f)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "linear: workspace");
     if (out_f == 1) return fg_launch_gemv_forward(ctx, x, wt, bias, y, batch, in_f, 0);
     ConvGeom g = mk_geom(batch, 1, 1, in_f, out_f, 1, 0, 0);
@@ -388,7 +387,6 @@ int fg_linear_backward_data(fg_ctx* ctx, const float* gy, const float* wt, float
                             void* wsv, size_t ws_bytes) {
     NEED(ctx, ctx && gy && wt && gx && wsv, "null argument");
     if (out_f == 1) return fg_launch_gemv_backward(ctx, nullptr, wt, nullptr, gy, gx, nullptr, nullptr, 0.f, batch, in_f, 0);
-    if (out_f % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "linear dgrad: out_features %% 4 != 0");
     if (ws_bytes < fg_linear_workspace_bytes(batch, in_f, out_f)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "linear: workspace");
     ConvGeom g = mk_geom(batch, 1, 1, in_f, out_f, 1, 0, 0);
     float* ws = (float*)wsv;
@@ -401,7 +399,6 @@ int fg_linear_backward_weight(fg_ctx* ctx, const float* x, const float* gy, floa
                               int in_f, int out_f, void* wsv, size_t ws_bytes) {
     NEED(ctx, ctx && x && gy && gw && wsv, "null argument");
     if (out_f == 1) return fg_launch_gemv_backward(ctx, x, gw /*unused as w*/, nullptr, gy, nullptr, gw, gb, beta, batch, in_f, 0);
-    if (in_f % 4 || out_f % 4) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "linear wgrad: features %% 4 != 0");
     if (ws_bytes < fg_linear_workspace_bytes(batch, in_f, out_f)) return fg_set_err(ctx, FG_ERR_WORKSPACE, "linear: workspace");
     ConvGeom g = mk_geom(batch, 1, 1, in_f, out_f, 1, 0, 0);
     return fg_conv_wgrad_run(ctx, g, x, gy, gw, gb, beta, (float*)wsv, (long long)(ws_bytes / 4));

@@ -329,6 +329,9 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
     if (n3 > need) need = n3;
     long long n4 = (long long)(CR_ROWBLOCKS_MAX + 2) * g.Cout;
     if (n4 > need) need = n4;
+    // ragged channel counts: the zero-padded copies of the operands (pad_operand) at the tail of the scratch
+    if (g.Cin % 4) need += M * fg_round_up(g.Cin, 4) + 8;
+    if (g.Cout % 4) need += outM * fg_round_up(g.Cout, 4) + 8;
     return need + 64;
 }
 // upper bound over the math modes, so fg_set_math can be toggled on a live net
@@ -359,6 +362,35 @@ static void fill_mspace(IgemmArgs& a, int B, int H, int W) {
     if (a.lgH < 0 || a.lgW < 0) a.lgH = a.lgW = -1;
 }
 
+
+// Channel counts that are not a multiple of 4 (a `--noiseDim 50` Linear, a 6-channel conv: train.lua's CLI accepts any, nn_utils.lua:35-39).
+// The contraction kernels gather their A operand in 16-byte pieces, so such a tensor is first copied into rows of round_up(C, 4)
+// floats with a zero tail (the packed weights are zero there as well); the copy lives at the TAIL of the caller's scratch.
+__global__ void pad_channels_kernel(const float* __restrict__ src, long long rows, int C, int Cp, float* __restrict__ dst) {
+    const long long n = rows * Cp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / Cp;
+        const int c = (int)(i - r * Cp);
+        dst[i] = c < C ? src[r * C + c] : 0.f;
+    }
+}
+// returns the operand to use (src itself when C % 4 == 0); shrinks *scratch_floats by what the copy takes; *rc on error
+static const float* pad_operand(fg_ctx* ctx, const float* src, long long rows, int C, float* scratch, long long* scratch_floats, int* Cp,
+                                int* rc) {
+    *rc = FG_OK; *Cp = C;
+    if (C % 4 == 0) return src;
+    *Cp = fg_round_up(C, 4);
+    const long long need = (rows * *Cp + 3) / 4 * 4;
+    const long long at = (*scratch_floats - need) / 4 * 4;          // 16-byte aligned inside a 16-byte aligned scratch
+    if (at < 0) { *rc = fg_set_err(ctx, FG_ERR_WORKSPACE, "ragged channel count %d: scratch %lld < %lld", C, *scratch_floats, need); return nullptr; }
+    float* dst = scratch + at;
+    const long long n = rows * *Cp;
+    const int blocks = (int)(n + 255) / 256 > 4096 ? 4096 : (int)((n + 255) / 256);
+    hipLaunchKernelGGL(pad_channels_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, ctx->stream, src, rows, C, *Cp, dst);
+    if (!g_fg_dry && hipGetLastError() != hipSuccess) { *rc = fg_set_err(ctx, FG_ERR_HIP, "pad_channels_kernel"); return nullptr; }
+    *scratch_floats = at;
+    return dst;
+}
 
 static void fill_wino(WinoArgs& w, const ConvGeom& g, int C, int N, int Npad) {
     w.B = g.B; w.H = g.H; w.W = g.W; w.C = C; w.N = N; w.Npad = Npad;
@@ -432,9 +464,12 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
         return FG_OK;
     }
     fill_mspace(a, g.B, g.H / st, g.W / st);                 // M-space = output pixels
+    int Ca = g.Cin, rcp;
+    x = pad_operand(ctx, x, (long long)g.B * g.H * g.W, g.Cin, scratch, &scratch_floats, &Ca, &rcp);
+    if (rcp) return rcp;
     a.A = x; a.Bp = wp_fwd; a.bias = bias; a.Out = y;
     a.alg_flops = alg_flops(g); a.tag = tag_of(g, 0);
-    a.Ha = g.H; a.Wa = g.W; a.Ca = g.Cin; a.Kpad = cf; a.asy = a.asx = 1;
+    a.Ha = g.H; a.Wa = g.W; a.Ca = Ca; a.Kpad = cf; a.asy = a.asx = 1;
     a.N = g.Cout; a.G = wm.G; a.Npad = rf;
     if (g.fold) {
         a.Ho = 2 * g.H; a.Wo = 2 * g.W; a.osy = a.osx = 2;
@@ -451,7 +486,7 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
             a.goff[0][t] = pack_off(t / g.k - g.pad, t % g.k - g.pad);
         }
     }
-    a.a_bytes = (long long)g.B * g.H * g.W * g.Cin * 4;
+    a.a_bytes = (long long)g.B * g.H * g.W * Ca * 4;
     int tile, splits;
     choose_igemm(a.M, rf, wm.G * (cf / 32), wm.P, ctx->math, &tile, &splits);
     if (tile == 4 && ctx->math == 6 && ((a.Ca % 16) || (a.Kpad % 16))) choose_igemm(a.M, rf, wm.G * (cf / 32), wm.P, 0, &tile, &splits);
@@ -539,9 +574,12 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
     }
     IgemmArgs a; memset(&a, 0, sizeof(a));
     fill_mspace(a, g.B, g.H, g.W);
+    int Ca = g.Cout, rcp;
+    gy = pad_operand(ctx, gy, (long long)g.B * g.H * g.W * (g.fold ? 4 : 1), g.Cout, scratch, &scratch_floats, &Ca, &rcp);
+    if (rcp) return rcp;
     a.A = gy; a.Bp = wp_bwd; a.bias = nullptr; a.Out = gx;
     a.alg_flops = alg_flops(g); a.tag = tag_of(g, 1);
-    a.Ca = g.Cout; a.Kpad = cb;
+    a.Ca = Ca; a.Kpad = cb;
     a.Ho = g.H; a.Wo = g.W; a.osy = a.osx = 1; a.N = g.Cin; a.Npad = rb;
     a.G = wm.G * wm.P;
     if (a.G > FG_MAX_GROUPS) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "conv dgrad: %d groups", a.G);
@@ -558,7 +596,7 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
             a.goff[0][t] = pack_off(g.pad - t / g.k, g.pad - t % g.k);
         }
     }
-    a.a_bytes = (long long)g.B * g.H * g.W * (g.fold ? 4 : 1) * g.Cout * 4;
+    a.a_bytes = (long long)g.B * g.H * g.W * (g.fold ? 4 : 1) * Ca * 4;
     int tile, splits;
     choose_igemm(a.M, rb, a.G * (cb / 32), 1, ctx->math, &tile, &splits);
     if (tile == 4 && ctx->math == 6 && ((a.Ca % 16) || (a.Kpad % 16))) choose_igemm(a.M, rb, a.G * (cb / 32), 1, 0, &tile, &splits);
@@ -603,13 +641,20 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
     if (g.B == 0) return FG_OK;
     WeightMap wm; fg_geom_weightmap(g, &wm);
     WgradArgs a; memset(&a, 0, sizeof(a));
+    const int st = g.stride == 2 ? 2 : 1;
+    const float* gy_ref = gy;                    // the bias gradient sums the caller's tensor (any channel count)
+    int Nd = g.Cout, Cx = g.Cin, rcp;
+    gy = pad_operand(ctx, gy, (long long)g.B * (g.H / st) * (g.W / st) * (g.fold ? 4 : 1), g.Cout, scratch, &scratch_floats, &Nd, &rcp);
+    if (rcp) return rcp;
+    x = pad_operand(ctx, x, (long long)g.B * g.H * g.W, g.Cin, scratch, &scratch_floats, &Cx, &rcp);
+    if (rcp) return rcp;
+    const bool ragged = Nd != g.Cout || Cx != g.Cin;
     a.dY = gy; a.X = x; a.Part = scratch;
     a.alg_flops = alg_flops(g); a.tag = tag_of(g, 2);
-    const int st = g.stride == 2 ? 2 : 1;
     a.Nb = g.B; a.Hm = g.H / st; a.Wm = g.W / st; a.M = g.B * a.Hm * a.Wm;          // M-space = output pixels
     a.lgH = ilog2_exact(a.Hm); a.lgW = ilog2_exact(a.Wm);
     if (a.lgH < 0 || a.lgW < 0) a.lgH = a.lgW = -1;
-    a.Nd = g.Cout; a.Cx = g.Cin; a.Hx = g.H; a.Wx = g.W; a.xsy = a.xsx = st;
+    a.Nd = Nd; a.Cx = Cx; a.Hx = g.H; a.Wx = g.W; a.xsy = a.xsx = st;
     a.G = wm.G;
     if (g.fold) {
         a.Hd = 2 * g.H; a.Wd = 2 * g.W; a.dsy = a.dsx = 2;
@@ -627,8 +672,8 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
             a.xox[0][t] = (signed char)(t % g.k - g.pad);
         }
     }
-    a.d_bytes = (long long)g.B * a.Hd * a.Wd * g.Cout * 4;
-    a.x_bytes = (long long)g.B * g.H * g.W * g.Cin * 4;
+    a.d_bytes = (long long)g.B * a.Hd * a.Wd * Nd * 4;
+    a.x_bytes = (long long)g.B * g.H * g.W * Cx * 4;
     int tile, rc;
     int cfg6 = -1;
     if (ctx->math == 6 && g.Cout % 16 == 0 && g.Cin % 16 == 0 && a.M >= 1024)   // Linear / tiny maps: too few pixels to reduce over
@@ -679,7 +724,7 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         const int nrb = wm.P * a.S;
         const long long nb = (long long)nrb * g.Cout;
         bool deferred = false;
-        if (gradb) {
+        if (gradb && !ragged) {                          // (ragged: the partial rows would be Nd wide -- the column-sum pass below)
             float* dp = fg_defer_alloc(ctx, nb);          // inside fg_net backward: final batched at the end
             if (dp) { a.bias_part = dp; deferred = true; }
             else if (need + nb <= scratch_floats) a.bias_part = scratch + need;
@@ -699,7 +744,7 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
         // bias grad = column sums of gy over all output pixels
         const long long rows = (long long)a.M * (g.fold ? 4 : 1);
         if ((long long)CR_ROWBLOCKS_MAX * g.Cout > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "bias grad: scratch");
-        if ((rc = fg_launch_colsum(ctx, gy, rows, g.Cout, beta, gradb, scratch))) return rc;
+        if ((rc = fg_launch_colsum(ctx, gy_ref, rows, g.Cout, beta, gradb, scratch))) return rc;
     }
     return FG_OK;
 }

@@ -536,7 +536,6 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
                         s.oc = v.a; s.oh = v.b; s.ow = v.c;
                         consumed = 2;
                     }
-                    if (l.a % 4) { fail(FG_ERR_UNSUPPORTED, "Linear in_features % 4 != 0", i); break; }
                 }
                 perm_c = perm_hw = 0;
                 break;
@@ -590,14 +589,14 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
                     review_factor = f;
                 }
                 if (g.stride == 2) {       // 3x3 stride-2 'same'-pad convs of create_D16_d (models.lua:289-291)
-                    if ((h & 1) || (w & 1) || l.a % 4 || l.c * l.c > FG_MAX_GROUPS) { fail(FG_ERR_UNSUPPORTED, "stride-2 conv: even H/W, nIn % 4", i); break; }
+                    if ((h & 1) || (w & 1) || l.c * l.c > FG_MAX_GROUPS) { fail(FG_ERR_UNSUPPORTED, "stride-2 conv: even H/W", i); break; }
                     s.oh = h / 2; s.ow = w / 2; s.kind = ST_CONV;
                 } else
                 if (l.a <= 4 && l.b % 64 == 0) s.kind = ST_THIN_IN;
                 else if (l.b <= 4 && l.a % 64 == 0) {
                     s.kind = ST_THIN_OUT;
                     if (i + 1 < nl && L[i + 1].type == FG_SIGMOID && !(l.q > 1.f)) { s.has_sigmoid = 1; consumed = 2; }
-                } else if (l.a % 4 == 0 && l.c * l.c <= FG_MAX_GROUPS) { s.kind = ST_CONV; fg_geom_set_wino(g, ctx->fusion); }   // 3x3: Winograd F(2x2, 3x3)
+                } else if (l.c * l.c <= FG_MAX_GROUPS) { s.kind = ST_CONV; fg_geom_set_wino(g, ctx->fusion); }   // 3x3: Winograd F(2x2, 3x3)
                 else fail(FG_ERR_UNSUPPORTED, "conv channel counts not supported", i);
                 break;
             }

@@ -633,7 +633,9 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
     // forward writes it twice, a fused PReLU backward also reads the PReLU's input)
     char plabel[48] = "";
     if (ctx->prof) snprintf(plabel, sizeof(plabel), "thin_in<%d,%d>", k, Cs);
-    FgProfScope prof(ctx, fg_intern(ctx, plabel), 0.0, 0.0,
+    // (alg_flops = the layer's 2 x MACs: the 5x5 / 7x7 instances are bound by the padded matrix pipe, not by these bytes -- bench.py
+    // files them under roofline.mfma_padded with their useful-FLOP fraction)
+    FgProfScope prof(ctx, fg_intern(ctx, plabel), 2.0 * B * H * W * (double)k * k * Cs * Cw, 0.0,
                      4.0 * B * H * W * ((double)Cs + (double)Cw * (1 + ((actf && actf->y) || (actb && actb->x) ? 1 : 0))));
     ThinEpi epi; memset(&epi, 0, sizeof(epi));
     // fold the neighbouring PReLU into the epilogue (MFMA variants): forward = plain PReLU only (no same-shape mask)
@@ -1239,7 +1241,7 @@ int fg_launch_thin_out_conv(fg_ctx* ctx, const float* in, const float* Wp, const
     // profile label "thin_out<k,Cs>": algorithmic bytes = the wide input read once + the thin output written once
     char plabel[48] = "";
     if (ctx->prof) snprintf(plabel, sizeof(plabel), "thin_out<%d,%d>", k, Cs);
-    FgProfScope prof(ctx, fg_intern(ctx, plabel), 0.0, 0.0, 4.0 * npix * ((double)Cw + Cs));
+    FgProfScope prof(ctx, fg_intern(ctx, plabel), 2.0 * npix * (double)k * k * Cs * Cw, 0.0, 4.0 * npix * ((double)Cw + Cs));
     if (rbuf && !flip && (k == 5 || k == 7) && (Cs == 1 || Cs == 3) && Cw % 32 == 0 && (long long)npix * 32 <= rbuf_floats) {
         dim3 grid(B * ((H + 3) / 4) * ((W + 31) / 32));
 #define TOR(KK, CC)                                                                                                  \
@@ -1617,7 +1619,7 @@ int fg_launch_thin_wgrad(fg_ctx* ctx, const float* thin, const float* wide, floa
     // profile label "thin_wgrad<k,Cs>": algorithmic bytes = both tensors read once (the per-block slabs are small)
     char plabel[48] = "";
     if (ctx->prof) snprintf(plabel, sizeof(plabel), "thin_wgrad<%d,%d>", k, Cs);
-    FgProfScope prof(ctx, fg_intern(ctx, plabel), 0.0, 0.0, 4.0 * B * H * W * ((double)Cw + Cs));
+    FgProfScope prof(ctx, fg_intern(ctx, plabel), 2.0 * B * H * W * (double)k * k * Cs * Cw, 0.0, 4.0 * B * H * W * ((double)Cw + Cs));
     {
         const long long npairs = ((long long)B * H * W + 1) / 2;
         int nb = (int)((npairs + 3) / 4 < TW_BLOCKS ? (npairs + 3) / 4 : TW_BLOCKS);

@@ -40,6 +40,17 @@ __device__ __forceinline__ f32x2 wn_load2(__amdgpu_buffer_rsrc_t r, int voff, in
 __device__ __forceinline__ f32x4 wn_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// two fp32 additions / subtractions in one VALU instruction (hipcc scalarises <2 x float> arithmetic into two v_add_f32 here)
+__device__ __forceinline__ f32x2 wn_pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 wn_pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ void wn_decode(int t, const WinoArgs& a, int& b, int& ty, int& tx) {
     if (a.lgTW >= 0) {
         tx = t & (a.TW - 1);
@@ -57,7 +68,9 @@ __device__ __forceinline__ void wn_decode(int t, const WinoArgs& a, int& b, int&
 // layer (act_x; data gradient) -- the same three epilogues as the implicit-GEMM kernels (igemm.hip fg_epilogue)
 // TRACE (measurement kernel only, FG_WINO_TRACE=1): s_memtime of wave 0 at entry, after the prologue's barrier, after every K chunk
 // and after the epilogue -> dbg_trace[block][0 .. NC + 2]; same row format as igemm_ws_trace_kernel (scripts/ws_trace_report.py)
-template <int EPI, int TRACE = 0>
+// DBG (trace kernels only; results are WRONG, timing is the point): bit 1 = no U stores, 2 = no input transform / V stores,
+// 4 = no global loads, 8 = no fragment reads -- what each class of the K loop's side work costs the matrix pipe
+template <int EPI, int TRACE = 0, int DBG = 0>
 __device__ __forceinline__ void wino_body(const WinoArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* rowoff = (int*)(smem + 2 * WN_STAGE);
@@ -205,34 +218,48 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
             _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                                \
                 const int sl = pr * 8 + m, h = m & 1, j = m >> 1, pos = 2 * pr + h;                        \
                 acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pr & 1][h][j], fb[pr & 1][h][j], acc[pos], 0, 0, 0); \
-                if (m < 4 && pr < 7) {                                                                     \
+                if (m < 4 && pr < 7 && !(DBG & 8)) {                                                       \
                     const int np = 2 * (pr + 1) + (m >> 1);                                                \
                     if ((m & 1) == 0) fa[(pr + 1) & 1][m >> 1] = *(const f32x4*)(Sc + a_rd + np * 512);    \
                     else fb[(pr + 1) & 1][m >> 1] = *(const f32x4*)(Sc + b_rd + np * 512);                 \
                 }                                                                                          \
                 if (HAS1) {                                                                                \
-                    if (m < 4 && pr == 7) {                                                                \
+                    if (m < 4 && pr == 7 && !(DBG & 8)) {                                                  \
                         if ((m & 1) == 0) fa[0][m >> 1] = *(const f32x4*)(Sn + a_rd + (m >> 1) * 512);     \
                         else fb[0][m >> 1] = *(const f32x4*)(Sn + b_rd + (m >> 1) * 512);                  \
                     }                                                                                      \
-                    if (sl < 8) *(f32x4*)(Us + sl * 1024) = ru[sl];                                        \
-                    if (sl >= 8 && sl < 24) {                                                              \
+                    if (sl < 8 && !(DBG & 1)) *(f32x4*)(Us + sl * 1024) = ru[sl];                          \
+                    if (sl >= 8 && sl < 24 && !(DBG & 2)) {                                                \
                         const int k = sl - 8, x = k >> 2, o = k & 3;                                       \
+                        if (DBG & 16) {                                                                    \
+                            if (o == 0) w_[0 + x] = wn_pk_sub(rv[0 + x], rv[8 + x]);                       \
+                            if (o == 1) w_[4 + x] = wn_pk_add(rv[4 + x], rv[8 + x]);                       \
+                            if (o == 2) w_[8 + x] = wn_pk_sub(rv[8 + x], rv[4 + x]);                       \
+                            if (o == 3) w_[12 + x] = wn_pk_sub(rv[4 + x], rv[12 + x]);                     \
+                        } else {                                                                           \
                         if (o == 0) w_[0 + x] = rv[0 + x] - rv[8 + x];                                     \
                         if (o == 1) w_[4 + x] = rv[4 + x] + rv[8 + x];                                     \
                         if (o == 2) w_[8 + x] = rv[8 + x] - rv[4 + x];                                     \
                         if (o == 3) w_[12 + x] = rv[4 + x] - rv[12 + x];                                   \
+                        }                                                                                  \
                     }                                                                                      \
-                    if (sl >= 24 && sl < 40) {                                                             \
+                    if (sl >= 24 && sl < 40 && !(DBG & 2)) {                                               \
                         const int k = sl - 24, i = k >> 2, o = k & 3;                                      \
                         f32x2 v_;                                                                          \
+                        if (DBG & 16) {                                                                    \
+                            if (o == 0) v_ = wn_pk_sub(w_[i * 4 + 0], w_[i * 4 + 2]);                      \
+                            if (o == 1) v_ = wn_pk_add(w_[i * 4 + 1], w_[i * 4 + 2]);                      \
+                            if (o == 2) v_ = wn_pk_sub(w_[i * 4 + 2], w_[i * 4 + 1]);                      \
+                            if (o == 3) v_ = wn_pk_sub(w_[i * 4 + 1], w_[i * 4 + 3]);                      \
+                        } else {                                                                           \
                         if (o == 0) v_ = w_[i * 4 + 0] - w_[i * 4 + 2];                                    \
                         if (o == 1) v_ = w_[i * 4 + 1] + w_[i * 4 + 2];                                    \
                         if (o == 2) v_ = w_[i * 4 + 2] - w_[i * 4 + 1];                                    \
                         if (o == 3) v_ = w_[i * 4 + 1] - w_[i * 4 + 3];                                    \
+                        }                                                                                  \
                         *(f32x2*)(Vs + k * 512) = v_;                                                      \
                     }                                                                                      \
-                    if (HAS2) {                                                                            \
+                    if (HAS2 && !(DBG & 4)) {                                                              \
                         if (sl >= 8 && sl < 16) ru[sl - 8] = wn_load4(ursrc, (uo + (sl - 8) * 1024) * 4, su2); \
                         if (sl >= 24 && sl < 40) rv[sl - 24] = wn_load2(xrsrc, voff[sl - 24], sx2);        \
                     }                                                                                      \
@@ -336,7 +363,8 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
 }
 template <int EPI>
 __global__ __launch_bounds__(256) void wino_kernel(const WinoArgs a) { wino_body<EPI, 0>(a); }
-__global__ __launch_bounds__(256) void wino_trace_kernel(const WinoArgs a) { wino_body<0, 1>(a); }
+template <int DBG>
+__global__ __launch_bounds__(256) void wino_trace_kernel(const WinoArgs a) { wino_body<0, 1, DBG>(a); }
 
 // FG_WINO_TRACE=1 (measurement only): EPI-0 launches run the trace kernel four times (three to settle the clocks); the per-block
 // s_memtime rows of the fourth are appended to FG_WS_TRACE_FILE in igemm_ws_trace_kernel's row format
@@ -347,12 +375,24 @@ static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, si
     if (hipMalloc((void**)&dvc, nblk * 128 * 8) != hipSuccess) return fg_set_err(ctx, FG_ERR_NOMEM, "trace buffer");
     (void)hipMemset(dvc, 0, nblk * 128 * 8);
     a.dbg_trace = dvc;
-    FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_trace_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int dbg = 0;
+    if (const char* e = getenv("FG_WINO_DBG")) dbg = atoi(e);
+    const void* fn = dbg == 1 ? (const void*)wino_trace_kernel<1> : dbg == 2 ? (const void*)wino_trace_kernel<2> : dbg == 4 ? (const void*)wino_trace_kernel<4> :
+                     dbg == 6 ? (const void*)wino_trace_kernel<6> : dbg == 7 ? (const void*)wino_trace_kernel<7> :
+                     dbg == 15 ? (const void*)wino_trace_kernel<15> : dbg == 16 ? (const void*)wino_trace_kernel<16> : (const void*)wino_trace_kernel<0>;
+    FG_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int rep = 0; rep < 4; ++rep) {
         (void)hipEventRecord(e0, ctx->stream);
-        hipLaunchKernelGGL(wino_trace_kernel, grid, dim3(256), lds, ctx->stream, a);
+        if (dbg == 1) hipLaunchKernelGGL(wino_trace_kernel<1>, grid, dim3(256), lds, ctx->stream, a);
+        else if (dbg == 2) hipLaunchKernelGGL(wino_trace_kernel<2>, grid, dim3(256), lds, ctx->stream, a);
+        else if (dbg == 4) hipLaunchKernelGGL(wino_trace_kernel<4>, grid, dim3(256), lds, ctx->stream, a);
+        else if (dbg == 6) hipLaunchKernelGGL(wino_trace_kernel<6>, grid, dim3(256), lds, ctx->stream, a);
+        else if (dbg == 7) hipLaunchKernelGGL(wino_trace_kernel<7>, grid, dim3(256), lds, ctx->stream, a);
+        else if (dbg == 15) hipLaunchKernelGGL(wino_trace_kernel<15>, grid, dim3(256), lds, ctx->stream, a);
+        else if (dbg == 16) hipLaunchKernelGGL(wino_trace_kernel<16>, grid, dim3(256), lds, ctx->stream, a);
+        else hipLaunchKernelGGL(wino_trace_kernel<0>, grid, dim3(256), lds, ctx->stream, a);
         (void)hipEventRecord(e1, ctx->stream);
     }
     FG_CHECK_LAUNCH(ctx);
@@ -367,7 +407,7 @@ static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, si
     FILE* f = fopen(path ? path : "/tmp/fg_ws_trace.txt", "a");
     if (f) {
         // (BN=128: scripts/ws_trace_report.py prices a step at 64 MFMAs x 64 cycles per wave -- one K chunk of this kernel)
-        fprintf(f, "# launch wino/%s BN=128 blocks=%zu T=%d Npad=%d C=%d splits=%d wall_us=%.1f\n", a.tag ? a.tag : "?", nblk, a.T, a.Npad, a.C, a.splits, wall_ms * 1e3);
+        fprintf(f, "# launch wino(dbg=%d)/%s BN=128 blocks=%zu T=%d Npad=%d C=%d splits=%d wall_us=%.1f\n", dbg, a.tag ? a.tag : "?", nblk, a.T, a.Npad, a.C, a.splits, wall_ms * 1e3);
         for (size_t b = 0; b < nblk; ++b) {
             const unsigned long long* r = host.data() + b * 128;
             const int kt = (int)(r[127] >> 32), xcc = (int)(r[127] & 0xffffffff);

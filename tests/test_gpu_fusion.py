@@ -31,7 +31,7 @@ def test_fusion_flags_roundtrip_and_reject_unknown_bits(ctx):
     ctx.set_fusion(FG_FUSE_THIN_SLAB)
     assert ctx.get_fusion() == FG_FUSE_THIN_SLAB
     with pytest.raises(FgError):
-        ctx.set_fusion(32)
+        ctx.set_fusion(64)
     ctx.set_fusion(FG_FUSE_DEFAULT)
     assert ctx.get_fusion() == FG_FUSE_DEFAULT
 

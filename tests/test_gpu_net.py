@@ -222,6 +222,33 @@ def test_G16_forward_backward(ctx):
     check_flat_grads(g.cpu().numpy(), G, "G16")
 
 
+@pytest.mark.parametrize("noiseDim", [50, 99])
+def test_G_with_a_noise_dimension_that_is_not_a_multiple_of_4(ctx, noiseDim):
+    """train.lua `--noiseDim` takes any value (NN_UTILS.createNoiseInputs, nn_utils.lua:35-39); the first Linear's ragged
+    in_features run on a zero-padded copy of the noise batch (these used to be refused)."""
+    from face_generator_amd import models
+    B, C = 6, 3
+    rng = np.random.default_rng(970 + noiseDim)
+    G = O.create_G32((C, 32, 32), noiseDim, rng, weight_init_=False)
+    for m in G.modules:
+        if isinstance(m, O.PReLU):
+            m.weight[0] = np.float32(rng.uniform(0.1, 0.4))
+    pG, gG = G.getParameters()
+    Gd = models.create_G((C, 32, 32), noiseDim).cuda(ctx, max_batch=B)
+    p, g = Gd.getParameters()
+    assert p.numel() == pG.size
+    p.copy_(torch.tensor(pG)); Gd.device_net.params_changed()
+    noise, img = draw_kink_safe(rng, lambda: rng.uniform(-1, 1, (B, noiseDim)).astype(np.float32), G.forward, [G])
+    gy = rng.standard_normal(img.shape).astype(np.float32)
+    gG[...] = 0
+    gin = G.backward(noise, gy)
+    y = Gd.device_net.forward(dev(noise, ctx.device))
+    close(nchw(y), img, atol=1e-5, what="G images, noiseDim %d" % noiseDim)
+    gx = Gd.device_net.backward(nhwc(gy, ctx.device), param_grads=True, input_grad=True)
+    close(gx.cpu().numpy().reshape(B, noiseDim), gin.reshape(B, noiseDim), atol=1e-4 * np.abs(gin).max() + 1e-8, what="noise gradient")
+    check_flat_grads(g.cpu().numpy(), G, "G(noiseDim %d)" % noiseDim)
+
+
 def _fill_nontrivial(net, rng):
     for m in O.walk_modules(net):
         if isinstance(m, O.PReLU):

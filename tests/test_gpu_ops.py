@@ -39,6 +39,11 @@ CONV_CASES = [
     (5, 32, 32, 64, 128, 5, 0),
     (2, 64, 32, 128, 256, 3, 0),
     (8, 32, 32, 64, 128, 3, 1),     # folded: four parities x 2x2 taps through the 128 x 64 tile
+    # channel counts that are not multiples of 4 (round 5: the operand is copied into zero-padded rows, conv_ops.hip pad_operand)
+    (2, 8, 8, 6, 10, 3, 0),
+    (3, 6, 6, 1, 32, 3, 0),         # one input channel, not a thin-layer width
+    (2, 8, 8, 30, 64, 5, 0),
+    (2, 4, 4, 10, 6, 3, 1),         # folded upsample, both sides ragged
 ]
 
 
@@ -74,7 +79,8 @@ def test_conv2d_forward_backward(ctx, B, H, W, Cin, Cout, k, up):
     close(gw2.cpu().numpy(), 2 * gw_d.cpu().numpy(), atol=1e-5 * max(np.abs(conv.gradWeight).max(), 1), what="acc")
 
 
-@pytest.mark.parametrize("B,K,N", [(4, 100, 8192), (6, 2048, 512), (128, 512, 512), (3, 64, 128), (130, 100, 256)])
+@pytest.mark.parametrize("B,K,N", [(4, 100, 8192), (6, 2048, 512), (128, 512, 512), (3, 64, 128), (130, 100, 256),
+                                   (5, 50, 256), (4, 99, 8192), (7, 64, 10), (6, 33, 7)])      # --noiseDim 50 / 99 (nn_utils.lua:35-39); ragged both ways
 def test_linear(ctx, B, K, N):
     from face_generator_amd import ops
     rng = np.random.default_rng(B + K + N)
