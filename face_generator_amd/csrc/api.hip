@@ -83,6 +83,8 @@ int fg_ctx_create(int device, fg_ctx** out) {
     if (const char* m = getenv("FG_DEFER_WFINISH")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WFINISH_BATCH;
     if (const char* m = getenv("FG_THIN_BIAS")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_THIN_BIAS;
     if (const char* m = getenv("FG_WINO")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WINOGRAD;
+    if (const char* m = getenv("FG_WINO_UP")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WINOGRAD_UP;
+    if (const char* m = getenv("FG_WINO_5X5")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WINOGRAD_5X5;
     c->fusion &= ~FG_FUSE_ADAM_PACK;        // measured slower than the two launches: opt-in
     if (const char* m = getenv("FG_ADAM_PACK")) if (atoi(m) != 0) c->fusion |= FG_FUSE_ADAM_PACK;
     ++g_real_ctx;
@@ -281,7 +283,7 @@ size_t fg_conv2d_workspace_bytes(int batch, int h, int w, int cin, int cout, int
     // (no context here: the bound covers both settings of FG_FUSE_WINOGRAD)
     size_t need = 0;
     for (int wn = 0; wn < 2; ++wn) {
-        ConvGeom g = mk_geom(batch, h, w, cin, cout, k, (k - 1) / 2, up, wn ? FG_FUSE_WINOGRAD : 0);
+        ConvGeom g = mk_geom(batch, h, w, cin, cout, k, (k - 1) / 2, up, wn ? FG_FUSE_ALL : 0);
         if (wn && !g.wino) break;
         long long pf = fg_geom_pack_floats(g, 0), pb = fg_geom_pack_floats(g, 1);
         const size_t n = (size_t)(a64(pf > pb ? pf : pb) + fg_conv_scratch_floats(g) + 64) * sizeof(float);

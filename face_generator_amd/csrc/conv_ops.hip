@@ -31,12 +31,22 @@ void fg_geom_weightmap(const ConvGeom& g, WeightMap* wm) {
 
 void fg_geom_packmap(const ConvGeom& g, WeightMap* wm) {
     fg_geom_weightmap(g, wm);
-    if (g.wino) { wm->kind = 2; wm->G = 16; wm->P = 1; }
+    if (g.wino) {
+        // 16 positions x (parities x groups) transformed sub-kernels per (out, in) pair; the same count in both packs
+        int P, KG; fg_wino_pack_shape(wm->kind, g.wino, 0, &P, &KG);
+        wm->wino = g.wino; wm->G = 16 * P * KG; wm->P = 1;
+    }
 }
+// g.wino: 1 = 3x3 / pad 1 layers, and nearest-x2-folded layers whose folded window is 3x3 at offset -1 (5x5 / pad 2, 3x3 / pad 1):
+// every output parity is a 3x3 / pad 1 convolution of the source; 2 = 5x5 / pad 2 layers as four 3x3 sub-kernels
 void fg_geom_set_wino(ConvGeom& g, int fusion) {
-    const bool on = (fusion & FG_FUSE_WINOGRAD) != 0;
-    g.wino = (on && g.k == 3 && g.pad == 1 && !g.fold && g.stride != 2 && g.H >= 2 && g.W >= 2 && (g.H & 1) == 0 && (g.W & 1) == 0 &&
-              g.Cin % 8 == 0 && g.Cout % 8 == 0 && g.Cin > 4 && g.Cout > 4) ? 1 : 0;
+    g.wino = 0;
+    if (g.stride == 2 || g.H < 2 || g.W < 2 || (g.H & 1) || (g.W & 1) || g.Cin % 8 || g.Cout % 8 || g.Cin <= 4 || g.Cout <= 4) return;
+    if (g.fold) {
+        int T, rmin; fg_fold_window(g.k, g.pad, &T, &rmin);
+        if ((fusion & FG_FUSE_WINOGRAD_UP) && T == 3 && rmin == -1) g.wino = 1;
+    } else if (g.k == 3 && g.pad == 1) { if (fusion & FG_FUSE_WINOGRAD) g.wino = 1; }
+    else if (g.k == 5 && g.pad == 2) { if (fusion & FG_FUSE_WINOGRAD_5X5) g.wino = 2; }
 }
 
 static inline int pad_rows(int n) { return n < 128 ? fg_round_up(n, 64) : fg_round_up(n, 128); }
@@ -53,7 +63,7 @@ void fg_geom_pack_dims(const ConvGeom& g, int* rows_f, int* cols_f, int* rows_b,
 long long fg_geom_pack_floats(const ConvGeom& g, int bwd) {
     WeightMap wm; fg_geom_packmap(g, &wm);
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
-    return (long long)wm.P * wm.G * (bwd ? (long long)rb * cb : (long long)rf * cf);
+    return (long long)wm.P * wm.G * (bwd ? (long long)rb * cb : (long long)rf * cf);      // (Winograd packs: G = 16 x parities x groups)
 }
 
 int fg_conv_pack(fg_ctx* ctx, const ConvGeom& g, const float* W, float* wp_fwd, float* wp_bwd) {
@@ -120,9 +130,10 @@ static void choose_igemm(long long M, int Npad, int ksteps, int P, int math, int
         *splits = s < 1 ? 1 : s;
     }
 }
+static void fill_wino(WinoArgs& w, const ConvGeom& g, int bwd);
 // Winograd launch: blocks of 64 tiles x 64 output channels; when they do not fill the chip the K chunks (8 channels each) are
 // split over gridDim.y, >= 4 chunks per split (the partials are summed by the pass behind the layer, like every split-K launch)
-static int choose_wino_splits(long long T, int Npad, int C) {
+static int choose_wino_splits(long long T, int Npad, int C) {      // Npad: all parities' channel blocks x 64; C: all groups' channels
     const long long blocks = ((T + 63) / 64) * (Npad / 64);
     const int nch = C / 8;
     if (blocks >= 192 || nch < 8) return 1;
@@ -287,10 +298,12 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
     if (g.wino) {
         // forward / data gradient run the Winograd kernel in every math mode: their split partials; the weight gradient below
         // (a smaller run-time batch may split further: splits x tiles is bounded by one round of 256 blocks of 64 tiles)
-        const int sf = choose_wino_splits(M / 4, rf, g.Cin), sb = choose_wino_splits(M / 4, rb, g.Cout);
-        const long long nf = sf > 1 ? (long long)sf * M * g.Cout : 0, nb = sb > 1 ? (long long)sb * M * g.Cin : 0;
+        WinoArgs wf, wb; memset(&wf, 0, sizeof(wf)); memset(&wb, 0, sizeof(wb));
+        fill_wino(wf, g, 0); fill_wino(wb, g, 1);
+        const int sf = choose_wino_splits(M / 4, wf.P * wf.Npad, wf.KG * wf.C), sb = choose_wino_splits(M / 4, wb.P * wb.Npad, wb.KG * wb.C);
+        const long long nf = sf > 1 ? (long long)sf * outM * g.Cout : 0, nb = sb > 1 ? (long long)sb * M * g.Cin : 0;
         need = nf > nb ? nf : nb;
-        if (need < 256LL * 64 * 4 * 64 + 64) need = 256LL * 64 * 4 * 64 + 64;
+        if (need < 256LL * 64 * 4 * 64 * (g.fold ? 4 : 1) + 64) need = 256LL * 64 * 4 * 64 * (g.fold ? 4 : 1) + 64;
     } else {
     choose_igemm(M, rf, wm.G * (cf / 32), wm.P, math, &tile, &splits);
     {
@@ -392,12 +405,38 @@ static const float* pad_operand(fg_ctx* ctx, const float* src, long long rows, i
     return dst;
 }
 
-static void fill_wino(WinoArgs& w, const ConvGeom& g, int C, int N, int Npad) {
-    w.B = g.B; w.H = g.H; w.W = g.W; w.C = C; w.N = N; w.Npad = Npad;
+// Winograd geometry of a g.wino layer (WinoArgs, fg_internal.h); the tile grid is the 2 x 2 tiling of the H x W SOURCE map.
+//   forward: 3x3: one group at (-1, -1);  5x5: four groups at (3a - 2, 3b - 2);  folded: one group, FOUR output parities
+//            (parity (py, px) of tile element (a, b) is output pixel (2 (2 ty + a) + py, 2 (2 tx + b) + px) of the 2H x 2W map)
+//   data gradient (the same convolution, taps flipped): 3x3 / 5x5: the same groups;  folded: four groups, group p reads the
+//            parity-p sub-grid of the 2H x 2W gradient (stride 2, offset p - 2), one output parity on the source map
+static void fill_wino(WinoArgs& w, const ConvGeom& g, int bwd) {
+    const int f = g.fold ? 2 : 1;
+    w.B = g.B;
     w.TH = g.H / 2; w.TW = g.W / 2; w.T = g.B * w.TH * w.TW;
     w.lgTH = ilog2_exact(w.TH); w.lgTW = ilog2_exact(w.TW);
     if (w.lgTH < 0 || w.lgTW < 0) w.lgTH = w.lgTW = -1;
-    w.x_bytes = (long long)g.B * g.H * g.W * C * 4;
+    w.isy = w.isx = 1; w.KG = 1; w.goy[0] = w.gox[0] = -1;
+    w.P = 1; w.osy = w.osx = 1; w.ooy[0] = w.oox[0] = 0;
+    if (g.wino == 2) {
+        w.KG = 4;
+        for (int q = 0; q < 4; ++q) { w.goy[q] = (signed char)(3 * (q >> 1) - 2); w.gox[q] = (signed char)(3 * (q & 1) - 2); }
+    }
+    if (!bwd) {
+        w.Hi = g.H; w.Wi = g.W; w.C = g.Cin; w.N = g.Cout; w.Ho = f * g.H; w.Wo = f * g.W;
+        if (g.fold) {
+            w.P = 4; w.osy = w.osx = 2;
+            for (int q = 0; q < 4; ++q) { w.ooy[q] = (signed char)(q >> 1); w.oox[q] = (signed char)(q & 1); }
+        }
+    } else {
+        w.Hi = f * g.H; w.Wi = f * g.W; w.C = g.Cout; w.N = g.Cin; w.Ho = g.H; w.Wo = g.W;
+        if (g.fold) {
+            w.KG = 4; w.isy = w.isx = 2;
+            for (int q = 0; q < 4; ++q) { w.goy[q] = (signed char)((q >> 1) - 2); w.gox[q] = (signed char)((q & 1) - 2); }
+        }
+    }
+    w.Npad = fg_round_up(w.N, 64);
+    w.x_bytes = (long long)g.B * w.Hi * w.Wi * w.C * 4;
 }
 
 // bf16x6 math mode (fg_set_math): the wave-specialised kernel reads both operands as split-bf16 planes; build them in
@@ -439,20 +478,24 @@ int fg_conv_forward_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const fl
     const int st = g.stride == 2 ? 2 : 1;
     if (st == 2 && (g.fold || (g.H & 1) || (g.W & 1))) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "stride-2 conv: even H/W, no folded upsample");
     if (g.wino) {
-        // Winograd F(2x2, 3x3) (wino.hip): un-split launches take the bias and the PReLU behind the layer in their epilogue, split
-        // ones leave partials for the same passes as the implicit GEMM's
+        // Winograd F(2x2, 3x3) (wino.hip): un-split launches take the bias, the PReLU behind the layer and the BatchNorm statistics in
+        // their epilogue, split ones leave partials for the same passes as the implicit GEMM's
         WinoArgs w; memset(&w, 0, sizeof(w));
-        fill_wino(w, g, g.Cin, g.Cout, rf);
+        fill_wino(w, g, 0);
         w.X = x; w.U = wp_fwd; w.bias = bias; w.Out = y;
         w.alg_flops = alg_flops(g); w.tag = tag_of(g, 0);
-        const int splits = choose_wino_splits(w.T, rf, g.Cin);
-        const long long out_count = (long long)g.B * g.H * g.W * g.Cout;
+        const int splits = choose_wino_splits(w.T, w.P * w.Npad, w.KG * w.C);
+        const long long out_count = (long long)g.B * w.Ho * w.Wo * g.Cout;
         w.splits = splits;
         if (splits > 1) {
             if ((long long)splits * out_count > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv fwd (winograd): scratch");
             w.Out = scratch; w.split_stride = out_count;
         }
         if (act && splits == 1 && act->y && act->slope && !act->mask && fg_fuse_prelu(ctx)) { w.act_y = act->y; w.act_slope = act->slope; }
+        if (stats_part && stats_rows && splits == 1) {      // one partial row per (tile block, parity, wave row)
+            const long long rows = 2LL * w.P * fg_cdiv(w.T, 64);
+            if (2 * rows * g.Cout <= stats_cap) { w.stats_part = stats_part; w.stats_rows = (int)rows; *stats_rows = (int)rows; }
+        }
         int rc = fg_launch_wino(ctx, w);
         if (rc) return rc;
         if (w.act_y) act->applied = 1;
@@ -537,13 +580,13 @@ int fg_conv_dgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* gy, const flo
     WeightMap wm; fg_geom_weightmap(g, &wm);
     int rf, cf, rb, cb; fg_geom_pack_dims(g, &rf, &cf, &rb, &cb);
     if (g.wino) {
-        // the data gradient of a 3x3 / pad 1 / stride 1 layer is the same convolution with flipped, transposed taps: the same
-        // Winograd kernel on the data-gradient pack (U of the flipped taps = U with positions 0 <-> 3 exchanged on both axes)
+        // the data gradient of a 'same'-padded stride-1 layer is the same convolution with flipped, transposed taps: the same Winograd
+        // kernel on the data-gradient pack (a folded layer: the four output parities become four K groups on the stride-2 sub-grids)
         WinoArgs w; memset(&w, 0, sizeof(w));
-        fill_wino(w, g, g.Cout, g.Cin, rb);
+        fill_wino(w, g, 1);
         w.X = gy; w.U = wp_bwd; w.bias = nullptr; w.Out = gx;
         w.alg_flops = alg_flops(g); w.tag = tag_of(g, 1);
-        const int splits = choose_wino_splits(w.T, rb, g.Cout);
+        const int splits = choose_wino_splits(w.T, w.P * w.Npad, w.KG * w.C);
         const long long out_count = (long long)g.B * g.H * g.W * g.Cin;
         w.splits = splits;
         if (splits > 1) {

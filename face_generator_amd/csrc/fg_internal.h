@@ -147,19 +147,28 @@ int fg_launch_sum_splits_actbwd(fg_ctx* ctx, const float* part, int splits, long
                                 const FgActBwd* actb);
 
 // ---------------------------------------------------------------------------------
-// Winograd F(2x2, 3x3) convolution (wino.hip): 3x3 / pad 1 / stride 1 layers, forward and data gradient.
-//   Out[b][y][x][n] = bias[n] + sum_{c, dy, dx} X[b][y + dy - 1][x + dx - 1][c] * g[n][c][dy][dx]   (g: the layer's taps for the
-//   forward pass, the flipped + transposed taps for the data gradient), evaluated as 16 position-wise contractions over the
-//   2x2-output tiles; U = G g G^T comes pre-transformed from the re-pack launch (WeightMap kind 2)
+// Winograd F(2x2, 3x3) contraction (wino.hip): 3x3 / pad 1 / stride 1 layers, folded nearest-x2 up-convolutions (each output parity
+// is a 3x3 convolution of the source) and 5x5 layers (four 3x3 sub-kernels), forward and data gradient.
+//   M-space = B x TH x TW tiles of 2 x 2 "output elements"; tile (ty, tx), element (a, b), parity p is output pixel
+//     (osy (2 ty + a) + ooy[p], osx (2 tx + b) + oox[p]);
+//   K = KG groups x C channels; group g reads patch element (i, j), 0 <= i, j < 4, of tile (ty, tx) at input pixel
+//     (isy (2 ty + i) + goy[g], isx (2 tx + j) + gox[g]), zero outside the input;
+//   Out = bias + sum_{g, c} A^T [ U[p][.][g][c] (.) B^T patch_g,c B ] A;  U = G taps G^T comes pre-transformed from the re-pack
+//   launch (WeightMap::wino, fg_wino_pack_at).
 // ---------------------------------------------------------------------------------
 struct WinoArgs {
-    const float* X;      // NHWC [B][H][W][C]
-    const float* U;      // packed [Npad / 64][C / 8][pos 16][k half 2][64][4]  (fg_wino_pack_index)
+    const float* X;      // NHWC [B][Hi][Wi][C]
+    const float* U;      // packed [P][Npad / 64][KG][C / 8][pos 16][k half 2][64][4]  (fg_wino_pack_index)
     const float* bias;   // [N] or nullptr (added only when splits == 1)
-    float* Out;          // NHWC [B][H][W][N]  (or [splits][...] partials)
-    int B, H, W, C, N, Npad;
-    int TH, TW, T;       // 2x2 tiles per column / row / in the batch (T = B * TH * TW)
+    float* Out;          // NHWC [B][Ho][Wo][N]  (or [splits][...] partials)
+    int B, Hi, Wi, C;
+    int TH, TW, T;       // tiles per column / row / in the batch (T = B * TH * TW)
     int lgTH, lgTW;      // log2 if both are powers of two, else -1
+    int isy, isx, KG;
+    signed char goy[4], gox[4];
+    int Ho, Wo, N, Npad; // Npad: output channels per parity, padded to 64
+    int P, osy, osx;
+    signed char ooy[4], oox[4];
     int splits;          // split over the K chunks (gridDim.y); partials at Out + s * split_stride
     long long split_stride;
     long long x_bytes;   // size of X in bytes (< 2 GiB: raw-buffer addressing)
@@ -168,15 +177,26 @@ struct WinoArgs {
     float* act_y;
     const float* act_x;
     float* act_part;     // 4 floats per block (fg_wino_blocks)
+    float* stats_part;   // optional (splits == 1, forward): BatchNorm partial sums of the raw accumulators, [2][stats_rows][N],
+    int stats_rows;      //   one row per (tile block, parity, wave row): stats_rows = 2 * P * ceil(T / 64)
     double alg_flops;    // host-side bookkeeping: reference-formulation FLOPs of this launch
     const char* tag;
     unsigned long long* dbg_trace;   // measurement only (FG_WINO_TRACE=1): s_memtime rows of wino_trace_kernel
 };
 int fg_launch_wino(fg_ctx* ctx, const WinoArgs& a);
 long long fg_wino_blocks(const WinoArgs& a);
-// packed position of U[pos][n][k] (n: output channel of the contraction, k: its reduction channel; Kpad % 8 == 0)
-__host__ __device__ static inline size_t fg_wino_pack_index(int pos, int n, int k, int Kpad) {
-    return ((((size_t)(n >> 6) * (Kpad >> 3) + (k >> 3)) * 16 + pos) * 2 + ((k >> 2) & 1)) * 256 + (n & 63) * 4 + (k & 3);
+// packed position of U[parity p][group g][pos][n][k] -- n: output channel of the contraction (< Npad, a multiple of 64), k: its
+// reduction channel (< Kpad, a multiple of 8): the (p, channel block n / 64, g) triple owns Kpad / 8 consecutive chunk images of
+// [pos 16][k half 2][64][4] floats, the order wino_kernel's LDS stage wants
+__host__ __device__ static inline size_t fg_wino_pack_at(int p, int g, int KG, int Npad, int Kpad, int pos, int n, int k) {
+    const size_t img = (((size_t)p * (Npad >> 6) + (n >> 6)) * KG + g) * (Kpad >> 3) + (k >> 3);
+    return ((img * 16 + pos) * 2 + ((k >> 2) & 1)) * 256 + (n & 63) * 4 + (k & 3);
+}
+// parities / K groups of the forward (bwd = 0) and data-gradient (bwd = 1) Winograd packs of a WeightMap with wino != 0
+__host__ __device__ static inline void fg_wino_pack_shape(int kind, int wino, int bwd, int* P, int* KG) {
+    const int par = kind == 1 ? 4 : 1, grp = wino == 2 ? 4 : 1;
+    *P = bwd ? 1 : par;
+    *KG = bwd ? par * grp : grp;
 }
 
 // ---------------------------------------------------------------------------------
@@ -211,6 +231,10 @@ int fg_launch_wgrad6(fg_ctx* ctx, const WgradArgs& a, int P, int cfg);
 // Reference-layout <-> packed-layout description of one weight tensor.
 struct WeightMap {
     int kind;            // 0 = plain conv / linear (k=1), 1 = nearest-x2 folded conv
+    int wino;            // packs hold Winograd F(2x2, 3x3) transforms U = G t G^T of 3x3 sub-kernels t (wino.hip):
+                         //   1 = one sub-kernel per output parity (kind 0: the 3x3 taps; kind 1: the folded 3x3 taps of each parity),
+                         //   2 = a 5x5 layer as four sub-kernels at tap offsets (0 | 3, 0 | 3) of the zero-extended 6x6 window.
+                         // forward pack: P parities x KG groups; data-gradient pack: one parity, the forward parities become groups
     int O, I, k, pad;    // reference W[O][I][k][k]
     int T, rmin;         // folded: window T x T, r = t + rmin
     int G;               // groups per parity (k*k plain, T*T folded)

@@ -1506,22 +1506,44 @@ __device__ __forceinline__ int dev_fold_r(int parity, int d, int pad) {
     return (v >= 0) ? (v >> 1) : -((-v + 1) >> 1);
 }
 
-// Winograd F(2x2, 3x3) weight transform (WeightMap kind 2, wino.hip): U[i][j] = (G g G^T)[i][j] of one (out, in) pair's nine taps,
-// G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].  The taps of the data gradient are the flipped ones, and G J = P G with P the
-// exchange of rows 0 <-> 3, so its transform is U[perm(i)][perm(j)]: fg_wino_bwd_pos.
-__device__ __forceinline__ float fg_wino_u(const float* w, int i, int j) {
+// Winograd F(2x2, 3x3) weight transform (WeightMap::wino, wino.hip): U[i][j] = (G t G^T)[i][j] of a 3x3 sub-kernel t,
+// G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].
+__device__ __forceinline__ float fg_wino_u(const float* t, int i, int j) {
     float r[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float w0 = w[a * 3], w1 = w[a * 3 + 1], w2 = w[a * 3 + 2];
+        const float w0 = t[a * 3], w1 = t[a * 3 + 1], w2 = t[a * 3 + 2];
         r[a] = j == 0 ? w0 : (j == 3 ? w2 : 0.5f * ((w0 + w2) + (j == 1 ? w1 : -w1)));
     }
     return i == 0 ? r[0] : (i == 3 ? r[2] : 0.5f * ((r[0] + r[2]) + (i == 1 ? r[1] : -r[1])));
 }
-__device__ __forceinline__ int fg_wino_bwd_pos(int pos) {
-    const int i = pos >> 2, j = pos & 3;
-    const int pi = i == 0 ? 3 : (i == 3 ? 0 : i), pj = j == 0 ? 3 : (j == 3 ? 0 : j);
-    return pi * 4 + pj;
+__device__ __forceinline__ float packed_from_taps(const WeightMap& wm, const float* w, int p, int g);
+// The 3x3 sub-kernel t of one (out, in) pair whose transform goes to (parity p, group g) of the forward (bwd = 0) or data-gradient
+// (bwd = 1) Winograd pack; w = the pair's k*k reference taps.
+//   forward: kind 0, k = 3: t = w;  kind 1 (folded nearest-x2, 3x3 window): t = the folded taps of parity p;
+//            wino 2 (5x5): group g = (a, b): t[dy][dx] = w[3a + dy][3b + dx] (0 beyond the 5x5 window)
+//   data gradient = the same convolution with the taps flipped and in / out exchanged: kind 0: t[dy][dx] = w[2-dy][2-dx];
+//            kind 1: group g = the forward parity, its folded taps flipped; wino 2: the sub-kernels of the FLIPPED 5x5 kernel,
+//            t[dy][dx] = w[4 - 3a - dy][4 - 3b - dx]
+__device__ __forceinline__ void fg_wino_subkernel(const WeightMap& wm, const float* w, int bwd, int p, int g, float* t) {
+    if (wm.wino == 2) {
+        const int a = g >> 1, b = g & 1;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int u = 3 * a + dy, v = 3 * b + dx;
+                const int uu = bwd ? 4 - u : u, vv = bwd ? 4 - v : v;
+                t[dy * 3 + dx] = (u < 5 && v < 5) ? w[uu * 5 + vv] : 0.f;
+            }
+        return;
+    }
+    const int par = wm.kind == 1 ? (bwd ? g : p) : 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int src = bwd ? 8 - q : q;
+        t[q] = wm.kind == 1 ? packed_from_taps(wm, w, par, src) : w[src];
+    }
 }
 
 // value of the (possibly tap-folded) weight for parity p, group g, reference out-channel o, in-channel i
@@ -1530,7 +1552,6 @@ __device__ __forceinline__ float packed_weight_value(const WeightMap& wm, const 
     const int kk = wm.k * wm.k;
     const float* w = W + ((size_t)o * wm.I + i) * kk;
     if (wm.kind == 0) return w[g];
-    if (wm.kind == 2) return fg_wino_u(w, g >> 2, g & 3);
     const int py = p >> 1, px = p & 1, ty = g / wm.T, tx = g - ty * wm.T;
     // source offset r = t + rmin collects the taps d with floor((parity + d - pad)/2) == r, i.e. d in {2r-parity+pad, +1}
     const int dy0 = 2 * (ty + wm.rmin) - py + wm.pad, dx0 = 2 * (tx + wm.rmin) - px + wm.pad;
@@ -1564,10 +1585,19 @@ __global__ void pack_weights_kernel(const WeightMap wm, int mode, const float* _
         int o = po, i = pi;
         if (wm.o_hw > 1) { int hw = po / wm.o_c, c = po - hw * wm.o_c; o = c * wm.o_hw + hw; }
         if (wm.i_hw > 1) { int hw = pi / wm.i_c, c = pi - hw * wm.i_c; i = c * wm.i_hw + hw; }
-        v = packed_weight_value(wm, W, p, (wm.kind == 2 && mode == 1) ? fg_wino_bwd_pos(g) : g, o, i);
+        if (wm.wino) {       // pg = (parity, group, position) of the Winograd pack
+            int PP, KG; fg_wino_pack_shape(wm.kind, wm.wino, mode, &PP, &KG);
+            const int pos = pg & 15, gg = (pg >> 4) % KG, pp = (pg >> 4) / KG;
+            float t[9];
+            fg_wino_subkernel(wm, W + ((size_t)o * wm.I + i) * wm.k * wm.k, mode, pp, gg, t);
+            v = fg_wino_u(t, pos >> 2, pos & 3);
+        } else
+        v = packed_weight_value(wm, W, p, g, o, i);
     }
-    if (wm.kind == 2) Bp[fg_wino_pack_index(g, row, col, cols_pad)] = v;      // the order wino_kernel's LDS stage wants
-    else Bp[idx] = v;
+    if (wm.wino) {
+        int PP, KG; fg_wino_pack_shape(wm.kind, wm.wino, mode, &PP, &KG);
+        Bp[fg_wino_pack_at((pg >> 4) / KG, (pg >> 4) % KG, KG, rows_pad, cols_pad, pg & 15, row, col)] = v;      // the order wino_kernel's LDS stage wants
+    } else Bp[idx] = v;
 }
 
 int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const float* W, float* Bp, int rows_pad,
@@ -1582,7 +1612,6 @@ int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const flo
 // packed value from a pair's k*k taps held in LDS (same arithmetic and summation order as packed_weight_value)
 __device__ __forceinline__ float packed_from_taps(const WeightMap& wm, const float* w, int p, int g) {
     if (wm.kind == 0) return w[g];
-    if (wm.kind == 2) return fg_wino_u(w, g >> 2, g & 3);
     const int py = p >> 1, px = p & 1, ty = g / wm.T, tx = g - ty * wm.T;
     const int dy0 = 2 * (ty + wm.rmin) - py + wm.pad, dx0 = 2 * (tx + wm.rmin) - px + wm.pad;
     float s = 0.f;
@@ -1654,8 +1683,15 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                 const float* w = taps + a * PK_ROW + b * kk;
                 float* d = jb.dst + (size_t)po * jb.cols + pi;
                 const size_t tile = (size_t)jb.rows * jb.cols;
-                if (wm.kind == 2) {      // Winograd: U[pos][out][in] in the order of wino_kernel's LDS stage
-                    for (int pg = 0; pg < 16; ++pg) jb.dst[fg_wino_pack_index(pg, po, pi, jb.cols)] = fg_wino_u(w, pg >> 2, pg & 3);
+                if (wm.wino) {           // Winograd: U[parity][group][pos][out][in] in the order of wino_kernel's LDS stage
+                    int PP, KG; fg_wino_pack_shape(wm.kind, wm.wino, 0, &PP, &KG);
+                    for (int pp = 0; pp < PP; ++pp)
+                        for (int gg = 0; gg < KG; ++gg) {
+                            float tt[9];
+                            fg_wino_subkernel(wm, w, 0, pp, gg, tt);
+                            for (int pos = 0; pos < 16; ++pos)
+                                jb.dst[fg_wino_pack_at(pp, gg, KG, jb.rows, jb.cols, pos, po, pi)] = fg_wino_u(tt, pos >> 2, pos & 3);
+                        }
                 } else
                 for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
             }
@@ -1666,10 +1702,13 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                 const float* w = taps + a * PK_ROW + b * kk;
                 float* d = jb.dst2 + (size_t)pi * jb.cols2 + po;
                 const size_t tile = (size_t)jb.rows2 * jb.cols2;
-                if (wm.kind == 2) {      // data gradient: roles of out / in exchanged, taps flipped
-                    for (int pg = 0; pg < 16; ++pg) {
-                        const int fp = fg_wino_bwd_pos(pg);
-                        jb.dst2[fg_wino_pack_index(pg, pi, po, jb.cols2)] = fg_wino_u(w, fp >> 2, fp & 3);
+                if (wm.wino) {           // data gradient: roles of out / in exchanged, taps flipped, parities become K groups
+                    int PP, KG; fg_wino_pack_shape(wm.kind, wm.wino, 1, &PP, &KG);
+                    for (int gg = 0; gg < KG; ++gg) {
+                        float tt[9];
+                        fg_wino_subkernel(wm, w, 1, 0, gg, tt);
+                        for (int pos = 0; pos < 16; ++pos)
+                            jb.dst2[fg_wino_pack_at(0, gg, KG, jb.rows2, jb.cols2, pos, pi, po)] = fg_wino_u(tt, pos >> 2, pos & 3);
                     }
                 } else
                 for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);

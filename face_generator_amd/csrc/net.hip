@@ -562,6 +562,7 @@ int fg_net_create(fg_ctx* ctx, const fg_layer_spec* L, int nl, int in_c, int in_
                     if (4 * T * T <= FG_MAX_GROUPS) {
                         s.kind = ST_CONV;
                         ConvGeom& g = s.geom; g.H = h; g.W = w; g.Cin = cv.a; g.Cout = cv.b; g.k = cv.c; g.pad = cv.d; g.fold = 1;
+                        fg_geom_set_wino(g, ctx->fusion);       // every output parity is a 3x3 convolution of the source: Winograd
                         s.w_n = (long long)cv.a * cv.b * cv.c * cv.c; s.b_n = cv.b;
                         s.w_off = poff; s.b_off = poff + s.w_n; poff += s.w_n + s.b_n;
                         n->layers[i + 1].w_off = s.w_off; n->layers[i + 1].w_n = s.w_n;

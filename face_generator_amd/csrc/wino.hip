@@ -1,19 +1,33 @@
 // Winograd F(2x2, 3x3) convolution on the fp32 matrix pipe of gfx950 (MI355X): forward and data gradient of the 3x3 / pad 1 /
-// stride 1 layers of D (models.lua:390-400) and of the coarse-to-fine nets (models_c2f.lua:124, 247-254), which the reference
-// hands to cuDNN v3 / THNN SpatialConvolutionMM.
+// stride 1 layers of D (models.lua:390-400) and of the coarse-to-fine nets (models_c2f.lua:124, 247-254), of the nearest-x2 +
+// 5x5 up-convolutions of G (models.lua:63-64, 68-69: after the tap fold each output parity IS a 3x3 / pad 1 convolution of the
+// source image), and of plain 5x5 layers (models_c2f.lua:125-126: four 3x3 sub-kernels at offsets (0|3, 0|3) of the zero-extended
+// 6x6 window) -- what the reference hands to cuDNN v3 / THNN SpatialConvolutionMM.
 //
-//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      d: 4x4 input patch of a 2x2 output tile, g: the 3x3 taps, (.) summed over the
-//                                              input channels = 16 independent [tiles x Cin] x [Cin x Cout] contractions
-//   16 multiplies per 4 outputs and channel pair instead of 36: 2.25 x fewer MFMAs than the 9-tap implicit GEMM.
+//   Y = A^T [ sum_{group, channel} (G g G^T) (.) (B^T d B) ] A     d: 4x4 input patch of a 2x2 output tile, g: 3x3 taps
+//   16 multiplies per 4 outputs and (channel, group) instead of 36: 2.25 x fewer MFMAs than the 9-tap implicit GEMM
+//   (25 / 16 x fewer for a 5x5 layer as four groups).
 //
-// Why it fits THIS part.  v_mfma_f32_32x32x2_f32 occupies a SIMD's matrix pipe for 64 cycles -- ~13 issue slots in which the
-// same wave can issue VALU / LDS / VMEM work for free.  So the kernel is ONE wave per SIMD (4 waves per CU) and every wave does
-// everything: a wave owns 32 tiles x 32 output channels for ALL 16 Winograd positions = 16 accumulator tiles = 256 accumulator
-// registers of the unified 512-entry file, which makes the output transform A^T m A lane-local (a lane holds the 16 positions
-// of its (tile, channel) pairs: no LDS round trip, no second kernel, no [16][T][Cout] intermediate in HBM), and the input
-// transform B^T d B runs in the issue shadow of the MFMAs (64 VALU per 64 MFMAs and wave).  The transformed weights
-// U = G g G^T come from the re-pack launch that runs once per optimizer step (pack kind 2), stored in exactly the order the
-// LDS stage wants them, so a K chunk of U is one contiguous 32 KB run.
+// One kernel, described by WinoArgs (fg_internal.h):
+//   * K groups: group g reads patch element (i, j) of tile (ty, tx) at input pixel (isy (2 ty + i) + goy[g], isx (2 tx + j) + gox[g])
+//     -- one group at (-1, -1) for a 3x3 layer; four for a 5x5 layer; four (one per parity, stride 2) for the data gradient of a
+//     folded up-convolution;
+//   * output parities: parity p writes tile element (a, b) to output pixel (osy (2 ty + a) + ooy[p], osx (2 tx + b) + oox[p]) and has
+//     its own U -- four for the forward pass of a folded up-convolution (the input transform is shared by the four).
+//
+// Why it fits THIS part.  v_mfma_f32_32x32x2_f32 occupies a SIMD's matrix pipe for 64 cycles, and a wave that is alone on its SIMD
+// issues LDS / VALU / VMEM work in that shadow almost for free (measured, profiles/r05_wino_dbg.txt: per 64 MFMAs the 32 fragment
+// reads cost 42 cycles, the 8 U stores 50, the whole input transform + its 16 LDS stores 68, the 24 global loads 150).  So the
+// kernel is ONE wave per SIMD (4 waves per CU) and every wave does everything: a wave owns 32 tiles x 32 output channels for
+// ALL 16 Winograd positions = 16 accumulator tiles = the 256 accumulator registers, which makes the output transform A^T m A
+// lane-local (a lane holds the 16 positions of its (tile, channel) pairs: no LDS round trip, no second kernel, no
+// [16][T][Cout] intermediate in HBM).  What is NOT free is WAITING for a global load: under the load of 256 such blocks a patch
+// load returns after 2 000 - 3 400 cycles, and hipcc's wait insertion is conservative across the loop (the first consumer of a
+// chunk drains EVERY outstanding load).  So a chunk has exactly one drain point, its first slot, and requests everything it
+// will ever request right behind it -- into a second register set for both operands, consumed one chunk later: at the drain
+// the youngest outstanding load is >= 52 MFMA slots (~3 600 cycles) old.  5 724 -> cycles per chunk.
+// The transformed weights U = G g G^T come from the re-pack launch that runs once per optimizer step (WeightMap kind 2),
+// stored in exactly the order the LDS stage wants them: a K chunk of U is one contiguous 32 KB run.
 //
 // Block = 256 threads, tile 64 tiles x 64 output channels, K chunk = 8 input channels, two LDS stages of 64 KB:
 //   V[pos 16][k half 2][tile 64][4]   U[pos 16][k half 2][channel 64][4]        (floats; k = 4 * half + j)
@@ -29,7 +43,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define FG_OOB 0x7FFFFFF0   // voffset marker: beyond any buffer (< 2 GiB) -> loads return zeros, stores are dropped
 
 #define WN_STAGE 16384      // floats per LDS stage: V 8192 + U 8192
@@ -40,13 +53,14 @@ __device__ __forceinline__ f32x2 wn_load2(__amdgpu_buffer_rsrc_t r, int voff, in
 __device__ __forceinline__ f32x4 wn_load4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-// two fp32 additions / subtractions in one VALU instruction (hipcc scalarises <2 x float> arithmetic into two v_add_f32 here)
-__device__ __forceinline__ f32x2 wn_pk_add(f32x2 a, f32x2 b) {
+// two fp32 additions / subtractions in one VALU instruction (hipcc scalarises <2 x float> arithmetic into two v_add_f32 here;
+// the packed form measured 5 724 -> 5 585 cycles per K chunk)
+__device__ __forceinline__ f32x2 wn_add(f32x2 a, f32x2 b) {
     f32x2 d;
     asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
-__device__ __forceinline__ f32x2 wn_pk_sub(f32x2 a, f32x2 b) {
+__device__ __forceinline__ f32x2 wn_sub(f32x2 a, f32x2 b) {
     f32x2 d;
     asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
     return d;
@@ -78,20 +92,23 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
-    // XCD-aware block -> (tile block, channel block): the channel blocks of one tile block re-read the same input patches and
-    // should share an L2 (the dispatcher deals block b to XCD b % 8; speed only, never relied on)
-    const int ntn = a.Npad >> 6;
+    // XCD-aware block -> (tile block, channel block): the channel blocks (and parities) of one tile block re-read the same input
+    // patches and should share an L2 (the dispatcher deals block b to XCD b % 8; speed only, never relied on)
+    const int nbn = a.Npad >> 6;                       // channel blocks per parity
+    const int ntn = nbn * a.P;
     const int nmt = (a.T + 63) >> 6;
     int lin = blockIdx.x;
     if ((nmt & 7) == 0) {
         const int xcd = lin & 7, loc = lin >> 3;
         lin = (xcd * (nmt >> 3) + loc / ntn) * ntn + loc % ntn;
     }
-    const int tile_m = lin / ntn, tile_n = lin - tile_m * ntn;
-    const int nch = a.C >> 3;
-    const int per = (nch + a.splits - 1) / a.splits;
+    const int tile_m = lin / ntn, cb = lin - tile_m * ntn;
+    const int par = cb / nbn, tile_n = cb - par * nbn;
+    const int nch = a.C >> 3;                          // chunks per K group
+    const int nct = nch * a.KG;
+    const int per = (nct + a.splits - 1) / a.splits;
     const int c0 = blockIdx.y * per;
-    const int NC = max(0, min(nch, c0 + per) - c0);
+    const int NC = max(0, min(nct, c0 + per) - c0);
 
     if (tid < 64) {
         const int t = tile_m * 64 + tid;
@@ -99,7 +116,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
         if (t < a.T) {
             int b, ty, tx;
             wn_decode(t, a, b, ty, tx);
-            off = ((b * a.H + 2 * ty) * a.W + 2 * tx) * a.N;
+            off = ((b * a.Ho + a.osy * 2 * ty + a.ooy[par]) * a.Wo + a.osx * 2 * tx + a.oox[par]) * a.N;
         }
         rowoff[tid] = off;
     }
@@ -107,33 +124,55 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
     // ---- this thread's share of the loads: (tile tl, channel pair q) of the input patch, 8 float4 of the U chunk
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, FG_OOB, 0x00020000);
+    // The K loop runs PAIRS of chunks (two register sets per operand, exchanged by unrolling, one path through the loop -- with
+    // a branch per chunk the 256 accumulators went through merge copies and spilled).  An odd chunk count is padded with a chunk
+    // of zeros: its loads go through a zero-length descriptor (every lane out of range = 0).
+    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, 0, 0x00020000);
+    const int NCE = (NC + 1) & ~1;
     int voff[16];
+    int pb, py0, px0;                                   // this thread's tile: sample row base, patch origin before the group offset
+    bool tvalid;
     {
-        const int tl = tid >> 2, q = tid & 3;
-        const int t = tile_m * 64 + tl;
+        const int t = tile_m * 64 + (tid >> 2);
         int b, ty, tx;
-        wn_decode(t < a.T ? t : 0, a, b, ty, tx);
-        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int y = y0 + (p >> 2), x = x0 + (p & 3);
-            const bool ok = t < a.T && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            voff[p] = ok ? (((b * a.H + y) * a.W + x) * a.C + 2 * q) * 4 : FG_OOB;
-        }
+        tvalid = t < a.T;
+        wn_decode(tvalid ? t : 0, a, b, ty, tx);
+        pb = b * a.Hi; py0 = a.isy * 2 * ty; px0 = a.isx * 2 * tx;
+    }
+#define WN_SET_GROUP(g)                                                                                    \
+    {                                                                                                      \
+        const int gy_ = py0 + a.goy[g], gx_ = px0 + a.gox[g];                                              \
+        _Pragma("unroll") for (int p = 0; p < 16; ++p) {                                                   \
+            const int y = gy_ + a.isy * (p >> 2), x = gx_ + a.isx * (p & 3);                               \
+            const bool ok = tvalid && (unsigned)y < (unsigned)a.Hi && (unsigned)x < (unsigned)a.Wi;        \
+            voff[p] = ok ? (((pb + y) * a.Wi + x) * a.C + 2 * (tid & 3)) * 4 : FG_OOB;                     \
+        }                                                                                                  \
     }
     const int vw = ((tid & 3) >> 1) * 256 + (tid >> 2) * 4 + (tid & 1) * 2;      // V store: [pos][half][tile][4], pos = immediate
     const int uo = tid * 4;                                                      // U: float4 number tid + 256 i of the chunk image
-    const int ubase = tile_n * nch;                                              // chunk images of this channel block
+    const int ubase = (par * nbn + tile_n) * nct;                                // chunk images of this (parity, channel block)
     const int a_rd = (lane >> 5) * 256 + (wm * 32 + (lane & 31)) * 4;
     const int b_rd = 8192 + (lane >> 5) * 256 + (wn * 32 + (lane & 31)) * 4;
 
-    f32x2 rv[16];
-    f32x4 ru[8];
-#define WN_LOAD(c)                                                                                         \
+    // the load cursor: cl = absolute chunk of the next request, (gl, ccl) = its K group / chunk inside the group
+    int cl = c0, gl = c0 / nch, ccl = c0 - gl * nch;
+    WN_SET_GROUP(gl < a.KG ? gl : 0);
+#define WN_ADVANCE()                                                                                       \
     {                                                                                                      \
-        const int sx = (c) * 32, su = (ubase + (c)) * 32768;                                               \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) ru[i] = wn_load4(ursrc, (uo + i * 1024) * 4, su);     \
-        _Pragma("unroll") for (int p = 0; p < 16; ++p) rv[p] = wn_load2(xrsrc, voff[p], sx);               \
+        ++cl;                                                                                              \
+        if (++ccl == nch) { ccl = 0; ++gl; if (gl < a.KG) WN_SET_GROUP(gl); }                              \
+    }
+
+    // two register sets per operand: while (RX, UX) -- chunk ci + 1 -- is transformed / stored, (RY, UY) receives chunk ci + 2
+    f32x2 rva[16], rvb[16];
+    f32x4 rua[8], rub[8];
+#define WN_LOAD(rv, ru)                                                                                    \
+    {                                                                                                      \
+        const int sx = ccl * 32, su = (ubase + cl) * 32768;                                                \
+        const bool real_ = cl < c0 + NC;                                                                   \
+        const __amdgpu_buffer_rsrc_t xr_ = real_ ? xrsrc : zrsrc, ur_ = real_ ? ursrc : zrsrc;             \
+        _Pragma("unroll") for (int p = 0; p < 16; ++p) rv[p] = wn_load2(xr_, voff[p], sx);                 \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) ru[i] = wn_load4(ur_, (uo + i * 1024) * 4, su);       \
     }
     // input transform B^T d B of this thread's patch (two channels at a time) and the stores of a whole chunk, not interleaved
     // with anything: the prologue
@@ -157,15 +196,17 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
         }                                                                                                  \
     }
 
+    const int col = tile_n * 64 + wn * 32 + (lane & 31);
+    const bool colok = col < a.N;
+    // bias: position (1, 1) starts from it (A^T e11 A = ones) -- unless the epilogue leaves BatchNorm statistics of the RAW
+    // accumulators (output - bias, the pivot of bn_stats_final), then it is added at the store
+    const bool bias_late = a.stats_part != nullptr;
+    const float bv = (a.bias != nullptr && a.splits == 1 && colok) ? a.bias[col] : 0.f;
     f32x16 acc[16];
-    {
-        const int col = tile_n * 64 + wn * 32 + (lane & 31);
-        float bv = (a.bias != nullptr && a.splits == 1 && col < a.N) ? a.bias[col] : 0.f;
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < 16; ++p)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][r] = (p == 5) ? bv : 0.f;
-    }
+        for (int r = 0; r < 16; ++r) acc[p][r] = (p == 5 && !bias_late) ? bv : 0.f;
 
     f32x4 fa[2][2], fb[2][2];       // fragment double buffer: [set][position of the pair]
     unsigned long long* trc = nullptr;
@@ -174,18 +215,10 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
         if (trc && lane == 0) trc[0] = __builtin_amdgcn_s_memtime();
     }
     if (NC > 0) {
-        // chunk 0 AND chunk 1 requested before anything waits: the second set of loads lands while the first is transformed
-        f32x2 rv0[16];
-        f32x4 ru0[8];
-        {
-            const int sx = c0 * 32, su = (ubase + c0) * 32768;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ru0[i] = wn_load4(ursrc, (uo + i * 1024) * 4, su);
-#pragma unroll
-            for (int p = 0; p < 16; ++p) rv0[p] = wn_load2(xrsrc, voff[p], sx);
-        }
-        if (NC > 1) WN_LOAD(c0 + 1);
-        WN_XFORM_STORE(smem, rv0, ru0);
+        // chunks 0 and 1 requested before anything waits: the second set of loads lands while the first is transformed
+        WN_LOAD(rva, rua); WN_ADVANCE();
+        WN_LOAD(rvb, rub); WN_ADVANCE();
+        WN_XFORM_STORE(smem, rva, rua);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (TRACE && trc && lane == 0) trc[1] = __builtin_amdgcn_s_memtime();
@@ -200,20 +233,23 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
     // One K chunk = 64 MFMA slots (8 position pairs x 2 positions x 4 k-steps).  Every slot is one MFMA followed by a small,
     // fixed slice of the other work, pinned in program order (sched_barrier) so that it issues in the MFMA's shadow:
     //   slots 8p .. 8p+3   the four fragment reads of the NEXT pair (pair 7: pair 0 of the next chunk, behind the barrier)
-    //   HAS1 (a next chunk exists; its raw loads were issued one chunk ago):
-    //     slots 0..7    U stores          slots 8..23  column pass of B^T d B       slots 24..40 row pass + V stores
+    //   HAS1 (a next chunk exists; its patch sits in RX and its U in UX, requested one chunk ago):
+    //     slots 0..7    U stores -- the FIRST of them is the chunk's only drain point
+    //     slots 8..23   column pass of B^T d B, in place in RX           slots 24..40 row pass + V stores
     //     end of slot 55: lgkmcnt(0) + barrier (stage s^1 complete, every wave is done reading stage s except its last pair,
     //     whose fragments are already in registers)
-    //   HAS2 (a chunk after that exists): its loads -- U in slots 8..15 (registers free after the U stores), the patch in
-    //     slots 24..39 (free after the column pass)
-#define WN_CHUNK(HAS1, HAS2, cnext2)                                                                       \
+    //   HAS2 (a chunk after that exists, the load cursor points at it): its 16 patch loads into RY in slots 0..7 and its 8 U
+    //     loads into UY in slots 8..11 -- right behind the drain, so that the NEXT chunk's drain finds nothing younger than 52 slots
+#define WN_CHUNK(HAS1, HAS2, RX, UX, RY, UY)                                                               \
     {                                                                                                      \
         const float* Sc = smem + s * WN_STAGE;                                                             \
         float* Sn = smem + (s ^ 1) * WN_STAGE;                                                             \
         float* Vs = Sn + vw;                                                                               \
         float* Us = Sn + 8192 + uo;                                                                        \
-        const int sx2 = (cnext2) * 32, su2 = (ubase + (cnext2)) * 32768;                                   \
-        f32x2 w_[16];                                                                                      \
+        const int sx2 = ccl * 32, su2 = (ubase + cl) * 32768;                                              \
+        const bool real_ = cl < c0 + NC;                                                                   \
+        const __amdgpu_buffer_rsrc_t xr_ = real_ ? xrsrc : zrsrc, ur_ = real_ ? ursrc : zrsrc;             \
+        f32x2 t_;                                                                                          \
         _Pragma("unroll") for (int pr = 0; pr < 8; ++pr) {                                                 \
             _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                                \
                 const int sl = pr * 8 + m, h = m & 1, j = m >> 1, pos = 2 * pr + h;                        \
@@ -228,40 +264,32 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
                         if ((m & 1) == 0) fa[0][m >> 1] = *(const f32x4*)(Sn + a_rd + (m >> 1) * 512);     \
                         else fb[0][m >> 1] = *(const f32x4*)(Sn + b_rd + (m >> 1) * 512);                  \
                     }                                                                                      \
-                    if (sl < 8 && !(DBG & 1)) *(f32x4*)(Us + sl * 1024) = ru[sl];                          \
-                    if (sl >= 8 && sl < 24 && !(DBG & 2)) {                                                \
-                        const int k = sl - 8, x = k >> 2, o = k & 3;                                       \
-                        if (DBG & 16) {                                                                    \
-                            if (o == 0) w_[0 + x] = wn_pk_sub(rv[0 + x], rv[8 + x]);                       \
-                            if (o == 1) w_[4 + x] = wn_pk_add(rv[4 + x], rv[8 + x]);                       \
-                            if (o == 2) w_[8 + x] = wn_pk_sub(rv[8 + x], rv[4 + x]);                       \
-                            if (o == 3) w_[12 + x] = wn_pk_sub(rv[4 + x], rv[12 + x]);                     \
-                        } else {                                                                           \
-                        if (o == 0) w_[0 + x] = rv[0 + x] - rv[8 + x];                                     \
-                        if (o == 1) w_[4 + x] = rv[4 + x] + rv[8 + x];                                     \
-                        if (o == 2) w_[8 + x] = rv[8 + x] - rv[4 + x];                                     \
-                        if (o == 3) w_[12 + x] = rv[4 + x] - rv[12 + x];                                   \
+                    if (sl < 8 && !(DBG & 1)) *(f32x4*)(Us + sl * 1024) = UX[sl];                          \
+                    if (HAS2 && !(DBG & 4)) {                                                              \
+                        if (sl < 8) {                                                                      \
+                            RY[2 * sl] = wn_load2(xr_, voff[2 * sl], sx2);                                 \
+                            RY[2 * sl + 1] = wn_load2(xr_, voff[2 * sl + 1], sx2);                         \
                         }                                                                                  \
+                        if (sl >= 8 && sl < 12) {                                                          \
+                            UY[2 * (sl - 8)] = wn_load4(ur_, (uo + 2 * (sl - 8) * 1024) * 4, su2);         \
+                            UY[2 * (sl - 8) + 1] = wn_load4(ur_, (uo + (2 * (sl - 8) + 1) * 1024) * 4, su2); \
+                        }                                                                                  \
+                    }                                                                                      \
+                    if (sl >= 8 && sl < 24 && !(DBG & 2)) {              /* column x: d -> w, in place */    \
+                        const int k = sl - 8, x = k >> 2, o = k & 3;                                       \
+                        if (o == 0) RX[0 + x] = wn_sub(RX[0 + x], RX[8 + x]);                              \
+                        if (o == 1) RX[12 + x] = wn_sub(RX[4 + x], RX[12 + x]);                            \
+                        if (o == 2) t_ = wn_add(RX[4 + x], RX[8 + x]);                                     \
+                        if (o == 3) { RX[8 + x] = wn_sub(RX[8 + x], RX[4 + x]); RX[4 + x] = t_; }          \
                     }                                                                                      \
                     if (sl >= 24 && sl < 40 && !(DBG & 2)) {                                               \
                         const int k = sl - 24, i = k >> 2, o = k & 3;                                      \
                         f32x2 v_;                                                                          \
-                        if (DBG & 16) {                                                                    \
-                            if (o == 0) v_ = wn_pk_sub(w_[i * 4 + 0], w_[i * 4 + 2]);                      \
-                            if (o == 1) v_ = wn_pk_add(w_[i * 4 + 1], w_[i * 4 + 2]);                      \
-                            if (o == 2) v_ = wn_pk_sub(w_[i * 4 + 2], w_[i * 4 + 1]);                      \
-                            if (o == 3) v_ = wn_pk_sub(w_[i * 4 + 1], w_[i * 4 + 3]);                      \
-                        } else {                                                                           \
-                        if (o == 0) v_ = w_[i * 4 + 0] - w_[i * 4 + 2];                                    \
-                        if (o == 1) v_ = w_[i * 4 + 1] + w_[i * 4 + 2];                                    \
-                        if (o == 2) v_ = w_[i * 4 + 2] - w_[i * 4 + 1];                                    \
-                        if (o == 3) v_ = w_[i * 4 + 1] - w_[i * 4 + 3];                                    \
-                        }                                                                                  \
+                        if (o == 0) v_ = wn_sub(RX[i * 4 + 0], RX[i * 4 + 2]);                             \
+                        if (o == 1) v_ = wn_add(RX[i * 4 + 1], RX[i * 4 + 2]);                             \
+                        if (o == 2) v_ = wn_sub(RX[i * 4 + 2], RX[i * 4 + 1]);                             \
+                        if (o == 3) v_ = wn_sub(RX[i * 4 + 1], RX[i * 4 + 3]);                             \
                         *(f32x2*)(Vs + k * 512) = v_;                                                      \
-                    }                                                                                      \
-                    if (HAS2 && !(DBG & 4)) {                                                              \
-                        if (sl >= 8 && sl < 16) ru[sl - 8] = wn_load4(ursrc, (uo + (sl - 8) * 1024) * 4, su2); \
-                        if (sl >= 24 && sl < 40) rv[sl - 24] = wn_load2(xrsrc, voff[sl - 24], sx2);        \
                     }                                                                                      \
                     if (sl == 55) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          \
                 }                                                                                          \
@@ -269,36 +297,37 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
             }                                                                                              \
         }                                                                                                  \
     }
-
+    // chunk ci multiplies stage s, transforms chunk ci + 1 from (RX, UX) and requests chunk ci + 2 into (RY, UY)
+#define WN_STAMP() { if (TRACE && trc && lane == 0) trc[2 + (ci < 119 ? ci : 119)] = __builtin_amdgcn_s_memtime(); ++ci; }
     int s = 0;
     int ci = 0;
-#define WN_STAMP() if (TRACE && trc && lane == 0) trc[2 + (ci < 119 ? ci : 119)] = __builtin_amdgcn_s_memtime();
-    for (; ci + 2 < NC; ++ci) {
-        WN_CHUNK(true, true, c0 + ci + 2);
+    if (NCE > 0) {
+        for (; ci + 2 < NCE;) {
+            WN_CHUNK(true, true, rvb, rub, rva, rua); WN_ADVANCE(); WN_STAMP();
+            s ^= 1;
+            WN_CHUNK(true, true, rva, rua, rvb, rub); WN_ADVANCE(); WN_STAMP();
+            s ^= 1;
+        }
+        WN_CHUNK(true, false, rvb, rub, rva, rua); WN_STAMP();
         s ^= 1;
-        WN_STAMP();
+        WN_CHUNK(false, false, rva, rua, rvb, rub);
+        if (ci < NC) WN_STAMP();
     }
-    if (ci + 1 < NC) {
-        WN_CHUNK(true, false, 0);
-        s ^= 1;
-        WN_STAMP();
-        ++ci;
-    }
-    if (ci < NC) { WN_CHUNK(false, false, 0); WN_STAMP(); }
 #undef WN_STAMP
+#undef WN_SET_GROUP
+#undef WN_ADVANCE
 #undef WN_LOAD
 #undef WN_XFORM_STORE
 #undef WN_CHUNK
 
     // ---- output transform A^T m A, lane-local, and the stores.  Lane l holds column (l & 31) and rows (r & 3) + 8 (r >> 2)
-    // + 4 (l >> 5) of each 32 x 32 accumulator tile; the 2 x 2 outputs of a tile are 0, N, W N, (W + 1) N floats from rowoff.
+    // + 4 (l >> 5) of each 32 x 32 accumulator tile; the 2 x 2 outputs of a tile are 0, osx N, osy Wo N, ... floats from rowoff.
     float* outp = a.Out + (size_t)blockIdx.y * a.split_stride;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
-    const int col = tile_n * 64 + wn * 32 + (lane & 31);
-    const bool colok = col < a.N;
-    const int oN = a.N * 4, oW = a.W * a.N * 4;
-    float sl_ = 0.f, ssum = 0.f;
+    const int oN = a.osx * a.N * 4, oW = a.osy * a.Wo * a.N * 4;
+    float sl_ = 0.f, ssum = 0.f, st1 = 0.f, st2 = 0.f;
     if (EPI != 0) sl_ = a.act_slope[0];
+    const float badd = bias_late ? bv : 0.f;
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         const int4 ro4 = *(const int4*)(rowoff + wm * 32 + 8 * r4 + 4 * (lane >> 5));
@@ -340,10 +369,15 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
                     ssum = fmaf(pos ? 0.f : x, y[e], ssum);      // masked elements read x = 0: they add 0 * g
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pos ? y[e] : sl_ * y[e]), orsrc, vo, so[e], 0);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[e]), orsrc, vo, so[e], 0);
+                    if (bias_late) {                             // BatchNorm statistics of the raw accumulators (rows past T are zero)
+                        st1 += y[e];
+                        st2 = fmaf(y[e], y[e], st2);
+                    }
+                    const float yo = y[e] + badd;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yo), orsrc, vo, so[e], 0);
                     if (EPI == 1) {
                         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)a.act_y, 0, FG_OOB, 0x00020000);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[e] > 0.f ? y[e] : sl_ * y[e]), yr, vo, so[e], 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(yo > 0.f ? yo : sl_ * yo), yr, vo, so[e], 0);
                     }
                 }
             }
@@ -353,6 +387,16 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ssum += __shfl_xor(ssum, o, 64);
         if (lane == 0) a.act_part[blockIdx.x * 4 + wid] = ssum;
+    }
+    if (EPI != 2 && bias_late) {
+        // one partial row per (tile block, parity, wave row): [2][stats_rows][N], summed by bn_stats_final
+        st1 += __shfl_xor(st1, 32, 64);
+        st2 += __shfl_xor(st2, 32, 64);
+        const int row = (tile_m * a.P + par) * 2 + wm;
+        if (lane < 32 && colok) {
+            a.stats_part[(size_t)row * a.N + col] = st1;
+            a.stats_part[((size_t)a.stats_rows + row) * a.N + col] = st2;
+        }
     }
     if (TRACE && trc && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0x0f70);        // the stores have left the wave
@@ -367,7 +411,13 @@ template <int DBG>
 __global__ __launch_bounds__(256) void wino_trace_kernel(const WinoArgs a) { wino_body<0, 1, DBG>(a); }
 
 // FG_WINO_TRACE=1 (measurement only): EPI-0 launches run the trace kernel four times (three to settle the clocks); the per-block
-// s_memtime rows of the fourth are appended to FG_WS_TRACE_FILE in igemm_ws_trace_kernel's row format
+// s_memtime rows of the fourth are appended to FG_WS_TRACE_FILE in igemm_ws_trace_kernel's row format.  FG_WINO_DBG selects a
+// variant with part of the K loop's side work removed (see wino_body).
+template <int DBG>
+static void wino_trace_go(const WinoArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    (void)hipFuncSetAttribute((const void*)wino_trace_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(wino_trace_kernel<DBG>, grid, dim3(256), lds, st, a);
+}
 static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, size_t lds) {
     WinoArgs a = a_in;
     const size_t nblk = (size_t)grid.x * grid.y;
@@ -377,22 +427,19 @@ static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, si
     a.dbg_trace = dvc;
     int dbg = 0;
     if (const char* e = getenv("FG_WINO_DBG")) dbg = atoi(e);
-    const void* fn = dbg == 1 ? (const void*)wino_trace_kernel<1> : dbg == 2 ? (const void*)wino_trace_kernel<2> : dbg == 4 ? (const void*)wino_trace_kernel<4> :
-                     dbg == 6 ? (const void*)wino_trace_kernel<6> : dbg == 7 ? (const void*)wino_trace_kernel<7> :
-                     dbg == 15 ? (const void*)wino_trace_kernel<15> : dbg == 16 ? (const void*)wino_trace_kernel<16> : (const void*)wino_trace_kernel<0>;
-    FG_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int rep = 0; rep < 4; ++rep) {
         (void)hipEventRecord(e0, ctx->stream);
-        if (dbg == 1) hipLaunchKernelGGL(wino_trace_kernel<1>, grid, dim3(256), lds, ctx->stream, a);
-        else if (dbg == 2) hipLaunchKernelGGL(wino_trace_kernel<2>, grid, dim3(256), lds, ctx->stream, a);
-        else if (dbg == 4) hipLaunchKernelGGL(wino_trace_kernel<4>, grid, dim3(256), lds, ctx->stream, a);
-        else if (dbg == 6) hipLaunchKernelGGL(wino_trace_kernel<6>, grid, dim3(256), lds, ctx->stream, a);
-        else if (dbg == 7) hipLaunchKernelGGL(wino_trace_kernel<7>, grid, dim3(256), lds, ctx->stream, a);
-        else if (dbg == 15) hipLaunchKernelGGL(wino_trace_kernel<15>, grid, dim3(256), lds, ctx->stream, a);
-        else if (dbg == 16) hipLaunchKernelGGL(wino_trace_kernel<16>, grid, dim3(256), lds, ctx->stream, a);
-        else hipLaunchKernelGGL(wino_trace_kernel<0>, grid, dim3(256), lds, ctx->stream, a);
+        switch (dbg) {
+            case 1: wino_trace_go<1>(a, grid, lds, ctx->stream); break;
+            case 2: wino_trace_go<2>(a, grid, lds, ctx->stream); break;
+            case 4: wino_trace_go<4>(a, grid, lds, ctx->stream); break;
+            case 6: wino_trace_go<6>(a, grid, lds, ctx->stream); break;
+            case 7: wino_trace_go<7>(a, grid, lds, ctx->stream); break;
+            case 15: wino_trace_go<15>(a, grid, lds, ctx->stream); break;
+            default: dbg = 0; wino_trace_go<0>(a, grid, lds, ctx->stream); break;
+        }
         (void)hipEventRecord(e1, ctx->stream);
     }
     FG_CHECK_LAUNCH(ctx);
@@ -407,7 +454,8 @@ static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, si
     FILE* f = fopen(path ? path : "/tmp/fg_ws_trace.txt", "a");
     if (f) {
         // (BN=128: scripts/ws_trace_report.py prices a step at 64 MFMAs x 64 cycles per wave -- one K chunk of this kernel)
-        fprintf(f, "# launch wino(dbg=%d)/%s BN=128 blocks=%zu T=%d Npad=%d C=%d splits=%d wall_us=%.1f\n", dbg, a.tag ? a.tag : "?", nblk, a.T, a.Npad, a.C, a.splits, wall_ms * 1e3);
+        fprintf(f, "# launch wino(dbg=%d)/%s BN=128 blocks=%zu T=%d Npad=%d C=%d KG=%d P=%d splits=%d wall_us=%.1f\n", dbg, a.tag ? a.tag : "?", nblk,
+                a.T, a.Npad, a.C, a.KG, a.P, a.splits, wall_ms * 1e3);
         for (size_t b = 0; b < nblk; ++b) {
             const unsigned long long* r = host.data() + b * 128;
             const int kt = (int)(r[127] >> 32), xcc = (int)(r[127] & 0xffffffff);
@@ -420,13 +468,15 @@ static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, si
     return FG_OK;
 }
 
-long long fg_wino_blocks(const WinoArgs& a) { return (long long)fg_cdiv(a.T, 64) * (a.Npad / 64); }
+long long fg_wino_blocks(const WinoArgs& a) { return (long long)fg_cdiv(a.T, 64) * (a.Npad / 64) * a.P; }
 
 int fg_launch_wino(fg_ctx* ctx, const WinoArgs& a) {
-    if (a.C % 8 || a.Npad % 64 || a.H % 2 || a.W % 2 || a.splits < 1) return fg_set_err(ctx, FG_ERR_INVALID, "winograd: C %% 8 / Npad %% 64 / even H, W");
+    if (a.C % 8 || a.Npad % 64 || a.splits < 1 || a.KG < 1 || a.KG > 4 || a.P < 1 || a.P > 4)
+        return fg_set_err(ctx, FG_ERR_INVALID, "winograd: C %% 8 / Npad %% 64 / 1..4 groups and parities");
     if ((a.act_y || a.act_x) && (a.splits != 1 || !a.act_slope || (a.act_y && a.act_x)))
         return fg_set_err(ctx, FG_ERR_INVALID, "winograd: a fused PReLU needs splits == 1 and its slope");
-    if (a.x_bytes <= 0 || a.x_bytes >= (long long)FG_OOB || (long long)a.B * a.H * a.W * a.N * 4 >= (long long)FG_OOB)
+    if (a.stats_part && (a.splits != 1 || a.act_x)) return fg_set_err(ctx, FG_ERR_INVALID, "winograd: statistics need an un-split forward launch");
+    if (a.x_bytes <= 0 || a.x_bytes >= (long long)FG_OOB || (long long)a.B * a.Ho * a.Wo * a.N * 4 >= (long long)FG_OOB)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "winograd: operands must be < 2 GiB per launch");
     const size_t lds = (size_t)(2 * WN_STAGE + 64) * sizeof(float);
     static bool attr_set = false;
@@ -437,12 +487,12 @@ int fg_launch_wino(fg_ctx* ctx, const WinoArgs& a) {
         attr_set = true;
     }
     dim3 grid((unsigned)fg_wino_blocks(a), a.splits, 1);
-    const double exec = 2.0 * (double)grid.x * 64 * 64 * 16.0 * a.C;       // MFMA FLOPs issued: 16 positions, every tile padded to 64 x 64
+    const double exec = 2.0 * (double)grid.x * 64 * 64 * 16.0 * a.C * a.KG;       // MFMA FLOPs issued: 16 positions, every tile padded to 64 x 64
     const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
     {
         static int tr = -1;
         if (tr < 0) { const char* e = getenv("FG_WINO_TRACE"); tr = e ? atoi(e) : 0; }
-        if (tr && epi == 0) return fg_wino_trace_launch(ctx, a, grid, lds);
+        if (tr && epi == 0 && !a.stats_part) return fg_wino_trace_launch(ctx, a, grid, lds);
     }
     char label[96];
     snprintf(label, sizeof(label), "wino_kernel<%d>/%s", epi, a.tag ? a.tag : "?");

@@ -62,8 +62,8 @@ class Context:
         """Optional kernel fusions (include/facegen_hip.h FG_FUSE_*): 1 = PReLU in the neighbouring contraction's epilogue,
         2 = one-pass matrix-pipe 3x3 thin-output convolution, 4 = all weight-gradient split-K sums of a backward pass in one launch,
         8 = Adam + the re-pack of every layer in one launch (measured slower: off by default), 16 = the bias gradient of a thin-input
-        convolution from its weight-gradient kernel (no separate column-sum pass), 32 = 3x3 convolutions as Winograd F(2x2, 3x3)
-        (read when a net is created); default 55."""
+        convolution from its weight-gradient kernel (no separate column-sum pass), 32 / 64 / 128 = 3x3 / nearest-x2-folded 5x5 / plain 5x5
+        convolutions as Winograd F(2x2, 3x3) (read when a net is created); default 247."""
         self.check(self.lib.fg_set_fusion(self.h, int(flags)))
 
     def get_fusion(self):

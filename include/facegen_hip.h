@@ -51,7 +51,7 @@ int fg_get_math(fg_ctx* ctx);
 
 /* Optional kernel fusions / variants (results equal to the un-fused path up to the summation order of a reduction; exposed so
  * the parity tests and the bench can run both ways).  Default: FG_FUSE_DEFAULT; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 / FG_DEFER_WFINISH=0 /
- * FG_THIN_BIAS=0 / FG_WINO=0 in the environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
+ * FG_THIN_BIAS=0 / FG_WINO=0 / FG_WINO_UP=0 / FG_WINO_5X5=0 in the environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
 enum {
     FG_FUSE_PRELU = 1,      /* an nn.PReLU between two contraction layers (models_c2f.lua:118-130, 242-255) rides on their
                              * epilogues: forward copy behind the producing layer, backward (+ slope-gradient partials) in
@@ -77,8 +77,15 @@ enum {
                              * convolution to a few fp32 roundings) instead of the 9-tap implicit GEMM.  Read when a net is created
                              * (fg_net_create: its packed weights hold the transformed taps) and per call by the module-level
                              * fg_conv2d_* entries; FG_WINO=0 clears it.  The weight gradient is not affected */
-    FG_FUSE_ALL = 63,
-    FG_FUSE_DEFAULT = 55
+    FG_FUSE_WINOGRAD_UP = 64,   /* the same for nn.SpatialUpSamplingNearest(2) + 5x5 / pad 2 convolutions (models.lua:63-64, 68-69): after
+                                 * the tap fold every output parity is a 3x3 / pad 1 convolution of the source image, so forward (four
+                                 * parities sharing one input transform) and data gradient (four stride-2 input groups) are Winograd
+                                 * contractions as well; FG_WINO_UP=0 clears it */
+    FG_FUSE_WINOGRAD_5X5 = 128, /* 5x5 / pad 2 / stride 1 convolutions (models_c2f.lua:125-126) as four 3x3 sub-kernels at tap offsets
+                                 * (0 | 3, 0 | 3) of the zero-extended 6x6 window: 64 instead of 100 multiplies per 2x2 outputs;
+                                 * FG_WINO_5X5=0 clears it */
+    FG_FUSE_ALL = 255,
+    FG_FUSE_DEFAULT = 247
 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);

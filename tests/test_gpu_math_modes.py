@@ -53,10 +53,11 @@ def test_bf16x6_contractions_are_not_less_accurate_than_fp32_mfma(ctx, shape):
         gwr = torch.nn.grad.conv2d_weight(xa, (Cout, Cin, k, k), gy.permute(0, 3, 1, 2).double(), padding=k // 2)
     xd, wd, bd, gyd = x.to(d), w.to(d), b.to(d), gy.to(d)
     err, outs = {}, {}
-    # fg_set_math selects the arithmetic of the implicit-GEMM contractions; a 3x3 layer's forward / data gradient run as Winograd
-    # F(2x2, 3x3) on the fp32 pipe in EITHER mode (FG_FUSE_WINOGRAD, round 5), so the comparison is made with that bit cleared
+    # fg_set_math selects the arithmetic of the implicit-GEMM contractions; the forward / data gradient of 3x3, 5x5 and
+    # folded up-convolution layers run as Winograd F(2x2, 3x3) on the fp32 pipe in EITHER mode (FG_FUSE_WINOGRAD*, round 5), so the
+    # comparison is made with those bits cleared
     fusion = ctx.get_fusion()
-    ctx.set_fusion(fusion & ~32)
+    ctx.set_fusion(fusion & ~(32 | 64 | 128))
     for mode in (0, 6):
         ctx.set_math(mode)
         y = ops.conv2d_forward(xd, wd, bd, upsample2x=bool(up))

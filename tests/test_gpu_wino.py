@@ -1,6 +1,9 @@
-"""Winograd F(2x2, 3x3) (csrc/wino.hip; fg_set_fusion bit FG_FUSE_WINOGRAD): forward and data gradient of the 3x3 / pad 1 /
-stride 1 layers (models.lua:390-400, models_c2f.lua:124, 247-254) against the oracle's direct convolution and against the
-library's own 9-tap implicit GEMM (the bit cleared), on the same seeded inputs.
+"""Winograd F(2x2, 3x3) (csrc/wino.hip; fg_set_fusion bits FG_FUSE_WINOGRAD / _UP / _5X5): forward and data gradient of
+  * the 3x3 / pad 1 / stride 1 layers (models.lua:390-400, models_c2f.lua:124, 247-254),
+  * the nearest-x2 + 5x5 up-convolutions (models.lua:63-64, 68-69): every output parity of the tap-folded layer is a 3x3 convolution
+    of the source image -- four parities forward, four stride-2 input groups backward,
+  * plain 5x5 / pad 2 layers (models_c2f.lua:125-126) as four 3x3 sub-kernels of the zero-extended 6x6 window,
+against the oracle's direct convolution and against the library's own implicit GEMM (the bits cleared), on the same seeded inputs.
 
 Tolerance: the transforms run in fp32 (B^T d B: two additions per value; G g G^T: halves and sums; A^T m A: sums of up to nine
 products of transformed values), so a result differs from the direct convolution's by a few fp32 roundings of the LARGEST partial
@@ -14,7 +17,8 @@ from gpu_util import nhwc, nchw, dev, close
 
 pytestmark = pytest.mark.gpu
 
-FG_FUSE_WINOGRAD, FG_FUSE_DEFAULT = 32, 55
+FG_FUSE_WINOGRAD, FG_FUSE_WINOGRAD_UP, FG_FUSE_WINOGRAD_5X5, FG_FUSE_DEFAULT = 32, 64, 128, 247
+WINO_ALL = FG_FUSE_WINOGRAD | FG_FUSE_WINOGRAD_UP | FG_FUSE_WINOGRAD_5X5
 
 
 @pytest.fixture(scope="module")
@@ -84,3 +88,74 @@ def test_winograd_is_exact_on_small_integers(ctx):
     w_d, b_d = dev(conv.weight, d), dev(conv.bias, d)
     assert np.array_equal(nchw(ops.conv2d_forward(nhwc(x, d), w_d, b_d)), y)
     assert np.array_equal(nchw(ops.conv2d_backward_data(nhwc(gy, d), w_d, (H, W))), gx)
+
+
+UP_CASES = [
+    # B, H, W (source), Cin, Cout, k, folded nearest-x2
+    (2, 8, 8, 128, 256, 5, 1),      # G's first up-convolution (models.lua:63-64)
+    (3, 16, 16, 256, 128, 5, 1),    # G's second (models.lua:68-69): 192 tiles = 3 blocks x (4 parities x 2 channel blocks)
+    (1, 4, 4, 32, 64, 5, 1),
+    (2, 8, 8, 64, 64, 3, 1),        # a folded 3x3: the 3x3 window of each parity has zero taps
+    (5, 6, 10, 16, 24, 5, 1),       # tile grid 3 x 5, ragged channel block
+    (2, 6, 6, 32, 64, 5, 0),        # plain 5x5: four sub-kernels
+    (3, 32, 32, 64, 128, 5, 0),     # models_c2f.lua:125 at 32x32
+    (2, 16, 16, 128, 256, 5, 0),    # models_c2f.lua:126
+    (2, 4, 8, 8, 8, 5, 0),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,up", UP_CASES)
+def test_winograd_up_and_5x5_layers(ctx, B, H, W, Cin, Cout, k, up):
+    from face_generator_amd import ops
+    rng = np.random.default_rng(B * 1000 + H * 100 + Cin + Cout + k + up)
+    pad = (k - 1) // 2
+    conv = O.SpatialConvolution(Cin, Cout, k, k, 1, 1, pad, pad, rng)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    ups = O.SpatialUpSamplingNearest(2)
+    xu = ups.forward(x) if up else x
+    y = conv.forward(xu)
+    gy = rng.standard_normal(y.shape).astype(np.float32)
+    gxu = conv.backward(xu, gy)
+    gx = ups.backward(x, gxu) if up else gxu
+    d = ctx.device
+    w_d, b_d = dev(conv.weight, d), dev(conv.bias, d)
+    got = {}
+    for flags in (FG_FUSE_DEFAULT, FG_FUSE_DEFAULT & ~WINO_ALL):
+        ctx.set_fusion(flags)
+        got[flags] = (nchw(ops.conv2d_forward(nhwc(x, d), w_d, b_d, upsample2x=bool(up))),
+                      nchw(ops.conv2d_backward_data(nhwc(gy, d), w_d, (H, W), upsample2x=bool(up))))
+    ctx.set_fusion(FG_FUSE_DEFAULT)
+    yw, gw = got[FG_FUSE_DEFAULT]
+    yi, gi = got[FG_FUSE_DEFAULT & ~WINO_ALL]
+    sy, sg = max(np.abs(y).max(), 1.0), max(np.abs(gx).max(), 1.0)
+    close(yw, y, atol=3e-5 * sy, what="winograd forward vs oracle")
+    close(gw, gx, atol=3e-5 * sg, what="winograd data gradient vs oracle")
+    close(yw, yi, atol=3e-5 * sy, what="winograd vs implicit GEMM forward")
+    close(gw, gi, atol=3e-5 * sg, what="winograd vs implicit GEMM data gradient")
+    assert not np.array_equal(yw, yi), "both settings of the Winograd bits gave identical bits: the switch selected nothing"
+
+
+@pytest.mark.parametrize("k,up", [(5, 1), (3, 1), (5, 0)])
+def test_winograd_up_and_5x5_are_exact_on_small_integers(ctx, k, up):
+    """As test_winograd_is_exact_on_small_integers, for the folded layers (the folded taps are sums of up to four multiples of 4) and
+    for the four sub-kernels of a 5x5 layer: pins the parity -> output pixel map, the stride-2 sub-grid groups of the data gradient,
+    the sub-kernel offsets (0 | 3) and the flipped 5x5 kernel's sub-kernels."""
+    from face_generator_amd import ops
+    rng = np.random.default_rng(70 + k + up)
+    B, H, W, Cin, Cout = 3, 12, 8, 24, 40
+    pad = (k - 1) // 2
+    conv = O.SpatialConvolution(Cin, Cout, k, k, 1, 1, pad, pad, rng)
+    conv.weight[...] = (4 * rng.integers(-2, 3, conv.weight.shape)).astype(np.float32)
+    conv.bias[...] = rng.integers(-8, 9, conv.bias.shape).astype(np.float32)
+    x = rng.integers(-3, 4, (B, Cin, H, W)).astype(np.float32)
+    ups = O.SpatialUpSamplingNearest(2)
+    xu = ups.forward(x) if up else x
+    y = conv.forward(xu)
+    gy = rng.integers(-3, 4, y.shape).astype(np.float32)
+    gxu = conv.backward(xu, gy)
+    gx = ups.backward(x, gxu) if up else gxu
+    d = ctx.device
+    ctx.set_fusion(FG_FUSE_DEFAULT)
+    w_d, b_d = dev(conv.weight, d), dev(conv.bias, d)
+    assert np.array_equal(nchw(ops.conv2d_forward(nhwc(x, d), w_d, b_d, upsample2x=bool(up))), y)
+    assert np.array_equal(nchw(ops.conv2d_backward_data(nhwc(gy, d), w_d, (H, W), upsample2x=bool(up))), gx)
