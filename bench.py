@@ -111,21 +111,23 @@ def _sha16(path):
         return None
 
 
-KERNEL_SOURCE = os.path.join(ROOT, "face_generator_amd", "csrc", "igemm.hip")
-# the dominant launch of the dominant kernel: nearest-x2 + 5x5 conv 256 -> 128 forward at B = 128 (models.lua:68-69):
-# reads the 33.5 MB input + 4.7 MB of folded weights, writes the 67.1 MB output
-DOMINANT_LAUNCH = dict(kernel="igemm_ws_kernel<128>", launch="nearest-x2 + 5x5 conv 256->128 forward, B=128 (models.lua:68-69)",
-                       algorithmic_bytes_per_launch=128 * 16 * 16 * 256 * 4 + 4 * 9 * 256 * 128 * 4 + 128 * 32 * 32 * 128 * 4 + 128 * 4,
-                       bench_one=["fwd", "4"], trace_prefix="igemm_ws_kernel<128>")
+KERNEL_SOURCE = os.path.join(ROOT, "face_generator_amd", "csrc", "wino.hip")
+# the dominant launch of the dominant kernel: nearest-x2 + 5x5 conv 256 -> 128 forward at B = 128 (models.lua:68-69), since round 5 a
+# Winograd F(2x2, 3x3) contraction over the four output parities: reads the 33.5 MB input + 8.4 MB of transformed weights
+# (4 parities x 16 positions x 256 x 128), writes the 67.1 MB output
+DOMINANT_LAUNCH = dict(kernel="wino_kernel", launch="nearest-x2 + 5x5 conv 256->128 forward, B=128 (models.lua:68-69), Winograd F(2x2,3x3) "
+                       "over four output parities",
+                       algorithmic_bytes_per_launch=128 * 16 * 16 * 256 * 4 + 4 * 16 * 256 * 128 * 4 + 128 * 32 * 32 * 128 * 4 + 128 * 4,
+                       bench_one=["fwd", "4"], trace_prefix="wino_kernel<0>")
 # configs[3]: the 5x5 conv 128 -> 256 at 64x64 (models_c2f.lua:126) -- in the step it runs as igemm_ws_act_kernel<128,1> (the PReLU
 # behind it in the epilogue: the pre-activation AND prelu(x) are stored); the module-level launch measured here is the same loop with
 # the plain epilogue (one store of the output), so both byte counts are given
-DOMINANT_LAUNCH_C2F = dict(kernel="igemm_ws_act_kernel<128,1>", launch="5x5 conv 128->256 forward at 64x64, B=128 (models_c2f.lua:126), "
-                           "measured on the plain-epilogue instantiation igemm_ws_kernel<128> of the same loop (module-level launch); the "
-                           "step's launch also stores prelu(x): + 536.9 MB of writes",
-                           algorithmic_bytes_per_launch=128 * 64 * 64 * 128 * 4 + 25 * 128 * 256 * 4 + 128 * 64 * 64 * 256 * 4 + 256 * 4,
-                           algorithmic_bytes_with_fused_prelu_store=128 * 64 * 64 * 128 * 4 + 25 * 128 * 256 * 4 + 2 * 128 * 64 * 64 * 256 * 4 + 256 * 4,
-                           bench_one=["fwd", "3", "0", "128", "64", "64", "128", "256", "5", "0"], trace_prefix="igemm_ws_kernel<128>")
+DOMINANT_LAUNCH_C2F = dict(kernel="wino_kernel", launch="5x5 conv 128->256 forward at 64x64, B=128 (models_c2f.lua:126): Winograd F(2x2,3x3) over "
+                           "four 3x3 sub-kernels; measured on the plain-epilogue instantiation wino_kernel<0> (module-level launch); the "
+                           "step's launch (wino_kernel<1>) also stores prelu(x): + 536.9 MB of writes",
+                           algorithmic_bytes_per_launch=128 * 64 * 64 * 128 * 4 + 4 * 16 * 128 * 256 * 4 + 128 * 64 * 64 * 256 * 4 + 256 * 4,
+                           algorithmic_bytes_with_fused_prelu_store=128 * 64 * 64 * 128 * 4 + 4 * 16 * 128 * 256 * 4 + 2 * 128 * 64 * 64 * 256 * 4 + 256 * 4,
+                           bench_one=["fwd", "3", "0", "128", "64", "64", "128", "256", "5", "0"], trace_prefix="wino_kernel<0>")
 
 
 def live_traffic(kernel, timeout=150, spec=None):
@@ -139,7 +141,7 @@ def live_traffic(kernel, timeout=150, spec=None):
     import subprocess
     import tempfile
     spec = spec or DOMINANT_LAUNCH
-    if kernel != spec["kernel"] or shutil.which("rocprofv3") is None:
+    if not kernel.startswith(spec["kernel"]) or shutil.which("rocprofv3") is None:
         return None
     vals = {}
     for pmc in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -186,7 +188,7 @@ def load_traffic(kernel, live=True, spec=None):
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
             continue
-        if tj.get("kernel") == kernel:
+        if tj.get("kernel") and kernel.startswith(tj["kernel"]):
             same = tj.get("kernel_source_sha16") is not None and tj.get("kernel_source_sha16") == _sha16(KERNEL_SOURCE)
             tj["freshness"] = "committed file profiles/%s, same kernel source as this run" % name if same else \
                               "stale: committed file profiles/%s from an earlier kernel source" % name

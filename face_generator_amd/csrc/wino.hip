@@ -57,12 +57,12 @@ __device__ __forceinline__ f32x4 wn_load4(__amdgpu_buffer_rsrc_t r, int voff, in
 // the packed form measured 5 724 -> 5 585 cycles per K chunk)
 __device__ __forceinline__ f32x2 wn_add(f32x2 a, f32x2 b) {
     f32x2 d;
-    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
 __device__ __forceinline__ f32x2 wn_sub(f32x2 a, f32x2 b) {
     f32x2 d;
-    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
 __device__ __forceinline__ void wn_decode(int t, const WinoArgs& a, int& b, int& ty, int& tx) {
@@ -234,12 +234,14 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
     // fixed slice of the other work, pinned in program order (sched_barrier) so that it issues in the MFMA's shadow:
     //   slots 8p .. 8p+3   the four fragment reads of the NEXT pair (pair 7: pair 0 of the next chunk, behind the barrier)
     //   HAS1 (a next chunk exists; its patch sits in RX and its U in UX, requested one chunk ago):
-    //     slots 0..7    U stores -- the FIRST of them is the chunk's only drain point
-    //     slots 8..23   column pass of B^T d B, in place in RX           slots 24..40 row pass + V stores
+    //     slots 0..7    U stores
+    //     slots 8..23   column pass of B^T d B, in place in RX     slots 24..39 row pass, in place     slots 40..55 V stores
     //     end of slot 55: lgkmcnt(0) + barrier (stage s^1 complete, every wave is done reading stage s except its last pair,
     //     whose fragments are already in registers)
-    //   HAS2 (a chunk after that exists, the load cursor points at it): its 16 patch loads into RY in slots 0..7 and its 8 U
-    //     loads into UY in slots 8..11 -- right behind the drain, so that the NEXT chunk's drain finds nothing younger than 52 slots
+    //   HAS2 (a chunk after that exists, the load cursor points at it): its 8 U loads into UY in slots 0, 2, .. 14 and its 16
+    //     patch loads into RY in slots 9, 11, .. 39 -- ONE request every other slot: a VMEM instruction holds the CU's address
+    //     path for ~16 cycles, and with four waves issuing two each per slot the waves queued for it (~52 cycles per request,
+    //     measured); the waits (counted exactly by hipcc) find U >= 49 and the patch >= 33 slots old
 #define WN_CHUNK(HAS1, HAS2, RX, UX, RY, UY)                                                               \
     {                                                                                                      \
         const float* Sc = smem + s * WN_STAGE;                                                             \
@@ -254,6 +256,9 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
             _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                                \
                 const int sl = pr * 8 + m, h = m & 1, j = m >> 1, pos = 2 * pr + h;                        \
                 acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pr & 1][h][j], fb[pr & 1][h][j], acc[pos], 0, 0, 0); \
+                if (TRACE == 2 && (sl & 7) == 0 && ci < 14) {                                              \
+                    if (trc && lane == 0) trc[8 + ci * 8 + (sl >> 3)] = __builtin_amdgcn_s_memtime();       \
+                }                                                                                          \
                 if (m < 4 && pr < 7 && !(DBG & 8)) {                                                       \
                     const int np = 2 * (pr + 1) + (m >> 1);                                                \
                     if ((m & 1) == 0) fa[(pr + 1) & 1][m >> 1] = *(const f32x4*)(Sc + a_rd + np * 512);    \
@@ -265,17 +270,14 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
                         else fb[0][m >> 1] = *(const f32x4*)(Sn + b_rd + (m >> 1) * 512);                  \
                     }                                                                                      \
                     if (sl < 8 && !(DBG & 1)) *(f32x4*)(Us + sl * 1024) = UX[sl];                          \
-                    if (HAS2 && !(DBG & 4)) {                                                              \
-                        if (sl < 8) {                                                                      \
-                            RY[2 * sl] = wn_load2(xr_, voff[2 * sl], sx2);                                 \
-                            RY[2 * sl + 1] = wn_load2(xr_, voff[2 * sl + 1], sx2);                         \
-                        }                                                                                  \
-                        if (sl >= 8 && sl < 12) {                                                          \
-                            UY[2 * (sl - 8)] = wn_load4(ur_, (uo + 2 * (sl - 8) * 1024) * 4, su2);         \
-                            UY[2 * (sl - 8) + 1] = wn_load4(ur_, (uo + (2 * (sl - 8) + 1) * 1024) * 4, su2); \
-                        }                                                                                  \
+                    if (HAS2 && !(DBG & 4)) {            /* one request every other slot: 16 per slot and CU queue up in the TA */ \
+                        if (sl < 16 && (sl & 1) == 0) UY[sl >> 1] = wn_load4(ur_, (uo + (sl >> 1) * 1024) * 4, su2); \
+                        if (sl >= 9 && sl < 41 && (sl & 1) == 1) RY[(sl - 9) >> 1] = wn_load2(xr_, voff[(sl - 9) >> 1], sx2); \
                     }                                                                                      \
-                    if (sl >= 8 && sl < 24 && !(DBG & 2)) {              /* column x: d -> w, in place */    \
+                    /* B^T d B in place in RX with plain v_add_f32 (they issue in the MFMA's shadow; the packed form costs the   \
+                       matrix pipe ~17 cycles each, measured): column pass slots 8..23, row pass 24..39, the sixteen stores 40..55 \
+                       -- a store never directly behind the addition that produces its value */            \
+                    if (sl >= 8 && sl < 24 && !(DBG & 2)) {                                                \
                         const int k = sl - 8, x = k >> 2, o = k & 3;                                       \
                         if (o == 0) RX[0 + x] = wn_sub(RX[0 + x], RX[8 + x]);                              \
                         if (o == 1) RX[12 + x] = wn_sub(RX[4 + x], RX[12 + x]);                            \
@@ -284,13 +286,12 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
                     }                                                                                      \
                     if (sl >= 24 && sl < 40 && !(DBG & 2)) {                                               \
                         const int k = sl - 24, i = k >> 2, o = k & 3;                                      \
-                        f32x2 v_;                                                                          \
-                        if (o == 0) v_ = wn_sub(RX[i * 4 + 0], RX[i * 4 + 2]);                             \
-                        if (o == 1) v_ = wn_add(RX[i * 4 + 1], RX[i * 4 + 2]);                             \
-                        if (o == 2) v_ = wn_sub(RX[i * 4 + 2], RX[i * 4 + 1]);                             \
-                        if (o == 3) v_ = wn_sub(RX[i * 4 + 1], RX[i * 4 + 3]);                             \
-                        *(f32x2*)(Vs + k * 512) = v_;                                                      \
+                        if (o == 0) RX[i * 4 + 0] = wn_sub(RX[i * 4 + 0], RX[i * 4 + 2]);                  \
+                        if (o == 1) RX[i * 4 + 3] = wn_sub(RX[i * 4 + 1], RX[i * 4 + 3]);                  \
+                        if (o == 2) t_ = wn_add(RX[i * 4 + 1], RX[i * 4 + 2]);                             \
+                        if (o == 3) { RX[i * 4 + 2] = wn_sub(RX[i * 4 + 2], RX[i * 4 + 1]); RX[i * 4 + 1] = t_; } \
                     }                                                                                      \
+                    if (sl >= 40 && sl < 56 && !(DBG & 2)) *(f32x2*)(Vs + (sl - 40) * 512) = RX[sl - 40];  \
                     if (sl == 55) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          \
                 }                                                                                          \
                 __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -298,7 +299,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
         }                                                                                                  \
     }
     // chunk ci multiplies stage s, transforms chunk ci + 1 from (RX, UX) and requests chunk ci + 2 into (RY, UY)
-#define WN_STAMP() { if (TRACE && trc && lane == 0) trc[2 + (ci < 119 ? ci : 119)] = __builtin_amdgcn_s_memtime(); ++ci; }
+#define WN_STAMP() { if (TRACE == 1 && trc && lane == 0) trc[2 + (ci < 119 ? ci : 119)] = __builtin_amdgcn_s_memtime(); ++ci; }
     int s = 0;
     int ci = 0;
     if (NCE > 0) {
@@ -400,7 +401,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
     }
     if (TRACE && trc && lane == 0) {
         __builtin_amdgcn_s_waitcnt(0x0f70);        // the stores have left the wave
-        trc[(NC < 120 ? NC : 120) + 2] = __builtin_amdgcn_s_memtime();
+        if (TRACE == 1) trc[(NC < 120 ? NC : 120) + 2] = __builtin_amdgcn_s_memtime();
         trc[127] = (unsigned long long)__builtin_amdgcn_s_getreg(((3 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)NC << 32);   // XCC_ID, NC
         trc[126] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);                                    // HW_ID
     }
@@ -409,6 +410,14 @@ template <int EPI>
 __global__ __launch_bounds__(256) void wino_kernel(const WinoArgs a) { wino_body<EPI, 0>(a); }
 template <int DBG>
 __global__ __launch_bounds__(256) void wino_trace_kernel(const WinoArgs a) { wino_body<0, 1, DBG>(a); }
+// FG_WINO_TRACE=2: s_memtime every 8 MFMA slots of the first 14 chunks -> dbg_trace[block][8 + 8 chunk + slot / 8]
+template <int DBG>
+__global__ __launch_bounds__(256) void wino_trace2_kernel(const WinoArgs a) { wino_body<0, 2, DBG>(a); }
+template <int DBG>
+static void wino_trace2_go(const WinoArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    (void)hipFuncSetAttribute((const void*)wino_trace2_kernel<DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(wino_trace2_kernel<DBG>, grid, dim3(256), lds, st, a);
+}
 
 // FG_WINO_TRACE=1 (measurement only): EPI-0 launches run the trace kernel four times (three to settle the clocks); the per-block
 // s_memtime rows of the fourth are appended to FG_WS_TRACE_FILE in igemm_ws_trace_kernel's row format.  FG_WINO_DBG selects a
@@ -432,6 +441,8 @@ static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, si
     for (int rep = 0; rep < 4; ++rep) {
         (void)hipEventRecord(e0, ctx->stream);
         switch (dbg) {
+            case 100: wino_trace2_go<0>(a, grid, lds, ctx->stream); break;       // 100 + DBG bits: the fine-grained trace
+            case 104: wino_trace2_go<4>(a, grid, lds, ctx->stream); break;       // no global loads
             case 1: wino_trace_go<1>(a, grid, lds, ctx->stream); break;
             case 2: wino_trace_go<2>(a, grid, lds, ctx->stream); break;
             case 4: wino_trace_go<4>(a, grid, lds, ctx->stream); break;
@@ -439,6 +450,7 @@ static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, si
             case 7: wino_trace_go<7>(a, grid, lds, ctx->stream); break;
             case 15: wino_trace_go<15>(a, grid, lds, ctx->stream); break;
             default: dbg = 0; wino_trace_go<0>(a, grid, lds, ctx->stream); break;
+
         }
         (void)hipEventRecord(e1, ctx->stream);
     }
@@ -460,6 +472,8 @@ static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, si
             const unsigned long long* r = host.data() + b * 128;
             const int kt = (int)(r[127] >> 32), xcc = (int)(r[127] & 0xffffffff);
             fprintf(f, "%zu %d %d %llu", b, xcc, kt, r[126]);
+            if (dbg >= 100) { for (int i = 0; i < 126; ++i) fprintf(f, " %llu", r[i]); }
+            else
             for (int i = 0; i < (kt < 120 ? kt : 120) + 3; ++i) fprintf(f, " %llu", r[i]);
             fprintf(f, "\n");
         }

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import torch7_nn as O
-from gpu_util import nhwc, nchw, dev, close, close_after_first_adam_step
+from gpu_util import nhwc, nchw, dev, close, close_after_first_adam_step, oracle_backward_on_device_branches
 
 pytestmark = pytest.mark.gpu
 
@@ -108,10 +108,9 @@ def test_G_forward_backward(ctx, C, B):
     st, Gd, Dd, rng = build(ctx, C, B, seed=100 + C + B)
     noise, img = draw_kink_safe(rng, lambda: rng.uniform(-1, 1, (B, 100)).astype(np.float32), st.G.forward, [st.G])
     gy = rng.standard_normal(img.shape).astype(np.float32)
-    st.gG[...] = 0
-    st.G.backward(noise, gy)
     dn = Gd.device_net
     y = dn.forward(dev(noise, ctx.device))
+    oracle_backward_on_device_branches(ctx, dn, st.G, noise, gy, st.gG)      # the oracle's backward on the device's PReLU decisions
     close(nchw(dn.layer_output(2)), st.G.modules[2].output, atol=2e-5, what="G prelu(view(linear))")
     close(nchw(dn.layer_output(6)), st.G.modules[6].output, atol=5e-5, what="G conv5+bn+prelu")
     close(nchw(dn.layer_output(10)), st.G.modules[10].output, atol=5e-5, what="G conv9+bn+prelu")
@@ -131,10 +130,9 @@ def test_D_forward_backward(ctx, C, B):
     O.set_dropout_masks(st.D, masks)
     x, out = draw_kink_safe(rng, lambda: rng.uniform(0, 1, (B, C, 32, 32)).astype(np.float32), st.D.forward, [st.D])
     gy = rng.standard_normal(out.shape).astype(np.float32)
-    st.gD[...] = 0
-    gx = st.D.backward(x, gy)
     dn = Dd.device_net
     y = dn.forward(nhwc(x, ctx.device), masks=[dev(m.reshape(-1), ctx.device) for m in masks])
+    gx = oracle_backward_on_device_branches(ctx, dn, st.D, x, gy, st.gD)
     close(nchw(dn.layer_output(3)), st.D.modules[3].output, atol=1e-5, what="D block1")
     close(nchw(dn.layer_output(15)), st.D.modules[15].output, atol=2e-5, what="D block4")
     close(y.cpu().numpy(), out, atol=1e-5, what="D probabilities")      # bar: 1e-4
@@ -214,9 +212,8 @@ def test_G16_forward_backward(ctx):
     noise, img = draw_kink_safe(rng, lambda: rng.uniform(-1, 1, (B, 100)).astype(np.float32), G.forward, [G])
     assert img.shape == (B, C, 16, 16)
     gy = rng.standard_normal(img.shape).astype(np.float32)
-    gG[...] = 0
-    G.backward(noise, gy)
     y = Gd.device_net.forward(dev(noise, ctx.device))
+    oracle_backward_on_device_branches(ctx, Gd.device_net, G, noise, gy, gG)
     close(nchw(y), img, atol=1e-5, what="G16 images")
     Gd.device_net.backward(nhwc(gy, ctx.device), param_grads=True)
     check_flat_grads(g.cpu().numpy(), G, "G16")
@@ -240,9 +237,8 @@ def test_G_with_a_noise_dimension_that_is_not_a_multiple_of_4(ctx, noiseDim):
     p.copy_(torch.tensor(pG)); Gd.device_net.params_changed()
     noise, img = draw_kink_safe(rng, lambda: rng.uniform(-1, 1, (B, noiseDim)).astype(np.float32), G.forward, [G])
     gy = rng.standard_normal(img.shape).astype(np.float32)
-    gG[...] = 0
-    gin = G.backward(noise, gy)
     y = Gd.device_net.forward(dev(noise, ctx.device))
+    gin = oracle_backward_on_device_branches(ctx, Gd.device_net, G, noise, gy, gG)
     close(nchw(y), img, atol=1e-5, what="G images, noiseDim %d" % noiseDim)
     gx = Gd.device_net.backward(nhwc(gy, ctx.device), param_grads=True, input_grad=True)
     close(gx.cpu().numpy().reshape(B, noiseDim), gin.reshape(B, noiseDim), atol=1e-4 * np.abs(gin).max() + 1e-8, what="noise gradient")
