@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["api.hip", "net.hip", "conv_ops.hip", "igemm.hip", "wino.hip", "pointwise.hip", "thin.hip", "step.hip"]
+SOURCES = ["api.hip", "net.hip", "conv_ops.hip", "igemm.hip", "wino.hip", "wino_wgrad.hip", "pointwise.hip", "thin.hip", "step.hip"]
 LIB = os.path.join(HERE, "libfacegen_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",

@@ -85,6 +85,7 @@ int fg_ctx_create(int device, fg_ctx** out) {
     if (const char* m = getenv("FG_WINO")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WINOGRAD;
     if (const char* m = getenv("FG_WINO_UP")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WINOGRAD_UP;
     if (const char* m = getenv("FG_WINO_5X5")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WINOGRAD_5X5;
+    if (const char* m = getenv("FG_WINO_WGRAD")) if (atoi(m) == 0) c->fusion &= ~FG_FUSE_WINOGRAD_WGRAD;
     c->fusion &= ~FG_FUSE_ADAM_PACK;        // measured slower than the two launches: opt-in
     if (const char* m = getenv("FG_ADAM_PACK")) if (atoi(m) != 0) c->fusion |= FG_FUSE_ADAM_PACK;
     ++g_real_ctx;
@@ -364,7 +365,7 @@ int fg_conv2d_backward_weight(fg_ctx* ctx, const float* x, const float* gy, floa
         if (gb) return fg_launch_colsum(ctx, gy, (long long)batch * h * w, cout, beta, gb, ws);
         return FG_OK;
     }
-    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, pad, up);
+    ConvGeom g = mk_geom(batch, h, w, cin, cout, k, pad, up, ctx->fusion);
     return fg_conv_wgrad_run(ctx, g, x, gy, gw, gb, beta, ws, (long long)(ws_bytes / 4));
 }
 

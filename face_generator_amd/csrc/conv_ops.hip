@@ -143,6 +143,37 @@ static int choose_wino_splits(long long T, int Npad, int C) {      // Npad: all 
     const int per = (nch + s - 1) / s;
     return (nch + per - 1) / per;          // every split non-empty
 }
+// Winograd-domain weight gradient (wino_wgrad.hip): blocks of 64 x 64 channel pairs per (parity, group) unit, the reduction over
+// the tiles (chunks of 8) split S ways so that one round of ~256 blocks fills the chip.  Taken where the tile grid is a power of
+// two each way, both channel counts fill whole 64-blocks and every block still reduces over >= 24 chunks with >= 3/4 of the chip
+// busy (D's 64 -> 128 ... 256 -> 512 layers on 16x16 ... 4x4 maps do not: 2 ... 32 channel blocks; they keep the tap-by-tap
+// kernels).  false = not taken.
+static bool choose_wino_wgrad(const ConvGeom& g, int* S, int* cps) {
+    if (!g.wino || g.stride == 2 || (g.Cout % 64) || (g.Cin % 64)) return false;
+    const int TH = g.H / 2, TW = g.W / 2;
+    if (ilog2_exact(TH) < 0 || ilog2_exact(TW) < 1) return false;
+    WeightMap wm; fg_geom_weightmap(g, &wm);
+    int P, KG; fg_wino_pack_shape(wm.kind, g.wino, 0, &P, &KG);
+    const long long T = (long long)g.B * TH * TW, nct = (T + 7) / 8;
+    const long long base = (long long)(g.Cout / 64) * (g.Cin / 64) * P * KG;
+    // (measurement / test knobs, read per call so that a test can reach the small-shape corners: FG_WINO_WGRAD_MIN_CHUNKS,
+    // FG_WINO_WGRAD_MIN_BLOCKS)
+    long long min_chunks = 24, min_blocks = 192;
+    if (const char* e = getenv("FG_WINO_WGRAD_MIN_CHUNKS")) min_chunks = atoll(e) > 0 ? atoll(e) : 1;
+    if (const char* e = getenv("FG_WINO_WGRAD_MIN_BLOCKS")) min_blocks = atoll(e);
+    long long s = base >= 256 ? 1 : 256 / base;
+    if (s > nct / min_chunks) s = nct / min_chunks;
+    if (s < 1 || base * s < min_blocks) return false;
+    const long long per = (nct + s - 1) / s;
+    *cps = (int)per;
+    *S = (int)((nct + per - 1) / per);          // every split non-empty
+    return true;
+}
+static long long wino_wgrad_part_floats(const ConvGeom& g, int S) {
+    WeightMap wm; fg_geom_weightmap(g, &wm);
+    int P, KG; fg_wino_pack_shape(wm.kind, g.wino, 0, &P, &KG);
+    return (long long)P * KG * S * 16 * g.Cout * g.Cin;
+}
 static void choose_wgrad(long long M, int Cout, int Cin, int G, int P, int* tile, int* S, int* mper, int* Npad, int* Cpad) {
     int bt = (Cout >= 128 && Cin >= 128) ? 128 : 64;
     {   // a Linear layer reduces over the B samples only (M = 128): with 128 x 128 tiles Linear(2048, 512) is 64 blocks of 8 K-steps
@@ -265,6 +296,11 @@ long long fg_conv_wgrad_part_floats(const ConvGeom& g) {
         const long long n6 = (long long)wm.P * wm.G * S6 * g.Cout * g.Cin;
         if (n6 > n) n = n6;
     }
+    int Sw, cpsw;
+    if (choose_wino_wgrad(g, &Sw, &cpsw)) {      // (either setting of FG_FUSE_WINOGRAD_WGRAD: the bit is read per call)
+        const long long nw = wino_wgrad_part_floats(g, Sw);
+        if (nw > n) n = nw;
+    }
     return n + 64;
 }
 
@@ -277,6 +313,10 @@ long long fg_conv_wgrad_bias_part_floats(const ConvGeom& g) {
     int wt, S, mper, Np, Cp;
     choose_wgrad(M, g.Cout, g.Cin, wm.G, wm.P, &wt, &S, &mper, &Np, &Cp);
     long long rows = (long long)wm.P * S;
+    {
+        int Sw, cpsw;
+        if (choose_wino_wgrad(g, &Sw, &cpsw) && (long long)wm.P * Sw > rows) rows = (long long)wm.P * Sw;
+    }
     int S6, mper6;
     const int cfg = M >= fg_wgrad_ws_minm() ? choose_wgrad_ws(M, g.Cout, g.Cin, wm.G, wm.P, &S6, &mper6) : -1;
     if (cfg >= 0) {
@@ -718,6 +758,44 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
     a.d_bytes = (long long)g.B * a.Hd * a.Wd * Nd * 4;
     a.x_bytes = (long long)g.B * g.H * g.W * Cx * 4;
     int tile, rc;
+    int Sw, cpsw;
+    if ((ctx->fusion & FG_FUSE_WINOGRAD_WGRAD) && ctx->math != 6 && !ragged && choose_wino_wgrad(g, &Sw, &cpsw)) {
+        // Winograd-domain weight gradient (wino_wgrad.hip): 16 instead of 36 / 9 / 25-of-36 multiplies per tile and channel pair
+        WinoArgs wf; memset(&wf, 0, sizeof(wf));
+        fill_wino(wf, g, 0);
+        WinoWgradArgs w; memset(&w, 0, sizeof(w));
+        w.X = x; w.dY = gy; w.B = g.B; w.Hi = wf.Hi; w.Wi = wf.Wi; w.Cx = g.Cin; w.Ho = wf.Ho; w.Wo = wf.Wo; w.Nd = g.Cout;
+        w.TH = wf.TH; w.TW = wf.TW; w.T = wf.T; w.lgTH = wf.lgTH; w.lgTW = wf.lgTW;
+        w.isy = wf.isy; w.isx = wf.isx; w.KG = wf.KG; w.P = wf.P; w.osy = wf.osy; w.osx = wf.osx;
+        memcpy(w.goy, wf.goy, 4); memcpy(w.gox, wf.gox, 4); memcpy(w.ooy, wf.ooy, 4); memcpy(w.oox, wf.oox, 4);
+        w.S = Sw; w.chunks_per_split = cpsw; w.Npad = g.Cout; w.Cpad = g.Cin;
+        w.x_bytes = a.x_bytes; w.d_bytes = a.d_bytes; w.alg_flops = a.alg_flops; w.tag = a.tag;
+        const long long need = wino_wgrad_part_floats(g, Sw);
+        if (need > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "conv wgrad (winograd): scratch %lld > %lld", need, scratch_floats);
+        const int nrb = w.P * Sw;
+        const long long nb = (long long)nrb * g.Cout;
+        bool deferred = false;
+        if (gradb) {
+            float* dp = fg_defer_alloc(ctx, nb);          // inside fg_net backward: final batched at the end
+            if (dp) { w.bias_part = dp; deferred = true; }
+            else if (need + nb <= scratch_floats) w.bias_part = scratch + need;
+        }
+        float* wp = (ctx->fusion & FG_FUSE_WFINISH_BATCH) ? fg_defer_alloc(ctx, need) : nullptr;    // inside fg_net backward: summed at the end
+        w.Part = wp ? wp : scratch;
+        if ((rc = fg_launch_wino_wgrad(ctx, w))) return rc;
+        wm.wino = g.wino;                                  // the partials are Winograd-domain: the finish applies G^T . G and the tap scatter
+        if (!(wp && fg_defer_push_wfinish(ctx, wm, w.Part, Sw, w.Npad, w.Cpad, beta, gradW)) &&
+            (rc = fg_launch_wgrad_finish(ctx, wm, w.Part, Sw, w.Npad, w.Cpad, beta, gradW))) return rc;
+        if (gradb && w.bias_part) {
+            if (deferred) { fg_defer_push(ctx, w.bias_part, nrb, g.Cout, beta, gradb); return FG_OK; }
+            return fg_launch_colsum_final(ctx, w.bias_part, nrb, g.Cout, beta, gradb);
+        }
+        if (gradb) {
+            if ((long long)CR_ROWBLOCKS_MAX * g.Cout > scratch_floats) return fg_set_err(ctx, FG_ERR_WORKSPACE, "bias grad: scratch");
+            return fg_launch_colsum(ctx, gy_ref, (long long)a.M * (g.fold ? 4 : 1), g.Cout, beta, gradb, scratch);
+        }
+        return FG_OK;
+    }
     int cfg6 = -1;
     if (ctx->math == 6 && g.Cout % 16 == 0 && g.Cin % 16 == 0 && a.M >= 1024)   // Linear / tiny maps: too few pixels to reduce over
         cfg6 = choose_wgrad6(a.M, g.Cout, g.Cin, wm.G, wm.P, &a.S, &a.m_per_split);

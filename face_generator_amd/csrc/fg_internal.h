@@ -228,6 +228,32 @@ int fg_wgrad_ws_bias_rows(const WgradArgs& a, int cfg);      // bias_part rows p
 // bf16x6 weight-gradient contraction; cfg 0: block tile 256 dY-channels x 128 X-channels, cfg 1: 128 x 256
 int fg_launch_wgrad6(fg_ctx* ctx, const WgradArgs& a, int P, int cfg);
 
+// ---------------------------------------------------------------------------------
+// Winograd-domain weight gradient (wino_wgrad.hip) of a WinoArgs layer:
+//   Part[unit = parity * KG + group][split][pos 16][Npad][Cpad] = sum over the split's tiles of dM'[pos][n] * V[pos][c]
+//   (dM' = A' dY A'^T of the tile's 2x2 gradient block with the signs of A's last row left out, V = B^T patch B);
+//   fg_launch_wgrad_finish with WeightMap::wino set sums the splits, applies the signs and G^T . G and scatters the sub-kernel
+//   gradients into the reference taps.  Geometry fields as in WinoArgs (forward orientation); the tile grid must be 2^a x 2^b, b >= 1.
+// ---------------------------------------------------------------------------------
+struct WinoWgradArgs {
+    const float* X;      // NHWC [B][Hi][Wi][Cx]   the layer's input
+    const float* dY;     // NHWC [B][Ho][Wo][Nd]   the gradient of its output
+    float* Part;
+    float* bias_part;    // optional [P][S][Nd]: per-channel sums of dY over each (parity, split)
+    int B, Hi, Wi, Cx, Ho, Wo, Nd;
+    int TH, TW, T, lgTH, lgTW;
+    int isy, isx, KG;
+    signed char goy[4], gox[4];
+    int P, osy, osx;
+    signed char ooy[4], oox[4];
+    int S, chunks_per_split;      // a chunk = 8 consecutive tiles
+    int Npad, Cpad;               // multiples of 64
+    long long x_bytes, d_bytes;
+    double alg_flops;
+    const char* tag;
+};
+int fg_launch_wino_wgrad(fg_ctx* ctx, const WinoWgradArgs& a);
+
 // Reference-layout <-> packed-layout description of one weight tensor.
 struct WeightMap {
     int kind;            // 0 = plain conv / linear (k=1), 1 = nearest-x2 folded conv

@@ -1881,6 +1881,84 @@ __device__ __forceinline__ void wgrad_finish_one(const WeightMap& wm, const floa
     float* gw = gradW + ((size_t)o * wm.I + i) * wm.k * wm.k + wi;
     *gw = (beta == 0.f) ? sum : beta * (*gw) + sum;
 }
+// Winograd-domain partials (WeightMap::wino, wino_wgrad.hip): Part[unit][split][pos 16][Npad][Cpad].  One thread per (out, in) pair:
+// sum the splits per position, apply the signs wino_wgrad_kernel left out of A's last row (s_i s_j, s = (1, 1, 1, -1)),
+// t = G^T (dL/dU) G, and scatter the sub-kernel gradient into the reference taps -- the exact adjoint of fg_wino_subkernel:
+//   wino 1, kind 0 (3x3): taps = t;   wino 1, kind 1 (folded): tap (dy, dx) collects t_p[fold(py, dy)][fold(px, dx)] of every parity p;
+//   wino 2 (5x5): tap (3a + dy, 3b + dx) = t_(a, b)[dy][dx].
+template <int K>
+__device__ __forceinline__ void wino_wgrad_finish_one(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
+                                                      float beta, float* __restrict__ gradW, int i, int o) {
+    if (i >= wm.I || o >= wm.O) return;
+    const size_t tile = (size_t)Npad * Cpad, e = (size_t)o * Cpad + i;
+    const int units = (wm.kind == 1 ? 4 : 1) * (wm.wino == 2 ? 4 : 1);
+    float g[K * K];
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) g[q] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (u >= units) break;
+        float du[16];
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            const float* __restrict__ b = Part + ((size_t)u * S * 16 + pos) * tile + e;
+            float sum = 0.f;
+            int s = 0;
+            for (; s + 4 <= S; s += 4) {
+                const float v0 = b[(size_t)s * 16 * tile], v1 = b[(size_t)(s + 1) * 16 * tile], v2 = b[(size_t)(s + 2) * 16 * tile],
+                            v3 = b[(size_t)(s + 3) * 16 * tile];
+                sum += v0; sum += v1; sum += v2; sum += v3;
+            }
+            for (; s < S; ++s) sum += b[(size_t)s * 16 * tile];
+            du[pos] = (((pos >> 2) == 3) != ((pos & 3) == 3)) ? -sum : sum;
+        }
+        float r[4][3], t[9];      // G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const float d0 = du[ii * 4], d1 = du[ii * 4 + 1], d2 = du[ii * 4 + 2], d3 = du[ii * 4 + 3];
+            r[ii][0] = d0 + 0.5f * (d1 + d2);
+            r[ii][1] = 0.5f * (d1 - d2);
+            r[ii][2] = 0.5f * (d1 + d2) + d3;
+        }
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+            t[0 * 3 + bb] = r[0][bb] + 0.5f * (r[1][bb] + r[2][bb]);
+            t[1 * 3 + bb] = 0.5f * (r[1][bb] - r[2][bb]);
+            t[2 * 3 + bb] = 0.5f * (r[1][bb] + r[2][bb]) + r[3][bb];
+        }
+        if (K == 5 && wm.wino == 2) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int uu = 3 * (u >> 1) + dy, vv = 3 * (u & 1) + dx;
+                    if (uu < K && vv < K) g[uu * K + vv] = t[dy * 3 + dx];
+                }
+        } else if (wm.kind == 1) {
+#pragma unroll
+            for (int dy = 0; dy < K; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) {
+                    const int ty = dev_fold_r(u >> 1, dy, wm.pad) - wm.rmin, tx = dev_fold_r(u & 1, dx, wm.pad) - wm.rmin;
+                    float v = 0.f;          // (a select chain, not an indexed read: t stays in registers)
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) v = (ty * 3 + tx == q) ? t[q] : v;
+                    g[dy * K + dx] += v;
+                }
+        } else if (K == 3) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) g[q] = t[q];
+        }
+    }
+    float* gw = gradW + ((size_t)o * wm.I + i) * (K * K);
+#pragma unroll
+    for (int q = 0; q < K * K; ++q) gw[q] = (beta == 0.f) ? g[q] : beta * gw[q] + g[q];
+}
+__device__ __forceinline__ void wino_wgrad_finish_any(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
+                                                      float beta, float* __restrict__ gradW, int i, int o) {
+    if (wm.k == 5) wino_wgrad_finish_one<5>(wm, Part, S, Npad, Cpad, beta, gradW, i, o);
+    else wino_wgrad_finish_one<3>(wm, Part, S, Npad, Cpad, beta, gradW, i, o);
+}
 // all weight-gradient reductions of a backward pass in one launch: block -> job by a scan over <= FG_DEFER_WMAX entries; inside
 // a job the blocks run (in-channel block, out-channel, tap) exactly as the grid of wgrad_finish_kernel does
 struct FgWFinishBatch { FgWFinishJob jobs[FG_DEFER_WMAX]; int n; };
@@ -1931,6 +2009,7 @@ __global__ __launch_bounds__(128) void wgrad_finish_jobs_kernel(const FgWFinishB
     }
     const int bx = (int)(l % jb.ib); l /= jb.ib;
     const int po = (int)(l % jb.wm.O), wi = (int)(l / jb.wm.O);
+    if (jb.wm.wino) { wino_wgrad_finish_any(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx * 128 + (int)threadIdx.x, po); return; }
     wgrad_finish_one(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx * 128 + (int)threadIdx.x, po, wi);
 }
 int fg_launch_wgrad_finish_jobs(fg_ctx* ctx, const FgWFinishJob* jobs, int n, long long blocks) {
@@ -1947,7 +2026,7 @@ bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
     if (!d || !d->wjobs || d->wn >= FG_DEFER_WMAX) return false;
     const bool brick = wm.kind == 0 && wm.k == 1 && wm.i_hw > 1 && wm.i_c > 0;     // Linear behind a View: 32 x 32 patches (ib = -1)
     const long long nb = brick ? (long long)wm.O * fg_cdiv(wm.i_c, 32) * fg_cdiv(wm.i_hw, 32)
-                               : (long long)fg_cdiv(wm.I, 128) * wm.O * wm.k * wm.k;
+                               : (long long)fg_cdiv(wm.I, 128) * wm.O * (wm.wino ? 1 : wm.k * wm.k);     // (Winograd partials: a thread owns all taps)
     if (d->wblocks + nb > 0x7fffffffLL) return false;
     FgWFinishJob& j = d->wjobs[d->wn++];
     j.wm = wm; j.part = Part; j.gradW = gradW; j.S = S; j.Npad = Npad; j.Cpad = Cpad; j.ib = brick ? -1 : fg_cdiv(wm.I, 128); j.beta = beta;
@@ -1959,11 +2038,13 @@ bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
 __global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
                                     float beta, float* __restrict__ gradW) {
     // x: packed in-channel (coalesced partial reads), y: packed out-channel, z: tap dy*k+dx
+    if (wm.wino) { wino_wgrad_finish_any(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y); return; }
     wgrad_finish_one(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, blockIdx.z);
 }
 int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,
                            float* gradW) {
-    dim3 grid(fg_cdiv(wm.I, 128), wm.O, wm.k * wm.k);
+    if (wm.wino && wm.k != 3 && wm.k != 5) return fg_set_err(ctx, FG_ERR_INVALID, "winograd weight-gradient finish: k = %d", wm.k);
+    dim3 grid(fg_cdiv(wm.I, 128), wm.O, wm.wino ? 1 : wm.k * wm.k);
     hipLaunchKernelGGL(wgrad_finish_kernel, grid, dim3(128), 0, ctx->stream, wm, Part, S, Npad, Cpad, beta, gradW);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;

@@ -1,0 +1,293 @@
+// Winograd F(2x2, 3x3) WEIGHT gradient on the fp32 matrix pipe of gfx950 (MI355X): the accGradParameters of the layers whose
+// forward / data gradient run in wino.hip -- the nearest-x2 + 5x5 up-convolutions of G (models.lua:63-64, 68-69), the 3x3 and 5x5
+// layers of the coarse-to-fine nets (models_c2f.lua:124-126, 247-254); the reference hands these to cuDNN v3 / THNN.
+//
+//   Y = A^T [ U (.) V ] A,  U = G g G^T,  V = B^T d B        (wino.hip)
+//   dL/dU[pos] = sum over tiles of  dM[pos] (.) V[pos],   dM = A dY A^T  (the 2x2 output-gradient block of a tile, 4x4)
+//   dL/dg      = G^T (dL/dU) G                                (wino_wgrad_finish_one in igemm.hip, after the split sums)
+// 16 multiplies per tile and (out, in) pair instead of 36: 2.25 x fewer MFMAs than the tap-by-tap contraction (wgrad_ws_kernel).
+//
+// Shape: per position an [out-channels x tiles] x [tiles x in-channels] contraction, the reduction running over the TILES of the
+// batch.  A block owns 64 out-channels x 64 in-channels of ONE (parity, group) unit for all 16 positions (a wave: 32 x 32 x 16 =
+// the 256 accumulator registers, as in wino_kernel) and a contiguous range of tile chunks (gridDim.y splits); the partial
+// dL/dU of every split goes to HBM and the finish pass (igemm.hip: wino_wgrad_finish_one) sums the splits, applies G^T . G and scatters the 3x3
+// sub-kernel gradients into the reference [O][I][k][k] taps (5x5: four sub-kernels; folded up-convolution: each 5x5 tap collects
+// the folded tap it was summed into, one per output parity).
+//
+// K chunk = 8 consecutive tiles; wave m transforms the tile PAIR (2m, 2m + 1) of the chunk for its lane's channel: lane = channel
+// (64 consecutive channels of one pixel = one coalesced 256-byte load), the two tiles of the pair are the two halves of a
+// register pair, so both transforms run as packed adds and a value pair is one ds_write_b64.  All tile arithmetic is
+// wave-uniform (scalar unit); a lane's offset is its channel.  Signs: A = [1 0; 1 1; 1 -1; 0 -1] -- the minus signs of its last
+// row are left out here (dM'[i][j] = s_i s_j dM[i][j], s = (1, 1, 1, -1)) and applied by the finish kernel.
+// LDS stage: dM'[pos 16][k half 2][out-channel 64][4 tiles] | V[pos 16][k half 2][in-channel 64][4 tiles]  (k = tile in chunk).
+#include "fg_internal.h"
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define FG_OOB 0x7FFFFFF0
+#define WW_STAGE 16384
+
+__device__ __forceinline__ float ww_load(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x2 ww_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 ww_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+__global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int nbc = a.Cpad >> 6;
+    const int tn = blockIdx.x / nbc, tc = blockIdx.x - tn * nbc;
+    const int pg = blockIdx.z, par = pg / a.KG, grp = pg - par * a.KG;
+    const int nct = (a.T + 7) >> 3;
+    const int c0 = blockIdx.y * a.chunks_per_split;
+    const int NC = max(0, min(nct, c0 + a.chunks_per_split) - c0);
+    const int NCE = (NC + 1) & ~1;
+
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)a.d_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
+    const int chD = tn * 64 + lane, chX = tc * 64 + lane;
+    const int vD = chD < a.Nd ? chD * 4 : FG_OOB, vX = chX < a.Cx ? chX * 4 : FG_OOB;      // a lane's offset is its channel
+    // byte strides of the scalar tile arithmetic
+    const int dRow = a.osy * a.Wo * a.Nd * 4, dCol = a.osx * a.Nd * 4;
+    const int xRow = a.isy * a.Wi * a.Cx * 4, xCol = a.isx * a.Cx * 4;
+    const int goy = a.goy[grp], gox = a.gox[grp], ooy = a.ooy[par], oox = a.oox[par];
+
+    // store offsets: [pos][k half][channel][4]: this wave's tile pair is k = 2 wid, 2 wid + 1
+    const int sw = (wid >> 1) * 256 + lane * 4 + (wid & 1) * 2;
+    const int a_rd = (lane >> 5) * 256 + (wm * 32 + (lane & 31)) * 4;
+    const int b_rd = 8192 + (lane >> 5) * 256 + (wn * 32 + (lane & 31)) * 4;
+
+    // scalar state of the load cursor (the chunk the next requests belong to)
+    int cl = c0;
+    int baseD = 0, baseX = 0, ymask = 0, xmask = 0;
+#define WW_CURSOR()                                                                                        \
+    {                                                                                                      \
+        const int t0 = cl * 8 + 2 * wid;                        /* first tile of this wave's pair */      \
+        const bool tv = t0 < a.T && cl < c0 + NC;                                                          \
+        const int tt = tv ? t0 : 0;                                                                        \
+        const int tx = tt & (a.TW - 1), ty = (tt >> a.lgTW) & (a.TH - 1), b = tt >> (a.lgTW + a.lgTH);     \
+        baseD = ((b * a.Ho + a.osy * 2 * ty + ooy) * a.Wo + a.osx * 2 * tx + oox) * a.Nd * 4;              \
+        const int y0 = a.isy * 2 * ty + goy, x0 = a.isx * 2 * tx + gox;                                    \
+        baseX = ((b * a.Hi + y0) * a.Wi + x0) * a.Cx * 4;                                                  \
+        ymask = 0; xmask = 0;                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) if (tv && (unsigned)(y0 + a.isy * i) < (unsigned)a.Hi) ymask |= 1 << i; \
+        _Pragma("unroll") for (int j = 0; j < 6; ++j) if ((unsigned)(x0 + a.isx * j) < (unsigned)a.Wi) xmask |= 1 << j;       \
+        if (!tv) xmask = 0;                                                                                \
+    }
+    // one value of the pair (tile half h: 0 = tile 2m, 1 = tile 2m + 1): patch element (i, j) / gradient element (r, e)
+#define WW_LDX(i, j, h) ww_load(xrsrc, ((ymask >> (i)) & (xmask >> ((j) + 2 * (h))) & 1) ? vX : FG_OOB, baseX + (i) * xRow + ((j) + 2 * (h)) * xCol)
+#define WW_LDD(r, e, h) ww_load(drsrc, xmask ? vD : FG_OOB, baseD + (r) * dRow + ((e) + 2 * (h)) * dCol)
+
+    f32x2 xa[16], xb[16], da[4], db[4];
+#define WW_LOAD_ALL(xs, ds)                                                                                \
+    {                                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) { ds[q].x = WW_LDD(q >> 1, q & 1, 0); ds[q].y = WW_LDD(q >> 1, q & 1, 1); } \
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) { xs[q].x = WW_LDX(q >> 2, q & 3, 0); xs[q].y = WW_LDX(q >> 2, q & 3, 1); } \
+    }
+    // the transforms of a whole chunk and its stores, not interleaved with anything (prologue).  dM' = A' dY A'^T with
+    // A' = [1 0; 1 1; 1 -1; 0 1] (signs applied by the finish kernel); V = B^T d B
+#define WW_XFORM_STORE(S, xs, ds)                                                                          \
+    {                                                                                                      \
+        float* Ms = (S) + sw;                                                                              \
+        float* Vs = (S) + 8192 + sw;                                                                       \
+        f32x2 u_[8];                                                                                       \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                    \
+            u_[0 + e] = ds[0 + e]; u_[2 + e] = ds[0 + e] + ds[2 + e]; u_[4 + e] = ds[0 + e] - ds[2 + e]; u_[6 + e] = ds[2 + e]; \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+            *(f32x2*)(Ms + (i * 4 + 0) * 512) = u_[i * 2];                                                 \
+            *(f32x2*)(Ms + (i * 4 + 1) * 512) = u_[i * 2] + u_[i * 2 + 1];                                 \
+            *(f32x2*)(Ms + (i * 4 + 2) * 512) = u_[i * 2] - u_[i * 2 + 1];                                 \
+            *(f32x2*)(Ms + (i * 4 + 3) * 512) = u_[i * 2 + 1];                                             \
+        }                                                                                                  \
+        f32x2 w_[16];                                                                                      \
+        _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                                    \
+            w_[0 + x] = xs[0 + x] - xs[8 + x];                                                             \
+            w_[4 + x] = xs[4 + x] + xs[8 + x];                                                             \
+            w_[8 + x] = xs[8 + x] - xs[4 + x];                                                             \
+            w_[12 + x] = xs[4 + x] - xs[12 + x];                                                           \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+            *(f32x2*)(Vs + (i * 4 + 0) * 512) = w_[i * 4 + 0] - w_[i * 4 + 2];                             \
+            *(f32x2*)(Vs + (i * 4 + 1) * 512) = w_[i * 4 + 1] + w_[i * 4 + 2];                             \
+            *(f32x2*)(Vs + (i * 4 + 2) * 512) = w_[i * 4 + 2] - w_[i * 4 + 1];                             \
+            *(f32x2*)(Vs + (i * 4 + 3) * 512) = w_[i * 4 + 1] - w_[i * 4 + 3];                             \
+        }                                                                                                  \
+    }
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    f32x2 bsum = {0.f, 0.f};          // bias gradient: the sum of the four gradient elements of every tile = position (1, 1) of dM'
+
+    f32x4 fa[2][2], fb[2][2];
+    if (NC > 0) {
+        WW_CURSOR(); WW_LOAD_ALL(xa, da); ++cl;
+        WW_CURSOR(); WW_LOAD_ALL(xb, db); ++cl;
+        bsum += (da[0] + da[1]) + (da[2] + da[3]);
+        WW_XFORM_STORE(smem, xa, da);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (NC > 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            fa[0][h] = *(const f32x4*)(smem + a_rd + h * 512);
+            fb[0][h] = *(const f32x4*)(smem + b_rd + h * 512);
+        }
+    }
+
+    // One K chunk = 64 MFMA slots, as in wino_kernel.  HAS1: the next chunk's values sit in (XS, DS), requested a chunk ago:
+    //   slots 0..5    dM' column / row pass (6 packed adds; the copies are free)       slots 8..23  dM' stores
+    //   slots 8..23   V column pass, in place        slots 24..39 V row pass, in place        slots 40..55 V stores
+    //   end of slot 55: lgkmcnt(0) + barrier
+    // HAS2: the chunk after that is requested into (XL, DL): cursor arithmetic (scalar) in slot 0, the 8 gradient values in
+    //   slots 1..4, the 32 patch values in slots 5..36 (one request per slot)
+#define WW_CHUNK(HAS1, HAS2, XS, DS, XL, DL)                                                               \
+    {                                                                                                      \
+        const float* Sc = smem + s * WW_STAGE;                                                             \
+        float* Sn = smem + (s ^ 1) * WW_STAGE;                                                             \
+        float* Ms = Sn + sw;                                                                               \
+        float* Vs = Sn + 8192 + sw;                                                                        \
+        f32x2 t_, u_[8], m_[16];                                                                           \
+        if (HAS2) WW_CURSOR();                                                                             \
+        _Pragma("unroll") for (int pr = 0; pr < 8; ++pr) {                                                 \
+            _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                                \
+                const int sl = pr * 8 + m, h = m & 1, j = m >> 1, pos = 2 * pr + h;                        \
+                acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pr & 1][h][j], fb[pr & 1][h][j], acc[pos], 0, 0, 0); \
+                if (m < 4 && pr < 7) {                                                                     \
+                    const int np = 2 * (pr + 1) + (m >> 1);                                                \
+                    if ((m & 1) == 0) fa[(pr + 1) & 1][m >> 1] = *(const f32x4*)(Sc + a_rd + np * 512);    \
+                    else fb[(pr + 1) & 1][m >> 1] = *(const f32x4*)(Sc + b_rd + np * 512);                 \
+                }                                                                                          \
+                if (HAS1) {                                                                                \
+                    if (m < 4 && pr == 7) {                                                                \
+                        if ((m & 1) == 0) fa[0][m >> 1] = *(const f32x4*)(Sn + a_rd + (m >> 1) * 512);     \
+                        else fb[0][m >> 1] = *(const f32x4*)(Sn + b_rd + (m >> 1) * 512);                  \
+                    }                                                                                      \
+                    if (HAS2) {                                                                            \
+                        if (sl >= 1 && sl < 5) {                                                           \
+                            const int q = sl - 1;                                                          \
+                            DL[q].x = WW_LDD(q >> 1, q & 1, 0); DL[q].y = WW_LDD(q >> 1, q & 1, 1);        \
+                        }                                                                                  \
+                        if (sl >= 5 && sl < 37) {                                                          \
+                            const int q = (sl - 5) >> 1, hh = (sl - 5) & 1;                                \
+                            if (hh == 0) XL[q].x = WW_LDX(q >> 2, q & 3, 0); else XL[q].y = WW_LDX(q >> 2, q & 3, 1); \
+                        }                                                                                  \
+                    }                                                                                      \
+                    /* dM': u = A' d (columns e = 0, 1), then m = u A'^T */                                  \
+                    if (sl == 0) { bsum = ww_add(bsum, ww_add(ww_add(DS[0], DS[1]), ww_add(DS[2], DS[3]))); } \
+                    if (sl == 1) { u_[0] = DS[0]; u_[1] = DS[1]; u_[6] = DS[2]; u_[7] = DS[3]; u_[2] = ww_add(DS[0], DS[2]); } \
+                    if (sl == 2) u_[3] = ww_add(DS[1], DS[3]);                                             \
+                    if (sl == 3) u_[4] = ww_sub(DS[0], DS[2]);                                             \
+                    if (sl == 4) u_[5] = ww_sub(DS[1], DS[3]);                                             \
+                    if (sl >= 5 && sl < 9) {                                                               \
+                        const int i = sl - 5;                                                              \
+                        m_[i * 4 + 0] = u_[i * 2]; m_[i * 4 + 3] = u_[i * 2 + 1];                          \
+                        m_[i * 4 + 1] = ww_add(u_[i * 2], u_[i * 2 + 1]);                                  \
+                        m_[i * 4 + 2] = ww_sub(u_[i * 2], u_[i * 2 + 1]);                                  \
+                    }                                                                                      \
+                    if (sl >= 10 && sl < 26) *(f32x2*)(Ms + (sl - 10) * 512) = m_[sl - 10];                \
+                    /* V = B^T d B in place in XS (wino_kernel's schedule) */                               \
+                    if (sl >= 8 && sl < 24) {                                                              \
+                        const int k = sl - 8, x = k >> 2, o = k & 3;                                       \
+                        if (o == 0) XS[0 + x] = ww_sub(XS[0 + x], XS[8 + x]);                              \
+                        if (o == 1) XS[12 + x] = ww_sub(XS[4 + x], XS[12 + x]);                            \
+                        if (o == 2) t_ = ww_add(XS[4 + x], XS[8 + x]);                                     \
+                        if (o == 3) { XS[8 + x] = ww_sub(XS[8 + x], XS[4 + x]); XS[4 + x] = t_; }          \
+                    }                                                                                      \
+                    if (sl >= 24 && sl < 40) {                                                             \
+                        const int k = sl - 24, i = k >> 2, o = k & 3;                                      \
+                        if (o == 0) XS[i * 4 + 0] = ww_sub(XS[i * 4 + 0], XS[i * 4 + 2]);                  \
+                        if (o == 1) XS[i * 4 + 3] = ww_sub(XS[i * 4 + 1], XS[i * 4 + 3]);                  \
+                        if (o == 2) t_ = ww_add(XS[i * 4 + 1], XS[i * 4 + 2]);                             \
+                        if (o == 3) { XS[i * 4 + 2] = ww_sub(XS[i * 4 + 2], XS[i * 4 + 1]); XS[i * 4 + 1] = t_; } \
+                    }                                                                                      \
+                    if (sl >= 40 && sl < 56) *(f32x2*)(Vs + (sl - 40) * 512) = XS[sl - 40];                \
+                    if (sl == 55) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          \
+                }                                                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+    int s = 0;
+    if (NCE > 0) {
+        for (int ci = 0; ci + 2 < NCE; ci += 2) {
+            WW_CHUNK(true, true, xb, db, xa, da); ++cl;
+            s ^= 1;
+            WW_CHUNK(true, true, xa, da, xb, db); ++cl;
+            s ^= 1;
+        }
+        WW_CHUNK(true, false, xb, db, xa, da);
+        s ^= 1;
+        WW_CHUNK(false, false, xa, da, xb, db);
+    }
+#undef WW_CURSOR
+#undef WW_LDX
+#undef WW_LDD
+#undef WW_LOAD_ALL
+#undef WW_XFORM_STORE
+#undef WW_CHUNK
+
+    // ---- partial dL/dU' of this split: Part[pg][split][pos][out][in]; lane l holds column (l & 31) = in-channel, rows = out-channels
+    {
+        float* outp = a.Part + (((size_t)pg * a.S + blockIdx.y) * 16) * (size_t)a.Npad * a.Cpad;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
+        const int col = tc * 64 + wn * 32 + (lane & 31);
+        const int row0 = tn * 64 + wm * 32 + 4 * (lane >> 5);
+        const int pstride = a.Npad * a.Cpad * 4;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            const int vo = (row * a.Cpad + col) * 4;
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[p][r]), orsrc, vo, p * pstride, 0);
+        }
+    }
+    // ---- bias-gradient partial: the four waves' sums of this block's channels (only the blocks of in-channel block 0, group 0)
+    if (a.bias_part && tc == 0 && grp == 0) {
+        __syncthreads();
+        float* red = smem;
+        red[wid * 64 + lane] = bsum.x + bsum.y;
+        __syncthreads();
+        if (wid == 0 && chD < a.Nd)
+            a.bias_part[((size_t)par * a.S + blockIdx.y) * a.Nd + chD] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+    }
+}
+
+int fg_launch_wino_wgrad(fg_ctx* ctx, const WinoWgradArgs& a) {
+    if (a.Npad % 64 || a.Cpad % 64 || a.S < 1 || a.lgTW < 1 || a.lgTH < 0 || a.P < 1 || a.KG < 1 || a.P * a.KG > 4)
+        return fg_set_err(ctx, FG_ERR_INVALID, "winograd wgrad: padded channels %% 64, power-of-two tile grid (>= 2 wide), <= 4 units");
+    if (a.x_bytes <= 0 || a.x_bytes >= (long long)FG_OOB || a.d_bytes <= 0 || a.d_bytes >= (long long)FG_OOB)
+        return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "winograd wgrad: operands must be < 2 GiB per launch");
+    const size_t lds = (size_t)(2 * WW_STAGE) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((a.Npad / 64) * (a.Cpad / 64), a.S, a.P * a.KG);
+    const double exec = 2.0 * (double)grid.x * grid.z * 64 * 64 * 16.0 * 8.0 * fg_cdiv(a.T, 8);
+    char label[96];
+    snprintf(label, sizeof(label), "wino_wgrad_kernel/%s", a.tag ? a.tag : "?");
+    FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
+    hipLaunchKernelGGL(wino_wgrad_kernel, grid, dim3(256), lds, ctx->stream, a);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}

@@ -63,7 +63,8 @@ class Context:
         2 = one-pass matrix-pipe 3x3 thin-output convolution, 4 = all weight-gradient split-K sums of a backward pass in one launch,
         8 = Adam + the re-pack of every layer in one launch (measured slower: off by default), 16 = the bias gradient of a thin-input
         convolution from its weight-gradient kernel (no separate column-sum pass), 32 / 64 / 128 = 3x3 / nearest-x2-folded 5x5 / plain 5x5
-        convolutions as Winograd F(2x2, 3x3) (read when a net is created); default 247."""
+        convolutions as Winograd F(2x2, 3x3) (read when a net is created), 256 = their weight gradients in the Winograd domain as
+        well; default 503."""
         self.check(self.lib.fg_set_fusion(self.h, int(flags)))
 
     def get_fusion(self):

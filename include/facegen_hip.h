@@ -51,7 +51,7 @@ int fg_get_math(fg_ctx* ctx);
 
 /* Optional kernel fusions / variants (results equal to the un-fused path up to the summation order of a reduction; exposed so
  * the parity tests and the bench can run both ways).  Default: FG_FUSE_DEFAULT; FG_FUSE_PRELU=0 / FG_THIN_SLAB=0 / FG_DEFER_WFINISH=0 /
- * FG_THIN_BIAS=0 / FG_WINO=0 / FG_WINO_UP=0 / FG_WINO_5X5=0 in the environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
+ * FG_THIN_BIAS=0 / FG_WINO=0 / FG_WINO_UP=0 / FG_WINO_5X5=0 / FG_WINO_WGRAD=0 in the environment clear a bit at fg_ctx_create, FG_ADAM_PACK=1 sets that one.  Replaces nothing in the reference. */
 enum {
     FG_FUSE_PRELU = 1,      /* an nn.PReLU between two contraction layers (models_c2f.lua:118-130, 242-255) rides on their
                              * epilogues: forward copy behind the producing layer, backward (+ slope-gradient partials) in
@@ -76,7 +76,7 @@ enum {
                              * (16 multiplies per 2x2 outputs instead of 36; transforms in fp32, results equal to the direct
                              * convolution to a few fp32 roundings) instead of the 9-tap implicit GEMM.  Read when a net is created
                              * (fg_net_create: its packed weights hold the transformed taps) and per call by the module-level
-                             * fg_conv2d_* entries; FG_WINO=0 clears it.  The weight gradient is not affected */
+                             * fg_conv2d_* entries; FG_WINO=0 clears it.  The weight gradient: FG_FUSE_WINOGRAD_WGRAD */
     FG_FUSE_WINOGRAD_UP = 64,   /* the same for nn.SpatialUpSamplingNearest(2) + 5x5 / pad 2 convolutions (models.lua:63-64, 68-69): after
                                  * the tap fold every output parity is a 3x3 / pad 1 convolution of the source image, so forward (four
                                  * parities sharing one input transform) and data gradient (four stride-2 input groups) are Winograd
@@ -84,8 +84,13 @@ enum {
     FG_FUSE_WINOGRAD_5X5 = 128, /* 5x5 / pad 2 / stride 1 convolutions (models_c2f.lua:125-126) as four 3x3 sub-kernels at tap offsets
                                  * (0 | 3, 0 | 3) of the zero-extended 6x6 window: 64 instead of 100 multiplies per 2x2 outputs;
                                  * FG_WINO_5X5=0 clears it */
-    FG_FUSE_ALL = 255,
-    FG_FUSE_DEFAULT = 247
+    FG_FUSE_WINOGRAD_WGRAD = 256, /* the WEIGHT gradient of the layers the three bits above select, in the Winograd domain as well
+                                   * (dL/dU = sum over tiles of A dY A^T (.) B^T d B, 16 instead of 36 multiplies per tile and
+                                   * channel pair; G^T . G and the tap scatter in the pass that sums the split partials), where the
+                                   * tile grid is 2^a x 2^b and the layer has enough tiles to reduce over; else, and with the bit
+                                   * cleared (FG_WINO_WGRAD=0), the tap-by-tap contraction.  Read per call */
+    FG_FUSE_ALL = 511,
+    FG_FUSE_DEFAULT = 503
 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);

@@ -30,7 +30,7 @@ typedef struct fg_gan fg_gan;
 enum { FG_OK = 0, FG_ERR_INVALID = -1, FG_ERR_HIP = -2, FG_ERR_NOMEM = -3, FG_ERR_UNSUPPORTED = -4, FG_ERR_WORKSPACE = -5 };
 int fg_set_math(fg_ctx* ctx, int mode);
 int fg_get_math(fg_ctx* ctx);
-enum { FG_FUSE_PRELU = 1, FG_FUSE_THIN_SLAB = 2, FG_FUSE_WFINISH_BATCH = 4, FG_FUSE_ADAM_PACK = 8, FG_FUSE_THIN_BIAS = 16, FG_FUSE_WINOGRAD = 32, FG_FUSE_WINOGRAD_UP = 64, FG_FUSE_WINOGRAD_5X5 = 128, FG_FUSE_ALL = 255, FG_FUSE_DEFAULT = 247 };
+enum { FG_FUSE_PRELU = 1, FG_FUSE_THIN_SLAB = 2, FG_FUSE_WFINISH_BATCH = 4, FG_FUSE_ADAM_PACK = 8, FG_FUSE_THIN_BIAS = 16, FG_FUSE_WINOGRAD = 32, FG_FUSE_WINOGRAD_UP = 64, FG_FUSE_WINOGRAD_5X5 = 128, FG_FUSE_WINOGRAD_WGRAD = 256, FG_FUSE_ALL = 511, FG_FUSE_DEFAULT = 503 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);
 enum { FG_DEVICE_NONE = -1 };

@@ -3,7 +3,9 @@
   * the nearest-x2 + 5x5 up-convolutions (models.lua:63-64, 68-69): every output parity of the tap-folded layer is a 3x3 convolution
     of the source image -- four parities forward, four stride-2 input groups backward,
   * plain 5x5 / pad 2 layers (models_c2f.lua:125-126) as four 3x3 sub-kernels of the zero-extended 6x6 window,
-against the oracle's direct convolution and against the library's own implicit GEMM (the bits cleared), on the same seeded inputs.
+against the oracle's direct convolution and against the library's own implicit GEMM (the bits cleared), on the same seeded inputs;
+and their WEIGHT gradients in the Winograd domain (csrc/wino_wgrad.hip, bit FG_FUSE_WINOGRAD_WGRAD) against the oracle's
+accGradParameters and the library's tap-by-tap contraction.
 
 Tolerance: the transforms run in fp32 (B^T d B: two additions per value; G g G^T: halves and sums; A^T m A: sums of up to nine
 products of transformed values), so a result differs from the direct convolution's by a few fp32 roundings of the LARGEST partial
@@ -17,7 +19,7 @@ from gpu_util import nhwc, nchw, dev, close
 
 pytestmark = pytest.mark.gpu
 
-FG_FUSE_WINOGRAD, FG_FUSE_WINOGRAD_UP, FG_FUSE_WINOGRAD_5X5, FG_FUSE_DEFAULT = 32, 64, 128, 247
+FG_FUSE_WINOGRAD, FG_FUSE_WINOGRAD_UP, FG_FUSE_WINOGRAD_5X5, FG_FUSE_WINOGRAD_WGRAD, FG_FUSE_DEFAULT = 32, 64, 128, 256, 503
 WINO_ALL = FG_FUSE_WINOGRAD | FG_FUSE_WINOGRAD_UP | FG_FUSE_WINOGRAD_5X5
 
 
@@ -159,3 +161,112 @@ def test_winograd_up_and_5x5_are_exact_on_small_integers(ctx, k, up):
     w_d, b_d = dev(conv.weight, d), dev(conv.bias, d)
     assert np.array_equal(nchw(ops.conv2d_forward(nhwc(x, d), w_d, b_d, upsample2x=bool(up))), y)
     assert np.array_equal(nchw(ops.conv2d_backward_data(nhwc(gy, d), w_d, (H, W), upsample2x=bool(up))), gx)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# weight gradient in the Winograd domain (wino_wgrad.hip): dL/dU = sum over tiles of (A dY A^T) (.) (B^T d B), dL/dg = G^T dL/dU G
+# ---------------------------------------------------------------------------------------------------------------------------------
+import os
+from contextlib import contextmanager
+
+
+@contextmanager
+def small_shapes_take_the_winograd_wgrad():
+    """The library takes the Winograd weight gradient where it pays (>= 24 eight-tile chunks per block, >= 192 blocks); its two
+    measurement knobs are read per call, so the small shapes below reach the kernel's corners (one chunk, odd chunk counts, a ragged
+    last chunk, a single channel block)."""
+    os.environ["FG_WINO_WGRAD_MIN_CHUNKS"] = "1"
+    os.environ["FG_WINO_WGRAD_MIN_BLOCKS"] = "1"
+    try:
+        yield
+    finally:
+        del os.environ["FG_WINO_WGRAD_MIN_CHUNKS"]
+        del os.environ["FG_WINO_WGRAD_MIN_BLOCKS"]
+
+
+def _wgrad_both(ctx, x, gy, k, up):
+    from face_generator_amd import ops
+    d = ctx.device
+    out = {}
+    for flags in (FG_FUSE_DEFAULT, FG_FUSE_DEFAULT & ~FG_FUSE_WINOGRAD_WGRAD):
+        ctx.set_fusion(flags)
+        gw, gb = ops.conv2d_backward_weight(nhwc(x, d), nhwc(gy, d), k, upsample2x=bool(up))
+        out[flags] = (gw.cpu().numpy(), gb.cpu().numpy())
+    ctx.set_fusion(FG_FUSE_DEFAULT)
+    return out[FG_FUSE_DEFAULT], out[FG_FUSE_DEFAULT & ~FG_FUSE_WINOGRAD_WGRAD]
+
+
+WGRAD_CASES = [
+    # B, H, W (source), Cin, Cout, k, folded nearest-x2
+    (3, 8, 8, 64, 64, 3, 0),        # 48 tiles = 6 chunks, one channel block
+    (1, 4, 4, 64, 128, 3, 0),       # 4 tiles: half a chunk
+    (5, 4, 4, 128, 64, 3, 0),       # 20 tiles: the last chunk holds 4
+    (2, 16, 8, 64, 64, 3, 0),       # tile grid 8 x 4
+    (2, 8, 8, 128, 256, 5, 1),      # G's first up-convolution (models.lua:63-64): four parities
+    (3, 16, 16, 256, 128, 5, 1),    # G's second (models.lua:68-69)
+    (2, 8, 8, 64, 64, 3, 1),        # folded 3x3: parities with zero taps
+    (2, 8, 8, 64, 128, 5, 0),       # plain 5x5: four sub-kernel groups at offsets (3a - 2, 3b - 2)
+    (7, 4, 4, 64, 64, 5, 0),        # 28 tiles = 3.5 chunks; every group's patches cross the border
+    (9, 32, 32, 64, 128, 3, 0),     # models_c2f.lua:247-254 shape, split over the tiles
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,up", WGRAD_CASES)
+def test_winograd_weight_gradient(ctx, B, H, W, Cin, Cout, k, up):
+    rng = np.random.default_rng(B * 1000 + H * 100 + Cin + Cout + k + up + 5)
+    pad = (k - 1) // 2
+    conv = O.SpatialConvolution(Cin, Cout, k, k, 1, 1, pad, pad, rng)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    xu = O.SpatialUpSamplingNearest(2).forward(x) if up else x
+    gy = rng.standard_normal((B, Cout, xu.shape[2], xu.shape[3])).astype(np.float32)
+    conv.zeroGradParameters()
+    conv.accGradParameters(xu, gy)
+    with small_shapes_take_the_winograd_wgrad():
+        (gw, gb), (gw0, gb0) = _wgrad_both(ctx, x, gy, k, up)
+    # tolerance: the transformed operands are sums of up to 4 (dM) and 4 (V) values, the 16 position sums run over all tiles and
+    # G^T . G mixes them with weights 1, 1/2, 1/4: a few fp32 roundings of the largest position sum -- 4e-5 * max|gradW| (the
+    # tap-by-tap contraction meets 3e-5)
+    sw, sb = max(np.abs(conv.gradWeight).max(), 1.0), max(np.abs(conv.gradBias).max(), 1.0)
+    close(gw, conv.gradWeight, atol=4e-5 * sw, what="winograd weight gradient vs oracle")
+    close(gw0, conv.gradWeight, atol=3e-5 * sw, what="tap-by-tap weight gradient vs oracle")
+    close(gb, conv.gradBias, atol=3e-5 * sb, what="bias gradient (winograd kernel's partial sums) vs oracle")
+    close(gb0, conv.gradBias, atol=3e-5 * sb, what="bias gradient vs oracle")
+    assert not np.array_equal(gw, gw0), "both settings of FG_FUSE_WINOGRAD_WGRAD gave identical bits: the switch selected nothing"
+
+
+@pytest.mark.parametrize("k,up", [(3, 0), (5, 1), (3, 1), (5, 0)])
+def test_winograd_weight_gradient_is_exact_on_small_integers(ctx, k, up):
+    """Small-integer x and gy: dM and V are integers, the 16 position sums are integers below 2^24, and G^T . G only halves and
+    quarters them (exact in binary), so the Winograd-domain weight gradient must equal the direct one BIT FOR BIT -- pins the tile
+    decode, the pair packing, the deferred signs of A's last row, the parity / group -> tap scatter and accGradParameters'
+    accumulate (beta = 1) semantics."""
+    from face_generator_amd import ops
+    rng = np.random.default_rng(170 + k + up)
+    B, H, W, Cin, Cout = 5, 8, 4, 64, 128
+    pad = (k - 1) // 2
+    conv = O.SpatialConvolution(Cin, Cout, k, k, 1, 1, pad, pad, rng)
+    x = rng.integers(-3, 4, (B, Cin, H, W)).astype(np.float32)
+    xu = O.SpatialUpSamplingNearest(2).forward(x) if up else x
+    gy = rng.integers(-3, 4, (B, Cout, xu.shape[2], xu.shape[3])).astype(np.float32)
+    conv.zeroGradParameters()
+    conv.accGradParameters(xu, gy)
+    d = ctx.device
+    with small_shapes_take_the_winograd_wgrad():
+        (gw, gb), (gw0, gb0) = _wgrad_both(ctx, x, gy, k, up)
+        assert np.array_equal(gw, conv.gradWeight) and np.array_equal(gb, conv.gradBias)
+        assert np.array_equal(gw0, conv.gradWeight) and np.array_equal(gb0, conv.gradBias)
+        gw2, gb2 = ops.conv2d_backward_weight(nhwc(x, d), nhwc(gy, d), k, upsample2x=bool(up), gw=dev(gw, d), gb=dev(gb, d), beta=1.0)
+    assert np.array_equal(gw2.cpu().numpy(), 2 * conv.gradWeight) and np.array_equal(gb2.cpu().numpy(), 2 * conv.gradBias)
+
+
+def test_winograd_weight_gradient_is_taken_at_the_baseline_shapes(ctx):
+    """Without the knobs: G's second up-convolution at B = 32 (256 -> 128 on 16x16, models.lua:68-69) takes the Winograd kernel
+    (different bits than the tap-by-tap contraction), D's 64 -> 128 layer on 16x16 (models.lua:390) does not (too few channel
+    blocks: identical bits either way)."""
+    rng = np.random.default_rng(99)
+    for (B, H, W, Cin, Cout, k, up, taken) in [(32, 16, 16, 256, 128, 5, 1, True), (16, 16, 16, 64, 128, 3, 0, False)]:
+        x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+        gy = rng.standard_normal((B, Cout, H * (2 if up else 1), W * (2 if up else 1))).astype(np.float32)
+        (gw, gb), (gw0, gb0) = _wgrad_both(ctx, x, gy, k, up)
+        close(gw, gw0, atol=4e-5 * max(np.abs(gw0).max(), 1.0), what="winograd vs tap-by-tap weight gradient")
+        assert np.array_equal(gw, gw0) == (not taken)
