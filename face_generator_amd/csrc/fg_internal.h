@@ -251,6 +251,7 @@ struct WinoWgradArgs {
     long long x_bytes, d_bytes;
     double alg_flops;
     const char* tag;
+    unsigned long long* dbg_trace;   // measurement only (FG_WINO_WGRAD_TRACE): s_memtime rows of wino_wgrad_trace_kernel
 };
 int fg_launch_wino_wgrad(fg_ctx* ctx, const WinoWgradArgs& a);
 

@@ -235,7 +235,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
     //   slots 8p .. 8p+3   the four fragment reads of the NEXT pair (pair 7: pair 0 of the next chunk, behind the barrier)
     //   HAS1 (a next chunk exists; its patch sits in RX and its U in UX, requested one chunk ago):
     //     slots 0..7    U stores
-    //     slots 8..23   column pass of B^T d B, in place in RX     slots 24..39 row pass, in place     slots 40..55 V stores
+    //     slot 8        column pass of B^T d B, in place in RX (one burst of 16 packed adds)    slot 10  row pass    slots 12..27 V stores
     //     end of slot 55: lgkmcnt(0) + barrier (stage s^1 complete, every wave is done reading stage s except its last pair,
     //     whose fragments are already in registers)
     //   HAS2 (a chunk after that exists, the load cursor points at it): its 8 U loads into UY in slots 0, 2, .. 14 and its 16
@@ -274,24 +274,26 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
                         if (sl < 16 && (sl & 1) == 0) UY[sl >> 1] = wn_load4(ur_, (uo + (sl >> 1) * 1024) * 4, su2); \
                         if (sl >= 9 && sl < 41 && (sl & 1) == 1) RY[(sl - 9) >> 1] = wn_load2(xr_, voff[(sl - 9) >> 1], sx2); \
                     }                                                                                      \
-                    /* B^T d B in place in RX with plain v_add_f32 (they issue in the MFMA's shadow; the packed form costs the   \
-                       matrix pipe ~17 cycles each, measured): column pass slots 8..23, row pass 24..39, the sixteen stores 40..55 \
-                       -- a store never directly behind the addition that produces its value */            \
-                    if (sl >= 8 && sl < 24 && !(DBG & 2)) {                                                \
-                        const int k = sl - 8, x = k >> 2, o = k & 3;                                       \
-                        if (o == 0) RX[0 + x] = wn_sub(RX[0 + x], RX[8 + x]);                              \
-                        if (o == 1) RX[12 + x] = wn_sub(RX[4 + x], RX[12 + x]);                            \
-                        if (o == 2) t_ = wn_add(RX[4 + x], RX[8 + x]);                                     \
-                        if (o == 3) { RX[8 + x] = wn_sub(RX[8 + x], RX[4 + x]); RX[4 + x] = t_; }          \
+                    /* B^T d B in place in RX: the column pass and the row pass as ONE burst of 16 packed adds each (a lone      \
+                       vector-ALU instruction behind an MFMA costs the wave ~14 matrix-pipe cycles, each further one of a burst   \
+                       4.3 -- scripts/ubench/issue.hip), then the sixteen stores, one per slot (they issue for free) */            \
+                    if (sl == 8 && !(DBG & 2)) {                                                           \
+                        _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                    \
+                            RX[0 + x] = wn_sub(RX[0 + x], RX[8 + x]);                                      \
+                            RX[12 + x] = wn_sub(RX[4 + x], RX[12 + x]);                                    \
+                            t_ = wn_add(RX[4 + x], RX[8 + x]);                                             \
+                            RX[8 + x] = wn_sub(RX[8 + x], RX[4 + x]); RX[4 + x] = t_;                      \
+                        }                                                                                  \
                     }                                                                                      \
-                    if (sl >= 24 && sl < 40 && !(DBG & 2)) {                                               \
-                        const int k = sl - 24, i = k >> 2, o = k & 3;                                      \
-                        if (o == 0) RX[i * 4 + 0] = wn_sub(RX[i * 4 + 0], RX[i * 4 + 2]);                  \
-                        if (o == 1) RX[i * 4 + 3] = wn_sub(RX[i * 4 + 1], RX[i * 4 + 3]);                  \
-                        if (o == 2) t_ = wn_add(RX[i * 4 + 1], RX[i * 4 + 2]);                             \
-                        if (o == 3) { RX[i * 4 + 2] = wn_sub(RX[i * 4 + 2], RX[i * 4 + 1]); RX[i * 4 + 1] = t_; } \
+                    if (sl == 10 && !(DBG & 2)) {                                                          \
+                        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
+                            RX[i * 4 + 0] = wn_sub(RX[i * 4 + 0], RX[i * 4 + 2]);                          \
+                            RX[i * 4 + 3] = wn_sub(RX[i * 4 + 1], RX[i * 4 + 3]);                          \
+                            t_ = wn_add(RX[i * 4 + 1], RX[i * 4 + 2]);                                     \
+                            RX[i * 4 + 2] = wn_sub(RX[i * 4 + 2], RX[i * 4 + 1]); RX[i * 4 + 1] = t_;      \
+                        }                                                                                  \
                     }                                                                                      \
-                    if (sl >= 40 && sl < 56 && !(DBG & 2)) *(f32x2*)(Vs + (sl - 40) * 512) = RX[sl - 40];  \
+                    if (sl >= 12 && sl < 28 && !(DBG & 2)) *(f32x2*)(Vs + (sl - 12) * 512) = RX[sl - 12];  \
                     if (sl == 55) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          \
                 }                                                                                          \
                 __builtin_amdgcn_sched_barrier(0);                                                         \

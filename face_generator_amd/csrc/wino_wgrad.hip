@@ -23,6 +23,7 @@
 #include "fg_internal.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -44,7 +45,10 @@ __device__ __forceinline__ f32x2 ww_sub(f32x2 a, f32x2 b) {
     return d;
 }
 
-__global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) {
+// TRACE (measurement kernels only, FG_WINO_WGRAD_TRACE=1 | 2): s_memtime rows in wino.hip's formats -- 1: wave 0 at entry, after the
+// prologue's barrier, after every K chunk and after the epilogue; 2: every 8 MFMA slots of the first 14 chunks
+template <int TRACE>
+__device__ __forceinline__ void ww_body(const WinoWgradArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,41 +60,69 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
     const int c0 = blockIdx.y * a.chunks_per_split;
     const int NC = max(0, min(nct, c0 + a.chunks_per_split) - c0);
     const int NCE = (NC + 1) & ~1;
+    unsigned long long* trc = nullptr;
+    if (TRACE) {
+        if (wid == 0 && a.dbg_trace) trc = a.dbg_trace + ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 128;
+        if (trc && lane == 0) trc[0] = __builtin_amdgcn_s_memtime();
+    }
+    int ci = 0;
 
-    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)a.d_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, (int)a.x_bytes, 0x00020000);
-    const int chD = tn * 64 + lane, chX = tc * 64 + lane;
-    const int vD = chD < a.Nd ? chD * 4 : FG_OOB, vX = chX < a.Cx ? chX * 4 : FG_OOB;      // a lane's offset is its channel
-    // byte strides of the scalar tile arithmetic
+    // A lane's offset = its channel + the row of its wave's tile pair (4 patch rows / 2 gradient rows, re-computed per chunk, row
+    // validity baked in: an invalid row's offset is out of range -> the load returns 0 without touching memory); the COLUMN of a
+    // request is a wave-uniform scalar offset (soffset is not range-checked, so the patch descriptor starts 2 pixels before X:
+    // every in-range row offset stays >= 0 for patch columns down to -2), its validity one v_cndmask on a per-chunk scalar bit.
     const int dRow = a.osy * a.Wo * a.Nd * 4, dCol = a.osx * a.Nd * 4;
     const int xRow = a.isy * a.Wi * a.Cx * 4, xCol = a.isx * a.Cx * 4;
+    const int xShift = 2 * a.Cx * 4;
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dY, 0, (int)a.d_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)a.X - xShift), 0, (int)a.x_bytes + xShift, 0x00020000);
+    const int chD = tn * 64 + lane, chX = tc * 64 + lane;
+    const int vD = chD < a.Nd ? chD * 4 : FG_OOB, vX = chX < a.Cx ? chX * 4 : FG_OOB;
     const int goy = a.goy[grp], gox = a.gox[grp], ooy = a.ooy[par], oox = a.oox[par];
+    const int cend = c0 + NC;
 
     // store offsets: [pos][k half][channel][4]: this wave's tile pair is k = 2 wid, 2 wid + 1
     const int sw = (wid >> 1) * 256 + lane * 4 + (wid & 1) * 2;
     const int a_rd = (lane >> 5) * 256 + (wm * 32 + (lane & 31)) * 4;
     const int b_rd = 8192 + (lane >> 5) * 256 + (wn * 32 + (lane & 31)) * 4;
 
-    // scalar state of the load cursor (the chunk the next requests belong to)
+    // the load cursor: chunk cl's requests use (vrow, vdr, colmask)
     int cl = c0;
-    int baseD = 0, baseX = 0, ymask = 0, xmask = 0;
-#define WW_CURSOR()                                                                                        \
+    int vrow[4], vdr[2], vo[24], colmask = 0;
+    int cur_b = 0, cur_y0 = 0, cur_x0 = 0, cur_dy = 0, cur_dx = 0, cur_tv = 0;
+    // (in pieces, so that the K loop can give each a slot of its own: a burst of n vector-ALU instructions behind an MFMA costs the
+    // wave ~14 + 4.3 (n - 1) cycles of matrix-pipe time, a lone one 14 -- scripts/ubench/issue.hip)
+#define WW_CURSOR_A()                                                                                      \
     {                                                                                                      \
         const int t0 = cl * 8 + 2 * wid;                        /* first tile of this wave's pair */      \
-        const bool tv = t0 < a.T && cl < c0 + NC;                                                          \
-        const int tt = tv ? t0 : 0;                                                                        \
-        const int tx = tt & (a.TW - 1), ty = (tt >> a.lgTW) & (a.TH - 1), b = tt >> (a.lgTW + a.lgTH);     \
-        baseD = ((b * a.Ho + a.osy * 2 * ty + ooy) * a.Wo + a.osx * 2 * tx + oox) * a.Nd * 4;              \
-        const int y0 = a.isy * 2 * ty + goy, x0 = a.isx * 2 * tx + gox;                                    \
-        baseX = ((b * a.Hi + y0) * a.Wi + x0) * a.Cx * 4;                                                  \
-        ymask = 0; xmask = 0;                                                                              \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) if (tv && (unsigned)(y0 + a.isy * i) < (unsigned)a.Hi) ymask |= 1 << i; \
-        _Pragma("unroll") for (int j = 0; j < 6; ++j) if ((unsigned)(x0 + a.isx * j) < (unsigned)a.Wi) xmask |= 1 << j;       \
-        if (!tv) xmask = 0;                                                                                \
+        cur_tv = (t0 < a.T && cl < cend) ? 1 : 0;                                                          \
+        const int tt = cur_tv ? t0 : 0;                                                                    \
+        const int tx = tt & (a.TW - 1), ty = (tt >> a.lgTW) & (a.TH - 1);                                  \
+        cur_b = tt >> (a.lgTW + a.lgTH);                                                                   \
+        cur_y0 = a.isy * 2 * ty + goy; cur_x0 = a.isx * 2 * tx + gox;                                      \
+        cur_dy = a.osy * 2 * ty + ooy; cur_dx = a.osx * 2 * tx + oox;                                      \
     }
+#define WW_CURSOR_B()                                                                                      \
+    {                                                                                                      \
+        const int rowbase = ((cur_b * a.Hi + cur_y0) * a.Wi + cur_x0) * a.Cx * 4 + xShift;                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            vrow[i] = (cur_tv && (unsigned)(cur_y0 + a.isy * i) < (unsigned)a.Hi) ? vX + (rowbase + i * xRow) : FG_OOB; \
+        colmask = 0;                                                                                       \
+        _Pragma("unroll") for (int j = 0; j < 6; ++j) if ((unsigned)(cur_x0 + a.isx * j) < (unsigned)a.Wi) colmask |= 1 << j; \
+        const int dbase = ((cur_b * a.Ho + cur_dy) * a.Wo + cur_dx) * a.Nd * 4;                            \
+        vdr[0] = cur_tv ? vD + dbase : FG_OOB;                                                             \
+        vdr[1] = cur_tv ? vD + (dbase + dRow) : FG_OOB;                                                    \
+    }
+    // the offset of patch element (row i, column j of the pair's 4 x 6 window): rows I0 .. I0 + 1
+#define WW_CURSOR_C(I0)                                                                                    \
+    {                                                                                                      \
+        _Pragma("unroll") for (int i = (I0); i < (I0) + 2; ++i)                                            \
+            _Pragma("unroll") for (int j = 0; j < 6; ++j) vo[i * 6 + j] = ((colmask >> j) & 1) ? vrow[i] : FG_OOB; \
+    }
+#define WW_CURSOR() { WW_CURSOR_A(); WW_CURSOR_B(); WW_CURSOR_C(0); WW_CURSOR_C(2); }
     // one value of the pair (tile half h: 0 = tile 2m, 1 = tile 2m + 1): patch element (i, j) / gradient element (r, e)
-#define WW_LDX(i, j, h) ww_load(xrsrc, ((ymask >> (i)) & (xmask >> ((j) + 2 * (h))) & 1) ? vX : FG_OOB, baseX + (i) * xRow + ((j) + 2 * (h)) * xCol)
-#define WW_LDD(r, e, h) ww_load(drsrc, xmask ? vD : FG_OOB, baseD + (r) * dRow + ((e) + 2 * (h)) * dCol)
+#define WW_LDX(i, j, h) ww_load(xrsrc, vo[(i) * 6 + (j) + 2 * (h)], ((j) + 2 * (h)) * xCol)
+#define WW_LDD(r, e, h) ww_load(drsrc, vdr[r], ((e) + 2 * (h)) * dCol)
 
     f32x2 xa[16], xb[16], da[4], db[4];
 #define WW_LOAD_ALL(xs, ds)                                                                                \
@@ -140,6 +172,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
     if (NC > 0) {
         WW_CURSOR(); WW_LOAD_ALL(xa, da); ++cl;
         WW_CURSOR(); WW_LOAD_ALL(xb, db); ++cl;
+        WW_CURSOR();                                     // chunk c0 + 2: requested by the first chunk of the K loop
         bsum += (da[0] + da[1]) + (da[2] + da[3]);
         WW_XFORM_STORE(smem, xa, da);
     }
@@ -151,13 +184,17 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
             fb[0][h] = *(const f32x4*)(smem + b_rd + h * 512);
         }
     }
+    if (TRACE && trc && lane == 0) trc[1] = __builtin_amdgcn_s_memtime();
+#define WW_STAMP() { if (TRACE == 1 && trc && lane == 0) trc[2 + (ci < 119 ? ci : 119)] = __builtin_amdgcn_s_memtime(); ++ci; }
 
     // One K chunk = 64 MFMA slots, as in wino_kernel.  HAS1: the next chunk's values sit in (XS, DS), requested a chunk ago:
-    //   slots 0..5    dM' column / row pass (6 packed adds; the copies are free)       slots 8..23  dM' stores
-    //   slots 8..23   V column pass, in place        slots 24..39 V row pass, in place        slots 40..55 V stores
+    //   slot 0        dM' (16 packed adds in one burst; the copies are free)           slots 2..17  dM' stores
+    //   slot 19       V column pass, in place (16 packed adds)      slot 21  V row pass        slots 23..38 V stores
     //   end of slot 55: lgkmcnt(0) + barrier
-    // HAS2: the chunk after that is requested into (XL, DL): cursor arithmetic (scalar) in slot 0, the 8 gradient values in
-    //   slots 1..4, the 32 patch values in slots 5..36 (one request per slot)
+    // (vector-ALU work in few bursts: a lone VALU instruction behind an MFMA costs the wave 14 matrix-pipe cycles, each further one
+    //  of a burst 4.3 -- scripts/ubench/issue.hip; LDS and buffer instructions issue for 0 .. 5)
+    // HAS2: the chunk after that is requested into (XL, DL): the 8 gradient values in slots 1..4, the 32 patch values in slots
+    //   5..36 (one request per slot); the cursor of the chunk after THAT in slots 57 (scalar), 58, 60, 61 (30 row / element offsets)
 #define WW_CHUNK(HAS1, HAS2, XS, DS, XL, DL)                                                               \
     {                                                                                                      \
         const float* Sc = smem + s * WW_STAGE;                                                             \
@@ -165,10 +202,12 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
         float* Ms = Sn + sw;                                                                               \
         float* Vs = Sn + 8192 + sw;                                                                        \
         f32x2 t_, u_[8], m_[16];                                                                           \
-        if (HAS2) WW_CURSOR();                                                                             \
         _Pragma("unroll") for (int pr = 0; pr < 8; ++pr) {                                                 \
             _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                                \
                 const int sl = pr * 8 + m, h = m & 1, j = m >> 1, pos = 2 * pr + h;                        \
+                if (TRACE == 2 && (sl & 7) == 0 && ci < 14) {                                              \
+                    if (trc && lane == 0) trc[8 + ci * 8 + (sl >> 3)] = __builtin_amdgcn_s_memtime();       \
+                }                                                                                          \
                 acc[pos] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pr & 1][h][j], fb[pr & 1][h][j], acc[pos], 0, 0, 0); \
                 if (m < 4 && pr < 7) {                                                                     \
                     const int np = 2 * (pr + 1) + (m >> 1);                                                \
@@ -190,35 +229,41 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
                             if (hh == 0) XL[q].x = WW_LDX(q >> 2, q & 3, 0); else XL[q].y = WW_LDX(q >> 2, q & 3, 1); \
                         }                                                                                  \
                     }                                                                                      \
-                    /* dM': u = A' d (columns e = 0, 1), then m = u A'^T */                                  \
-                    if (sl == 0) { bsum = ww_add(bsum, ww_add(ww_add(DS[0], DS[1]), ww_add(DS[2], DS[3]))); } \
-                    if (sl == 1) { u_[0] = DS[0]; u_[1] = DS[1]; u_[6] = DS[2]; u_[7] = DS[3]; u_[2] = ww_add(DS[0], DS[2]); } \
-                    if (sl == 2) u_[3] = ww_add(DS[1], DS[3]);                                             \
-                    if (sl == 3) u_[4] = ww_sub(DS[0], DS[2]);                                             \
-                    if (sl == 4) u_[5] = ww_sub(DS[1], DS[3]);                                             \
-                    if (sl >= 5 && sl < 9) {                                                               \
-                        const int i = sl - 5;                                                              \
-                        m_[i * 4 + 0] = u_[i * 2]; m_[i * 4 + 3] = u_[i * 2 + 1];                          \
-                        m_[i * 4 + 1] = ww_add(u_[i * 2], u_[i * 2 + 1]);                                  \
-                        m_[i * 4 + 2] = ww_sub(u_[i * 2], u_[i * 2 + 1]);                                  \
+                    if (HAS2 && sl == 57) { ++cl; WW_CURSOR_A(); }     /* the cursor of the chunk after: slots without other work */ \
+                    if (HAS2 && sl == 58) { WW_CURSOR_B(); }                                               \
+                    if (HAS2 && sl == 60) { WW_CURSOR_C(0); }                                              \
+                    if (HAS2 && sl == 61) { WW_CURSOR_C(2); }                                              \
+                    /* dM': u = A' d (columns e = 0, 1), then m = u A'^T -- one burst */                     \
+                    if (sl == 0) {                                                                         \
+                        bsum = ww_add(bsum, ww_add(ww_add(DS[0], DS[1]), ww_add(DS[2], DS[3])));           \
+                        u_[0] = DS[0]; u_[1] = DS[1]; u_[6] = DS[2]; u_[7] = DS[3];                        \
+                        u_[2] = ww_add(DS[0], DS[2]); u_[3] = ww_add(DS[1], DS[3]);                        \
+                        u_[4] = ww_sub(DS[0], DS[2]); u_[5] = ww_sub(DS[1], DS[3]);                        \
+                        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
+                            m_[i * 4 + 0] = u_[i * 2]; m_[i * 4 + 3] = u_[i * 2 + 1];                      \
+                            m_[i * 4 + 1] = ww_add(u_[i * 2], u_[i * 2 + 1]);                              \
+                            m_[i * 4 + 2] = ww_sub(u_[i * 2], u_[i * 2 + 1]);                              \
+                        }                                                                                  \
                     }                                                                                      \
-                    if (sl >= 10 && sl < 26) *(f32x2*)(Ms + (sl - 10) * 512) = m_[sl - 10];                \
-                    /* V = B^T d B in place in XS (wino_kernel's schedule) */                               \
-                    if (sl >= 8 && sl < 24) {                                                              \
-                        const int k = sl - 8, x = k >> 2, o = k & 3;                                       \
-                        if (o == 0) XS[0 + x] = ww_sub(XS[0 + x], XS[8 + x]);                              \
-                        if (o == 1) XS[12 + x] = ww_sub(XS[4 + x], XS[12 + x]);                            \
-                        if (o == 2) t_ = ww_add(XS[4 + x], XS[8 + x]);                                     \
-                        if (o == 3) { XS[8 + x] = ww_sub(XS[8 + x], XS[4 + x]); XS[4 + x] = t_; }          \
+                    if (sl >= 2 && sl < 18) *(f32x2*)(Ms + (sl - 2) * 512) = m_[sl - 2];                   \
+                    /* V = B^T d B in place in XS: the column pass and the row pass, one burst each */      \
+                    if (sl == 19) {                                                                        \
+                        _Pragma("unroll") for (int x = 0; x < 4; ++x) {                                    \
+                            XS[0 + x] = ww_sub(XS[0 + x], XS[8 + x]);                                      \
+                            XS[12 + x] = ww_sub(XS[4 + x], XS[12 + x]);                                    \
+                            t_ = ww_add(XS[4 + x], XS[8 + x]);                                             \
+                            XS[8 + x] = ww_sub(XS[8 + x], XS[4 + x]); XS[4 + x] = t_;                      \
+                        }                                                                                  \
                     }                                                                                      \
-                    if (sl >= 24 && sl < 40) {                                                             \
-                        const int k = sl - 24, i = k >> 2, o = k & 3;                                      \
-                        if (o == 0) XS[i * 4 + 0] = ww_sub(XS[i * 4 + 0], XS[i * 4 + 2]);                  \
-                        if (o == 1) XS[i * 4 + 3] = ww_sub(XS[i * 4 + 1], XS[i * 4 + 3]);                  \
-                        if (o == 2) t_ = ww_add(XS[i * 4 + 1], XS[i * 4 + 2]);                             \
-                        if (o == 3) { XS[i * 4 + 2] = ww_sub(XS[i * 4 + 2], XS[i * 4 + 1]); XS[i * 4 + 1] = t_; } \
+                    if (sl == 21) {                                                                        \
+                        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
+                            XS[i * 4 + 0] = ww_sub(XS[i * 4 + 0], XS[i * 4 + 2]);                          \
+                            XS[i * 4 + 3] = ww_sub(XS[i * 4 + 1], XS[i * 4 + 3]);                          \
+                            t_ = ww_add(XS[i * 4 + 1], XS[i * 4 + 2]);                                     \
+                            XS[i * 4 + 2] = ww_sub(XS[i * 4 + 2], XS[i * 4 + 1]); XS[i * 4 + 1] = t_;      \
+                        }                                                                                  \
                     }                                                                                      \
-                    if (sl >= 40 && sl < 56) *(f32x2*)(Vs + (sl - 40) * 512) = XS[sl - 40];                \
+                    if (sl >= 23 && sl < 39) *(f32x2*)(Vs + (sl - 23) * 512) = XS[sl - 23];                \
                     if (sl == 55) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          \
                 }                                                                                          \
                 __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -227,17 +272,23 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
     }
     int s = 0;
     if (NCE > 0) {
-        for (int ci = 0; ci + 2 < NCE; ci += 2) {
-            WW_CHUNK(true, true, xb, db, xa, da); ++cl;
+        for (; ci + 2 < NCE;) {
+            WW_CHUNK(true, true, xb, db, xa, da);
+            WW_STAMP();
             s ^= 1;
-            WW_CHUNK(true, true, xa, da, xb, db); ++cl;
+            WW_CHUNK(true, true, xa, da, xb, db);
+            WW_STAMP();
             s ^= 1;
         }
         WW_CHUNK(true, false, xb, db, xa, da);
+        WW_STAMP();
         s ^= 1;
         WW_CHUNK(false, false, xa, da, xb, db);
+        WW_STAMP();
     }
 #undef WW_CURSOR
+#undef WW_CURSOR_A
+#undef WW_CURSOR_B
 #undef WW_LDX
 #undef WW_LDD
 #undef WW_LOAD_ALL
@@ -269,6 +320,62 @@ __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) 
         if (wid == 0 && chD < a.Nd)
             a.bias_part[((size_t)par * a.S + blockIdx.y) * a.Nd + chD] = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
     }
+    if (TRACE && trc && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (TRACE == 1) trc[(NC < 120 ? NC : 120) + 2] = __builtin_amdgcn_s_memtime();
+        trc[127] = (unsigned long long)__builtin_amdgcn_s_getreg(((3 - 1) << 11) | (0 << 6) | 20) | ((unsigned long long)NC << 32);   // XCC_ID, NC
+        trc[126] = (unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | (0 << 6) | 4);                                    // HW_ID
+    }
+#undef WW_STAMP
+}
+__global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) { ww_body<0>(a); }
+template <int TRACE>
+__global__ __launch_bounds__(256) void wino_wgrad_trace_kernel(const WinoWgradArgs a) { ww_body<TRACE>(a); }
+
+// FG_WINO_WGRAD_TRACE=1 | 2 (measurement only): the launch runs the trace kernel four times (three to settle the clocks); the per-block
+// s_memtime rows of the fourth are appended to FG_WS_TRACE_FILE (row formats of wino.hip: scripts/ws_trace_report.py,
+// scripts/wino_trace2_report.py)
+static int ww_trace_launch(fg_ctx* ctx, const WinoWgradArgs& a_in, dim3 grid, size_t lds, int mode) {
+    WinoWgradArgs a = a_in;
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z;
+    unsigned long long* dvc = nullptr;
+    if (hipMalloc((void**)&dvc, nblk * 128 * 8) != hipSuccess) return fg_set_err(ctx, FG_ERR_NOMEM, "trace buffer");
+    (void)hipMemset(dvc, 0, nblk * 128 * 8);
+    a.dbg_trace = dvc;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute((const void*)wino_wgrad_trace_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)wino_wgrad_trace_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int rep = 0; rep < 4; ++rep) {
+        (void)hipEventRecord(e0, ctx->stream);
+        if (mode == 2) hipLaunchKernelGGL(wino_wgrad_trace_kernel<2>, grid, dim3(256), lds, ctx->stream, a);
+        else hipLaunchKernelGGL(wino_wgrad_trace_kernel<1>, grid, dim3(256), lds, ctx->stream, a);
+        (void)hipEventRecord(e1, ctx->stream);
+    }
+    FG_CHECK_LAUNCH(ctx);
+    FG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float wall_ms = 0.f;
+    (void)hipEventElapsedTime(&wall_ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    std::vector<unsigned long long> host(nblk * 128);
+    FG_HIP(ctx, hipMemcpy(host.data(), dvc, nblk * 128 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dvc);
+    const char* path = getenv("FG_WS_TRACE_FILE");
+    FILE* f = fopen(path ? path : "/tmp/fg_ws_trace.txt", "a");
+    if (f) {
+        fprintf(f, "# launch wino_wgrad(dbg=%d)/%s BN=128 blocks=%zu T=%d Npad=%d Cpad=%d units=%d S=%d wall_us=%.1f\n", mode == 2 ? 100 : 0, a.tag ? a.tag : "?", nblk,
+                a.T, a.Npad, a.Cpad, a.P * a.KG, a.S, wall_ms * 1e3);
+        for (size_t b = 0; b < nblk; ++b) {
+            const unsigned long long* r = host.data() + b * 128;
+            const int kt = (int)(r[127] >> 32), xcc = (int)(r[127] & 0xffffffff);
+            fprintf(f, "%zu %d %d %llu", b, xcc, kt, r[126]);
+            if (mode == 2) { for (int i = 0; i < 126; ++i) fprintf(f, " %llu", r[i]); }
+            else for (int i = 0; i < (kt < 120 ? kt : 120) + 3; ++i) fprintf(f, " %llu", r[i]);
+            fprintf(f, "\n");
+        }
+        fclose(f);
+    }
+    return FG_OK;
 }
 
 int fg_launch_wino_wgrad(fg_ctx* ctx, const WinoWgradArgs& a) {
@@ -284,6 +391,11 @@ int fg_launch_wino_wgrad(fg_ctx* ctx, const WinoWgradArgs& a) {
     }
     dim3 grid((a.Npad / 64) * (a.Cpad / 64), a.S, a.P * a.KG);
     const double exec = 2.0 * (double)grid.x * grid.z * 64 * 64 * 16.0 * 8.0 * fg_cdiv(a.T, 8);
+    {
+        static int tr = -1;
+        if (tr < 0) { const char* e = getenv("FG_WINO_WGRAD_TRACE"); tr = e ? atoi(e) : 0; }
+        if (tr) return ww_trace_launch(ctx, a, grid, lds, tr);
+    }
     char label[96];
     snprintf(label, sizeof(label), "wino_wgrad_kernel/%s", a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
