@@ -351,6 +351,10 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
         // bf16x6: a smaller run-time batch may pick split-K where the full batch does not; its partials are bounded by
         // 256 blocks x one 256x128 tile each
         if (math == 6 && rf % 64 == 0 && n < 256LL * 256 * 128 + 64) n = 256LL * 256 * 128 + 64;
+        //  the 128 x 128 split-K branch of choose_igemm (a Linear over >= 32768 input features) splits until ONE round
+        // of 256 blocks is full: a SMALLER run-time batch has fewer row blocks and therefore more splits -- its partials are
+        // bounded by 256 tiles of 128 x 128, not by the planned batch's split count
+        if (math != 6 && rf % 128 == 0 && wm.G * (cf / 32) >= 1024 && n < 256LL * 128 * 128 + 64) n = 256LL * 128 * 128 + 64;
         if (math == 6 && rf % 64 == 0) n += ((M * g.Cin + (long long)wm.P * wm.G * rf * cf) * 3 + 1) / 2 + 64;   // split planes
         if (n > need) need = n;
     }
@@ -780,7 +784,7 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
             if (dp) { w.bias_part = dp; deferred = true; }
             else if (need + nb <= scratch_floats) w.bias_part = scratch + need;
         }
-        float* wp = (ctx->fusion & FG_FUSE_WFINISH_BATCH) ? fg_defer_alloc(ctx, need) : nullptr;    // inside fg_net backward: summed at the end
+        float* wp = fg_defer_parks_w(ctx) ? fg_defer_alloc(ctx, need) : nullptr;    // inside fg_net backward: summed at the end
         w.Part = wp ? wp : scratch;
         if ((rc = fg_launch_wino_wgrad(ctx, w))) return rc;
         wm.wino = g.wino;                                  // the partials are Winograd-domain: the finish applies G^T . G and the tap scatter
@@ -828,7 +832,7 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
             if (dp) { a.bias_part = dp; deferred = true; }
             else if (need + nb <= scratch_floats) a.bias_part = scratch + need;
         }
-        float* wp = (ctx->fusion & FG_FUSE_WFINISH_BATCH) ? fg_defer_alloc(ctx, need) : nullptr;    // inside fg_net backward: summed at the end
+        float* wp = fg_defer_parks_w(ctx) ? fg_defer_alloc(ctx, need) : nullptr;    // inside fg_net backward: summed at the end
         if (wp) a.Part = wp;
         if ((rc = fg_launch_wgrad_ws(ctx, a, wm.P, cfgw))) return rc;
         if (!(wp && fg_defer_push_wfinish(ctx, wm, a.Part, a.S, a.Npad, a.Cpad, beta, gradW)) &&
@@ -850,7 +854,7 @@ int fg_conv_wgrad_run(fg_ctx* ctx, const ConvGeom& g, const float* x, const floa
             if (dp) { a.bias_part = dp; deferred = true; }
             else if (need + nb <= scratch_floats) a.bias_part = scratch + need;
         }
-        float* wp = (ctx->fusion & FG_FUSE_WFINISH_BATCH) ? fg_defer_alloc(ctx, need) : nullptr;    // inside fg_net backward: summed at the end
+        float* wp = fg_defer_parks_w(ctx) ? fg_defer_alloc(ctx, need) : nullptr;    // inside fg_net backward: summed at the end
         if (wp) a.Part = wp;
         if ((rc = fg_launch_wgrad(ctx, a, wm.P, tile))) return rc;
         if (!(wp && fg_defer_push_wfinish(ctx, wm, a.Part, a.S, a.Npad, a.Cpad, beta, gradW)) &&

@@ -282,6 +282,11 @@ struct FgWFinishJob { WeightMap wm; const float* part; float* gradW; int S, Npad
 long long fg_conv_wgrad_part_floats(const struct ConvGeom& g);
 long long fg_conv_wgrad_bias_part_floats(const struct ConvGeom& g);   // its bias-gradient partial rows (deferred final)
 bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta, float* gradW);
+// true inside the backward pass of a net whose workspace reserved room for parked weight-gradient partials (FG_FUSE_WFINISH_BATCH on
+// at its creation AND now, job table not full)
+static inline bool fg_defer_parks_w(const fg_ctx* ctx) {
+    return (ctx->fusion & FG_FUSE_WFINISH_BATCH) && ctx->defer && ctx->defer->wjobs && ctx->defer->wn < FG_DEFER_WMAX;
+}
 int fg_launch_wgrad_finish_jobs(fg_ctx* ctx, const FgWFinishJob* jobs, int n, long long blocks);
 // One launch re-packs every layer of a net after an optimizer step.
 struct PackJob {

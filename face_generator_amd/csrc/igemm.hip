@@ -1886,32 +1886,38 @@ __device__ __forceinline__ void wgrad_finish_one(const WeightMap& wm, const floa
 // t = G^T (dL/dU) G, and scatter the sub-kernel gradient into the reference taps -- the exact adjoint of fg_wino_subkernel:
 //   wino 1, kind 0 (3x3): taps = t;   wino 1, kind 1 (folded): tap (dy, dx) collects t_p[fold(py, dy)][fold(px, dx)] of every parity p;
 //   wino 2 (5x5): tap (3a + dy, 3b + dx) = t_(a, b)[dy][dx].
+// Threads: a block of 128 owns one out-channel and 128 in-channels of a one-unit layer, or 32 in-channels x the 4 units (parities /
+// groups) of a folded / 5x5 layer (thread = (unit, in-channel): the 16 position sums of a split are 16 independent loads in flight,
+// the units' tap contributions meet in LDS).
+#define FG_WINO_FINISH_LDS (25 * 128)
+__host__ __device__ static inline int fg_wino_finish_tpu(const WeightMap& wm) { return (wm.kind == 1 || wm.wino == 2) ? 32 : 128; }
 template <int K>
-__device__ __forceinline__ void wino_wgrad_finish_one(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
-                                                      float beta, float* __restrict__ gradW, int i, int o) {
-    if (i >= wm.I || o >= wm.O) return;
-    const size_t tile = (size_t)Npad * Cpad, e = (size_t)o * Cpad + i;
+__device__ __forceinline__ void wino_wgrad_finish_block(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
+                                                        float beta, float* __restrict__ gradW, int bx, int o, float* sh) {
     const int units = (wm.kind == 1 ? 4 : 1) * (wm.wino == 2 ? 4 : 1);
+    const int tpu = fg_wino_finish_tpu(wm);
+    const int tid = threadIdx.x, u = units == 1 ? 0 : tid / tpu, il = units == 1 ? tid : tid - u * tpu;
+    const int i = bx * tpu + il;
+    const bool live = i < wm.I && o < wm.O;
+    const size_t tile = (size_t)Npad * Cpad;
     float g[K * K];
 #pragma unroll
     for (int q = 0; q < K * K; ++q) g[q] = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        if (u >= units) break;
+    if (live) {
         float du[16];
 #pragma unroll
-        for (int pos = 0; pos < 16; ++pos) {
-            const float* __restrict__ b = Part + ((size_t)u * S * 16 + pos) * tile + e;
-            float sum = 0.f;
-            int s = 0;
-            for (; s + 4 <= S; s += 4) {
-                const float v0 = b[(size_t)s * 16 * tile], v1 = b[(size_t)(s + 1) * 16 * tile], v2 = b[(size_t)(s + 2) * 16 * tile],
-                            v3 = b[(size_t)(s + 3) * 16 * tile];
-                sum += v0; sum += v1; sum += v2; sum += v3;
-            }
-            for (; s < S; ++s) sum += b[(size_t)s * 16 * tile];
-            du[pos] = (((pos >> 2) == 3) != ((pos & 3) == 3)) ? -sum : sum;
+        for (int pos = 0; pos < 16; ++pos) du[pos] = 0.f;
+        const float* __restrict__ b = Part + (size_t)u * S * 16 * tile + (size_t)o * Cpad + i;
+        for (int s = 0; s < S; ++s) {
+            float v[16];
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) v[pos] = b[((size_t)s * 16 + pos) * tile];
+#pragma unroll
+            for (int pos = 0; pos < 16; ++pos) du[pos] += v[pos];
         }
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos)
+            if (((pos >> 2) == 3) != ((pos & 3) == 3)) du[pos] = -du[pos];
         float r[4][3], t[9];      // G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
@@ -1930,40 +1936,49 @@ __device__ __forceinline__ void wino_wgrad_finish_one(const WeightMap& wm, const
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int uu = 3 * (u >> 1) + dy, vv = 3 * (u & 1) + dx;
-                    if (uu < K && vv < K) g[uu * K + vv] = t[dy * 3 + dx];
-                }
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int q = 0; q < K * K; ++q)      // (select chains, not indexed accesses: g and t stay in registers)
+                        g[q] = (q == (3 * (u >> 1) + dy) * K + 3 * (u & 1) + dx && 3 * (u >> 1) + dy < K && 3 * (u & 1) + dx < K) ? t[dy * 3 + dx] : g[q];
         } else if (wm.kind == 1) {
 #pragma unroll
             for (int dy = 0; dy < K; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < K; ++dx) {
                     const int ty = dev_fold_r(u >> 1, dy, wm.pad) - wm.rmin, tx = dev_fold_r(u & 1, dx, wm.pad) - wm.rmin;
-                    float v = 0.f;          // (a select chain, not an indexed read: t stays in registers)
+                    float v = 0.f;
 #pragma unroll
                     for (int q = 0; q < 9; ++q) v = (ty * 3 + tx == q) ? t[q] : v;
-                    g[dy * K + dx] += v;
+                    g[dy * K + dx] = v;
                 }
         } else if (K == 3) {
 #pragma unroll
             for (int q = 0; q < 9; ++q) g[q] = t[q];
         }
     }
+    if (units > 1) {        // the units' contributions to one (out, in) pair: summed in unit order
+#pragma unroll
+        for (int q = 0; q < K * K; ++q) sh[q * 128 + tid] = g[q];
+        __syncthreads();
+        if (u != 0 || !live) return;
+#pragma unroll
+        for (int q = 0; q < K * K; ++q) g[q] = ((sh[q * 128 + il] + sh[q * 128 + tpu + il]) + sh[q * 128 + 2 * tpu + il]) + sh[q * 128 + 3 * tpu + il];
+    } else if (!live) return;
     float* gw = gradW + ((size_t)o * wm.I + i) * (K * K);
 #pragma unroll
     for (int q = 0; q < K * K; ++q) gw[q] = (beta == 0.f) ? g[q] : beta * gw[q] + g[q];
 }
 __device__ __forceinline__ void wino_wgrad_finish_any(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
-                                                      float beta, float* __restrict__ gradW, int i, int o) {
-    if (wm.k == 5) wino_wgrad_finish_one<5>(wm, Part, S, Npad, Cpad, beta, gradW, i, o);
-    else wino_wgrad_finish_one<3>(wm, Part, S, Npad, Cpad, beta, gradW, i, o);
+                                                      float beta, float* __restrict__ gradW, int bx, int o, float* sh) {
+    if (wm.k == 5) wino_wgrad_finish_block<5>(wm, Part, S, Npad, Cpad, beta, gradW, bx, o, sh);
+    else wino_wgrad_finish_block<3>(wm, Part, S, Npad, Cpad, beta, gradW, bx, o, sh);
 }
 // all weight-gradient reductions of a backward pass in one launch: block -> job by a scan over <= FG_DEFER_WMAX entries; inside
 // a job the blocks run (in-channel block, out-channel, tap) exactly as the grid of wgrad_finish_kernel does
 struct FgWFinishBatch { FgWFinishJob jobs[FG_DEFER_WMAX]; int n; };
 __global__ __launch_bounds__(128) void wgrad_finish_jobs_kernel(const FgWFinishBatch b) {
     __shared__ float tl[32][33];
+    __shared__ float wsh[FG_WINO_FINISH_LDS];
     int j = 0;
     while (j + 1 < b.n && (long long)blockIdx.x >= b.jobs[j + 1].blk0) ++j;
     const FgWFinishJob& jb = b.jobs[j];
@@ -2009,7 +2024,7 @@ __global__ __launch_bounds__(128) void wgrad_finish_jobs_kernel(const FgWFinishB
     }
     const int bx = (int)(l % jb.ib); l /= jb.ib;
     const int po = (int)(l % jb.wm.O), wi = (int)(l / jb.wm.O);
-    if (jb.wm.wino) { wino_wgrad_finish_any(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx * 128 + (int)threadIdx.x, po); return; }
+    if (jb.wm.wino) { wino_wgrad_finish_any(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx, po, wsh); return; }
     wgrad_finish_one(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx * 128 + (int)threadIdx.x, po, wi);
 }
 int fg_launch_wgrad_finish_jobs(fg_ctx* ctx, const FgWFinishJob* jobs, int n, long long blocks) {
@@ -2026,10 +2041,11 @@ bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
     if (!d || !d->wjobs || d->wn >= FG_DEFER_WMAX) return false;
     const bool brick = wm.kind == 0 && wm.k == 1 && wm.i_hw > 1 && wm.i_c > 0;     // Linear behind a View: 32 x 32 patches (ib = -1)
     const long long nb = brick ? (long long)wm.O * fg_cdiv(wm.i_c, 32) * fg_cdiv(wm.i_hw, 32)
-                               : (long long)fg_cdiv(wm.I, 128) * wm.O * (wm.wino ? 1 : wm.k * wm.k);     // (Winograd partials: a thread owns all taps)
+                               : (wm.wino ? (long long)fg_cdiv(wm.I, fg_wino_finish_tpu(wm)) * wm.O       // (Winograd partials: wino_wgrad_finish_block)
+                                          : (long long)fg_cdiv(wm.I, 128) * wm.O * wm.k * wm.k);
     if (d->wblocks + nb > 0x7fffffffLL) return false;
     FgWFinishJob& j = d->wjobs[d->wn++];
-    j.wm = wm; j.part = Part; j.gradW = gradW; j.S = S; j.Npad = Npad; j.Cpad = Cpad; j.ib = brick ? -1 : fg_cdiv(wm.I, 128); j.beta = beta;
+    j.wm = wm; j.part = Part; j.gradW = gradW; j.S = S; j.Npad = Npad; j.Cpad = Cpad; j.ib = brick ? -1 : fg_cdiv(wm.I, wm.wino ? fg_wino_finish_tpu(wm) : 128); j.beta = beta;
     j.blk0 = d->wblocks;
     d->wblocks += nb;
     return true;
@@ -2038,13 +2054,14 @@ bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
 __global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
                                     float beta, float* __restrict__ gradW) {
     // x: packed in-channel (coalesced partial reads), y: packed out-channel, z: tap dy*k+dx
-    if (wm.wino) { wino_wgrad_finish_any(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y); return; }
+    __shared__ float wsh[FG_WINO_FINISH_LDS];
+    if (wm.wino) { wino_wgrad_finish_any(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x, blockIdx.y, wsh); return; }
     wgrad_finish_one(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, blockIdx.z);
 }
 int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,
                            float* gradW) {
     if (wm.wino && wm.k != 3 && wm.k != 5) return fg_set_err(ctx, FG_ERR_INVALID, "winograd weight-gradient finish: k = %d", wm.k);
-    dim3 grid(fg_cdiv(wm.I, 128), wm.O, wm.wino ? 1 : wm.k * wm.k);
+    dim3 grid(fg_cdiv(wm.I, wm.wino ? fg_wino_finish_tpu(wm) : 128), wm.O, wm.wino ? 1 : wm.k * wm.k);
     hipLaunchKernelGGL(wgrad_finish_kernel, grid, dim3(128), 0, ctx->stream, wm, Part, S, Npad, Cpad, beta, gradW);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;

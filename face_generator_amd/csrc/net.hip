@@ -159,15 +159,17 @@ static void make_plan(fg_net* n, int B) {
         // host queried stays valid whatever fg_set_fusion does later: a bit switched on afterwards finds no arena and falls back to
         // the per-layer reduction (fg_defer_alloc returns null), it never overruns and never asks for more.
         const bool park_w = n->park_w;
-        int parked = 0;
+        //  the backward pass walks the stages in REVERSE, so the layers that park are the LAST FG_DEFER_WMAX
+        // parametrised convolutions / Linears of the plan, not the first
+        int nconv = 0, seen = 0;
+        for (auto& s : n->st) if (s.kind == ST_CONV && s.w_n > 0) ++nconv;
         for (auto& s : n->st) {
+            const bool parks = s.kind == ST_CONV && s.w_n > 0 && park_w && (nconv - seen++) <= FG_DEFER_WMAX;
             // (ST_CONV: the wave-specialised weight gradient leaves one bias partial row per (parity, split, tap, X tile, loader
             // pixel lane) -- up to FG_WS_BIAS_ROWS_MAX rows; sized exactly)
             if (s.kind == ST_CONV) { ConvGeom g = s.geom; g.B = B; dn += (fg_conv_wgrad_bias_part_floats(g) + 63) / 64 * 64; }
             // ... and its split-K / parity partials stay until the batched weight-gradient reduction at the end of the pass
-            if (s.kind == ST_CONV && s.w_n > 0 && park_w && parked < FG_DEFER_WMAX) {
-                ConvGeom g = s.geom; g.B = B; dn += (fg_conv_wgrad_part_floats(g) + 63) / 64 * 64; ++parked;
-            }
+            if (parks) { ConvGeom g = s.geom; g.B = B; dn += (fg_conv_wgrad_part_floats(g) + 63) / 64 * 64; }
             else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT || s.kind == ST_GEMV) dn += (long long)CR_ROWBLOCKS_MAX * s.oc + 64;
             if (s.has_prelu || s.kind == ST_PRELU || s.kind == ST_ACTPOOL) dn += 1024 + 64;
             // a PReLU whose backward rides on the epilogue of the neighbouring contraction leaves 4 partials per block
@@ -339,8 +341,10 @@ static int backward_run_stages(fg_net* n) {
             case ST_AVGPOOL: if (need_gx) rc = fg_launch_avgpool_backward(ctx, gcur, gxb, B, s.ih, s.iw, s.ic); break;
             case ST_SDROPOUT: if (need_gx) rc = fg_launch_scale_mask_nc(ctx, gcur, mask, 1.f, gxb, B, s.ih * s.iw, s.ic); break;
             case ST_ACTMAXPOOL:
-                if (need_gx)
-                    rc = fg_launch_maxpool_prelu_backward(ctx, xin, gcur, P + s.slope_off, gxb, want_p ? Gp + s.slope_off : nullptr, B, s.ih,
+                // (also when only the slope gradient is wanted -- the fused stage can be the net's first one behind a
+                //  no-op View, where no input gradient exists)
+                if (need_gx || want_p)
+                    rc = fg_launch_maxpool_prelu_backward(ctx, xin, gcur, P + s.slope_off, need_gx ? gxb : nullptr, want_p ? Gp + s.slope_off : nullptr, B, s.ih,
                                                           s.iw, s.ic, scratch, mask, s.mask_kind ? 1.f / (1.f - s.p) : 1.f);
                 break;
             case ST_MAXPOOL:
@@ -807,7 +811,9 @@ static int backward_run(fg_net* n) {
     fg_ctx* ctx = n->ctx;
     n->defer.arena = n->run_ws + n->defer_off; n->defer.cap = n->defer_floats;
     n->defer.used = 0; n->defer.n = 0; n->defer.blocks = 0;
-    n->defer.wjobs = n->wjobs; n->defer.wn = 0; n->defer.wblocks = 0;
+    //  a net created with FG_FUSE_WFINISH_BATCH off reserved no room for parked weight-gradient partials: no job table,
+    // so fg_conv_wgrad_run does not eat the arena of the bias / slope partials when the bit is switched on later
+    n->defer.wjobs = n->park_w ? n->wjobs : nullptr; n->defer.wn = 0; n->defer.wblocks = 0;
     ctx->defer = &n->defer;
     const int rc = backward_run_stages(n);
     const int rf = fg_defer_flush(ctx);

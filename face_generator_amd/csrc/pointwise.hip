@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(256) void maxpool_prelu_bwd_kernel(const float* __r
         for (int k = 0; k < 4; ++k) {
             const bool pos = xv[k] > 0.f;
             const float gk = (k == am) ? g : 0.f;
-            gx[o[k]] = pos ? gk : a * gk;
+            if (gx) gx[o[k]] = pos ? gk : a * gk;           // (null: the stage is the net's first and no input gradient was asked for)
             if (k == am && !pos) s = fmaf(xv[k], g, s);
         }
     }

@@ -3,6 +3,13 @@
 // N or K of the GEMM view is 3 (or 27), so MFMA tiles would be > 90 % padding: these are HBM/VALU-bound and
 // run on the vector ALU with coalesced NHWC accesses and weights held in registers.
 #include "fg_internal.h"
+// FG_THIN_DBG (drop the gathers / the stores of thin_in_mfma_kernel: timing experiments, WRONG results) exists only in builds with
+// -DFG_MEASURE; the production kernel carries no such branch
+#ifdef FG_MEASURE
+#define FG_THIN_DBG_BIT(v, b) ((v) & (b))
+#else
+#define FG_THIN_DBG_BIT(v, b) 0
+#endif
 #include <string.h>
 #include <stdlib.h>
 typedef float tw_f32x16 __attribute__((ext_vector_type(16)));   // MFMA 32x32 accumulator
@@ -337,7 +344,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
             const int d = kdesc[ks];
             const int yy = y + (d & 3) - 1, xx = x + ((d >> 2) & 3) - 1;
             float a = 0.f;
-            if (ok && (d >> 8) && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W && !(nt_store & 4))
+            if (ok && (d >> 8) && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W && !FG_THIN_DBG_BIT(nt_store, 4))
                 a = in[(size_t)((t - y + yy) * W + xx) * CS + ((d >> 4) & 15)];
             av[ks] = a;
         }
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(256) void thin_in_mfma_kernel(const float* __restri
                 const int pl = i * 4 + (lane >> 4), c4 = (lane & 15) * 4;
                 const tw_f32x4 v = *(const tw_f32x4*)(ts + pl * TS_LD + c4);
                 const int p = tile * 32 + pl;
-                if (p < npix && !(nt_store & 2)) {
+                if (p < npix && !FG_THIN_DBG_BIT(nt_store, 2)) {
                     // measurement switches: FG_THIN_NT=1 streaming stores that do not allocate in L2; FG_THIN_DBG bit 0 drops the
                     // stores, bit 1 the gathers (what is left of the kernel without them)
                     if (nt_store & 1) __builtin_nontemporal_store(v, (tw_f32x4*)(out + (size_t)p * Cw + cb + c4));
@@ -668,9 +675,11 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         if (tpw_env < 0) { const char* e = getenv("FG_THIN_TPW"); tpw_env = e ? atoi(e) : 0; }
         if (nt_env < 0) {
             const char* e = getenv("FG_THIN_NT"); nt_env = e ? (atoi(e) & 1) : 0;
-            const char* dbg = getenv("FG_THIN_DBG"); if (dbg) nt_env |= (atoi(dbg) & 3) << 1;      // measurement only: results are wrong
+#ifdef FG_MEASURE
+            const char* dbg = getenv("FG_THIN_DBG"); if (dbg) nt_env |= (atoi(dbg) & 3) << 1;      // measurement builds only: results are wrong
+#endif
         }
-        const int tpw = tpw_env > 0 ? tpw_env : 4;
+        const int tpw = tpw_env > 0 ? (tpw_env > 16 ? 16 : tpw_env) : 4;
         const int nt_store = nt_env;
         int nb = fg_cdiv(fg_cdiv(npix, 32), 4 * tpw);
         if (nb > 2048) nb = 2048;

@@ -140,7 +140,8 @@ def make_specs(layers):
 class DeviceNet:
     """An nn.Sequential compiled by fg_net_create, with its flat parameter / gradient vectors
     (== Module:getParameters(), train.lua:151-152), BN running stats and workspace as torch device tensors."""
-    _count = 0          # nets built by this process (salt of the default dropout-mask key)
+    _count = 0          # nets built by this process
+    _count_by_structure = {}      # crc32(structure) -> nets of that structure built so far (salt of the default dropout-mask key)
 
     def __init__(self, ctx, layers, in_dims, max_batch, params=None, grads=None):
         """params / grads: optional slices of a larger flat vector shared by several nets (nn.ConcatSequential)."""
@@ -171,11 +172,18 @@ class DeviceNet:
         self.train = True
         self.sync_buf, self._sync_reduce = None, None
         # Philox streams are keyed by (seed, counter) only: the dropout masks must not share the noise stream's key (S.noise_seed:
-        # small integers, seed + rank), and two nets must not share one either -- not even two with the same parameter count
-        # (two identical D's, the branches of a CompositeDeviceNet).  Key = a tag in the upper 32 bits (a namespace no
-        # noise seed reaches) + the number of nets this process has built so far: the same program draws the same masks every run.
+        # small integers, seed + rank), and two nets must not share one either -- not even two with the same structure (two
+        # identical D's, the branches of a CompositeDeviceNet).  Default key = a tag in the upper 32 bits (a namespace no
+        # noise seed reaches) + crc32 of the net's STRUCTURE (layer specs, input dims) + its ordinal among the nets of that very
+        # structure built so far: building, dropping or re-ordering OTHER nets does not move it.  A training run does
+        # not rely on the default: S.set_dist / S.seed re-key every net from OPT.seed and the rank (state.py), which is also what
+        # makes the masks of a resumed run repeat.
+        import zlib
+        crc = zlib.crc32(repr(([tuple(l) for l in self.layers], tuple(in_dims))).encode()) & 0xFFFFFF
+        ordinal = DeviceNet._count_by_structure.get(crc, 0) + 1
+        DeviceNet._count_by_structure[crc] = ordinal
         DeviceNet._count += 1
-        self.mask_seed, self.mask_offset = (0x4D41534B << 32) + DeviceNet._count, 0
+        self.mask_seed, self.mask_offset = (0x4D41534B << 32) + (crc << 8) + (ordinal & 0xFF), 0
         self._masks = None
         self._batch = 0
         self._x = None

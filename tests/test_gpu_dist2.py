@@ -75,6 +75,17 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     d = j["dry_collective"]
     assert d["ranks_agree"] is True and d["ranks_walked"] == 2 and len(d["schedule_sha16"]) == 16 and d["this_run"], d
     assert any(" allreduce f32 2863239 " in l for l in d["this_run"])                  # D's flat gradient, models.lua:382-416
+    # round 5: the legs a first SCALE record needs -- each rank's compute-only time and what it leaves of the
+    # step (scaling efficiency from THIS run alone), the other BatchNorm mode, the strong-scaling split of the global batch of 128
+    assert len(j["per_rank_compute_ms"]) == 2 and all(v > 0 for v in j["per_rank_compute_ms"])
+    assert 0 < j["compute_over_step"] <= 1.05, j["compute_over_step"]           # (5 %: two short timed regions on a shared GPU)
+    assert abs(j["exchange_exposed_ms_per_step"] - (j["ms_per_step"] - max(j["per_rank_compute_ms"]))) < 1e-9
+    mg = j["multi_gpu"]
+    assert set(mg) == {"compute_only", "sync_bn", "strong"}, sorted(mg)
+    for name, leg in mg.items():
+        assert "error" not in leg, (name, leg)
+        assert leg["value"] > 0 and leg["ms_per_step"] > 0 and len(leg["per_rank_ms_per_step"]) == 2 and leg["note"], (name, leg)
+    assert mg["compute_only"]["batch_per_gpu"] == 16 and mg["sync_bn"]["batch_per_gpu"] == 16 and mg["strong"]["batch_per_gpu"] == 64
     c = j["c2f"]                                                                     # configs[4]-style: B/2 per rank, D_it = 2
     assert "error" not in c, c
     assert c["value"] > 0 and c["config"]["batch_per_gpu"] == 8 and "D_it=2" in c["config"]["workload"]

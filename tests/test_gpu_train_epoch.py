@@ -221,6 +221,113 @@ def test_adversarial_train_epoch_config1_gray_batch16(ctx, tmp_path):
     assert len(adversarial.accs) <= 20
 
 
+def _cfg2_epoch_setup(ctx, tmp_path, B, C, seed):
+    """A fresh pair of G32 / D32b nets + trainer from one seed (initial parameters, noise stream, dropout-mask keys all derived
+    from it: S.set_dist re-keys the nets), so that two set-ups in one process walk the same trajectory."""
+    from face_generator_amd import models, nn_utils, adversarial
+    from face_generator_amd.state import S
+    rng = np.random.default_rng(seed)
+    G = O.create_G32((C, 32, 32), 100, rng, weight_init_=False)
+    D = O.create_D32b((C, 32, 32), rng)
+    st = O.GanState(G, D)
+    S.reset()
+    adversarial.accs.clear()
+    S.OPT.update(batchSize=B, noiseDim=100, N_epoch=3 * B // 2, saveFreq=100, save=str(tmp_path), seed=7, D_iterations=2, G_iterations=2)
+    S.IMG_DIMENSIONS = (C, 32, 32)
+    Gd = models.create_G((C, 32, 32), 100)
+    Dd = models.create_D((C, 32, 32))
+    S.MODEL_G = nn_utils.activateCuda(Gd)
+    S.MODEL_D = nn_utils.activateCuda(Dd)
+    S.set_dist(None)                                 # rng / noise seed / mask keys <- OPT.seed
+    pG, _ = S.MODEL_G.getParameters(); pD, _ = S.MODEL_D.getParameters()
+    pG.copy_(torch.tensor(st.pG)); pD.copy_(torch.tensor(st.pD))
+    dnG, dnD = Gd.device_net, Dd.device_net
+    dnG.params_changed(); dnD.params_changed()
+    tr = S.trainer()
+    return st, dnG, dnD, tr, Recorder(tr, dnG, dnD)
+
+
+def test_adversarial_train_epoch_cfg2_batch128_two_iterations_and_a_holding_gate(ctx, tmp_path):
+    """BASELINE configs[1] at its own batch through the LOOP: 32x32x3, B = 128, D_iterations = 2,
+    G_iterations = 2 (adversarial.lua:240-288 run the closures k times per batch), N_epoch = 192 -> batches of 128, 128 and the
+    64-image tail, and the maxAccuracyD gate (adversarial.lua:156-178) HOLDING at least once and training at least once.
+    The threshold is found, not guessed: a first pass with the gate open records D's accuracy per D-step; the threshold is put
+    between the running maximum and the first accuracy above it, so the same trajectory (same seed -> same parameters, noise
+    and masks) trains up to that step and holds there.  Then the real pass is compared step by step with the oracle's loop."""
+    from face_generator_amd import adversarial
+    from face_generator_amd.state import S
+    B, C, N = 128, 3, 200
+    data = ListDataset([np.random.default_rng(2300 + i).uniform(0, 1, (C, 32, 32)).astype(np.float32) for i in range(N)])
+    st, dnG, dnD, tr, rec = _cfg2_epoch_setup(ctx, tmp_path, B, C, 2200)
+    adversarial.train(data, 1.01, 1)
+    tv = [float(s["conf"][0, 0] + s["conf"][1, 1]) / float(s["conf"].sum()) for s in rec.steps if s["kind"] == "D"]
+    assert len(tv) == 6 and all(s["trained"] for s in rec.steps if s["kind"] == "D")
+    hold_at = next((k for k in range(1, len(tv)) if tv[k] > max(tv[:k])), None)
+    assert hold_at is not None, "D's accuracy never rose above its first values in the open-gate pass: %s" % tv
+    max_acc = 0.5 * (max(tv[:hold_at]) + tv[hold_at])
+    first_pass_D = [s["out"].copy() for s in rec.steps if s["kind"] == "D"]
+
+    st, dnG, dnD, tr, rec = _cfg2_epoch_setup(ctx, tmp_path, B, C, 2200)
+    interval = 1
+    replay = random.Random(7)
+    oracle_accs = []
+    tV = adversarial.train(data, max_acc, interval)
+    steps = rec.steps
+    dsteps_dev = [s for s in steps if s["kind"] == "D"]
+    for k in range(hold_at + 1):       # the same trajectory up to and including the step that holds
+        assert np.array_equal(dsteps_dev[k]["out"], first_pass_D[k]), "the second set-up left the first one's trajectory at D-step %d" % k
+    assert [s["trained"] for s in dsteps_dev[:hold_at + 1]] == [True] * hold_at + [False]
+    G_bns = [m for m in st.G.modules if isinstance(m, O.SpatialBatchNormalization)]
+
+    def before_step(kind, k):
+        s = steps[k]
+        assert s["kind"] == kind, "step %d: device ran a %s-step, the reference loop a %s-step" % (k, s["kind"], kind)
+        load_state(st, s["state"], G_bns)
+
+    noise_q = [(s["noise"] if s["noise"] is not None else (s["args"][1] if s["kind"] == "D" else s["args"][0])).reshape(-1, 100)
+               for s in steps]
+    mask_q = [s["masks"] for s in steps]
+    real_q = [s["args"][0] for s in steps if s["kind"] == "D"]
+    qi = dict(n=0, m=0)
+
+    def draw_noise(n):
+        z = noise_q[qi["n"]]; qi["n"] += 1
+        assert z.shape[0] == n, "noise batch %d drawn by the device loop, %d by the reference loop" % (z.shape[0], n)
+        return z
+
+    def draw_masks(b):
+        m = mask_q[qi["m"]]; qi["m"] += 1
+        return [mm.reshape(b, -1) for mm in m]
+
+    log = O.train_epoch(st, data, dict(S.OPT), max_acc, interval, oracle_accs, lambda n: replay.randrange(n),
+                        draw_noise, draw_masks, before_step)
+    assert [it["batch"] for it in log["iters"]] == [128, 128, 64] and all(len(it["D"]) == 2 and len(it["G"]) == 2 for it in log["iters"])
+    assert sum(len(it["D"]) + len(it["G"]) for it in log["iters"]) == len(steps) == 12
+    assert log["not_trained"] >= 1 and log["trained"] >= 1 and log["trained"] + log["not_trained"] == 6
+    k = 0
+    dsteps = iter(real_q)
+    for it in log["iters"]:
+        for r in it["D"]:
+            s = steps[k]; k += 1
+            real = next(dsteps)
+            close(np.transpose(real, (0, 3, 1, 2)), r["inputs"][:real.shape[0]], atol=0, what="real half (pick order)")
+            close(s["out"], r["out"].reshape(-1), atol=1e-5, what="D-step %d outputs (B = %d)" % (k, it["batch"]))
+            assert abs(s["loss"] - r["f_bce"]) <= 1e-5 * abs(r["f_bce"])
+            assert (s["conf"] == r["conf"]).all()
+            assert s["trained"] == r["trained"], "gate decision differs at step %d" % k
+        for r in it["G"]:
+            s = steps[k]; k += 1
+            close(s["samples"], r["samples"], atol=1e-5, what="G-step %d samples (B = %d)" % (k, it["batch"]))
+            close(s["out"], r["out"].reshape(-1), atol=1e-5, what="G-step %d D outputs" % k)
+            assert abs(s["loss"] - r["f_bce"]) <= 1e-5 * abs(r["f_bce"])
+    assert abs(tV - log["totalValid"]) < 1e-12
+    assert adversarial.accs == oracle_accs and len(oracle_accs) <= interval
+    # a held D-step moved nothing: the state recorded before the next step equals the state before the held one
+    held = next(i for i, s in enumerate(steps) if s["kind"] == "D" and not s["trained"])
+    assert np.array_equal(steps[held]["state"]["pD"], steps[held + 1]["state"]["pD"])
+    assert steps[held]["state"]["adam"]["D"]["t"] == steps[held + 1]["state"]["adam"]["D"]["t"]
+
+
 def test_gate_blocks_training_when_accuracy_is_high(ctx):
     """adversarial.lua:167-178 + interruptable_optimizers.lua:60-66: when the mean accuracy is >= maxAccuracyD, fevalD
     returns false,false and D's parameters, Adam moments and step count do not move."""
