@@ -139,14 +139,22 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
         wn_decode(tvalid ? t : 0, a, b, ty, tx);
         pb = b * a.Hi; py0 = a.isy * 2 * ty; px0 = a.isx * 2 * tx;
     }
+    // (the four groups' offsets as packed bytes in two scalar registers: an indexed read of the kernel arguments is a scalar
+    // memory load -- ~1 us of latency on every group switch and in the prologue)
+    const int goy4 = *(const int*)a.goy, gox4 = *(const int*)a.gox;
+#define WN_GOFF(pk, g) ((int)(signed char)((pk) >> (8 * (g))))
+    const int cstep = a.isx * a.C * 4;
 #define WN_SET_GROUP(g)                                                                                    \
     {                                                                                                      \
-        const int gy_ = py0 + a.goy[g], gx_ = px0 + a.gox[g];                                              \
-        _Pragma("unroll") for (int p = 0; p < 16; ++p) {                                                   \
-            const int y = gy_ + a.isy * (p >> 2), x = gx_ + a.isx * (p & 3);                               \
-            const bool ok = tvalid && (unsigned)y < (unsigned)a.Hi && (unsigned)x < (unsigned)a.Wi;        \
-            voff[p] = ok ? (((pb + y) * a.Wi + x) * a.C + 2 * (tid & 3)) * 4 : FG_OOB;                     \
+        const int gy_ = py0 + WN_GOFF(goy4, g), gx_ = px0 + WN_GOFF(gox4, g);                              \
+        int rb_[4]; bool rok_[4], cok_[4];                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+            const int y = gy_ + a.isy * i;                                                                 \
+            rok_[i] = tvalid & ((unsigned)y < (unsigned)a.Hi);                                              \
+            rb_[i] = (((pb + y) * a.Wi + gx_) * a.C + 2 * (tid & 3)) * 4;                                  \
+            cok_[i] = (unsigned)(gx_ + a.isx * i) < (unsigned)a.Wi;                                        \
         }                                                                                                  \
+        _Pragma("unroll") for (int p = 0; p < 16; ++p) voff[p] = (rok_[p >> 2] & cok_[p & 3]) ? rb_[p >> 2] + (p & 3) * cstep : FG_OOB; \
     }
     const int vw = ((tid & 3) >> 1) * 256 + (tid >> 2) * 4 + (tid & 1) * 2;      // V store: [pos][half][tile][4], pos = immediate
     const int uo = tid * 4;                                                      // U: float4 number tid + 256 i of the chunk image
@@ -218,6 +226,13 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
         // chunks 0 and 1 requested before anything waits: the second set of loads lands while the first is transformed
         WN_LOAD(rva, rua); WN_ADVANCE();
         WN_LOAD(rvb, rub); WN_ADVANCE();
+    }
+    // the 256 accumulator registers are written HERE, under the latency of the requests above (left to itself hipcc sinks the
+    // initialisation behind the prologue's barrier, ~3 600 cycles on every block's critical path: 720 v_accvgpr_write)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[p]));
+    __builtin_amdgcn_sched_barrier(0);
+    if (NC > 0) {
         WN_XFORM_STORE(smem, rva, rua);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -318,6 +333,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
     }
 #undef WN_STAMP
 #undef WN_SET_GROUP
+#undef WN_GOFF
 #undef WN_ADVANCE
 #undef WN_LOAD
 #undef WN_XFORM_STORE

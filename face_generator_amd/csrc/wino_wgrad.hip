@@ -173,6 +173,12 @@ __device__ __forceinline__ void ww_body(const WinoWgradArgs& a) {
         WW_CURSOR(); WW_LOAD_ALL(xa, da); ++cl;
         WW_CURSOR(); WW_LOAD_ALL(xb, db); ++cl;
         WW_CURSOR();                                     // chunk c0 + 2: requested by the first chunk of the K loop
+    }
+    // (the accumulators are written under the latency of the requests above; hipcc would sink their initialisation behind the barrier)
+#pragma unroll
+    for (int p = 0; p < 16; ++p) asm volatile("" : "+a"(acc[p]));
+    __builtin_amdgcn_sched_barrier(0);
+    if (NC > 0) {
         bsum += (da[0] + da[1]) + (da[2] + da[3]);
         WW_XFORM_STORE(smem, xa, da);
     }
