@@ -3,7 +3,7 @@
 # workloads, PMC passes on the dominant kernels.  usage (through gpurun): bash scripts/collect_profiles.sh <tag>
 #   -> gpurun_out/<tag>_*; copy what is to be judged into profiles/
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p $OUT
@@ -13,13 +13,15 @@ rocprofv3 --kernel-trace --stats -d $OUT/p1 -o run -- python bench.py --workload
 python scripts/rocpd_stats.py $OUT/p1/run_results.db auto > $OUT/${TAG}_bench_kernel_stats.md
 rocprofv3 --kernel-trace --stats -d $OUT/p2 -o run -- python bench.py --workload c2f --steps 6 --warmup 2 --no-cpu-baseline --no-alt-math --no-roofline > /dev/null 2>&1
 python scripts/rocpd_stats.py $OUT/p2/run_results.db auto > $OUT/${TAG}_c2f_kernel_stats.md
+rm -f $OUT/${TAG}_pmc_raw.txt
 for which in fwd wgrad; do
   for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
     d=$OUT/pmc_${which}_$(echo $pmc | tr ' ' '_')
     rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $d -- python scripts/bench_one.py $which 4 > /dev/null 2>&1
     echo "## $which : $pmc" >> $OUT/${TAG}_pmc_raw.txt
-    python scripts/pmc_summary.py $d igemm >> $OUT/${TAG}_pmc_raw.txt 2>&1
-    python scripts/pmc_summary.py $d wgrad_kernel >> $OUT/${TAG}_pmc_raw.txt 2>&1
+    python scripts/pmc_summary.py $d wino_kernel >> $OUT/${TAG}_pmc_raw.txt 2>&1
+    python scripts/pmc_summary.py $d wino_wgrad_kernel >> $OUT/${TAG}_pmc_raw.txt 2>&1
+    python scripts/pmc_summary.py $d wgrad_finish >> $OUT/${TAG}_pmc_raw.txt 2>&1
     rm -rf $d
   done
 done
@@ -31,7 +33,7 @@ d = json.loads(open("$OUT/${TAG}_bench.json").read().strip().splitlines()[-1])
 r = d["roofline"]
 if r.get("traffic_freshness") == "live":
     import hashlib
-    sha = hashlib.sha256(open("face_generator_amd/csrc/igemm.hip", "rb").read()).hexdigest()[:16]
+    sha = hashlib.sha256(open("face_generator_amd/csrc/wino.hip", "rb").read()).hexdigest()[:16]
     json.dump({"kernel": r["kernel"], "launch": r["traffic_note"].split(";")[0], "hbm_bytes_per_launch": r["traffic"],
                "algorithmic_bytes_per_launch": r["algorithmic_bytes"], "kernel_source_sha16": sha,
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) spawned by bench.py, $TAG"},
