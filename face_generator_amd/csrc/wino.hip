@@ -15,17 +15,16 @@
 //   * output parities: parity p writes tile element (a, b) to output pixel (osy (2 ty + a) + ooy[p], osx (2 tx + b) + oox[p]) and has
 //     its own U -- four for the forward pass of a folded up-convolution (the input transform is shared by the four).
 //
-// Why it fits THIS part.  v_mfma_f32_32x32x2_f32 occupies a SIMD's matrix pipe for 64 cycles, and a wave that is alone on its SIMD
-// issues LDS / VALU / VMEM work in that shadow almost for free (measured, profiles/r05_wino_dbg.txt: per 64 MFMAs the 32 fragment
-// reads cost 42 cycles, the 8 U stores 50, the whole input transform + its 16 LDS stores 68, the 24 global loads 150).  So the
-// kernel is ONE wave per SIMD (4 waves per CU) and every wave does everything: a wave owns 32 tiles x 32 output channels for
-// ALL 16 Winograd positions = 16 accumulator tiles = the 256 accumulator registers, which makes the output transform A^T m A
-// lane-local (a lane holds the 16 positions of its (tile, channel) pairs: no LDS round trip, no second kernel, no
-// [16][T][Cout] intermediate in HBM).  What is NOT free is WAITING for a global load: under the load of 256 such blocks a patch
-// load returns after 2 000 - 3 400 cycles, and hipcc's wait insertion is conservative across the loop (the first consumer of a
-// chunk drains EVERY outstanding load).  So a chunk has exactly one drain point, its first slot, and requests everything it
-// will ever request right behind it -- into a second register set for both operands, consumed one chunk later: at the drain
-// the youngest outstanding load is >= 52 MFMA slots (~3 600 cycles) old.  5 724 -> cycles per chunk.
+// Why it fits THIS part.  A wave owns 32 tiles x 32 output channels for ALL 16 Winograd positions = 16 accumulator tiles = the 256
+// accumulator registers, which makes the output transform A^T m A lane-local (a lane holds the 16 positions of its (tile, channel)
+// pairs: no LDS round trip, no second kernel, no [16][T][Cout] intermediate in HBM).  That is ONE wave per SIMD (4 waves per CU),
+// and every wave does everything.  What the side work costs such a wave was measured instruction by instruction
+// (scripts/ubench/issue.hip, profiles/r05_ubench_issue.txt; v_mfma_f32_32x32x2_f32 = 64 pipe cycles): LDS, buffer and scalar
+// instructions issue in the MFMA's shadow for 0 .. 5 cycles until their unit saturates (LDS: 8 cycles per ds_write_b64, 16 per
+// ds_read_b128 and CU; address unit: 8 per buffer_load_dword) -- but a vector-ALU instruction is NOT hidden: a lone one behind an MFMA
+// costs 14 pipe cycles, each further one of a burst 4.3.  So: one request per slot, the stores one per slot, and the input transform
+// as two bursts of 16 packed adds (4 990 -> 4 430 cycles per 4 096-cycle chunk).  Requests go into a second register set for both
+// operands and are consumed one chunk later (hipcc's wait insertion is exact then: the youngest load a wait covers is >= 33 slots old).
 // The transformed weights U = G g G^T come from the re-pack launch that runs once per optimizer step (WeightMap kind 2),
 // stored in exactly the order the LDS stage wants them: a K chunk of U is one contiguous 32 KB run.
 //
@@ -54,7 +53,7 @@ __device__ __forceinline__ f32x4 wn_load4(__amdgpu_buffer_rsrc_t r, int voff, in
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 // two fp32 additions / subtractions in one VALU instruction (hipcc scalarises <2 x float> arithmetic into two v_add_f32 here;
-// the packed form measured 5 724 -> 5 585 cycles per K chunk)
+// the packed form is half the VALU instructions)
 __device__ __forceinline__ f32x2 wn_add(f32x2 a, f32x2 b) {
     f32x2 d;
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
