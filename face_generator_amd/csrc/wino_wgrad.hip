@@ -387,7 +387,8 @@ static int ww_trace_launch(fg_ctx* ctx, const WinoWgradArgs& a_in, dim3 grid, si
 int fg_launch_wino_wgrad(fg_ctx* ctx, const WinoWgradArgs& a) {
     if (a.Npad % 64 || a.Cpad % 64 || a.S < 1 || a.lgTW < 1 || a.lgTH < 0 || a.P < 1 || a.KG < 1 || a.P * a.KG > 4)
         return fg_set_err(ctx, FG_ERR_INVALID, "winograd wgrad: padded channels %% 64, power-of-two tile grid (>= 2 wide), <= 4 units");
-    if (a.x_bytes <= 0 || a.x_bytes >= (long long)FG_OOB || a.d_bytes <= 0 || a.d_bytes >= (long long)FG_OOB)
+    // (the patch descriptor starts 2 pixels in front of X and is that much longer: the out-of-range marker must stay out of range)
+    if (a.x_bytes <= 0 || a.x_bytes + 8LL * a.Cx >= (long long)FG_OOB || a.d_bytes <= 0 || a.d_bytes >= (long long)FG_OOB)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "winograd wgrad: operands must be < 2 GiB per launch");
     const size_t lds = (size_t)(2 * WW_STAGE) * sizeof(float);
     static bool attr_set = false;
