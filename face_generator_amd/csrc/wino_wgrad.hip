@@ -4,20 +4,20 @@
 //
 //   Y = A^T [ U (.) V ] A,  U = G g G^T,  V = B^T d B        (wino.hip)
 //   dL/dU[pos] = sum over tiles of  dM[pos] (.) V[pos],   dM = A dY A^T  (the 2x2 output-gradient block of a tile, 4x4)
-//   dL/dg      = G^T (dL/dU) G                                (wino_wgrad_finish_one in igemm.hip, after the split sums)
+//   dL/dg      = G^T (dL/dU) G                                (wino_wgrad_finish_block in igemm.hip, after the split sums)
 // 16 multiplies per tile and (out, in) pair instead of 36: 2.25 x fewer MFMAs than the tap-by-tap contraction (wgrad_ws_kernel).
 //
 // Shape: per position an [out-channels x tiles] x [tiles x in-channels] contraction, the reduction running over the TILES of the
 // batch.  A block owns 64 out-channels x 64 in-channels of ONE (parity, group) unit for all 16 positions (a wave: 32 x 32 x 16 =
 // the 256 accumulator registers, as in wino_kernel) and a contiguous range of tile chunks (gridDim.y splits); the partial
-// dL/dU of every split goes to HBM and the finish pass (igemm.hip: wino_wgrad_finish_one) sums the splits, applies G^T . G and scatters the 3x3
-// sub-kernel gradients into the reference [O][I][k][k] taps (5x5: four sub-kernels; folded up-convolution: each 5x5 tap collects
+// dL/dU of every split goes to HBM and the finish pass (igemm.hip: wino_wgrad_finish_block) sums the splits, applies G^T . G and
+// scatters the 3x3 sub-kernel gradients into the reference [O][I][k][k] taps (5x5: four sub-kernels; folded up-convolution: each 5x5 tap collects
 // the folded tap it was summed into, one per output parity).
 //
 // K chunk = 8 consecutive tiles; wave m transforms the tile PAIR (2m, 2m + 1) of the chunk for its lane's channel: lane = channel
 // (64 consecutive channels of one pixel = one coalesced 256-byte load), the two tiles of the pair are the two halves of a
 // register pair, so both transforms run as packed adds and a value pair is one ds_write_b64.  All tile arithmetic is
-// wave-uniform (scalar unit); a lane's offset is its channel.  Signs: A = [1 0; 1 1; 1 -1; 0 -1] -- the minus signs of its last
+// wave-uniform (scalar unit); a lane's offset is its channel + the row of its tile pair, re-computed once per chunk.  Signs: A = [1 0; 1 1; 1 -1; 0 -1] -- the minus signs of its last
 // row are left out here (dM'[i][j] = s_i s_j dM[i][j], s = (1, 1, 1, -1)) and applied by the finish kernel.
 // LDS stage: dM'[pos 16][k half 2][out-channel 64][4 tiles] | V[pos 16][k half 2][in-channel 64][4 tiles]  (k = tile in chunk).
 #include "fg_internal.h"
