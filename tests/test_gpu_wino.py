@@ -188,11 +188,16 @@ def _wgrad_both(ctx, x, gy, k, up):
     from face_generator_amd import ops
     d = ctx.device
     out = {}
-    for flags in (FG_FUSE_DEFAULT, FG_FUSE_DEFAULT & ~FG_FUSE_WINOGRAD_WGRAD):
-        ctx.set_fusion(flags)
-        gw, gb = ops.conv2d_backward_weight(nhwc(x, d), nhwc(gy, d), k, upsample2x=bool(up))
-        out[flags] = (gw.cpu().numpy(), gb.cpu().numpy())
-    ctx.set_fusion(FG_FUSE_DEFAULT)
+    math = ctx.get_math()
+    ctx.set_math(0)        # the Winograd weight gradient belongs to the fp32 mode (fg_set_math(6) keeps its own bf16x6 weight gradient)
+    try:
+        for flags in (FG_FUSE_DEFAULT, FG_FUSE_DEFAULT & ~FG_FUSE_WINOGRAD_WGRAD):
+            ctx.set_fusion(flags)
+            gw, gb = ops.conv2d_backward_weight(nhwc(x, d), nhwc(gy, d), k, upsample2x=bool(up))
+            out[flags] = (gw.cpu().numpy(), gb.cpu().numpy())
+    finally:
+        ctx.set_fusion(FG_FUSE_DEFAULT)
+        ctx.set_math(math)
     return out[FG_FUSE_DEFAULT], out[FG_FUSE_DEFAULT & ~FG_FUSE_WINOGRAD_WGRAD]
 
 
@@ -251,11 +256,16 @@ def test_winograd_weight_gradient_is_exact_on_small_integers(ctx, k, up):
     conv.zeroGradParameters()
     conv.accGradParameters(xu, gy)
     d = ctx.device
+    math = ctx.get_math()
     with small_shapes_take_the_winograd_wgrad():
         (gw, gb), (gw0, gb0) = _wgrad_both(ctx, x, gy, k, up)
         assert np.array_equal(gw, conv.gradWeight) and np.array_equal(gb, conv.gradBias)
         assert np.array_equal(gw0, conv.gradWeight) and np.array_equal(gb0, conv.gradBias)
-        gw2, gb2 = ops.conv2d_backward_weight(nhwc(x, d), nhwc(gy, d), k, upsample2x=bool(up), gw=dev(gw, d), gb=dev(gb, d), beta=1.0)
+        ctx.set_math(0)
+        try:
+            gw2, gb2 = ops.conv2d_backward_weight(nhwc(x, d), nhwc(gy, d), k, upsample2x=bool(up), gw=dev(gw, d), gb=dev(gb, d), beta=1.0)
+        finally:
+            ctx.set_math(math)
     assert np.array_equal(gw2.cpu().numpy(), 2 * conv.gradWeight) and np.array_equal(gb2.cpu().numpy(), 2 * conv.gradBias)
 
 
