@@ -230,7 +230,7 @@ int fg_launch_wgrad6(fg_ctx* ctx, const WgradArgs& a, int P, int cfg);
 
 // ---------------------------------------------------------------------------------
 // Winograd-domain weight gradient (wino_wgrad.hip) of a WinoArgs layer:
-//   Part[unit = parity * KG + group][split][pos 16][Npad][Cpad] = sum over the split's tiles of dM'[pos][n] * V[pos][c]
+//   Part[unit = parity * KG + group][split][Npad][Cpad][pos 16] = sum over the split's tiles of dM'[pos][n] * V[pos][c]
 //   (dM' = A' dY A'^T of the tile's 2x2 gradient block with the signs of A's last row left out, V = B^T patch B);
 //   fg_launch_wgrad_finish with WeightMap::wino set sums the splits, applies the signs and G^T . G and scatters the sub-kernel
 //   gradients into the reference taps.  Geometry fields as in WinoArgs (forward orientation); the tile grid must be 2^a x 2^b, b >= 1.

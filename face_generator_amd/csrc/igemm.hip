@@ -1881,7 +1881,7 @@ __device__ __forceinline__ void wgrad_finish_one(const WeightMap& wm, const floa
     float* gw = gradW + ((size_t)o * wm.I + i) * wm.k * wm.k + wi;
     *gw = (beta == 0.f) ? sum : beta * (*gw) + sum;
 }
-// Winograd-domain partials (WeightMap::wino, wino_wgrad.hip): Part[unit][split][pos 16][Npad][Cpad].  One thread per (out, in) pair:
+// Winograd-domain partials (WeightMap::wino, wino_wgrad.hip): Part[unit][split][Npad][Cpad][pos 16].  One thread per (out, in) pair:
 // sum the splits per position, apply the signs wino_wgrad_kernel left out of A's last row (s_i s_j, s = (1, 1, 1, -1)),
 // t = G^T (dL/dU) G, and scatter the sub-kernel gradient into the reference taps -- the exact adjoint of fg_wino_subkernel:
 //   wino 1, kind 0 (3x3): taps = t;   wino 1, kind 1 (folded): tap (dy, dx) collects t_p[fold(py, dy)][fold(px, dx)] of every parity p;
@@ -1907,13 +1907,13 @@ __device__ __forceinline__ void wino_wgrad_finish_block(const WeightMap& wm, con
         float du[16];
 #pragma unroll
         for (int pos = 0; pos < 16; ++pos) du[pos] = 0.f;
-        const float* __restrict__ b = Part + (size_t)u * S * 16 * tile + (size_t)o * Cpad + i;
+        const float4* __restrict__ b = (const float4*)(Part + ((size_t)u * S * tile + (size_t)o * Cpad + i) * 16);
         for (int s = 0; s < S; ++s) {
-            float v[16];
+            float4 v[4];
 #pragma unroll
-            for (int pos = 0; pos < 16; ++pos) v[pos] = b[((size_t)s * 16 + pos) * tile];
+            for (int q = 0; q < 4; ++q) v[q] = b[(size_t)s * tile * 4 + q];
 #pragma unroll
-            for (int pos = 0; pos < 16; ++pos) du[pos] += v[pos];
+            for (int q = 0; q < 4; ++q) { du[4 * q] += v[q].x; du[4 * q + 1] += v[q].y; du[4 * q + 2] += v[q].z; du[4 * q + 3] += v[q].w; }
         }
 #pragma unroll
         for (int pos = 0; pos < 16; ++pos)

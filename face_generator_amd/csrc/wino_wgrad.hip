@@ -60,6 +60,7 @@ __device__ __forceinline__ void ww_body(const WinoWgradArgs& a) {
     const int c0 = blockIdx.y * a.chunks_per_split;
     const int NC = max(0, min(nct, c0 + a.chunks_per_split) - c0);
     const int NCE = (NC + 1) & ~1;
+    if (NC <= 0) return;             // (never: fg_launch_wino_wgrad refuses a split without chunks; keeps the zero accumulators of that path out of scratch)
     unsigned long long* trc = nullptr;
     if (TRACE) {
         if (wid == 0 && a.dbg_trace) trc = a.dbg_trace + ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z)) * 128;
@@ -301,20 +302,24 @@ __device__ __forceinline__ void ww_body(const WinoWgradArgs& a) {
 #undef WW_XFORM_STORE
 #undef WW_CHUNK
 
-    // ---- partial dL/dU' of this split: Part[pg][split][pos][out][in]; lane l holds column (l & 31) = in-channel, rows = out-channels
+    // ---- partial dL/dU' of this split: Part[pg][split][out][in][pos 16] -- the 16 positions of a channel pair are 64 contiguous bytes
+    // (four 16-byte stores per accumulator row here, four 16-byte loads per split in the finish pass).  Lane l holds column (l & 31) =
+    // in-channel; rows = out-channels
     {
         float* outp = a.Part + (((size_t)pg * a.S + blockIdx.y) * 16) * (size_t)a.Npad * a.Cpad;
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_OOB, 0x00020000);
         const int col = tc * 64 + wn * 32 + (lane & 31);
         const int row0 = tn * 64 + wm * 32 + 4 * (lane >> 5);
-        const int pstride = a.Npad * a.Cpad * 4;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + (r & 3) + 8 * (r >> 2);
-            const int vo = (row * a.Cpad + col) * 4;
+            const int vo = (row * a.Cpad + col) * 64;
+            __builtin_amdgcn_sched_barrier(0);           // one accumulator row at a time (16 reads of the accumulator file, 4 stores)
 #pragma unroll
-            for (int p = 0; p < 16; ++p)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[p][r]), orsrc, vo, p * pstride, 0);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc[4 * q][r], acc[4 * q + 1][r], acc[4 * q + 2][r], acc[4 * q + 3][r]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v), orsrc, vo, q * 16, 0);
+            }
         }
     }
     // ---- bias-gradient partial: the four waves' sums of this block's channels (only the blocks of in-channel block 0, group 0)
@@ -385,6 +390,8 @@ static int ww_trace_launch(fg_ctx* ctx, const WinoWgradArgs& a_in, dim3 grid, si
 }
 
 int fg_launch_wino_wgrad(fg_ctx* ctx, const WinoWgradArgs& a) {
+    if (a.chunks_per_split < 1 || (long long)(a.S - 1) * a.chunks_per_split >= (a.T + 7) / 8)
+        return fg_set_err(ctx, FG_ERR_INVALID, "winograd wgrad: a split without chunks (S = %d x %d chunks, %d tiles)", a.S, a.chunks_per_split, a.T);
     if (a.Npad % 64 || a.Cpad % 64 || a.S < 1 || a.lgTW < 1 || a.lgTH < 0 || a.P < 1 || a.KG < 1 || a.P * a.KG > 4)
         return fg_set_err(ctx, FG_ERR_INVALID, "winograd wgrad: padded channels %% 64, power-of-two tile grid (>= 2 wide), <= 4 units");
     // (the patch descriptor starts 2 pixels in front of X and is that much longer: the out-of-range marker must stay out of range)
