@@ -19,13 +19,22 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, measure=False):
+    """measure=True builds libfacegen_hip_measure.so (objects csrc/*.m.o) with -DFG_MEASURE: the s_memtime trace kernels, their
+    wrong-result DBG variants and the FG_*_TRACE / FG_DEBUG_NOSTORE / FG_THIN_TPW|NT|DBG switches exist ONLY there
+    (FACEGEN_HIP_LIB points the binding at it; scripts/gpu.sh trace-* modes do).  The default library has none of them."""
+    if measure:
+        return _build(force, verbose, ".m.o", LIB.replace(".so", "_measure.so"), FLAGS + ["-DFG_MEASURE"])
+    return _build(force, verbose, ".o", LIB, FLAGS)
+
+
+def _build(force, verbose, osuf, LIB, FLAGS):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "facegen_hip.h"))
     objs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", osuf))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
@@ -41,4 +50,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, measure="--measure" in sys.argv)

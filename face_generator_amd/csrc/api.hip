@@ -9,6 +9,15 @@
 #include <stdlib.h>
 
 static char g_err[512] = "";
+bool fg_attr_first(fg_ctx* ctx, const void* key) {
+    for (const void* k : ctx->attr_keys) if (k == key) return false;
+    ctx->attr_keys.push_back(key);
+    return true;
+}
+bool g_fg_launch_log = false;
+void fg_log_launch_line(const char* name, dim3 grid, dim3 block, size_t lds) {
+    fprintf(stderr, "fg-launch %s grid=%u,%u,%u block=%u lds=%zu\n", name, grid.x, grid.y, grid.z, block.x, lds);
+}
 bool g_fg_dry = false;      // fg_internal.h: a planning-only context exists in this process
 
 int fg_set_err(fg_ctx* c, int code, const char* fmt, ...) {
@@ -54,6 +63,8 @@ static int g_dry_ctx = 0;
 
 int fg_ctx_create(int device, fg_ctx** out) {
     if (!out) return fg_set_err(nullptr, FG_ERR_INVALID, "fg_ctx_create: null out");
+    if (const char* m = getenv("FG_LAUNCH_LOG")) g_fg_launch_log = atoi(m) != 0;
+    fg_plan_env_init();
     if (device == FG_DEVICE_NONE) {
         if (g_real_ctx) return fg_set_err(nullptr, FG_ERR_INVALID, "fg_ctx_create: a planning-only context cannot join a process that holds a device context");
         fg_ctx* c = new fg_ctx();
@@ -114,6 +125,11 @@ int fg_set_fusion(fg_ctx* ctx, int flags) {
     return FG_OK;
 }
 int fg_get_fusion(fg_ctx* ctx) { return ctx ? ctx->fusion : -1; }
+int fg_test_set_wino_wgrad_thresholds(fg_ctx* ctx, long long min_chunks, long long min_blocks) {
+    if (!ctx) return FG_ERR_INVALID;
+    fg_plan_set_wino_wgrad_thresholds(min_chunks, min_blocks);
+    return FG_OK;
+}
 
 // one wave: sleeps in 4096-cycle naps until `ticks` of the 100 MHz counter have passed (bounded by max_naps)
 __global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, unsigned long long ticks, long long max_naps) {

@@ -20,6 +20,9 @@ struct ConvGeom {
     int o_c, o_hw, i_c, i_hw;
 };
 
+// where the Winograd-domain weight gradient is taken (chunks per block, blocks per launch): process-wide planning thresholds
+void fg_plan_env_init();                 // FG_WINO_WGRAD_MIN_CHUNKS / _MIN_BLOCKS, read ONCE (first fg_ctx_create)
+void fg_plan_set_wino_wgrad_thresholds(long long min_chunks, long long min_blocks);   // <= 0: the defaults (24, 192)
 void fg_geom_weightmap(const ConvGeom& g, WeightMap* wm);
 // the map the PACKS of the layer are built with: fg_geom_weightmap, or kind 2 (16 Winograd positions) for a g.wino layer.
 // (The weight gradient always uses fg_geom_weightmap: it is computed tap by tap whatever the forward algorithm.)

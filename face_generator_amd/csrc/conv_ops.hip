@@ -148,6 +148,18 @@ static int choose_wino_splits(long long T, int Npad, int C) {      // Npad: all 
 // two each way, both channel counts fill whole 64-blocks and every block still reduces over >= 24 chunks with >= 3/4 of the chip
 // busy (D's 64 -> 128 ... 256 -> 512 layers on 16x16 ... 4x4 maps do not: 2 ... 32 channel blocks; they keep the tap-by-tap
 // kernels).  false = not taken.
+static long long g_ww_min_chunks = 24, g_ww_min_blocks = 192;
+void fg_plan_env_init() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    if (const char* e = getenv("FG_WINO_WGRAD_MIN_CHUNKS")) g_ww_min_chunks = atoll(e) > 0 ? atoll(e) : 1;
+    if (const char* e = getenv("FG_WINO_WGRAD_MIN_BLOCKS")) g_ww_min_blocks = atoll(e);
+}
+void fg_plan_set_wino_wgrad_thresholds(long long min_chunks, long long min_blocks) {
+    g_ww_min_chunks = min_chunks > 0 ? min_chunks : 24;
+    g_ww_min_blocks = min_blocks > 0 ? min_blocks : 192;
+}
 static bool choose_wino_wgrad(const ConvGeom& g, int* S, int* cps) {
     if (!g.wino || g.stride == 2 || (g.Cout % 64) || (g.Cin % 64)) return false;
     const int TH = g.H / 2, TW = g.W / 2;
@@ -156,11 +168,9 @@ static bool choose_wino_wgrad(const ConvGeom& g, int* S, int* cps) {
     int P, KG; fg_wino_pack_shape(wm.kind, g.wino, 0, &P, &KG);
     const long long T = (long long)g.B * TH * TW, nct = (T + 7) / 8;
     const long long base = (long long)(g.Cout / 64) * (g.Cin / 64) * P * KG;
-    // (measurement / test knobs, read per call so that a test can reach the small-shape corners: FG_WINO_WGRAD_MIN_CHUNKS,
-    // FG_WINO_WGRAD_MIN_BLOCKS)
-    long long min_chunks = 24, min_blocks = 192;
-    if (const char* e = getenv("FG_WINO_WGRAD_MIN_CHUNKS")) min_chunks = atoll(e) > 0 ? atoll(e) : 1;
-    if (const char* e = getenv("FG_WINO_WGRAD_MIN_BLOCKS")) min_blocks = atoll(e);
+    // (planning thresholds of the process: the environment is read once, at the first fg_ctx_create; the parity tests reach the
+    // small-shape corners through fg_test_set_wino_wgrad_thresholds)
+    const long long min_chunks = g_ww_min_chunks, min_blocks = g_ww_min_blocks;
     long long s = base >= 256 ? 1 : 256 / base;
     if (s > nct / min_chunks) s = nct / min_chunks;
     if (s < 1 || base * s < min_blocks) return false;
@@ -343,7 +353,8 @@ static long long scratch_for_math(const ConvGeom& g, int math) {
         const int sf = choose_wino_splits(M / 4, wf.P * wf.Npad, wf.KG * wf.C), sb = choose_wino_splits(M / 4, wb.P * wb.Npad, wb.KG * wb.C);
         const long long nf = sf > 1 ? (long long)sf * outM * g.Cout : 0, nb = sb > 1 ? (long long)sb * M * g.Cin : 0;
         need = nf > nb ? nf : nb;
-        if (need < 256LL * 64 * 4 * 64 * (g.fold ? 4 : 1) + 64) need = 256LL * 64 * 4 * 64 * (g.fold ? 4 : 1) + 64;
+        // (256 blocks x 64 tiles x 4 outputs x 64 channels: the block count already includes the four parities of a folded layer)
+        if (need < 256LL * 64 * 4 * 64 + 64) need = 256LL * 64 * 4 * 64 + 64;
     } else {
     choose_igemm(M, rf, wm.G * (cf / 32), wm.P, math, &tile, &splits);
     {

@@ -33,6 +33,7 @@ struct fg_ctx {
     char err[512];
     int sm_count;
     int math = 0;        // 0: native fp32 MFMA; 6: fp32 emulated with six split-bf16 plane products (fg_set_math)
+    std::vector<const void*> attr_keys;   // fg_attr_first: call sites whose kernels had their dynamic-LDS limit raised on THIS context's device
     int fusion = FG_FUSE_DEFAULT;   // fg_set_fusion: which optional kernel fusions / variants are on (default from the environment)
     // optional per-launch HIP-event timing of the contraction kernels (bench.py roofline leg)
     bool prof = false;
@@ -43,6 +44,9 @@ struct fg_ctx {
     hipStream_t clk_stream = nullptr;
     unsigned long long* clk_dev = nullptr;
 };
+// true the first time `key` (the address of a call site's static) is seen on this context: hipFuncSetAttribute is per device, so
+// the "done" flag belongs to the context, not to a process-wide static (one host thread may drive several devices)
+bool fg_attr_first(fg_ctx* ctx, const void* key);
 const char* fg_intern(fg_ctx* ctx, const char* s);  // stable pointer for a profile label
 // RAII helper: records an event pair around one launch when profiling is on
 struct FgProfScope {
@@ -58,9 +62,18 @@ int fg_set_err(fg_ctx* c, int code, const char* fmt, ...);
 // sync-BN pauses, bucket boundaries, the order / size / stream of every collective -- runs unchanged; "device" buffers are
 // host allocations nobody dereferences.  A process is either planning-only or real, never both.
 extern bool g_fg_dry;
+// FG_LAUNCH_LOG=1 (read at fg_ctx_create): one stderr line per kernel launch -- name, grid, block, dynamic LDS.  Works in planning-only
+// mode too, which makes the dispatch list of a whole training iteration readable on a machine without a GPU.
+extern bool g_fg_launch_log;
+void fg_log_launch_line(const char* name, dim3 grid, dim3 block, size_t lds);
+template <typename... A>
+static inline void fg_log_launch(const char* name, dim3 grid, dim3 block, size_t lds, hipStream_t, A&&...) { fg_log_launch_line(name, grid, block, lds); }
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernelName, ...)                                            \
-    do { if (!g_fg_dry) hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__); } while (0)
+    do {                                                                               \
+        if (g_fg_launch_log) fg_log_launch(#kernelName, __VA_ARGS__);                  \
+        if (!g_fg_dry) hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);          \
+    } while (0)
 #define FG_HIP(ctx, call)                                                              \
     do {                                                                               \
         if (g_fg_dry) break;                                                           \

@@ -65,10 +65,15 @@ __device__ __forceinline__ void fg_store_acc_tile(__amdgpu_buffer_rsrc_t orsrc, 
 // (act_x: 16 loads of x per tile in flight, then 16 stores; the wave's share of the slope gradient goes to
 // act_part[part_idx]).  EPI selects the variant at compile time (0 plain, 1 act_y, 2 act_x): the kernels without a fused
 // PReLU keep their register allocation.
+#ifdef FG_MEASURE
+#define FG_STORE_RANGE(a) ((a).dbg_nostore ? 0 : FG_OOB)     // FG_DEBUG_NOSTORE=1: the stores go to a zero-sized buffer (results are WRONG)
+#else
+#define FG_STORE_RANGE(a) FG_OOB
+#endif
 template <int MI, int NI, int EPI>
 __device__ __forceinline__ void fg_epilogue(const IgemmArgs& a, float* outp, const int* rowoff, int row_base, int col_base,
                                             const f32x16 (&acc)[MI][NI], int lane, int part_idx) {
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, a.dbg_nostore ? 0 : FG_OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, FG_STORE_RANGE(a), 0x00020000);
     if constexpr (EPI == 2) {
         const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.act_x, 0, FG_OOB, 0x00020000);
         const float sl = a.act_slope[0];
@@ -574,6 +579,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_act_kernel(const IgemmArgs a)
 // loader instructions per MFMA was measured first and changed nothing: 118.2 vs 118.5 TFLOP/s -- these layers are not issue-bound.)
 template <int EPI>
 __global__ __launch_bounds__(512, 4) void igemm_ws64x3_kernel(const IgemmArgs a) { igemm_ws_body<64, EPI, WS_BM, 3>(a); }
+#ifdef FG_MEASURE       // measurement build only (libfacegen_hip_measure.so): trace kernels, their calibration and launcher
 template <int BN>
 __global__ __launch_bounds__(512, 2) void igemm_ws_trace_kernel(const IgemmArgs a) { igemm_ws_body<BN, 0, WS_BM, (BN == 64 ? 3 : WS_NS), 1>(a); }
 // FG_WS_TRACE=1 (measurement only): EPI-0 launches run the trace kernel; the per-block s_memtime rows are copied back after the
@@ -687,6 +693,7 @@ static bool fg_ws_trace_on() {
     if (on < 0) { const char* e = getenv("FG_WS_TRACE"); on = e ? atoi(e) : 0; }
     return on != 0;
 }
+#endif   // FG_MEASURE
 static bool fg_ws64_ns3() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("FG_IGEMM_WS64_NS3"); on = e ? atoi(e) : 1; }
@@ -694,17 +701,18 @@ static bool fg_ws64_ns3() {
 }
 static int launch_igemm_ws64x3(fg_ctx* ctx, const IgemmArgs& a, int P) {
     const size_t lds = (size_t)(3 * (WS_BM + 64) * WS_LDK + WS_BM) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static char attr_key;                      // one key per call site (and template instance); the flag lives in the context
+    if (fg_attr_first(ctx, &attr_key)) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws64x3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / 64) * P, a.splits, 1);
     const double exec = 2.0 * (double)grid.x * WS_BM * 64 * (double)a.G * a.Kpad;
     const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
+#ifdef FG_MEASURE
     if (fg_ws_trace_on() && epi == 0 && !a.stats_part) return fg_ws_trace_launch(ctx, a, 64, grid, lds);
+#endif
     char label[96];
     snprintf(label, sizeof(label), "igemm_ws64x3_kernel<%d>/%s", epi, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);
@@ -718,17 +726,18 @@ template <int BN>
 static int launch_igemm_ws(fg_ctx* ctx, const IgemmArgs& a, int P) {
     if (BN == 64 && fg_ws64_ns3()) return launch_igemm_ws64x3(ctx, a, P);
     const size_t lds = (size_t)(WS_NS * (WS_BM + BN) * WS_LDK + WS_BM) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static char attr_key;                      // one key per call site (and template instance); the flag lives in the context
+    if (fg_attr_first(ctx, &attr_key)) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_act_kernel<BN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws_act_kernel<BN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / BN) * P, a.splits, 1);
     const double exec = 2.0 * (double)grid.x * WS_BM * BN * (double)a.G * a.Kpad;
     const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
+#ifdef FG_MEASURE
     if (BN == 128 && fg_ws_trace_on() && epi == 0 && !a.stats_part) return fg_ws_trace_launch(ctx, a, 128, grid, lds);
+#endif
     char label[96];
     if (epi) snprintf(label, sizeof(label), "igemm_ws_act_kernel<%d,%d>/%s", BN, epi, a.tag ? a.tag : "?");
     else snprintf(label, sizeof(label), "igemm_ws_kernel<%d>/%s", BN, a.tag ? a.tag : "?");
@@ -962,10 +971,9 @@ __global__ __launch_bounds__(512, 2) void igemm_ws6_kernel(const IgemmArgs a) {
 template <int BN>
 static int launch_igemm_ws6(fg_ctx* ctx, const IgemmArgs& a, int P) {
     const size_t lds = (size_t)W6_NS * (WS_BM + BN) * W6_ROWB + WS_BM * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static char attr_key;                      // one key per call site (and template instance); the flag lives in the context
+    if (fg_attr_first(ctx, &attr_key)) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_ws6_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     if (a.a_bytes / 4 * 6 >= (long long)FG_OOB) return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "igemm bf16x6: A planes must be < 2 GiB");
     dim3 grid(fg_cdiv(a.M, WS_BM) * (a.Npad / BN) * P, a.splits, 1);
@@ -1018,15 +1026,14 @@ int fg_launch_split_planes(fg_ctx* ctx, const float* src, long long rows, int C,
 template <int BM, int BN, int BK>
 static int launch_igemm_t(fg_ctx* ctx, const IgemmArgs& a, int P) {
     const size_t lds = (size_t)(2 * (BM + BN) * (BK + 4) + BM) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static char attr_key;                      // one key per call site (and template instance); the flag lives in the context
+    if (fg_attr_first(ctx, &attr_key)) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_kernel<BM, BN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_act_kernel<BM, BN, BK, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)igemm_act_kernel<BM, BN, BK, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
-        attr_set = true;
     }
     dim3 grid(fg_cdiv(a.M, BM) * (a.Npad / BN) * P, a.splits, 1);
     // executed FLOPs: every tile runs the full padded contraction
@@ -1057,11 +1064,15 @@ long long fg_igemm_blocks(const IgemmArgs& a, int P, int tile) {
 int fg_launch_igemm(fg_ctx* ctx, const IgemmArgs& a_in, int P, int tile) {
     IgemmArgs a = a_in;
     a.P = P;
-    {   // measurement only: how much of a launch is its output stores?
+#ifdef FG_MEASURE
+    {   // measurement build only: how much of a launch is its output stores?
         static int ns = -1;
         if (ns < 0) { const char* e = getenv("FG_DEBUG_NOSTORE"); ns = e ? atoi(e) : 0; }
         a.dbg_nostore = ns;
     }
+#else
+    a.dbg_nostore = 0;
+#endif
     if ((a.act_y || a.act_x) && (a.splits != 1 || a.A6 || !a.act_slope || (a.act_y && a.act_x)))
         return fg_set_err(ctx, FG_ERR_INVALID, "igemm: a fused PReLU needs splits == 1, the fp32 path and its slope");
     if (a.Ca % 4 != 0 || a.Kpad % 32 != 0) return fg_set_err(ctx, FG_ERR_INVALID, "igemm: Ca %% 4 / Kpad %% 32");
@@ -1458,11 +1469,10 @@ __global__ __launch_bounds__(256, OCC) void wgrad_kernel(const WgradArgs a) {
 template <int BT, int BK, int OCC>
 static int launch_wgrad_t(fg_ctx* ctx, const WgradArgs& a, int P) {
     const size_t lds = (size_t)(4 * BK * BT) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static char attr_key;                      // one key per call site (and template instance); the flag lives in the context
+    if (fg_attr_first(ctx, &attr_key)) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_kernel<BT, BK, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds));
-        attr_set = true;
     }
     dim3 grid((a.Npad / BT) * (a.Cpad / BT), a.S, P * a.G);
     const double exec = 2.0 * (double)a.Npad * a.Cpad * (double)P * a.G * (double)a.S * fg_round_up(a.m_per_split, 32);
@@ -1881,6 +1891,48 @@ __device__ __forceinline__ void wgrad_finish_one(const WeightMap& wm, const floa
     float* gw = gradW + ((size_t)o * wm.I + i) * wm.k * wm.k + wi;
     *gw = (beta == 0.f) ? sum : beta * (*gw) + sum;
 }
+// The same reduction for a k x k layer, one block per (out-channel, 128 in-channels) and ALL taps: a thread sums the taps of its
+// channel pair one after the other (each sum in wgrad_finish_one's order: bit-identical), the block then writes the
+// [in-channel][tap] run of the reference layout contiguously through LDS.  (One block per tap wrote one word per 36- / 100-byte
+// stride: every line of the gradient was touched by k*k blocks -- 39 us for D's 11 MB, round 5.)  k*k <= 25 (the LDS patch).
+__host__ __device__ static inline bool fg_finish_all_taps(const WeightMap& wm) { return !wm.wino && wm.k > 1 && wm.k * wm.k <= 25; }
+__device__ __forceinline__ void wgrad_finish_taps(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
+                                                  float beta, float* __restrict__ gradW, int bx, int po, float* sh) {
+    const int kk = wm.k * wm.k;
+    const int pi = bx * 128 + (int)threadIdx.x;
+    const size_t tile = (size_t)Npad * Cpad;
+    const size_t e = (size_t)po * Cpad + pi;
+    if (pi < wm.I && po < wm.O) {
+        for (int wi = 0; wi < kk; ++wi) {
+            const int dy = wi / wm.k, dx = wi - dy * wm.k;
+            float sum = 0.f;
+            auto run = [&](const float* __restrict__ b) {
+                int s = 0;
+                for (; s + 4 <= S; s += 4) {
+                    const float v0 = b[(size_t)s * tile], v1 = b[(size_t)(s + 1) * tile], v2 = b[(size_t)(s + 2) * tile], v3 = b[(size_t)(s + 3) * tile];
+                    sum += v0; sum += v1; sum += v2; sum += v3;
+                }
+                for (; s < S; ++s) sum += b[(size_t)s * tile];
+            };
+            if (wm.kind == 0) {
+                run(Part + (size_t)wi * S * tile + e);
+            } else {
+                for (int p = 0; p < 4; ++p) {
+                    const int ty = dev_fold_r(p >> 1, dy, wm.pad) - wm.rmin;
+                    const int tx = dev_fold_r(p & 1, dx, wm.pad) - wm.rmin;
+                    const int pg = p * wm.G + ty * wm.T + tx;
+                    run(Part + (size_t)pg * S * tile + e);
+                }
+            }
+            sh[(int)threadIdx.x * kk + wi] = sum;
+        }
+    }
+    __syncthreads();
+    if (po >= wm.O) return;
+    const int nI = min(128, wm.I - bx * 128);
+    float* __restrict__ base = gradW + ((size_t)po * wm.I + (size_t)bx * 128) * kk;
+    for (int idx = (int)threadIdx.x; idx < nI * kk; idx += 128) base[idx] = (beta == 0.f) ? sh[idx] : beta * base[idx] + sh[idx];
+}
 // Winograd-domain partials (WeightMap::wino, wino_wgrad.hip): Part[unit][split][Npad][Cpad][pos 16].  One thread per (out, in) pair:
 // sum the splits per position, apply the signs wino_wgrad_kernel left out of A's last row (s_i s_j, s = (1, 1, 1, -1)),
 // t = G^T (dL/dU) G, and scatter the sub-kernel gradient into the reference taps -- the exact adjoint of fg_wino_subkernel:
@@ -2025,6 +2077,7 @@ __global__ __launch_bounds__(128) void wgrad_finish_jobs_kernel(const FgWFinishB
     const int bx = (int)(l % jb.ib); l /= jb.ib;
     const int po = (int)(l % jb.wm.O), wi = (int)(l / jb.wm.O);
     if (jb.wm.wino) { wino_wgrad_finish_any(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx, po, wsh); return; }
+    if (fg_finish_all_taps(jb.wm)) { wgrad_finish_taps(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx, po, wsh); return; }
     wgrad_finish_one(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx * 128 + (int)threadIdx.x, po, wi);
 }
 int fg_launch_wgrad_finish_jobs(fg_ctx* ctx, const FgWFinishJob* jobs, int n, long long blocks) {
@@ -2042,7 +2095,7 @@ bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
     const bool brick = wm.kind == 0 && wm.k == 1 && wm.i_hw > 1 && wm.i_c > 0;     // Linear behind a View: 32 x 32 patches (ib = -1)
     const long long nb = brick ? (long long)wm.O * fg_cdiv(wm.i_c, 32) * fg_cdiv(wm.i_hw, 32)
                                : (wm.wino ? (long long)fg_cdiv(wm.I, fg_wino_finish_tpu(wm)) * wm.O       // (Winograd partials: wino_wgrad_finish_block)
-                                          : (long long)fg_cdiv(wm.I, 128) * wm.O * wm.k * wm.k);
+                                          : (long long)fg_cdiv(wm.I, 128) * wm.O * (fg_finish_all_taps(wm) ? 1 : wm.k * wm.k));
     if (d->wblocks + nb > 0x7fffffffLL) return false;
     FgWFinishJob& j = d->wjobs[d->wn++];
     j.wm = wm; j.part = Part; j.gradW = gradW; j.S = S; j.Npad = Npad; j.Cpad = Cpad; j.ib = brick ? -1 : fg_cdiv(wm.I, wm.wino ? fg_wino_finish_tpu(wm) : 128); j.beta = beta;
@@ -2056,12 +2109,13 @@ __global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict_
     // x: packed in-channel (coalesced partial reads), y: packed out-channel, z: tap dy*k+dx
     __shared__ float wsh[FG_WINO_FINISH_LDS];
     if (wm.wino) { wino_wgrad_finish_any(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x, blockIdx.y, wsh); return; }
+    if (fg_finish_all_taps(wm)) { wgrad_finish_taps(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x, blockIdx.y, wsh); return; }
     wgrad_finish_one(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, blockIdx.z);
 }
 int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,
                            float* gradW) {
     if (wm.wino && wm.k != 3 && wm.k != 5) return fg_set_err(ctx, FG_ERR_INVALID, "winograd weight-gradient finish: k = %d", wm.k);
-    dim3 grid(fg_cdiv(wm.I, wm.wino ? fg_wino_finish_tpu(wm) : 128), wm.O, wm.wino ? 1 : wm.k * wm.k);
+    dim3 grid(fg_cdiv(wm.I, wm.wino ? fg_wino_finish_tpu(wm) : 128), wm.O, (wm.wino || fg_finish_all_taps(wm)) ? 1 : wm.k * wm.k);
     hipLaunchKernelGGL(wgrad_finish_kernel, grid, dim3(128), 0, ctx->stream, wm, Part, S, Npad, Cpad, beta, gradW);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
@@ -2311,12 +2365,11 @@ int fg_wgrad_ws_bias_rows(const WgradArgs& a, int cfg) { return a.G * (a.Cpad / 
 int fg_launch_wgrad_ws(fg_ctx* ctx, const WgradArgs& a, int P, int cfg) {
     const int RTd = cfg == 0 ? 256 : 128, QTx = cfg == 0 ? 128 : (cfg == 1 ? 256 : 64);
     const size_t lds = cfg == 2 ? (size_t)3 * 64 * (128 + 64) * sizeof(float) : (size_t)3 * 16 * (256 + 128) * sizeof(float);
-    static bool attr_set[3] = {false, false, false};
-    if (!attr_set[cfg]) {
+    static char attr_key[3];
+    if (fg_attr_first(ctx, &attr_key[cfg])) {
         if (cfg == 0) FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         else if (cfg == 1) FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         else FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws_kernel<0, 128, 64, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set[cfg] = true;
     }
     if ((a.Nd % RTd) || (a.Cx % QTx) || a.Npad != a.Nd || a.Cpad != a.Cx)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad_ws: %d x %d channels do not tile %d x %d", a.Nd, a.Cx, RTd, QTx);
@@ -2514,10 +2567,9 @@ template <int MI, int NI>
 static int launch_wgrad6_t(fg_ctx* ctx, const WgradArgs& a, int P) {
     constexpr int RT = MI * 64, QT = NI * 64;
     const size_t lds = (size_t)3 * 16 * ((RT / 16 * 96 + 64) + (QT / 16 * 96 + 64));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static char attr_key;                      // one key per call site (and template instance); the flag lives in the context
+    if (fg_attr_first(ctx, &attr_key)) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)wgrad_ws6_kernel<MI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     if ((a.Nd % RT) || (a.Cx % QT) || a.Npad != a.Nd || a.Cpad != a.Cx)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "wgrad bf16x6: %d x %d channels do not tile %d x %d", a.Nd, a.Cx, RT, QT);

@@ -671,16 +671,18 @@ int fg_launch_thin_in_conv(fg_ctx* ctx, const float* in, const float* Wp, const 
         for (int q = 0; q < 15; ++q) { if ((1 << q) == H) lgH = q; if ((1 << q) == W) lgW = q; }
         // tiles per wave: every wave first fetches its 2 x 14 weight fragments, so one tile per wave is all set-up latency
         // (1 -> 4 tiles per wave with the next tile's gather in flight: 17.6 -> 15.5 us for the 33 / 67 MB outputs)
+#ifdef FG_MEASURE       // measurement build only: tiles per wave, non-temporal stores, and the (wrong-result) DBG variants
         static int tpw_env = -1, nt_env = -1;
         if (tpw_env < 0) { const char* e = getenv("FG_THIN_TPW"); tpw_env = e ? atoi(e) : 0; }
         if (nt_env < 0) {
             const char* e = getenv("FG_THIN_NT"); nt_env = e ? (atoi(e) & 1) : 0;
-#ifdef FG_MEASURE
-            const char* dbg = getenv("FG_THIN_DBG"); if (dbg) nt_env |= (atoi(dbg) & 3) << 1;      // measurement builds only: results are wrong
-#endif
+            const char* dbg = getenv("FG_THIN_DBG"); if (dbg) nt_env |= (atoi(dbg) & 3) << 1;
         }
         const int tpw = tpw_env > 0 ? (tpw_env > 16 ? 16 : tpw_env) : 4;
         const int nt_store = nt_env;
+#else
+        const int tpw = 4, nt_store = 0;
+#endif
         int nb = fg_cdiv(fg_cdiv(npix, 32), 4 * tpw);
         if (nb > 2048) nb = 2048;
         if (nb < 1) nb = 1;

@@ -425,6 +425,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs& a) {
 }
 template <int EPI>
 __global__ __launch_bounds__(256) void wino_kernel(const WinoArgs a) { wino_body<EPI, 0>(a); }
+#ifdef FG_MEASURE       // measurement build only (libfacegen_hip_measure.so, build.py): the default library has no trace / DBG kernels
 template <int DBG>
 __global__ __launch_bounds__(256) void wino_trace_kernel(const WinoArgs a) { wino_body<0, 1, DBG>(a); }
 // FG_WINO_TRACE=2: s_memtime every 8 MFMA slots of the first 14 chunks -> dbg_trace[block][8 + 8 chunk + slot / 8]
@@ -498,6 +499,7 @@ static int fg_wino_trace_launch(fg_ctx* ctx, const WinoArgs& a_in, dim3 grid, si
     }
     return FG_OK;
 }
+#endif   // FG_MEASURE
 
 long long fg_wino_blocks(const WinoArgs& a) { return (long long)fg_cdiv(a.T, 64) * (a.Npad / 64) * a.P; }
 
@@ -510,21 +512,22 @@ int fg_launch_wino(fg_ctx* ctx, const WinoArgs& a) {
     if (a.x_bytes <= 0 || a.x_bytes >= (long long)FG_OOB || (long long)a.B * a.Ho * a.Wo * a.N * 4 >= (long long)FG_OOB)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "winograd: operands must be < 2 GiB per launch");
     const size_t lds = (size_t)(2 * WN_STAGE + 64) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static char attr_key;
+    if (fg_attr_first(ctx, &attr_key)) {                // per context = per device (one host thread may drive several devices)
         FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     dim3 grid((unsigned)fg_wino_blocks(a), a.splits, 1);
     const double exec = 2.0 * (double)grid.x * 64 * 64 * 16.0 * a.C * a.KG;       // MFMA FLOPs issued: 16 positions, every tile padded to 64 x 64
     const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
+#ifdef FG_MEASURE
     {
         static int tr = -1;
         if (tr < 0) { const char* e = getenv("FG_WINO_TRACE"); tr = e ? atoi(e) : 0; }
         if (tr && epi == 0 && !a.stats_part) return fg_wino_trace_launch(ctx, a, grid, lds);
     }
+#endif
     char label[96];
     snprintf(label, sizeof(label), "wino_kernel<%d>/%s", epi, a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);

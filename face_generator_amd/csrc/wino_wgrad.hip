@@ -340,6 +340,7 @@ __device__ __forceinline__ void ww_body(const WinoWgradArgs& a) {
 #undef WW_STAMP
 }
 __global__ __launch_bounds__(256) void wino_wgrad_kernel(const WinoWgradArgs a) { ww_body<0>(a); }
+#ifdef FG_MEASURE       // measurement build only (libfacegen_hip_measure.so)
 template <int TRACE>
 __global__ __launch_bounds__(256) void wino_wgrad_trace_kernel(const WinoWgradArgs a) { ww_body<TRACE>(a); }
 
@@ -388,6 +389,7 @@ static int ww_trace_launch(fg_ctx* ctx, const WinoWgradArgs& a_in, dim3 grid, si
     }
     return FG_OK;
 }
+#endif   // FG_MEASURE
 
 int fg_launch_wino_wgrad(fg_ctx* ctx, const WinoWgradArgs& a) {
     if (a.chunks_per_split < 1 || (long long)(a.S - 1) * a.chunks_per_split >= (a.T + 7) / 8)
@@ -398,18 +400,19 @@ int fg_launch_wino_wgrad(fg_ctx* ctx, const WinoWgradArgs& a) {
     if (a.x_bytes <= 0 || a.x_bytes + 8LL * a.Cx >= (long long)FG_OOB || a.d_bytes <= 0 || a.d_bytes >= (long long)FG_OOB)
         return fg_set_err(ctx, FG_ERR_UNSUPPORTED, "winograd wgrad: operands must be < 2 GiB per launch");
     const size_t lds = (size_t)(2 * WW_STAGE) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static char attr_key;
+    if (fg_attr_first(ctx, &attr_key)) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     dim3 grid((a.Npad / 64) * (a.Cpad / 64), a.S, a.P * a.KG);
     const double exec = 2.0 * (double)grid.x * grid.z * 64 * 64 * 16.0 * 8.0 * fg_cdiv(a.T, 8);
+#ifdef FG_MEASURE
     {
         static int tr = -1;
         if (tr < 0) { const char* e = getenv("FG_WINO_WGRAD_TRACE"); tr = e ? atoi(e) : 0; }
         if (tr) return ww_trace_launch(ctx, a, grid, lds, tr);
     }
+#endif
     char label[96];
     snprintf(label, sizeof(label), "wino_wgrad_kernel/%s", a.tag ? a.tag : "?");
     FgProfScope prof(ctx, fg_intern(ctx, label), a.alg_flops, exec, 0.0);

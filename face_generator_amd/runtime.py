@@ -179,11 +179,15 @@ class DeviceNet:
         # not rely on the default: S.set_dist / S.seed re-key every net from OPT.seed and the rank (state.py), which is also what
         # makes the masks of a resumed run repeat.
         import zlib
-        crc = zlib.crc32(repr(([tuple(l) for l in self.layers], tuple(in_dims))).encode()) & 0xFFFFFF
+        crc = zlib.crc32(repr(([tuple(l) for l in self.layers], tuple(in_dims))).encode()) & 0xFFFFFFFF
         ordinal = DeviceNet._count_by_structure.get(crc, 0) + 1
         DeviceNet._count_by_structure[crc] = ordinal
         DeviceNet._count += 1
-        self.mask_seed, self.mask_offset = (0x4D41534B << 32) + (crc << 8) + (ordinal & 0xFF), 0
+        # 16-bit tag | the full 32-bit crc | 16-bit ordinal (8 bits wrapped at the 257th net of one structure and the
+        # 1st and 257th then shared a Philox stream); past 65 535 nets of one structure the caller has to key them itself
+        if ordinal > 0xFFFF:
+            raise FgError("more than 65535 nets of one structure in this process: assign net.mask_seed explicitly (state.S.seed does)")
+        self.mask_seed, self.mask_offset = (0x4D4B << 48) + (crc << 16) + ordinal, 0
         self._masks = None
         self._batch = 0
         self._x = None

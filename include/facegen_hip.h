@@ -45,7 +45,12 @@ enum {
  * relative); measured more accurate than mode 0 against fp64 and ~1.7x faster.  Domain: finite operands below 2^127 in
  * magnitude (an infinity, or a value that rounds to the bf16 infinity, splits into inf - inf = NaN where mode 0 would
  * propagate inf); operands below 2^-110 lose their low plane to underflow (relative error up to 2^-16 on those).  Replaces nothing in the reference (its
- * cudnn backend picks algorithms internally, models.lua:1-2); exposed so parity can be run in both modes. */
+ * cudnn backend picks algorithms internally, models.lua:1-2); exposed so parity can be run in both modes.
+ * PRECEDENCE: the Winograd bits of fg_set_fusion win over this switch -- the forward / data gradient of every layer that
+ * FG_FUSE_WINOGRAD / _UP / _5X5 cover (3x3, folded up-convolutions, 5x5: most of the FLOPs of both workloads) runs the fp32 Winograd
+ * kernels in either mode, and those round ~1.7x worse than the direct fp32 contraction.  A true mode-6 run (the accuracy contract
+ * above on every large contraction) needs fg_set_fusion(flags & ~(FG_FUSE_WINOGRAD | FG_FUSE_WINOGRAD_UP | FG_FUSE_WINOGRAD_5X5 |
+ * FG_FUSE_WINOGRAD_WGRAD)) before the nets are created. */
 int fg_set_math(fg_ctx* ctx, int mode);
 int fg_get_math(fg_ctx* ctx);
 
@@ -94,6 +99,11 @@ enum {
 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);
+/* Test hook (parity tests only; replaces nothing in the reference): the two planning thresholds that decide where the Winograd-domain
+ * weight gradient is taken -- at least `min_chunks` eight-tile chunks per block and `min_blocks` blocks per launch (defaults 24, 192;
+ * <= 0 restores a default).  Process-wide; also read ONCE from FG_WINO_WGRAD_MIN_CHUNKS / FG_WINO_WGRAD_MIN_BLOCKS at the first
+ * fg_ctx_create.  Lets small shapes reach the kernel's corners (one chunk, ragged last chunk, a single channel block). */
+int fg_test_set_wino_wgrad_thresholds(fg_ctx* ctx, long long min_chunks, long long min_blocks);
 
 /* ---- context / memory (replaces cutorch.setDevice / cutorch streams, train.lua:79-80) ----
  * fg_ctx_create(FG_DEVICE_NONE, ...) makes a PLANNING-ONLY context: the process needs no HIP device, no kernel is launched and no

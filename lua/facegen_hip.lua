@@ -33,6 +33,7 @@ int fg_get_math(fg_ctx* ctx);
 enum { FG_FUSE_PRELU = 1, FG_FUSE_THIN_SLAB = 2, FG_FUSE_WFINISH_BATCH = 4, FG_FUSE_ADAM_PACK = 8, FG_FUSE_THIN_BIAS = 16, FG_FUSE_WINOGRAD = 32, FG_FUSE_WINOGRAD_UP = 64, FG_FUSE_WINOGRAD_5X5 = 128, FG_FUSE_WINOGRAD_WGRAD = 256, FG_FUSE_ALL = 511, FG_FUSE_DEFAULT = 503 };
 int fg_set_fusion(fg_ctx* ctx, int flags);
 int fg_get_fusion(fg_ctx* ctx);
+int fg_test_set_wino_wgrad_thresholds(fg_ctx* ctx, long long min_chunks, long long min_blocks);
 enum { FG_DEVICE_NONE = -1 };
 int fg_ctx_create(int device, fg_ctx** out);
 int fg_ctx_destroy(fg_ctx* ctx);

@@ -48,6 +48,7 @@ kstats)
   head -45 $OUT/${TAG}_bench_kernel_stats.md; head -40 $OUT/${TAG}_c2f_kernel_stats.md ;;
 trace-wino)
   TAG=${1:-wtr}; DBG=${2:-0}
+  python -m face_generator_amd.build --measure > /dev/null 2>&1; export FACEGEN_HIP_LIB=$PWD/face_generator_amd/libfacegen_hip_measure.so   # the trace kernels exist only there
   rm -f $OUT/${TAG}_trace.txt
   for shape in "128 16 16 64 128 3 0" "128 32 32 128 256 3 0" "128 16 16 256 128 5 1" "128 64 64 128 256 5 0"; do
     FG_WINO_DBG=$DBG FG_WINO_TRACE=1 FG_WS_TRACE_FILE=$OUT/${TAG}_trace.txt timeout 120 python scripts/bench_one.py fwd 2 0 $shape > /dev/null 2>&1
@@ -57,6 +58,7 @@ trace-wino)
   gzip -f $OUT/${TAG}_trace.txt ;;
 trace-wgrad)
   TAG=${1:-wwtr}
+  python -m face_generator_amd.build --measure > /dev/null 2>&1; export FACEGEN_HIP_LIB=$PWD/face_generator_amd/libfacegen_hip_measure.so
   rm -f $OUT/${TAG}_t1.txt $OUT/${TAG}_t2.txt
   for shape in "128 16 16 256 128 5 1" "128 8 8 128 256 5 1" "128 64 64 64 128 5 0" "128 32 32 128 256 3 0"; do
     FG_WINO_WGRAD_TRACE=1 FG_WS_TRACE_FILE=$OUT/${TAG}_t1.txt timeout 120 python scripts/bench_one.py wgrad 2 0 $shape > /dev/null 2>&1

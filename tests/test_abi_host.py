@@ -32,6 +32,23 @@ def test_header_symbols_all_exported(lib):
     assert lib.fg_version().startswith(b"facegen_hip")
 
 
+def test_default_library_has_no_trace_or_wrong_result_variants(lib):
+    """VERDICT r5 item 3 / ADVICE r5: the s_memtime trace kernels, their DBG variants (results are WRONG by design) and the
+    FG_DEBUG_NOSTORE switch are compiled only into libfacegen_hip_measure.so (-DFG_MEASURE, build.py --measure).  No environment
+    variable can make the default library return garbage: the names are not even in its string table."""
+    from face_generator_amd import _lib
+    blob = open(_lib.lib_path(), "rb").read()
+    hits = sorted(set(m.decode() for m in re.findall(rb"FG_[A-Z0-9_]*(?:DBG|TRACE|NOSTORE)[A-Z0-9_]*", blob)))
+    assert hits == [], hits
+    for name in (b"wino_trace", b"wino_wgrad_trace", b"igemm_ws_trace", b"trace_calib", b"FG_THIN_TPW", b"FG_THIN_NT"):
+        assert name not in blob, name
+    # the planning thresholds of the Winograd weight gradient are no longer read from the environment per call
+    src = open(os.path.join(ROOT, "face_generator_amd", "csrc", "conv_ops.hip")).read()
+    body = src[src.index("static bool choose_wino_wgrad"):]
+    body = body[:body.index("\n}\n")]
+    assert "getenv" not in body
+
+
 def test_no_gpu_fails_loudly_not_silently(lib):
     if torch.cuda.is_available():
         pytest.skip("GPU present")

@@ -172,16 +172,16 @@ from contextlib import contextmanager
 
 @contextmanager
 def small_shapes_take_the_winograd_wgrad():
-    """The library takes the Winograd weight gradient where it pays (>= 24 eight-tile chunks per block, >= 192 blocks); its two
-    measurement knobs are read per call, so the small shapes below reach the kernel's corners (one chunk, odd chunk counts, a ragged
-    last chunk, a single channel block)."""
-    os.environ["FG_WINO_WGRAD_MIN_CHUNKS"] = "1"
-    os.environ["FG_WINO_WGRAD_MIN_BLOCKS"] = "1"
+    """The library takes the Winograd weight gradient where it pays (>= 24 eight-tile chunks per block, >= 192 blocks); the test hook
+    fg_test_set_wino_wgrad_thresholds lowers both planning thresholds so the small shapes below reach the kernel's corners (one chunk,
+    odd chunk counts, a ragged last chunk, a single channel block)."""
+    from face_generator_amd.runtime import get_context
+    ctx = get_context(0)
+    ctx.check(ctx.lib.fg_test_set_wino_wgrad_thresholds(ctx.h, 1, 1))
     try:
         yield
     finally:
-        del os.environ["FG_WINO_WGRAD_MIN_CHUNKS"]
-        del os.environ["FG_WINO_WGRAD_MIN_BLOCKS"]
+        ctx.check(ctx.lib.fg_test_set_wino_wgrad_thresholds(ctx.h, 0, 0))
 
 
 def _wgrad_both(ctx, x, gy, k, up):
