@@ -520,9 +520,8 @@ def build_c2f(args, ctx, torch, coll, world, rank, B, d_it):
     G.inner.device_net.mask_seed = D.inner.device_net.mask_seed = 1000 + rank
     tr = adversarial_c2f.TrainerC2F(ctx, G, D, dict(batchSize=B), dist=coll)
     fine = ctx.uniform((B, Sz, Sz, 3), 0.0, 1.0, seed=70 + rank)
-    coarse = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(fine.permute(0, 3, 1, 2), 2), scale_factor=2)
-    coarse = coarse.permute(0, 2, 3, 1).contiguous()          # synthetic-input preparation (dataset_c2f.lua:49-61)
-    diff = (fine - coarse).contiguous()
+    from face_generator_amd import dataset_c2f
+    coarse, diff = dataset_c2f.toResultDevice(fine, Sz // 2, ctx=ctx)    # dataset_c2f.lua:49-61 through fg_c2f_coarse_diff (image.scale)
     h = B // 2
     diff_r, coarse_r, coarse_f = diff[:h].contiguous(), coarse[:h].contiguous(), coarse[h:].contiguous()
 
@@ -538,7 +537,7 @@ def build_c2f(args, ctx, torch, coll, world, rank, B, d_it):
             tr.step_G(S.next_noise(ctx, B, Sz * Sz).view(B, Sz, Sz, 1), coarse)
     which = "configs[3]" if (world == 1 and d_it == 1) else "configs[4]-style"
     return dict(tr=tr, iteration=iteration, flops=(C2F_FLOP_PER_IMAGE if d_it == 1 else C2F_D2_FLOP_PER_IMAGE) * B,
-                data="synthetic (U[0,1) fine images, coarse = 2x box down / nearest up, diff = fine - coarse, U(-1,1) noise planes)",
+                data="synthetic (U[0,1) fine images, coarse = image.scale down to 32 and back up to 64 (fg_c2f_coarse_diff), diff = fine - coarse, U(-1,1) noise planes)",
                 config={"workload": "%s: 64x64 color coarse-to-fine G_d/D_c, batch %d per GPU, Adam, D_it=%d, G_it=1" % (which, B, d_it),
                         "batch_per_gpu": B, "global_batch": world * B, "parallelism": "dp%d" % world})
 

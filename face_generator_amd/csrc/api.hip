@@ -125,6 +125,20 @@ int fg_set_fusion(fg_ctx* ctx, int flags) {
     return FG_OK;
 }
 int fg_get_fusion(fg_ctx* ctx) { return ctx ? ctx->fusion : -1; }
+int fg_scale_bilinear(fg_ctx* ctx, const float* src, float* dst, int n, int c, int hs, int ws, int hd, int wd, int layout) {
+    NEED(ctx, ctx, "null ctx");
+    if (!src || !dst || n < 0 || c < 1 || hs < 1 || ws < 1 || hd < 1 || wd < 1 || (layout != 0 && layout != 1))
+        return fg_set_err(ctx, FG_ERR_INVALID, "fg_scale_bilinear: bad argument (n=%d c=%d %dx%d -> %dx%d layout=%d)", n, c, hs, ws, hd, wd, layout);
+    return fg_launch_scale_bilinear(ctx, src, dst, n, c, hs, ws, hd, wd, layout, nullptr, nullptr);
+}
+int fg_c2f_coarse_diff(fg_ctx* ctx, const float* fine, float* coarse, float* diff, float* tmp, int n, int c, int s, int cs, int layout) {
+    NEED(ctx, ctx, "null ctx");
+    if (!fine || !coarse || !diff || !tmp || n < 0 || c < 1 || s < 1 || cs < 1 || (layout != 0 && layout != 1))
+        return fg_set_err(ctx, FG_ERR_INVALID, "fg_c2f_coarse_diff: bad argument (n=%d c=%d s=%d cs=%d layout=%d)", n, c, s, cs, layout);
+    int rc = fg_launch_scale_bilinear(ctx, fine, tmp, n, c, s, s, cs, cs, layout, nullptr, nullptr);       // dataset_c2f.lua:54
+    if (rc) return rc;
+    return fg_launch_scale_bilinear(ctx, tmp, coarse, n, c, cs, cs, s, s, layout, fine, diff);              // :55 and :59-61
+}
 int fg_test_set_wino_wgrad_thresholds(fg_ctx* ctx, long long min_chunks, long long min_blocks) {
     if (!ctx) return FG_ERR_INVALID;
     fg_plan_set_wino_wgrad_thresholds(min_chunks, min_blocks);

@@ -420,6 +420,9 @@ int fg_launch_colsum_final_thin(fg_ctx* ctx, const float* part, int nrb, float* 
 float* fg_defer_alloc(fg_ctx* ctx, long long floats);
 void fg_defer_push(fg_ctx* ctx, const float* part, int nrb, int C, float beta, float* out);
 int fg_defer_flush(fg_ctx* ctx);
+// image.scale (Torch7 `image`, bilinear): src [N][Hs][Ws][C] (nchw: [N][C][Hs][Ws]) -> dst at Hd x Wd; diff = sub_from - dst (optional)
+int fg_launch_scale_bilinear(fg_ctx*, const float* src, float* dst, int N, int C, int Hs, int Ws, int Hd, int Wd, int nchw,
+                             const float* sub_from, float* diff);
 int fg_launch_zero_insert2(fg_ctx*, const float* g, float* out, int B, int H, int W, int C);   // g [B][H][W][C] -> out [B][2H][2W][C]
 
 // thin convolutions (3 <-> wide channels), NHWC, stride 1, "same" pad, odd k <= 7

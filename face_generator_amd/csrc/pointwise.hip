@@ -1678,6 +1678,85 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+// ---------------------------------------------------------------------------------------------------------------------------------
+// image.scale(src, width, height) of the Torch7 `image` package, default mode 'bilinear' (dataset_c2f.lua:53-56): the width pass
+// of image_(Main_scaleLinear_rowcol) over every row, then its height pass over every column of the (float) intermediate.  Per axis:
+// up-scaling interpolates linearly with scale = (src - 1) / (dst - 1) (end points onto end points), down-scaling is a box mean with
+// fractional coverage of the two end pixels (scale = src / dst), equal lengths copy.  One thread per output element; every product,
+// sum and quotient is rounded on its own, in the reference's order (no FMA contraction) -- bit-for-bit the C loop (provenance of the
+// algorithm: include/facegen_hip.h fg_scale_bilinear).  sub_from (optional): also writes diff = sub_from - result (dataset_c2f.lua:59-61).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct ScaleTerm { int i0, i1; float w0, w1, n; int has_last, div; };
+__device__ __forceinline__ ScaleTerm fg_scale_plan(int src_len, int dst_len, int di) {
+#pragma clang fp contract(off)
+    ScaleTerm t;
+    t.w0 = 1.f; t.w1 = 0.f; t.n = 1.f; t.has_last = 0; t.div = 0;
+    if (dst_len > src_len) {
+        if (src_len == 1 || di == dst_len - 1) { t.i0 = src_len - 1; t.i1 = t.i0 + 1; return t; }
+        const float scale = (float)(src_len - 1) / (float)(dst_len - 1);
+        float f = (float)di * scale;
+        const int i = (int)f;
+        f = f - (float)i;
+        t.i0 = i; t.i1 = i + 1; t.w0 = 1.f - f; t.w1 = f; t.has_last = 1;
+        return t;
+    }
+    if (dst_len < src_len) {
+        const float scale = (float)src_len / (float)dst_len;
+        const float s0 = (float)di * scale, s1 = (float)(di + 1) * scale;
+        t.i0 = (int)s0; t.i1 = (int)s1;
+        const float f0 = s0 - (float)t.i0, f1 = s1 - (float)t.i1;
+        t.w0 = 1.f - f0;
+        float n = t.w0;
+        for (int si = t.i0 + 1; si < t.i1; ++si) n = n + 1.f;
+        t.has_last = t.i1 < src_len;
+        t.w1 = f1;
+        if (t.has_last) n = n + f1;
+        t.n = n; t.div = 1;
+        return t;
+    }
+    t.i0 = di; t.i1 = di + 1;
+    return t;
+}
+template <typename F>
+__device__ __forceinline__ float fg_scale_eval(const ScaleTerm& t, F fetch) {
+#pragma clang fp contract(off)
+    float acc = t.w0 * fetch(t.i0);
+    for (int si = t.i0 + 1; si < t.i1; ++si) acc = acc + fetch(si);
+    if (t.has_last) { const float v = t.w1 * fetch(t.i1); acc = acc + v; }
+    if (t.div) acc = acc / t.n;
+    return acc;
+}
+__global__ __launch_bounds__(256) void scale_bilinear_kernel(const float* __restrict__ src, float* __restrict__ dst, long long total, int C, int Hs,
+                                                             int Ws, int Hd, int Wd, int nchw, const float* __restrict__ sub_from,
+                                                             float* __restrict__ diff) {
+#pragma clang fp contract(off)
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    long long r = idx;
+    int c, x, y;
+    if (nchw) { x = (int)(r % Wd); r /= Wd; y = (int)(r % Hd); r /= Hd; c = (int)(r % C); r /= C; }
+    else { c = (int)(r % C); r /= C; x = (int)(r % Wd); r /= Wd; y = (int)(r % Hd); r /= Hd; }
+    const long long n = r;
+    const long long sy = nchw ? Ws : (long long)Ws * C, sx = nchw ? 1 : C;
+    const float* img = src + (nchw ? (n * C + c) * (long long)Hs * Ws : n * (long long)Hs * Ws * C + c);
+    const ScaleTerm th = fg_scale_plan(Ws, Wd, x), tv = fg_scale_plan(Hs, Hd, y);
+    const float v = fg_scale_eval(tv, [&](int j) {
+        const float* row = img + j * sy;
+        return fg_scale_eval(th, [&](int i) { return row[i * sx]; });
+    });
+    dst[idx] = v;
+    if (diff) diff[idx] = sub_from[idx] - v;
+    }
+}
+int fg_launch_scale_bilinear(fg_ctx* ctx, const float* src, float* dst, int N, int C, int Hs, int Ws, int Hd, int Wd, int nchw,
+                             const float* sub_from, float* diff) {
+    const long long total = (long long)N * C * Hd * Wd;
+    if (total == 0) return FG_OK;
+    hipLaunchKernelGGL(scale_bilinear_kernel, FG_GRID(total, 256), dim3(256), 0, ctx->stream, src, dst, total, C, Hs, Ws, Hd, Wd, nchw,
+                       sub_from, diff);
+    FG_CHECK_LAUNCH(ctx);
+    return FG_OK;
+}
+
 // mode 0: uniform(lo,hi)  1: bernoulli(keep=lo)  2: normal(mean=lo, std=hi)
 __global__ void rng_kernel(uint64_t seed, uint64_t offset, float* __restrict__ out, long long n, float lo, float hi,
                            int mode) {

@@ -163,3 +163,38 @@ def adam_step(ctx, p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, gsc
     ctx.check(ctx.lib.fg_adam_fused(ctx.h, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), gscale,
                                     l1_mul, l2, clamp, lr, beta1, beta2, eps, t,
                                     g_out.data_ptr() if g_out is not None else None))
+
+
+def scale_bilinear(x, width, height, layout="nhwc", ctx=None):
+    """image.scale(x, width, height) (Torch7 `image`, bilinear; dataset_c2f.lua:54-55) on a device batch: x [N][H][W][C] (layout
+    "nhwc") or [N][C][H][W] ("nchw").  include/facegen_hip.h fg_scale_bilinear."""
+    ctx = ctx or get_context()
+    nchw = {"nhwc": 0, "nchw": 1}[layout]
+    x = x.contiguous()
+    if nchw:
+        N, C, H, W = x.shape
+        y = ctx.empty(N, C, height, width)
+    else:
+        N, H, W, C = x.shape
+        y = ctx.empty(N, height, width, C)
+    ctx.check(ctx.lib.fg_scale_bilinear(ctx.h, x.data_ptr(), y.data_ptr(), N, C, H, W, height, width, nchw))
+    return y
+
+
+def c2f_coarse_diff(fine, coarse_scale, layout="nhwc", ctx=None):
+    """dataset._toResult's arithmetic (dataset_c2f.lua:53-61) on a device batch of square images: -> (coarse, diff) with
+    coarse = scale(scale(fine, cs, cs), s, s) and diff = fine - coarse.  include/facegen_hip.h fg_c2f_coarse_diff."""
+    ctx = ctx or get_context()
+    nchw = {"nhwc": 0, "nchw": 1}[layout]
+    fine = fine.contiguous()
+    if nchw:
+        N, C, S, S2 = fine.shape
+    else:
+        N, S, S2, C = fine.shape
+    if S != S2:
+        raise ValueError("c2f_coarse_diff: square images expected, got %dx%d" % (S, S2))
+    coarse, diff = torch.empty_like(fine), torch.empty_like(fine)
+    tmp = ctx.empty(N * C * coarse_scale * coarse_scale)
+    ctx.check(ctx.lib.fg_c2f_coarse_diff(ctx.h, fine.data_ptr(), coarse.data_ptr(), diff.data_ptr(), tmp.data_ptr(), N, C, S,
+                                         coarse_scale, nchw))
+    return coarse, diff

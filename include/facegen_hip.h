@@ -340,6 +340,18 @@ int fg_gan_pending(const fg_gan* gan);   /* 1 while D's update is deferred behin
 int fg_parzen_min_dist(fg_ctx* ctx, const float* gen, const float* cond, const float* fine, int n, long long elems,
                        float* dist, float* min_out);
 
+/* ---- the c2f data step in front of the train closure (dataset_c2f.lua:49-61, `dataset._toResult`) ----
+ * fg_scale_bilinear = image.scale(src, width, height) of the Torch7 `image` package (default mode 'bilinear'; un-vendored luarocks
+ * dependency, restated in oracle/image_scale.py): width pass then height pass; per axis up-scaling interpolates with
+ * (src - 1) / (dst - 1) ("corners onto corners"), down-scaling is a box mean with fractional end coverage, equal sizes copy.
+ * Bit-for-bit the C float loop.  src [n][hs][ws][c] (layout 0 = NHWC, the library's activation layout) or [n][c][hs][ws]
+ * (layout 1 = NCHW, the reference's image tensors); dst likewise at hd x wd.
+ * fg_c2f_coarse_diff = the whole step: coarse = scale(scale(fine, cs, cs), s, s), diff = fine - coarse, for n square images of
+ * side s; tmp holds n * c * cs * cs floats. */
+int fg_scale_bilinear(fg_ctx* ctx, const float* src, float* dst, int n, int c, int hs, int ws, int hd, int wd, int layout);
+int fg_c2f_coarse_diff(fg_ctx* ctx, const float* fine, float* coarse, float* diff, float* tmp, int n, int c, int s, int cs,
+                       int layout);
+
 /* ---- module-level ops (nn.Module protocol: updateOutput / updateGradInput / accGradParameters), NHWC ----
  * conv / linear take REFERENCE-layout weights and pack them into `ws` on the fly. */
 size_t fg_conv2d_workspace_bytes(int batch, int h, int w, int cin, int cout, int k, int upsample2x);

@@ -129,6 +129,8 @@ int fg_gan_update(fg_gan* gan, int which);
 int fg_gan_finish_pending(fg_gan* gan);
 int fg_gan_pending(const fg_gan* gan);
 int fg_parzen_min_dist(fg_ctx* ctx, const float* gen, const float* cond, const float* fine, int n, long long elems, float* dist, float* min_out);
+int fg_scale_bilinear(fg_ctx* ctx, const float* src, float* dst, int n, int c, int hs, int ws, int hd, int wd, int layout);
+int fg_c2f_coarse_diff(fg_ctx* ctx, const float* fine, float* coarse, float* diff, float* tmp, int n, int c, int s, int cs, int layout);
 size_t fg_conv2d_workspace_bytes(int batch, int h, int w, int cin, int cout, int k, int upsample2x);
 int fg_conv2d_forward(fg_ctx* ctx, const float* x, const float* w_oihw, const float* bias, float* y, int batch, int h, int w, int cin, int cout, int k, int pad, int upsample2x, void* ws, size_t ws_bytes);
 int fg_conv2d_backward_data(fg_ctx* ctx, const float* gy, const float* w_oihw, float* gx, int batch, int h, int w, int cin, int cout, int k, int pad, int upsample2x, void* ws, size_t ws_bytes);
