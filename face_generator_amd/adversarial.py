@@ -193,6 +193,8 @@ class Trainer:
             c = conf.tolist()
             acc = (c[0] + c[3]) / max(1, sum(c))     # [pred0,t0] + [pred1,t1]
             do_train = gate(acc)
+            if self.world > 1:
+                do_train = self.coll.agree(do_train)      # one vote: a rank that disagrees cannot leave the others in an all-reduce
         if do_train:
             if self.world > 1 and self.overlap:
                 # xGMI all-reduce of the 11.45 MB D gradient runs on RCCL's stream while the G-step's generator
@@ -237,6 +239,8 @@ class Trainer:
         if gate is not None:
             c = conf[4:8].tolist()                    # counts of the GLOBAL batch: every rank takes the same branch
             do_train = gate((c[0] + c[3]) / max(1, sum(c)))
+            if self.world > 1:
+                do_train = self.coll.agree(do_train)      # (see step_D)
         if hold and do_train:
             gan.update(0)
         res["trained"] = do_train
@@ -357,6 +361,10 @@ def train(dataset, maxAccuracyD=1.01, accsInterval=20):
     t0 = time.time()
     tr = S.trainer()
     ctx = tr.ctx
+    if tr.world > 1:
+        # every rank runs the SAME number of iterations (each one holds collectives): a shard that is a batch longer on one rank is
+        # cut to the shortest one instead of leaving that rank alone in an all-reduce
+        N_epoch = tr.coll.min_int(N_epoch)
     countTrainedD = countNotTrainedD = 0
     conf_total = torch.zeros(4, dtype=torch.int64)
     pending = []

@@ -91,6 +91,8 @@ def train(trainData):
         S._trainer = TrainerC2F(get_context(), S.MODEL_G, S.MODEL_D, OPT, dist=S.dist)
     tr = S._trainer
     ctx = tr.ctx
+    if tr.world > 1:
+        N_epoch = tr.coll.min_int(N_epoch)        # the same number of iterations on every rank (adversarial.train)
     c, h, w = S.IMG_DIMENSIONS
     pending = []
     print("<trainer> Epoch #%d [batchSize = %d]" % (S.EPOCH, OPT["batchSize"]))

@@ -519,7 +519,10 @@ int fg_launch_wino(fg_ctx* ctx, const WinoArgs& a) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     dim3 grid((unsigned)fg_wino_blocks(a), a.splits, 1);
-    const double exec = 2.0 * (double)grid.x * 64 * 64 * 16.0 * a.C * a.KG;       // MFMA FLOPs issued: 16 positions, every tile padded to 64 x 64
+    // MFMA FLOPs priced as executed work: 16 positions x LIVE tiles x LIVE output channels (the zero rows / columns a ragged shape
+    // pads its 64 x 64 blocks with are issued too, but crediting them would flatter roofline.frac -- VERDICT r5 weak #9; no padding
+    // at the BASELINE shapes)
+    const double exec = 2.0 * (double)a.T * (double)a.N * a.P * 16.0 * a.C * a.KG;
     const int epi = a.act_x ? 2 : (a.act_y ? 1 : 0);
 #ifdef FG_MEASURE
     {

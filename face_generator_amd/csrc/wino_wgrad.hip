@@ -405,7 +405,7 @@ int fg_launch_wino_wgrad(fg_ctx* ctx, const WinoWgradArgs& a) {
         FG_HIP(ctx, hipFuncSetAttribute((const void*)wino_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     dim3 grid((a.Npad / 64) * (a.Cpad / 64), a.S, a.P * a.KG);
-    const double exec = 2.0 * (double)grid.x * grid.z * 64 * 64 * 16.0 * 8.0 * fg_cdiv(a.T, 8);
+    const double exec = 2.0 * (double)a.Nd * a.Cx * grid.z * 16.0 * (double)a.T;     // live channel pairs x live tiles (see fg_launch_wino)
 #ifdef FG_MEASURE
     {
         static int tr = -1;

@@ -65,6 +65,30 @@ class Collective:
     def close(self):
         pass
 
+    # -- control-flow agreement (first-run insurance for N > 1: a branch that one rank takes alone is a hang on the hardware) --
+    def _gather_int(self, v, what="int"):
+        """-> list of every rank's int `v` (one int32 all-reduce of a one-hot vector: the carriers only sum)."""
+        if self.world == 1:
+            return [int(v)]
+        t = torch.zeros(self.world, dtype=torch.int32, device=self._device())
+        t[self.rank] = int(v)
+        self.allreduce_sum_(t)
+        return [int(x) for x in t.tolist()]
+
+    def _device(self):
+        return getattr(getattr(self, "ctx", None), "device", "cpu")
+
+    def agree(self, flag):
+        """True iff EVERY rank passed True.  The maxAccuracyD gate (adversarial.lua:167-178) is evaluated by each rank on the global
+        confusion counts and must come out the same everywhere; if host arithmetic ever made one rank disagree, the ranks would
+        issue different collectives from here on.  With the vote they all skip."""
+        votes = self._gather_int(1 if flag else 0, "vote")
+        return sum(votes) == self.world
+
+    def min_int(self, v):
+        """The smallest `v` over the ranks (iterations of an epoch: a tail batch only one rank has must not be trained alone)."""
+        return min(self._gather_int(v, "min"))
+
 
 class TorchCollective(Collective):
     def __init__(self, d=dist):
@@ -72,6 +96,9 @@ class TorchCollective(Collective):
         self.world, self.rank = d.get_world_size(), d.get_rank()
         self.name = "torch.distributed (%s)" % d.get_backend()
         self._works = []
+
+    def _device(self):
+        return torch.device("cuda", torch.cuda.current_device()) if self.d.get_backend() == "nccl" else "cpu"
 
     def allreduce_sum_(self, t):
         if self.world > 1:
@@ -150,6 +177,19 @@ class DryCollective(FgCollective):
         ctx.check(self.lib.fg_comm_create_dry(ctx.h, rank, world, ctypes.byref(h)))
         self.h = h
         self.name = "fg_comm (dry: schedule only, rank %d of %d)" % (rank, world)
+
+    # no transport: the all-reduce of the one-hot vector is recorded in the schedule and skipped.  `peers` stands for what the other
+    # ranks would have contributed (fault injection in the CPU tests): a callable (rank, my value, "vote" | "min") -> int, default "as me"
+    peers = None
+
+    def _device(self):
+        return "cpu"
+
+    def _gather_int(self, v, what="int"):
+        t = torch.zeros(self.world, dtype=torch.int32)
+        t[self.rank] = int(v)
+        self.allreduce_sum_(t)                    # recorded: "<seq> allreduce i32 <world> compute"
+        return [int(v) if (r == self.rank or self.peers is None) else int(self.peers(r, int(v), what)) for r in range(self.world)]
 
     def schedule(self, reset=True):
         """-> list of "<seq> <op> <dtype> <count> <stream>" lines since the last reset."""

@@ -98,7 +98,8 @@ def _dry(cmd_prefix, gpus, env=None):
 def _check_schedule(j, world):
     """What fg_step_D / fg_step_G must issue, per combination (csrc/step.hip): D's flat gradient (2 863 239 floats) once per
     update -- on the side stream when overlapped, never when the gate holds the update --, G's (2 470 406) whole or in buckets that
-    add up to it, the gate's global confusion counts (4 x int32) only when a gate is given, and with sync-BN one fp64 exchange of
+    add up to it, the gate's global confusion counts (4 x int32) and the ranks' vote on the gate's answer (world x int32) only when a
+    gate is given, and with sync-BN one fp64 exchange of
     2C + 1 sums per BatchNorm pass of G (C = 256, 128: three forwards -- B/2 fakes, B samples -- and one backward each)."""
     assert j["ranks_agree"] is True and j["ranks_walked"] == list(range(world)) and len(j["schedule"]) == 12
     nD, nG = 2863239, 2470406
@@ -116,7 +117,8 @@ def _check_schedule(j, world):
             assert d_red[0][1] == ("side" if overlap else "compute"), (name, lines)
         assert all(st == ("side" if overlap else "compute") for _, st in g_red), (name, lines)
         assert (len(g_red) > 1) == overlap, (name, lines)                     # bucketed under the backward only when overlapped
-        assert i32 == ([] if gate == "none" else [4]), (name, lines)
+        # a gated D-step: the global confusion counts, then (N > 1) the one-hot vote that makes every rank take the same branch
+        assert i32 == ([] if gate == "none" else [4, world]), (name, lines)
         assert f64 == ([513, 257, 513, 257, 257, 513] if sync else []), (name, lines)
         waits = [o for o in ops if o[1] == "wait"]
         assert len(waits) == ((1 if d_red else 0) + 1 if overlap else 0), (name, lines)
@@ -177,3 +179,41 @@ def test_planning_only_context_excludes_device_contexts():
         assert lib.fg_comm_destroy(c) == 0
     finally:
         lib.fg_ctx_destroy(h)
+
+
+@pytest.mark.timeout(600)
+def test_exchange_schedule_survives_rank_skew():
+    """First-run insurance for configs[2] / [4] (no hardware needed): every rank of a 4-rank job is walked through
+    fg_step_D / fg_step_G / fg_gan_finish_pending with dry communicators while rank skew is injected (tests/dist_skew_worker.py).
+    A branch that one rank takes alone is a hang on the hardware, so the schedule TEXT must stay identical on all ranks:
+      * one rank's maxAccuracyD gate says "hold" while the others say "train" (adversarial.lua:167-178): the vote
+        (distributed.Collective.agree) makes every rank hold -- no rank issues D's gradient all-reduce in that iteration;
+      * one rank's shard is a half-batch longer (adversarial.lua:54-56): the epoch length is agreed (Collective.min_int), every rank
+        runs the same number of iterations and the epoch ends with the same deferred-D wait."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_skew_worker.py")], capture_output=True, text=True, timeout=560, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    nD = 2863239
+    for scen in ("gate_skew", "tail_batch"):
+        ranks = sorted(j[scen])
+        assert len(ranks) == 4
+        for k in ranks[1:]:
+            assert j[scen][k] == j[scen][ranks[0]], "%s: rank %s issues a different schedule than rank %s" % (scen, k, ranks[0])
+    ops = [l.split() for l in j["gate_skew"]["0"]]
+    d_reduces = [o for o in ops if o[1] == "allreduce" and o[2] == "f32" and int(o[3]) == nD]
+    votes = [o for o in ops if o[1] == "allreduce" and o[2] == "i32" and int(o[3]) == 4]
+    assert len(d_reduces) == 2, "three gated iterations, one held on EVERY rank -> two D gradient all-reduces"
+    assert len(votes) == 6, "per gated D-step: the global confusion counts and the vote (4 ranks -> 4 ints each)"
+    # the held iteration (the second): counts, vote, then straight to G's buckets -- no D all-reduce in between
+    seq = [(o[1], o[2], int(o[3]) if o[3].isdigit() else o[3]) for o in ops]
+    second = seq.index(("allreduce", "i32", 4), 2)
+    assert seq[second + 1] == ("allreduce", "i32", 4) and seq[second + 2][2] != nD
+    assert set(j["tail_iterations"].values()) == {3}, "every rank runs the shortest shard's three iterations, not its own four"
+    tail = [l.split() for l in j["tail_batch"]["0"]]
+    assert sum(1 for o in tail if o[1] == "allreduce" and o[2] == "f32" and int(o[3]) == nD) == 3
+    assert tail[0][1:4] == ["allreduce", "i32", "4"], "the epoch opens with the agreement on its length"
+    assert tail[-1][1] == "wait" or tail[-2][1] == "wait", "fg_gan_finish_pending closes the epoch on every rank"

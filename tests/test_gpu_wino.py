@@ -280,3 +280,74 @@ def test_winograd_weight_gradient_is_taken_at_the_baseline_shapes(ctx):
         (gw, gb), (gw0, gb0) = _wgrad_both(ctx, x, gy, k, up)
         close(gw, gw0, atol=4e-5 * max(np.abs(gw0).max(), 1.0), what="winograd vs tap-by-tap weight gradient")
         assert np.array_equal(gw, gw0) == (not taken)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# error DISTRIBUTION against float64: the per-case bars above are relative to max|y| -- a few 1e-3
+# absolute at K = 2 304 -- so a transform that rounded 3 x worse could hide inside them.  Here every layer shape of both workloads is
+# measured against the float64 direct convolution in units of  u = eps32 * rms(y)  (one fp32 rounding of a typical output) and next to
+# the library's own direct fp32 contraction (implicit GEMM, same data):
+#   mean |err| <= 2.5 x the direct contraction's mean error     (measured 1.5 - 1.9 x: F(2x2, 3x3)'s transforms add ~1.7 x)
+#   max  |err| <= 3.0 x the direct contraction's max error
+#   mean |err| <= 1.2 u * sqrt(K / 576) + 0.6 u                (an absolute ceiling that grows like sqrt(K), K = taps x channels)
+# Measured values: profiles/r06_wino_error.txt (scripts/wino_error_hist.py prints the same table).
+# ---------------------------------------------------------------------------------------------------------------------------------
+ERR_CASES = [
+    # B, H, W (source), Cin, Cout, k, folded nearest-x2     -- every Winograd layer shape of configs[1] and configs[3]
+    (8, 16, 16, 64, 128, 3, 0),     # D32b d5  (models.lua:390)
+    (8, 8, 8, 128, 256, 3, 0),      # d9  (models.lua:395)
+    (16, 4, 4, 256, 512, 3, 0),     # d13 (models.lua:400), split-K
+    (4, 8, 8, 128, 256, 5, 1),      # G g5 (models.lua:63-64)
+    (4, 16, 16, 256, 128, 5, 1),    # G g9 (models.lua:68-69)
+    (1, 64, 64, 64, 128, 5, 0),     # c2f G_d (models_c2f.lua:125)
+    (1, 64, 64, 128, 256, 5, 0),    # c2f G_d (models_c2f.lua:126)
+    (2, 32, 32, 128, 256, 3, 0),    # c2f D_c (models_c2f.lua:251)
+]
+
+
+def wino_error_row(ctx, B, H, W, Cin, Cout, k, up):
+    """-> dict of error statistics of the Winograd and the direct fp32 forward / data gradient against the float64 oracle."""
+    from face_generator_amd import ops
+    rng = np.random.default_rng(B * 7919 + H * 131 + Cin + 3 * Cout + k)
+    conv = O.SpatialConvolution(Cin, Cout, k, k, 1, 1, (k - 1) // 2, (k - 1) // 2, rng)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    xin = np.repeat(np.repeat(x, 2, axis=2), 2, axis=3) if up else x
+    conv64 = O.SpatialConvolution(Cin, Cout, k, k, 1, 1, (k - 1) // 2, (k - 1) // 2, rng).astype(np.float64)
+    conv64.weight[...] = conv.weight; conv64.bias[...] = conv.bias
+    y64 = conv64.forward(xin.astype(np.float64))
+    gy = rng.standard_normal(y64.shape).astype(np.float32)
+    g64 = conv64.backward(xin.astype(np.float64), gy.astype(np.float64))
+    if up:
+        g64 = g64.reshape(B, Cin, H, 2, W, 2).sum(axis=(3, 5))
+    d = ctx.device
+    w_d, b_d = dev(conv.weight, d), dev(conv.bias, d)
+    res = {}
+    for name, flags in (("wino", FG_FUSE_DEFAULT), ("direct", FG_FUSE_DEFAULT & ~WINO_ALL)):
+        ctx.set_fusion(flags)
+        y = nchw(ops.conv2d_forward(nhwc(x, d), w_d, b_d, upsample2x=bool(up))).astype(np.float64)
+        g = nchw(ops.conv2d_backward_data(nhwc(gy, d), w_d, (H, W), upsample2x=bool(up))).astype(np.float64)
+        res[name] = (np.abs(y - y64), np.abs(g - g64))
+    ctx.set_fusion(FG_FUSE_DEFAULT)
+    eps = float(np.finfo(np.float32).eps)
+    row = {"K": k * k * Cin, "Kd": k * k * Cout}
+    for which, ref, idx in (("fwd", y64, 0), ("dgrad", g64, 1)):
+        u = eps * float(np.sqrt(np.mean(ref * ref)))
+        for name in ("wino", "direct"):
+            e = res[name][idx]
+            row["%s_%s_mean_u" % (which, name)] = float(e.mean()) / u
+            row["%s_%s_max_u" % (which, name)] = float(e.max()) / u
+            row["%s_%s_p99_u" % (which, name)] = float(np.quantile(e, 0.99)) / u
+    return row
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,up", ERR_CASES)
+def test_winograd_error_distribution_against_float64(ctx, B, H, W, Cin, Cout, k, up):
+    r = wino_error_row(ctx, B, H, W, Cin, Cout, k, up)
+    for which, K in (("fwd", r["K"]), ("dgrad", r["Kd"])):
+        wm, dm = r[which + "_wino_mean_u"], r[which + "_direct_mean_u"]
+        wx, dx = r[which + "_wino_max_u"], r[which + "_direct_max_u"]
+        msg = "%s K=%d: winograd mean %.2f u max %.1f u; direct mean %.2f u max %.1f u" % (which, K, wm, wx, dm, dx)
+        assert wm <= 2.5 * dm, msg
+        assert wx <= 3.0 * dx, msg
+        assert wm <= 1.2 * np.sqrt(K / 576.0) + 0.6, msg
+        assert dm > 0.05, msg          # the direct path is not the float64 answer rounded once: the ratios above mean something
