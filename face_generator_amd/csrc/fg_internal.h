@@ -452,8 +452,10 @@ int fg_launch_thin_unpack_grad(fg_ctx*, const float* gw, float* gradW, int O, in
 int fg_launch_gemv_forward(fg_ctx*, const float* x, const float* w, const float* b, float* y, int B, int K,
                            int sigmoid);
 // gy is grad wrt y (post-sigmoid if sigmoid) ; writes gx [B][K] (optional), gradw[K], gradb[1] (acc*old + new)
+// actb (optional): the nn.PReLU [+ nn.Dropout] in front of the layer, folded into this launch (actb->applied; slope-gradient partials
+// through the deferred final of an fg_net backward pass, like the contraction epilogues)
 int fg_launch_gemv_backward(fg_ctx*, const float* x, const float* w, const float* y, const float* gy, float* gx,
-                            float* gw, float* gb, float acc, int B, int K, int sigmoid);
+                            float* gw, float* gb, float acc, int B, int K, int sigmoid, const FgActBwd* actb = nullptr);
 
 // BCECriterion forward+backward fused: loss (device scalar), grad[B], confusion[4] = [pred][target] counts
 int fg_launch_bce(fg_ctx*, const float* prob, const float* target, float* loss, float* grad, int* confusion, int B);

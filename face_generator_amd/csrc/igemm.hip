@@ -1687,8 +1687,10 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         }
         __syncthreads();
         const int ng = wm.P * wm.G;
-        {   // forward pack [p][g][O_pad][I_pad]: lanes run over the in-channel
-            const int a = t >> 4, b = t & 15, po = po0 + a, pi = pi0 + b;
+        {   // forward pack [p][g][O_pad][I_pad]: lanes run over the in-channel.  Winograd pack (chunk images [pos][k half][64 out][4 in]):
+            // lanes run over the OUT-channel and a wave holds one quad of in-channels, so that each of its stores is one contiguous
+            // 256-byte run of an image (lanes over the in-channel wrote four 64-byte pieces per store: 28 us per re-pack, round 5)
+            const int a = wm.wino ? (t & 15) : (t >> 4), b = wm.wino ? (t >> 4) : (t & 15), po = po0 + a, pi = pi0 + b;
             if (po < jb.rows && pi < jb.cols) {
                 const float* w = taps + a * PK_ROW + b * kk;
                 float* d = jb.dst + (size_t)po * jb.cols + pi;
@@ -1706,8 +1708,9 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                 for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
             }
         }
-        {   // data-gradient pack [p][g][I_pad][O_pad]: lanes run over the out-channel
-            const int a = t & 15, b = t >> 4, po = po0 + a, pi = pi0 + b;
+        {   // data-gradient pack [p][g][I_pad][O_pad]: lanes run over the out-channel (Winograd: over the in-channel, which is the
+            // 64-wide axis of ITS images; see above)
+            const int a = wm.wino ? (t >> 4) : (t & 15), b = wm.wino ? (t & 15) : (t >> 4), po = po0 + a, pi = pi0 + b;
             if (pi < jb.rows2 && po < jb.cols2) {
                 const float* w = taps + a * PK_ROW + b * kk;
                 float* d = jb.dst2 + (size_t)pi * jb.cols2 + po;
@@ -1891,47 +1894,51 @@ __device__ __forceinline__ void wgrad_finish_one(const WeightMap& wm, const floa
     float* gw = gradW + ((size_t)o * wm.I + i) * wm.k * wm.k + wi;
     *gw = (beta == 0.f) ? sum : beta * (*gw) + sum;
 }
-// The same reduction for a k x k layer, one block per (out-channel, 128 in-channels) and ALL taps: a thread sums the taps of its
-// channel pair one after the other (each sum in wgrad_finish_one's order: bit-identical), the block then writes the
-// [in-channel][tap] run of the reference layout contiguously through LDS.  (One block per tap wrote one word per 36- / 100-byte
-// stride: every line of the gradient was touched by k*k blocks -- 39 us for D's 11 MB, round 5.)  k*k <= 25 (the LDS patch).
-__host__ __device__ static inline bool fg_finish_all_taps(const WeightMap& wm) { return !wm.wino && wm.k > 1 && wm.k * wm.k <= 25; }
+// The same reduction for a plain k x k layer (k = 3 | 5), one block per (out-channel, 128 in-channels) and ALL taps: a thread keeps one
+// running sum per tap and walks the splits two at a time -- 2 k^2 independent loads in flight (one thread per (channel pair, tap)
+// walked its S = 7 ... 51 partials four at a time: the launch was bound by memory latency x occupancy, 39 us for D's ~85 MB).  Every
+// tap's additions stay in ascending split order (bit-identical to wgrad_finish_one); the block then writes the [in-channel][tap] run
+// of the reference layout contiguously through LDS instead of one word per 36- / 100-byte stride.
+__host__ __device__ static inline bool fg_finish_all_taps(const WeightMap& wm) { return !wm.wino && wm.kind == 0 && (wm.k == 3 || wm.k == 5); }
+template <int K>
 __device__ __forceinline__ void wgrad_finish_taps(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
                                                   float beta, float* __restrict__ gradW, int bx, int po, float* sh) {
-    const int kk = wm.k * wm.k;
+    constexpr int kk = K * K;
     const int pi = bx * 128 + (int)threadIdx.x;
     const size_t tile = (size_t)Npad * Cpad;
-    const size_t e = (size_t)po * Cpad + pi;
     if (pi < wm.I && po < wm.O) {
-        for (int wi = 0; wi < kk; ++wi) {
-            const int dy = wi / wm.k, dx = wi - dy * wm.k;
-            float sum = 0.f;
-            auto run = [&](const float* __restrict__ b) {
-                int s = 0;
-                for (; s + 4 <= S; s += 4) {
-                    const float v0 = b[(size_t)s * tile], v1 = b[(size_t)(s + 1) * tile], v2 = b[(size_t)(s + 2) * tile], v3 = b[(size_t)(s + 3) * tile];
-                    sum += v0; sum += v1; sum += v2; sum += v3;
-                }
-                for (; s < S; ++s) sum += b[(size_t)s * tile];
-            };
-            if (wm.kind == 0) {
-                run(Part + (size_t)wi * S * tile + e);
-            } else {
-                for (int p = 0; p < 4; ++p) {
-                    const int ty = dev_fold_r(p >> 1, dy, wm.pad) - wm.rmin;
-                    const int tx = dev_fold_r(p & 1, dx, wm.pad) - wm.rmin;
-                    const int pg = p * wm.G + ty * wm.T + tx;
-                    run(Part + (size_t)pg * S * tile + e);
-                }
+        const float* __restrict__ b = Part + (size_t)po * Cpad + pi;       // tap wi, split s at b[(wi * S + s) * tile]
+        float sum[kk];
+#pragma unroll
+        for (int wi = 0; wi < kk; ++wi) sum[wi] = 0.f;
+        int s = 0;
+        for (; s + 2 <= S; s += 2) {
+            float v0[kk], v1[kk];
+#pragma unroll
+            for (int wi = 0; wi < kk; ++wi) {
+                v0[wi] = b[((size_t)wi * S + s) * tile];
+                v1[wi] = b[((size_t)wi * S + s + 1) * tile];
             }
-            sh[(int)threadIdx.x * kk + wi] = sum;
+#pragma unroll
+            for (int wi = 0; wi < kk; ++wi) { sum[wi] += v0[wi]; sum[wi] += v1[wi]; }
         }
+        if (s < S) {
+#pragma unroll
+            for (int wi = 0; wi < kk; ++wi) sum[wi] += b[((size_t)wi * S + s) * tile];
+        }
+#pragma unroll
+        for (int wi = 0; wi < kk; ++wi) sh[(int)threadIdx.x * kk + wi] = sum[wi];
     }
     __syncthreads();
     if (po >= wm.O) return;
     const int nI = min(128, wm.I - bx * 128);
     float* __restrict__ base = gradW + ((size_t)po * wm.I + (size_t)bx * 128) * kk;
     for (int idx = (int)threadIdx.x; idx < nI * kk; idx += 128) base[idx] = (beta == 0.f) ? sh[idx] : beta * base[idx] + sh[idx];
+}
+__device__ __forceinline__ void wgrad_finish_taps_any(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
+                                                      float beta, float* __restrict__ gradW, int bx, int po, float* sh) {
+    if (wm.k == 5) wgrad_finish_taps<5>(wm, Part, S, Npad, Cpad, beta, gradW, bx, po, sh);
+    else wgrad_finish_taps<3>(wm, Part, S, Npad, Cpad, beta, gradW, bx, po, sh);
 }
 // Winograd-domain partials (WeightMap::wino, wino_wgrad.hip): Part[unit][split][Npad][Cpad][pos 16].  One thread per (out, in) pair:
 // sum the splits per position, apply the signs wino_wgrad_kernel left out of A's last row (s_i s_j, s = (1, 1, 1, -1)),
@@ -2077,7 +2084,7 @@ __global__ __launch_bounds__(128) void wgrad_finish_jobs_kernel(const FgWFinishB
     const int bx = (int)(l % jb.ib); l /= jb.ib;
     const int po = (int)(l % jb.wm.O), wi = (int)(l / jb.wm.O);
     if (jb.wm.wino) { wino_wgrad_finish_any(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx, po, wsh); return; }
-    if (fg_finish_all_taps(jb.wm)) { wgrad_finish_taps(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx, po, wsh); return; }
+    if (fg_finish_all_taps(jb.wm)) { wgrad_finish_taps_any(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx, po, wsh); return; }
     wgrad_finish_one(jb.wm, jb.part, jb.S, jb.Npad, jb.Cpad, jb.beta, jb.gradW, bx * 128 + (int)threadIdx.x, po, wi);
 }
 int fg_launch_wgrad_finish_jobs(fg_ctx* ctx, const FgWFinishJob* jobs, int n, long long blocks) {
@@ -2109,7 +2116,7 @@ __global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict_
     // x: packed in-channel (coalesced partial reads), y: packed out-channel, z: tap dy*k+dx
     __shared__ float wsh[FG_WINO_FINISH_LDS];
     if (wm.wino) { wino_wgrad_finish_any(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x, blockIdx.y, wsh); return; }
-    if (fg_finish_all_taps(wm)) { wgrad_finish_taps(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x, blockIdx.y, wsh); return; }
+    if (fg_finish_all_taps(wm)) { wgrad_finish_taps_any(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x, blockIdx.y, wsh); return; }
     wgrad_finish_one(wm, Part, S, Npad, Cpad, beta, gradW, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, blockIdx.z);
 }
 int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,

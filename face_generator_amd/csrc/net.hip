@@ -256,7 +256,8 @@ static int backward_run_stages(fg_net* n) {
             }
             case ST_GEMV:
                 rc = fg_launch_gemv_backward(ctx, xin, P + s.w_off, yout, gcur, gxb, want_p ? Gp + s.w_off : nullptr,
-                                             want_p ? Gp + s.b_off : nullptr, 0.f, B, s.ic, s.has_sigmoid);
+                                             want_p ? Gp + s.b_off : nullptr, 0.f, B, s.ic, s.has_sigmoid, pf ? &actb : nullptr);
+                prelu_folded = pf && !rc && actb.applied;
                 break;
             case ST_THIN_IN: {
                 const int k = s.geom.k;

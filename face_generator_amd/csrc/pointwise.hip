@@ -1494,10 +1494,16 @@ int fg_launch_gemv_forward(fg_ctx* ctx, const float* x, const float* w, const fl
 }
 // dl[b] = gy[b]*y(1-y) (or gy); gx[b][k] = dl[b] w[k]; gw[k] = sum_b dl[b] x[b][k]; gb = sum dl.
 // block = 64 columns x 4 batch lanes, grid over K; block 0 also reduces the bias gradient.
+// ACT: the nn.PReLU [+ nn.Dropout] in FRONT of the Linear(K -> 1) rides on this kernel (models.lua:410-412): the stored gradient is the
+// one wrt the PReLU's input, g * mask * mscale * (xp > 0 ? 1 : slope), and every block leaves its part of the slope gradient
+// sum_{xp <= 0} xp * (g * mask * mscale) in apart[block] -- the expressions of prelu_bwd_kernel (one launch less per backward pass).
+template <int ACT>
 __global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ y, const float* __restrict__ gy,
                                                        float* __restrict__ gx, float* __restrict__ gw,
-                                                       float* __restrict__ gb, float acc, int B, int K, int sigmoid) {
+                                                       float* __restrict__ gb, float acc, int B, int K, int sigmoid,
+                                                       const float* __restrict__ xp, const float* __restrict__ slope,
+                                                       const float* __restrict__ mask, float mscale, float* __restrict__ apart) {
     extern __shared__ float dl[];  // [B] then [4][64] partials
     float* red = dl + B;
     __shared__ float sh[4];
@@ -1508,12 +1514,24 @@ __global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + tx;
-    float s = 0.f;
+    float s = 0.f, ss = 0.f;
+    const float sl = ACT ? slope[0] : 0.f;
     if (k < K) {
         const float wk = gx ? w[k] : 0.f;
         for (int b = ty; b < B; b += 4) {
             if (gw) s = fmaf(dl[b], x[(size_t)b * K + k], s);
-            if (gx) gx[(size_t)b * K + k] = dl[b] * wk;
+            if (gx) {
+                float g = dl[b] * wk;
+                if (ACT) {
+                    const size_t i = (size_t)b * K + k;
+                    if (mask) g = g * (mask[i] * mscale);
+                    const float xv = xp[i];
+                    const bool pos = xv > 0.f;
+                    ss = fmaf(pos ? 0.f : xv, g, ss);
+                    g = pos ? g : sl * g;
+                }
+                gx[(size_t)b * K + k] = g;
+            }
         }
     }
     red[ty * 64 + tx] = s;
@@ -1522,7 +1540,13 @@ __global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__
         const float t = (red[tx] + red[64 + tx]) + (red[128 + tx] + red[192 + tx]);
         gw[k] = (acc == 0.f ? 0.f : acc * gw[k]) + t;
     }
+    if (ACT && apart) {
+        __syncthreads();
+        ss = block_sum(ss, sh);
+        if (threadIdx.x == 0) apart[blockIdx.x] = ss;
+    }
     if (blockIdx.x == 0 && gb) {
+        __syncthreads();
         float sb = 0.f;
         for (int b = threadIdx.x; b < B; b += blockDim.x) sb += dl[b];
         sb = block_sum(sb, sh);
@@ -1530,10 +1554,26 @@ __global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__
     }
 }
 int fg_launch_gemv_backward(fg_ctx* ctx, const float* x, const float* w, const float* y, const float* gy, float* gx,
-                            float* gw, float* gb, float acc, int B, int K, int sigmoid) {
+                            float* gw, float* gb, float acc, int B, int K, int sigmoid, const FgActBwd* actb) {
+    if (actb) actb->applied = 0;
     if (B == 0) return FG_OK;
-    hipLaunchKernelGGL(gemv_bwd_kernel, dim3(fg_cdiv(K, 64)), dim3(256), (B + 256) * sizeof(float), ctx->stream, x, w, y,
-                       gy, gx, gw, gb, acc, B, K, sigmoid);
+    const dim3 grid(fg_cdiv(K, 64));
+    // the PReLU [+ Dropout] in front: folded when its input gradient is wanted and its slope-gradient partials have a home (the
+    // deferred final of an fg_net backward pass) or are not wanted
+    if (actb && actb->x && gx) {
+        float* dpart = actb->gslope ? fg_defer_alloc(ctx, grid.x) : nullptr;
+        if (!actb->gslope || dpart) {
+            hipLaunchKernelGGL(gemv_bwd_kernel<1>, grid, dim3(256), (B + 256) * sizeof(float), ctx->stream, x, w, y, gy, gx, gw, gb, acc, B, K,
+                               sigmoid, actb->x, actb->slope, actb->mask, actb->mscale, dpart);
+            FG_CHECK_LAUNCH(ctx);
+            if (dpart) fg_defer_push(ctx, dpart, (int)grid.x, 1, 0.f, actb->gslope);
+            actb->applied = 1;
+            return FG_OK;
+        }
+    }
+    hipLaunchKernelGGL(gemv_bwd_kernel<0>, grid, dim3(256), (B + 256) * sizeof(float), ctx->stream, x, w, y,
+                       gy, gx, gw, gb, acc, B, K, sigmoid, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1.f,
+                       (float*)nullptr);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }

@@ -172,7 +172,7 @@ def build(rng):
         return rng.uniform(-s, s, shape).astype(np.float32)
 
     def conv(cls, ni, no, k, extra=None):
-        s = 1.0 / np.sqrt(ni * k * k)
+        s = 4.0 / np.sqrt(ni * k * k)          # (4 x Torch's reset range: the fixture's activations must spread)
         f = {"nInputPlane": ni, "nOutputPlane": no, "kW": k, "kH": k, "dW": 1, "dH": 1, "padW": (k - 1) // 2, "padH": (k - 1) // 2}
         if cls.startswith("cudnn"):
             f.update({"groups": 1, "iSize": Obj("torch.LongStorage", None)})
@@ -192,7 +192,7 @@ def build(rng):
                 [("weight", np.array([rng.uniform(0.1, 0.4)], np.float32))])
 
     def linear(ni, no):
-        s = 1.0 / np.sqrt(ni)
+        s = 4.0 / np.sqrt(ni)
         return ("nn.Linear", {"addBuffer": empty()}, [("weight", u((no, ni), s)), ("bias", u((no,), s))])
 
     def longs(*v):

@@ -287,9 +287,12 @@ def test_winograd_weight_gradient_is_taken_at_the_baseline_shapes(ctx):
 # absolute at K = 2 304 -- so a transform that rounded 3 x worse could hide inside them.  Here every layer shape of both workloads is
 # measured against the float64 direct convolution in units of  u = eps32 * rms(y)  (one fp32 rounding of a typical output) and next to
 # the library's own direct fp32 contraction (implicit GEMM, same data):
-#   mean |err| <= 2.5 x the direct contraction's mean error     (measured 1.5 - 1.9 x: F(2x2, 3x3)'s transforms add ~1.7 x)
-#   max  |err| <= 3.0 x the direct contraction's max error
-#   mean |err| <= 1.2 u * sqrt(K / 576) + 0.6 u                (an absolute ceiling that grows like sqrt(K), K = taps x channels)
+#   mean |err| <= 1.5 x the direct contraction's mean error,  max |err| <= 1.5 x its max error
+#   mean |err| <= 3.0 u,  max |err| <= 24 u        (absolute ceilings, independent of the direct path)
+# Measured (MI355X, round 6): Winograd mean 1.33 - 2.28 u, max 8.1 - 16.2 u at every K from 576 to 6 400 -- it does NOT grow with K (the
+# 16 position sums are pairwise-like: 4 k-steps per MFMA, fp32 accumulators per position) -- while the direct fp32 contraction's
+# sequential K loop goes from 1.2 u (K = 576) to 4.6 u (K = 6 400): ratio 1.15 at D's 3x3 layers, ~0.5 at the 5x5 layers.  (DESIGN
+# up to round 5 said "1.7 x the direct convolution's rounding"; that was measured against max|y| at small K only.)
 # Measured values: profiles/r06_wino_error.txt (scripts/wino_error_hist.py prints the same table).
 # ---------------------------------------------------------------------------------------------------------------------------------
 ERR_CASES = [
@@ -347,7 +350,6 @@ def test_winograd_error_distribution_against_float64(ctx, B, H, W, Cin, Cout, k,
         wm, dm = r[which + "_wino_mean_u"], r[which + "_direct_mean_u"]
         wx, dx = r[which + "_wino_max_u"], r[which + "_direct_max_u"]
         msg = "%s K=%d: winograd mean %.2f u max %.1f u; direct mean %.2f u max %.1f u" % (which, K, wm, wx, dm, dx)
-        assert wm <= 2.5 * dm, msg
-        assert wx <= 3.0 * dx, msg
-        assert wm <= 1.2 * np.sqrt(K / 576.0) + 0.6, msg
+        assert wm <= 1.5 * dm and wx <= 1.5 * dx, msg
+        assert wm <= 3.0 and wx <= 24.0, msg
         assert dm > 0.05, msg          # the direct path is not the float64 answer rounded once: the ratios above mean something
