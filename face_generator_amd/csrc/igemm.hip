@@ -1527,6 +1527,22 @@ __device__ __forceinline__ float fg_wino_u(const float* t, int i, int j) {
     }
     return i == 0 ? r[0] : (i == 3 ? r[2] : 0.5f * ((r[0] + r[2]) + (i == 1 ? r[1] : -r[1])));
 }
+// all 16 positions at once: the row pass once (12 values), then the column pass -- the SAME expressions as fg_wino_u position by
+// position (bit-identical), ~60 operations instead of 16 x 20 with run-time selects (the re-pack launch was VALU-bound: 28 us)
+__device__ __forceinline__ void fg_wino_u16(const float* t, float* u) {
+    float r[3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float w0 = t[a * 3], w1 = t[a * 3 + 1], w2 = t[a * 3 + 2];
+        const float e = w0 + w2;
+        r[a][0] = w0; r[a][1] = 0.5f * (e + w1); r[a][2] = 0.5f * (e + (-w1)); r[a][3] = w2;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float e = r[0][j] + r[2][j];
+        u[0 + j] = r[0][j]; u[4 + j] = 0.5f * (e + r[1][j]); u[8 + j] = 0.5f * (e + (-r[1][j])); u[12 + j] = r[2][j];
+    }
+}
 __device__ __forceinline__ float packed_from_taps(const WeightMap& wm, const float* w, int p, int g);
 // The 3x3 sub-kernel t of one (out, in) pair whose transform goes to (parity p, group g) of the forward (bwd = 0) or data-gradient
 // (bwd = 1) Winograd pack; w = the pair's k*k reference taps.
@@ -1699,10 +1715,12 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                     int PP, KG; fg_wino_pack_shape(wm.kind, wm.wino, 0, &PP, &KG);
                     for (int pp = 0; pp < PP; ++pp)
                         for (int gg = 0; gg < KG; ++gg) {
-                            float tt[9];
+                            float tt[9], uu[16];
                             fg_wino_subkernel(wm, w, 0, pp, gg, tt);
-                            for (int pos = 0; pos < 16; ++pos)
-                                jb.dst[fg_wino_pack_at(pp, gg, KG, jb.rows, jb.cols, pos, po, pi)] = fg_wino_u(tt, pos >> 2, pos & 3);
+                            fg_wino_u16(tt, uu);
+                            float* d0 = jb.dst + fg_wino_pack_at(pp, gg, KG, jb.rows, jb.cols, 0, po, pi);      // position stride: 512 floats
+#pragma unroll
+                            for (int pos = 0; pos < 16; ++pos) d0[pos * 512] = uu[pos];
                         }
                 } else
                 for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
@@ -1718,10 +1736,12 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                 if (wm.wino) {           // data gradient: roles of out / in exchanged, taps flipped, parities become K groups
                     int PP, KG; fg_wino_pack_shape(wm.kind, wm.wino, 1, &PP, &KG);
                     for (int gg = 0; gg < KG; ++gg) {
-                        float tt[9];
+                        float tt[9], uu[16];
                         fg_wino_subkernel(wm, w, 1, 0, gg, tt);
-                        for (int pos = 0; pos < 16; ++pos)
-                            jb.dst2[fg_wino_pack_at(0, gg, KG, jb.rows2, jb.cols2, pos, pi, po)] = fg_wino_u(tt, pos >> 2, pos & 3);
+                        fg_wino_u16(tt, uu);
+                        float* d0 = jb.dst2 + fg_wino_pack_at(0, gg, KG, jb.rows2, jb.cols2, 0, pi, po);
+#pragma unroll
+                        for (int pos = 0; pos < 16; ++pos) d0[pos * 512] = uu[pos];
                     }
                 } else
                 for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);

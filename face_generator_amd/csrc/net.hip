@@ -171,6 +171,8 @@ static void make_plan(fg_net* n, int B) {
             // ... and its split-K / parity partials stay until the batched weight-gradient reduction at the end of the pass
             if (parks) { ConvGeom g = s.geom; g.B = B; dn += (fg_conv_wgrad_part_floats(g) + 63) / 64 * 64; }
             else if (s.kind == ST_THIN_IN || s.kind == ST_THIN_OUT || s.kind == ST_GEMV) dn += (long long)CR_ROWBLOCKS_MAX * s.oc + 64;
+            // (the sliced Linear(K -> 1) backward: weight-gradient rows, bias and slope partials per 16-sample slice -- fg_launch_gemv_backward)
+            if (s.kind == ST_GEMV) dn += (long long)fg_cdiv(B, 16) * (s.ic + 4 + fg_cdiv(s.ic, 64)) + 192;
             if (s.has_prelu || s.kind == ST_PRELU || s.kind == ST_ACTPOOL) dn += 1024 + 64;
             // a PReLU whose backward rides on the epilogue of the neighbouring contraction leaves 4 partials per block
             if (s.kind == ST_PRELU && s.mask_kind == 0)

@@ -1494,16 +1494,10 @@ int fg_launch_gemv_forward(fg_ctx* ctx, const float* x, const float* w, const fl
 }
 // dl[b] = gy[b]*y(1-y) (or gy); gx[b][k] = dl[b] w[k]; gw[k] = sum_b dl[b] x[b][k]; gb = sum dl.
 // block = 64 columns x 4 batch lanes, grid over K; block 0 also reduces the bias gradient.
-// ACT: the nn.PReLU [+ nn.Dropout] in FRONT of the Linear(K -> 1) rides on this kernel (models.lua:410-412): the stored gradient is the
-// one wrt the PReLU's input, g * mask * mscale * (xp > 0 ? 1 : slope), and every block leaves its part of the slope gradient
-// sum_{xp <= 0} xp * (g * mask * mscale) in apart[block] -- the expressions of prelu_bwd_kernel (one launch less per backward pass).
-template <int ACT>
 __global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ y, const float* __restrict__ gy,
                                                        float* __restrict__ gx, float* __restrict__ gw,
-                                                       float* __restrict__ gb, float acc, int B, int K, int sigmoid,
-                                                       const float* __restrict__ xp, const float* __restrict__ slope,
-                                                       const float* __restrict__ mask, float mscale, float* __restrict__ apart) {
+                                                       float* __restrict__ gb, float acc, int B, int K, int sigmoid) {
     extern __shared__ float dl[];  // [B] then [4][64] partials
     float* red = dl + B;
     __shared__ float sh[4];
@@ -1514,24 +1508,12 @@ __global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__
     __syncthreads();
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + tx;
-    float s = 0.f, ss = 0.f;
-    const float sl = ACT ? slope[0] : 0.f;
+    float s = 0.f;
     if (k < K) {
         const float wk = gx ? w[k] : 0.f;
         for (int b = ty; b < B; b += 4) {
             if (gw) s = fmaf(dl[b], x[(size_t)b * K + k], s);
-            if (gx) {
-                float g = dl[b] * wk;
-                if (ACT) {
-                    const size_t i = (size_t)b * K + k;
-                    if (mask) g = g * (mask[i] * mscale);
-                    const float xv = xp[i];
-                    const bool pos = xv > 0.f;
-                    ss = fmaf(pos ? 0.f : xv, g, ss);
-                    g = pos ? g : sl * g;
-                }
-                gx[(size_t)b * K + k] = g;
-            }
+            if (gx) gx[(size_t)b * K + k] = dl[b] * wk;
         }
     }
     red[ty * 64 + tx] = s;
@@ -1540,40 +1522,94 @@ __global__ __launch_bounds__(256) void gemv_bwd_kernel(const float* __restrict__
         const float t = (red[tx] + red[64 + tx]) + (red[128 + tx] + red[192 + tx]);
         gw[k] = (acc == 0.f ? 0.f : acc * gw[k]) + t;
     }
-    if (ACT && apart) {
-        __syncthreads();
-        ss = block_sum(ss, sh);
-        if (threadIdx.x == 0) apart[blockIdx.x] = ss;
-    }
     if (blockIdx.x == 0 && gb) {
-        __syncthreads();
         float sb = 0.f;
         for (int b = threadIdx.x; b < B; b += blockDim.x) sb += dl[b];
         sb = block_sum(sb, sh);
         if (threadIdx.x == 0) gb[0] = (acc == 0.f ? 0.f : acc * gb[0]) + sb;
     }
 }
+// The same backward inside an fg_net backward pass, with the nn.PReLU [+ nn.Dropout] in FRONT of the Linear(K -> 1) folded in
+// (models.lua:410-412): grid (K / 64, row slices of 16 samples) instead of K / 64 blocks that each walk the whole batch (8 blocks for
+// K = 512: latency-bound), the stored gradient is the one wrt the PReLU's input, g * mask * mscale * (xp > 0 ? 1 : slope) -- the
+// expressions of prelu_bwd_kernel -- and every sum (weight gradient rows, bias gradient, slope gradient) leaves per-block partials
+// for the deferred final of the pass (fixed order).  One launch instead of two, 64 blocks instead of 8.
+#define GEMV_BWD_ROWS 16
+__global__ __launch_bounds__(256) void gemv_bwd_act_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ y, const float* __restrict__ gy,
+                                                           float* __restrict__ gx, float* __restrict__ gwp, float* __restrict__ gbp,
+                                                           int B, int K, int sigmoid, const float* __restrict__ xp,
+                                                           const float* __restrict__ slope, const float* __restrict__ mask, float mscale,
+                                                           float* __restrict__ apart) {
+    __shared__ float dl[GEMV_BWD_ROWS];
+    __shared__ float red[4 * 64];
+    __shared__ float sh[4];
+    const int b0 = blockIdx.y * GEMV_BWD_ROWS, nb = min(GEMV_BWD_ROWS, B - b0);
+    if ((int)threadIdx.x < nb) {
+        const int b = b0 + threadIdx.x;
+        const float v = sigmoid ? y[b] : 0.f;
+        dl[threadIdx.x] = sigmoid ? gy[b] * v * (1.f - v) : gy[b];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + tx;
+    float s = 0.f, ss = 0.f;
+    const float sl = xp ? slope[0] : 0.f;
+    if (k < K) {
+        const float wk = w[k];
+        for (int r = ty; r < nb; r += 4) {
+            const size_t i = (size_t)(b0 + r) * K + k;
+            if (gwp) s = fmaf(dl[r], x[i], s);
+            float g = dl[r] * wk;
+            if (xp) {
+                if (mask) g = g * (mask[i] * mscale);
+                const float xv = xp[i];
+                const bool pos = xv > 0.f;
+                ss = fmaf(pos ? 0.f : xv, g, ss);
+                g = pos ? g : sl * g;
+            }
+            gx[i] = g;
+        }
+    }
+    red[ty * 64 + tx] = s;
+    __syncthreads();
+    if (ty == 0 && k < K && gwp) gwp[(size_t)blockIdx.y * K + k] = (red[tx] + red[64 + tx]) + (red[128 + tx] + red[192 + tx]);
+    if (apart) {
+        ss = block_sum(ss, sh);
+        if (threadIdx.x == 0) apart[blockIdx.y * gridDim.x + blockIdx.x] = ss;
+    }
+    if (blockIdx.x == 0 && gbp && threadIdx.x == 0) {
+        float sb = 0.f;
+        for (int r = 0; r < nb; ++r) sb += dl[r];
+        gbp[blockIdx.y] = sb;
+    }
+}
 int fg_launch_gemv_backward(fg_ctx* ctx, const float* x, const float* w, const float* y, const float* gy, float* gx,
                             float* gw, float* gb, float acc, int B, int K, int sigmoid, const FgActBwd* actb) {
     if (actb) actb->applied = 0;
     if (B == 0) return FG_OK;
-    const dim3 grid(fg_cdiv(K, 64));
-    // the PReLU [+ Dropout] in front: folded when its input gradient is wanted and its slope-gradient partials have a home (the
-    // deferred final of an fg_net backward pass) or are not wanted
-    if (actb && actb->x && gx) {
-        float* dpart = actb->gslope ? fg_defer_alloc(ctx, grid.x) : nullptr;
-        if (!actb->gslope || dpart) {
-            hipLaunchKernelGGL(gemv_bwd_kernel<1>, grid, dim3(256), (B + 256) * sizeof(float), ctx->stream, x, w, y, gy, gx, gw, gb, acc, B, K,
-                               sigmoid, actb->x, actb->slope, actb->mask, actb->mscale, dpart);
+    // inside an fg_net backward pass (deferred finals available), input gradient wanted, nothing to accumulate onto: the sliced
+    // kernel, with the PReLU [+ Dropout] in front folded in when the caller describes one
+    if (gx && acc == 0.f && ctx->defer && ctx->defer->n + 3 <= FG_DEFER_MAX) {
+        const dim3 grid(fg_cdiv(K, 64), fg_cdiv(B, GEMV_BWD_ROWS));
+        const bool act = actb && actb->x;
+        float* gwp = gw ? fg_defer_alloc(ctx, (long long)grid.y * K) : nullptr;
+        float* gbp = gb ? fg_defer_alloc(ctx, grid.y) : nullptr;
+        float* ap = (act && actb->gslope) ? fg_defer_alloc(ctx, (long long)grid.x * grid.y) : nullptr;
+        if ((!gw || gwp) && (!gb || gbp) && (!(act && actb->gslope) || ap)) {
+            hipLaunchKernelGGL(gemv_bwd_act_kernel, grid, dim3(256), 0, ctx->stream, x, w, y, gy, gx, gwp, gbp, B, K, sigmoid,
+                               act ? actb->x : (const float*)nullptr, act ? actb->slope : (const float*)nullptr,
+                               act ? actb->mask : (const float*)nullptr, act ? actb->mscale : 1.f, ap);
             FG_CHECK_LAUNCH(ctx);
-            if (dpart) fg_defer_push(ctx, dpart, (int)grid.x, 1, 0.f, actb->gslope);
-            actb->applied = 1;
+            if (gwp) fg_defer_push(ctx, gwp, (int)grid.y, K, 0.f, gw);
+            if (gbp) fg_defer_push(ctx, gbp, (int)grid.y, 1, 0.f, gb);
+            if (ap) fg_defer_push(ctx, ap, (int)(grid.x * grid.y), 1, 0.f, actb->gslope);
+            if (act) actb->applied = 1;
             return FG_OK;
         }
     }
-    hipLaunchKernelGGL(gemv_bwd_kernel<0>, grid, dim3(256), (B + 256) * sizeof(float), ctx->stream, x, w, y,
-                       gy, gx, gw, gb, acc, B, K, sigmoid, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 1.f,
-                       (float*)nullptr);
+    hipLaunchKernelGGL(gemv_bwd_kernel, dim3(fg_cdiv(K, 64)), dim3(256), (B + 256) * sizeof(float), ctx->stream, x, w, y,
+                       gy, gx, gw, gb, acc, B, K, sigmoid);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
 }
