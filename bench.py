@@ -183,7 +183,7 @@ def load_traffic(kernel, live=True, spec=None):
             return tj
     if spec is not None and spec is not DOMINANT_LAUNCH:
         return None
-    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:

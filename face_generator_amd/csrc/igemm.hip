@@ -1544,6 +1544,7 @@ __device__ __forceinline__ void fg_wino_u16(const float* t, float* u) {
     }
 }
 __device__ __forceinline__ float packed_from_taps(const WeightMap& wm, const float* w, int p, int g);
+__device__ __forceinline__ float folded_tap_at(const WeightMap& wm, const float* w, int py, int px, int ty, int tx);
 // The 3x3 sub-kernel t of one (out, in) pair whose transform goes to (parity p, group g) of the forward (bwd = 0) or data-gradient
 // (bwd = 1) Winograd pack; w = the pair's k*k reference taps.
 //   forward: kind 0, k = 3: t = w;  kind 1 (folded nearest-x2, 3x3 window): t = the folded taps of parity p;
@@ -1568,7 +1569,9 @@ __device__ __forceinline__ void fg_wino_subkernel(const WeightMap& wm, const flo
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         const int src = bwd ? 8 - q : q;
-        t[q] = wm.kind == 1 ? packed_from_taps(wm, w, par, src) : w[src];
+        // (a Winograd pack of a folded layer has the 3 x 3 window T = 3 -- fg_geom_set_wino --: window coordinates as constants, not
+        // src / wm.T at run time: the nine integer divisions per sub-kernel were a third of the re-pack launch's instructions)
+        t[q] = wm.kind == 1 ? folded_tap_at(wm, w, par >> 1, par & 1, src / 3, src % 3) : w[src];
     }
 }
 
@@ -1638,7 +1641,11 @@ int fg_launch_pack_weights(fg_ctx* ctx, const WeightMap& wm, int mode, const flo
 // packed value from a pair's k*k taps held in LDS (same arithmetic and summation order as packed_weight_value)
 __device__ __forceinline__ float packed_from_taps(const WeightMap& wm, const float* w, int p, int g) {
     if (wm.kind == 0) return w[g];
-    const int py = p >> 1, px = p & 1, ty = g / wm.T, tx = g - ty * wm.T;
+    const int ty = g / wm.T;
+    return folded_tap_at(wm, w, p >> 1, p & 1, ty, g - ty * wm.T);
+}
+// the folded tap at window position (ty, tx) of output parity (py, px): the sum of the <= 2 x 2 reference taps that land on it
+__device__ __forceinline__ float folded_tap_at(const WeightMap& wm, const float* w, int py, int px, int ty, int tx) {
     const int dy0 = 2 * (ty + wm.rmin) - py + wm.pad, dx0 = 2 * (tx + wm.rmin) - px + wm.pad;
     float s = 0.f;
 #pragma unroll
@@ -1696,10 +1703,14 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         const int PK_ROW = PK_ROW_OF(kk);
         const int patch = (int)(loc >> 8), t = (int)(loc & 255);
         const int po0 = (patch / jb.npi) * 16, pi0 = (patch % jb.npi) * 16;
-        for (int e = t; e < 16 * run; e += 256) {
-            const int a = e / run, off = e - a * run;
-            const int po = po0 + a, pi = pi0 + off / kk;
-            taps[a * PK_ROW + off] = (po < wm.O && pi < wm.I) ? pk_load<ADAM>(params, ad, ak, w0 + ((long long)po * wm.I + pi0) * kk + off) : 0.f;
+        // (16 runs of 16 * kk floats; rows outside the layer read as zero.  No run-time division: the in-channel bound is a bound on
+        // the offset inside the run)
+        const int off_end = min(run, (wm.I - pi0) * kk);
+        for (int a = 0; a < 16; ++a) {
+            const int po = po0 + a;
+            const long long src = w0 + ((long long)po * wm.I + pi0) * kk;
+            for (int off = t; off < run; off += 256)
+                taps[a * PK_ROW + off] = (po < wm.O && off < off_end) ? pk_load<ADAM>(params, ad, ak, src + off) : 0.f;
         }
         __syncthreads();
         const int ng = wm.P * wm.G;
@@ -1987,7 +1998,18 @@ __device__ __forceinline__ void wino_wgrad_finish_block(const WeightMap& wm, con
 #pragma unroll
         for (int pos = 0; pos < 16; ++pos) du[pos] = 0.f;
         const float4* __restrict__ b = (const float4*)(Part + ((size_t)u * S * tile + (size_t)o * Cpad + i) * 16);
-        for (int s = 0; s < S; ++s) {
+        int s = 0;
+        for (; s + 2 <= S; s += 2) {          // two splits = eight 16-byte loads in flight; the additions stay in split order
+            float4 v[4], v2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = b[(size_t)s * tile * 4 + q]; v2[q] = b[(size_t)(s + 1) * tile * 4 + q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                du[4 * q] += v[q].x; du[4 * q + 1] += v[q].y; du[4 * q + 2] += v[q].z; du[4 * q + 3] += v[q].w;
+                du[4 * q] += v2[q].x; du[4 * q + 1] += v2[q].y; du[4 * q + 2] += v2[q].z; du[4 * q + 3] += v2[q].w;
+            }
+        }
+        for (; s < S; ++s) {
             float4 v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = b[(size_t)s * tile * 4 + q];
