@@ -316,10 +316,6 @@ struct PackJob {
     float* dst2;          // data-gradient pack
     int rows2, cols2;     // its padded dims (rows = in-channels, cols = out-channels)
     int npo, npi;         // patches along the out / in channel axis (over the padded extents)
-    int roles;            // mode 7, Winograd layers: > 1 = one block per (patch, sub-kernel) -- the forward pack's parity x group
-                          // sub-kernels, then the data-gradient pack's groups -- instead of one block per patch doing all of them
-                          // (256 patches of G's two up-convolutions = one block per CU, each thread a 2 000-instruction serial
-                          // chain with 128 stores: 28 us).  Every role re-reads the patch, so such a job is not Adam-fusable
 };
 // prof_bytes: algorithmic bytes of the launch for the profile (every parameter read once, every packed element written once)
 // lds_floats: dynamic shared memory of the launch = max over the jobs of fg_pack_lds_floats(mode, k)

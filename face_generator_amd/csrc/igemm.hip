@@ -1701,9 +1701,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         // with the in-channel fastest (forward pack) and, in a second role, with the out-channel fastest (data-gradient pack).
         const int kk = wm.k * wm.k, run = 16 * kk;
         const int PK_ROW = PK_ROW_OF(kk);
-        const int roles = jb.roles > 1 ? jb.roles : 1;
-        const int blk = (int)(loc >> 8), t = (int)(loc & 255);
-        const int patch = blk / roles, role = roles > 1 ? blk - patch * roles : -1;       // role < 0: this block makes everything
+        const int patch = (int)(loc >> 8), t = (int)(loc & 255);
         const int po0 = (patch / jb.npi) * 16, pi0 = (patch % jb.npi) * 16;
         // (16 runs of 16 * kk floats; rows outside the layer read as zero.  No run-time division: the in-channel bound is a bound on
         // the offset inside the run)
@@ -1728,7 +1726,6 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                     int PP, KG; fg_wino_pack_shape(wm.kind, wm.wino, 0, &PP, &KG);
                     for (int pp = 0; pp < PP; ++pp)
                         for (int gg = 0; gg < KG; ++gg) {
-                            if (role >= 0 && role != pp * KG + gg) continue;
                             float tt[9], uu[16];
                             fg_wino_subkernel(wm, w, 0, pp, gg, tt);
                             fg_wino_u16(tt, uu);
@@ -1749,9 +1746,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
                 const size_t tile = (size_t)jb.rows2 * jb.cols2;
                 if (wm.wino) {           // data gradient: roles of out / in exchanged, taps flipped, parities become K groups
                     int PP, KG; fg_wino_pack_shape(wm.kind, wm.wino, 1, &PP, &KG);
-                    int Pf, KGf; fg_wino_pack_shape(wm.kind, wm.wino, 0, &Pf, &KGf);
                     for (int gg = 0; gg < KG; ++gg) {
-                        if (role >= 0 && role != Pf * KGf + gg) continue;
                         float tt[9], uu[16];
                         fg_wino_subkernel(wm, w, 1, 0, gg, tt);
                         fg_wino_u16(tt, uu);

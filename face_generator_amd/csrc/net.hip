@@ -844,13 +844,7 @@ static int build_pack_jobs(fg_net* n) {
                 j.dst2 = s.wp_bwd; j.rows2 = rb; j.cols2 = cb;
                 const int opad = rf > cb ? rf : cb, ipad = cf > rb ? cf : rb;
                 j.npo = (opad + 15) / 16; j.npi = (ipad + 15) / 16;
-                j.roles = 1;
-                if (wm.wino) {
-                    int Pf, KGf, Pb, KGb;
-                    fg_wino_pack_shape(wm.kind, wm.wino, 0, &Pf, &KGf); fg_wino_pack_shape(wm.kind, wm.wino, 1, &Pb, &KGb);
-                    j.roles = Pf * KGf + KGb;
-                }
-                j.start = start; j.count = (long long)j.npo * j.npi * 256 * j.roles;
+                j.start = start; j.count = (long long)j.npo * j.npi * 256;
                 jobs.push_back(j);
                 start += j.count;
             } else if (wm.k == 1 && wm.i_hw > 1 && wm.i_c > 0) {   // Linear behind a View: 16 x 16 x 16 bricks (mode 10)
@@ -892,7 +886,7 @@ static int build_pack_jobs(fg_net* n) {
     n->adam_fusable = true;
     std::vector<std::pair<long long, long long>> cov;          // [from, to) of the flat parameter vector read by a pack job
     for (auto& j : jobs) {
-        if (j.mode <= 1 || (j.mode == 7 && j.roles > 1)) n->adam_fusable = false;
+        if (j.mode <= 1) n->adam_fusable = false;
         const long long cnt = (j.mode == 7 || j.mode == 8 || j.mode == 10) ? (long long)j.wm.O * j.wm.I * j.wm.k * j.wm.k : j.count;
         cov.push_back({j.src_off, j.src_off + cnt});
     }
