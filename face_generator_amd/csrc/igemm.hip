@@ -1705,12 +1705,29 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         const int po0 = (patch / jb.npi) * 16, pi0 = (patch % jb.npi) * 16;
         // (16 runs of 16 * kk floats; rows outside the layer read as zero.  No run-time division: the in-channel bound is a bound on
         // the offset inside the run)
+        // Four rows' loads are issued before their LDS stores: with one load -> wait -> store per iteration the 256 blocks of G's two
+        // up-convolutions (one per CU, four waves) spent 33 us walking 32 dependent memory latencies.
         const int off_end = min(run, (wm.I - pi0) * kk);
-        for (int a = 0; a < 16; ++a) {
-            const int po = po0 + a;
-            const long long src = w0 + ((long long)po * wm.I + pi0) * kk;
-            for (int off = t; off < run; off += 256)
-                taps[a * PK_ROW + off] = (po < wm.O && off < off_end) ? pk_load<ADAM>(params, ad, ak, src + off) : 0.f;
+        const int nj = (run + 255) >> 8;                     // <= 4 (k <= 7)
+        for (int a0 = 0; a0 < 16; a0 += 4) {
+            float v[4][4];
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                const int po = po0 + a0 + aa;
+                const long long src = w0 + ((long long)po * wm.I + pi0) * kk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int off = t + 256 * j;
+                    v[aa][j] = (j < nj && po < wm.O && off < off_end) ? pk_load<ADAM>(params, ad, ak, src + off) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int off = t + 256 * j;
+                    if (j < nj && off < run) taps[(a0 + aa) * PK_ROW + off] = v[aa][j];
+                }
         }
         __syncthreads();
         const int ng = wm.P * wm.G;
@@ -1931,19 +1948,27 @@ __device__ __forceinline__ void wgrad_finish_one(const WeightMap& wm, const floa
 // tap's additions stay in ascending split order (bit-identical to wgrad_finish_one); the block then writes the [in-channel][tap] run
 // of the reference layout contiguously through LDS instead of one word per 36- / 100-byte stride.
 __host__ __device__ static inline bool fg_finish_all_taps(const WeightMap& wm) { return !wm.wino && wm.kind == 0 && (wm.k == 3 || wm.k == 5); }
+// in-channels per block: 128 (one thread each), or -- long reductions, S >= 12 -- 32 with the splits dealt to FOUR thread groups
+// (group q sums the contiguous range [q * ceil(S / 4), ...) in ascending order, the four group sums are added in group order): D's
+// 128 -> 256 layer has 27 splits x 9 taps = 243 partials per channel pair and only 256 x 128 pairs -- one thread per pair left 256
+// blocks walking 14 dependent load batches each while the rest of the launch had long finished (35 us for 83 MB)
+__host__ __device__ static inline int fg_finish_taps_tpb(int S) { return S >= 12 ? 32 : 128; }
 template <int K>
 __device__ __forceinline__ void wgrad_finish_taps(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
                                                   float beta, float* __restrict__ gradW, int bx, int po, float* sh) {
     constexpr int kk = K * K;
-    const int pi = bx * 128 + (int)threadIdx.x;
+    const int tpb = fg_finish_taps_tpb(S), ngrp = 128 / tpb;
+    const int il = (int)threadIdx.x % tpb, q = (int)threadIdx.x / tpb;
+    const int pi = bx * tpb + il;
     const size_t tile = (size_t)Npad * Cpad;
+    const int per = (S + ngrp - 1) / ngrp, s0 = q * per, s1 = min(S, s0 + per);
+    float sum[kk];
+#pragma unroll
+    for (int wi = 0; wi < kk; ++wi) sum[wi] = 0.f;
     if (pi < wm.I && po < wm.O) {
         const float* __restrict__ b = Part + (size_t)po * Cpad + pi;       // tap wi, split s at b[(wi * S + s) * tile]
-        float sum[kk];
-#pragma unroll
-        for (int wi = 0; wi < kk; ++wi) sum[wi] = 0.f;
-        int s = 0;
-        for (; s + 2 <= S; s += 2) {
+        int s = s0;
+        for (; s + 2 <= s1; s += 2) {
             float v0[kk], v1[kk];
 #pragma unroll
             for (int wi = 0; wi < kk; ++wi) {
@@ -1953,18 +1978,23 @@ __device__ __forceinline__ void wgrad_finish_taps(const WeightMap& wm, const flo
 #pragma unroll
             for (int wi = 0; wi < kk; ++wi) { sum[wi] += v0[wi]; sum[wi] += v1[wi]; }
         }
-        if (s < S) {
+        if (s < s1) {
 #pragma unroll
             for (int wi = 0; wi < kk; ++wi) sum[wi] += b[((size_t)wi * S + s) * tile];
         }
-#pragma unroll
-        for (int wi = 0; wi < kk; ++wi) sh[(int)threadIdx.x * kk + wi] = sum[wi];
     }
+    // sh: [group][in-channel][tap] -- 128 * kk floats in either shape
+#pragma unroll
+    for (int wi = 0; wi < kk; ++wi) sh[(q * tpb + il) * kk + wi] = sum[wi];
     __syncthreads();
     if (po >= wm.O) return;
-    const int nI = min(128, wm.I - bx * 128);
-    float* __restrict__ base = gradW + ((size_t)po * wm.I + (size_t)bx * 128) * kk;
-    for (int idx = (int)threadIdx.x; idx < nI * kk; idx += 128) base[idx] = (beta == 0.f) ? sh[idx] : beta * base[idx] + sh[idx];
+    const int nI = min(tpb, wm.I - bx * tpb);
+    float* __restrict__ base = gradW + ((size_t)po * wm.I + (size_t)bx * tpb) * kk;
+    for (int idx = (int)threadIdx.x; idx < nI * kk; idx += 128) {
+        float t = sh[idx];
+        for (int g = 1; g < ngrp; ++g) t += sh[g * tpb * kk + idx];
+        base[idx] = (beta == 0.f) ? t : beta * base[idx] + t;
+    }
 }
 __device__ __forceinline__ void wgrad_finish_taps_any(const WeightMap& wm, const float* __restrict__ Part, int S, int Npad, int Cpad,
                                                       float beta, float* __restrict__ gradW, int bx, int po, float* sh) {
@@ -1999,15 +2029,16 @@ __device__ __forceinline__ void wino_wgrad_finish_block(const WeightMap& wm, con
         for (int pos = 0; pos < 16; ++pos) du[pos] = 0.f;
         const float4* __restrict__ b = (const float4*)(Part + ((size_t)u * S * tile + (size_t)o * Cpad + i) * 16);
         int s = 0;
-        for (; s + 2 <= S; s += 2) {          // two splits = eight 16-byte loads in flight; the additions stay in split order
-            float4 v[4], v2[4];
+        for (; s + 4 <= S; s += 4) {          // four splits = sixteen 16-byte loads in flight; the additions stay in split order
+            float4 v[4][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { v[q] = b[(size_t)s * tile * 4 + q]; v2[q] = b[(size_t)(s + 1) * tile * 4 + q]; }
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                du[4 * q] += v[q].x; du[4 * q + 1] += v[q].y; du[4 * q + 2] += v[q].z; du[4 * q + 3] += v[q].w;
-                du[4 * q] += v2[q].x; du[4 * q + 1] += v2[q].y; du[4 * q + 2] += v2[q].z; du[4 * q + 3] += v2[q].w;
-            }
+                for (int q = 0; q < 4; ++q) v[e][q] = b[(size_t)(s + e) * tile * 4 + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { du[4 * q] += v[e][q].x; du[4 * q + 1] += v[e][q].y; du[4 * q + 2] += v[e][q].z; du[4 * q + 3] += v[e][q].w; }
         }
         for (; s < S; ++s) {
             float4 v[4];
@@ -2144,10 +2175,11 @@ bool fg_defer_push_wfinish(fg_ctx* ctx, const WeightMap& wm, const float* Part, 
     const bool brick = wm.kind == 0 && wm.k == 1 && wm.i_hw > 1 && wm.i_c > 0;     // Linear behind a View: 32 x 32 patches (ib = -1)
     const long long nb = brick ? (long long)wm.O * fg_cdiv(wm.i_c, 32) * fg_cdiv(wm.i_hw, 32)
                                : (wm.wino ? (long long)fg_cdiv(wm.I, fg_wino_finish_tpu(wm)) * wm.O       // (Winograd partials: wino_wgrad_finish_block)
-                                          : (long long)fg_cdiv(wm.I, 128) * wm.O * (fg_finish_all_taps(wm) ? 1 : wm.k * wm.k));
+                                          : (fg_finish_all_taps(wm) ? (long long)fg_cdiv(wm.I, fg_finish_taps_tpb(S)) * wm.O
+                                                                    : (long long)fg_cdiv(wm.I, 128) * wm.O * wm.k * wm.k));
     if (d->wblocks + nb > 0x7fffffffLL) return false;
     FgWFinishJob& j = d->wjobs[d->wn++];
-    j.wm = wm; j.part = Part; j.gradW = gradW; j.S = S; j.Npad = Npad; j.Cpad = Cpad; j.ib = brick ? -1 : fg_cdiv(wm.I, wm.wino ? fg_wino_finish_tpu(wm) : 128); j.beta = beta;
+    j.wm = wm; j.part = Part; j.gradW = gradW; j.S = S; j.Npad = Npad; j.Cpad = Cpad; j.ib = brick ? -1 : fg_cdiv(wm.I, wm.wino ? fg_wino_finish_tpu(wm) : (fg_finish_all_taps(wm) ? fg_finish_taps_tpb(S) : 128)); j.beta = beta;
     j.blk0 = d->wblocks;
     d->wblocks += nb;
     return true;
@@ -2164,7 +2196,8 @@ __global__ void wgrad_finish_kernel(const WeightMap wm, const float* __restrict_
 int fg_launch_wgrad_finish(fg_ctx* ctx, const WeightMap& wm, const float* Part, int S, int Npad, int Cpad, float beta,
                            float* gradW) {
     if (wm.wino && wm.k != 3 && wm.k != 5) return fg_set_err(ctx, FG_ERR_INVALID, "winograd weight-gradient finish: k = %d", wm.k);
-    dim3 grid(fg_cdiv(wm.I, wm.wino ? fg_wino_finish_tpu(wm) : 128), wm.O, (wm.wino || fg_finish_all_taps(wm)) ? 1 : wm.k * wm.k);
+    dim3 grid(fg_cdiv(wm.I, wm.wino ? fg_wino_finish_tpu(wm) : (fg_finish_all_taps(wm) ? fg_finish_taps_tpb(S) : 128)), wm.O,
+              (wm.wino || fg_finish_all_taps(wm)) ? 1 : wm.k * wm.k);
     hipLaunchKernelGGL(wgrad_finish_kernel, grid, dim3(128), 0, ctx->stream, wm, Part, S, Npad, Cpad, beta, gradW);
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;

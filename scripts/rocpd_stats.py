@@ -20,7 +20,15 @@ def main():
     cur = db.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     namecol = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    rows = sorted(cur.execute("select %s, start, end from kernels" % namecol), key=lambda r: r[1])
+    gridcols = [c for c in cols if c.lower() in ("grid_size_x", "grid_x", "grid_size")][:1]
+    rows = sorted(cur.execute("select %s, start, end%s from kernels" % (namecol, (", " + gridcols[0]) if gridcols else "")), key=lambda r: r[1])
+    shapes = {}                                   # (kernel, grid) -> [calls, ms]: launches of one kernel with different grids, apart
+    if gridcols:
+        for r in rows:
+            a = shapes.setdefault((short(r[0]), r[3]), [0, 0.0])
+            a[0] += 1
+            a[1] += (r[2] - r[1]) / 1e6
+        rows = [r[:3] for r in rows]
     setup = {}
     if iters == "auto":
         first = next((i for i, r in enumerate(rows) if short(r[0]) == "rng_multi_kernel"), 0)
@@ -48,6 +56,14 @@ def main():
     print("\ntotal kernel time %.3f ms over %d dispatches; first-to-last span %.3f ms" % (total, len(rows), span))
     if iters:
         print("%.1f iterations: %.3f ms of kernel time and %.1f dispatches per iteration" % (iters, total / iters, len(rows) / iters))
+    multi = sorted(set(k for (k, g) in shapes if sum(1 for (k2, g2) in shapes if k2 == k) > 1))
+    if multi and "--by-grid" in sys.argv:
+        print("\nper launch shape (kernels launched with more than one grid; grid = work-items along x):")
+        print("| kernel | grid x | calls | avg us |\n|---|---|---|---|")
+        for k in sorted(multi, key=lambda k: -agg.get(k, [0, 0])[1])[:14]:
+            for (k2, g), (n, ms) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                if k2 == k and n >= 3:
+                    print("| %s | %s | %d | %.1f |" % (k, g, n, 1000 * ms / n))
     if setup:
         print("\nbefore the first training closure (net construction; NOT in the table): %d dispatches, %.3f ms -- %s"
               % (sum(v[0] for v in setup.values()), sum(v[1] for v in setup.values()),
