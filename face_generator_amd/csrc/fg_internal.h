@@ -487,24 +487,45 @@ __device__ __forceinline__ float fg_prep_grad(float g, float p, float gscale, fl
 }
 struct AdamScalars { float step, ob1, ob2; };      // lr * sqrt(1 - b2^t) / (1 - b1^t), 1 - b1, 1 - b2 (host side, in double)
 AdamScalars fg_adam_scalars(const AdamArgs& a);
-__device__ __forceinline__ float fg_adam_elem(const AdamArgs& a, const AdamScalars& k, long long i) {
+// one element's arithmetic (registers in, registers out): shared by the scalar and the 16-byte forms below
+__device__ __forceinline__ void fg_adam_math(const AdamArgs& a, const AdamScalars& k, float p, float graw, float mo, float vo,
+                                             float* pn, float* mn, float* vn, float* gp) {
 #pragma clang fp contract(off)
-    const float p = a.p[i];
-    const float g = fg_prep_grad(a.g[i], p, a.gscale, a.l1_mul, a.l2, a.clamp);
+    const float g = fg_prep_grad(graw, p, a.gscale, a.l1_mul, a.l2, a.clamp);
     // interruptable_optimizers.lua:78-90 : m = b1*m + (1-b1) g ; v = b2*v + (1-b2) g*g ; denom = sqrt(v)+eps
-    const float m1 = a.m[i] * a.beta1, m2 = k.ob1 * g;
+    const float m1 = mo * a.beta1, m2 = k.ob1 * g;
     const float m = m1 + m2;
-    const float v1 = a.v[i] * a.beta2, v2 = (k.ob2 * g) * g;
+    const float v1 = vo * a.beta2, v2 = (k.ob2 * g) * g;
     const float v = v1 + v2;
     const float denom = sqrtf(v) + a.eps;
     const float q = m / denom;
     const float u = k.step * q;
-    const float pn = p - u;
+    *pn = p - u; *mn = m; *vn = v; *gp = g;
+}
+__device__ __forceinline__ float fg_adam_elem(const AdamArgs& a, const AdamScalars& k, long long i) {
+    float pn, m, v, g;
+    fg_adam_math(a, k, a.p[i], a.g[i], a.m[i], a.v[i], &pn, &m, &v, &g);
     a.m[i] = m;
     a.v[i] = v;
     a.p[i] = pn;
     if (a.gout) a.gout[i] = g;
     return pn;
+}
+// (dword-aligned 16-byte vector: gfx950 takes global_load / store_dwordx4 at any dword address -- the second moment of a net with an
+// odd parameter count, v = m + n, is not 16-byte aligned)
+typedef float fg_f4u __attribute__((ext_vector_type(4), aligned(4)));
+// four consecutive elements through 16-byte loads and stores: a dword-per-lane store makes the
+// L2 fetch the line it is about to overwrite (profiles/r06_pmc_tail.txt: adam_kernel fetched its 43 MB of operands PLUS ~its 32 MB of
+// results), a 16-byte-per-lane store does not (bn_apply: fetch = operands)
+__device__ __forceinline__ void fg_adam_elem4(const AdamArgs& a, const AdamScalars& k, long long i) {
+    const fg_f4u p = *(const fg_f4u*)(a.p + i), g = *(const fg_f4u*)(a.g + i), m = *(const fg_f4u*)(a.m + i), v = *(const fg_f4u*)(a.v + i);
+    float pn[4], mn[4], vn[4], gp[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) fg_adam_math(a, k, p[e], g[e], m[e], v[e], &pn[e], &mn[e], &vn[e], &gp[e]);
+    *(fg_f4u*)(a.m + i) = fg_f4u{mn[0], mn[1], mn[2], mn[3]};
+    *(fg_f4u*)(a.v + i) = fg_f4u{vn[0], vn[1], vn[2], vn[3]};
+    *(fg_f4u*)(a.p + i) = fg_f4u{pn[0], pn[1], pn[2], pn[3]};
+    if (a.gout) *(fg_f4u*)(a.gout + i) = fg_f4u{gp[0], gp[1], gp[2], gp[3]};
 }
 // the optimizer step and the re-pack in ONE pass: every pack job takes its weights from the Adam update of that element (each
 // parameter is read by exactly one job; mode 9 jobs update the parameters no pack reads)

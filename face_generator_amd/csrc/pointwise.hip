@@ -1658,7 +1658,14 @@ __device__ __forceinline__ float sgnf(float v) { return fg_sgnf(v); }
 __device__ __forceinline__ float prep_grad(float g, float p, float gscale, float l1mul, float l2, float clamp) {
     return fg_prep_grad(g, p, gscale, l1mul, l2, clamp);
 }
-__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a, const AdamScalars k) {
+__global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a, const AdamScalars k, int vec4) {
+    if (vec4) {       // 16-byte form: n / 4 quads, then the <= 3 trailing elements
+        const long long nq = a.n >> 2;
+        for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (long long)gridDim.x * blockDim.x)
+            fg_adam_elem4(a, k, q << 2);
+        if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) (void)fg_adam_elem(a, k, (nq << 2) + threadIdx.x);
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long long)gridDim.x * blockDim.x)
         (void)fg_adam_elem(a, k, i);
 }
@@ -1673,7 +1680,8 @@ int fg_launch_adam(fg_ctx* ctx, const AdamArgs& a) {
     if (a.n == 0) return FG_OK;
     {
         FgProfScope prof(ctx, fg_intern(ctx, "adam_kernel"), 0.0, 0.0, 28.0 * (double)a.n);   // read p, g, m, v; write p, m, v
-        hipLaunchKernelGGL(adam_kernel, FG_GRID(a.n, 256), dim3(256), 0, ctx->stream, a, fg_adam_scalars(a));
+        const int vec4 = a.n >= 4;
+        hipLaunchKernelGGL(adam_kernel, FG_GRID(vec4 ? (a.n + 3) / 4 : a.n, 256), dim3(256), 0, ctx->stream, a, fg_adam_scalars(a), vec4);
     }
     FG_CHECK_LAUNCH(ctx);
     return FG_OK;
