@@ -1731,60 +1731,47 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
         }
         __syncthreads();
         const int ng = wm.P * wm.G;
-        if (wm.wino) {
-            // Winograd packs (chunk images [pos][k half][64 n][4 k]; n = out-channel forward, in-channel data gradient).  A thread owns
-            // one n and one QUAD of k: four channel pairs -> sixteen 16-byte stores per sub-kernel, each wave-store a contiguous 1 KB.
-            // (One pair per thread wrote dwords: a dword-per-lane store makes the L2 fetch the line first -- scripts/ubench/store_width.hip,
-            // profiles/r06_store_width.txt -- and the re-pack fetched 5 x the parameters it reads.)  The four 64-thread groups take the
-            // sub-kernels in turn: forward (parity, group) pairs, then the data gradient's groups.
-            int Pf, KGf, Pb, KGb;
-            fg_wino_pack_shape(wm.kind, wm.wino, 0, &Pf, &KGf); fg_wino_pack_shape(wm.kind, wm.wino, 1, &Pb, &KGb);
-            const int nf = Pf * KGf, sub = t >> 6, e = t & 63, xl = e >> 2, kq = e & 3;
-            for (int role = sub; role < nf; role += 4) {
-                const int po = po0 + xl, pi = pi0 + 4 * kq;
-                if (po >= jb.rows || pi >= jb.cols) continue;
-                float uu[4][16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float tt[9];
-                    fg_wino_subkernel(wm, taps + xl * PK_ROW + (4 * kq + j) * kk, 0, role / KGf, role % KGf, tt);
-                    fg_wino_u16(tt, uu[j]);
-                }
-                float* d0 = jb.dst + fg_wino_pack_at(role / KGf, role % KGf, KGf, jb.rows, jb.cols, 0, po, pi);      // position stride: 512 floats
-#pragma unroll
-                for (int pos = 0; pos < 16; ++pos) *(float4*)(d0 + pos * 512) = make_float4(uu[0][pos], uu[1][pos], uu[2][pos], uu[3][pos]);
-            }
-            for (int gg = (sub + 4 - (nf & 3)) & 3; gg < KGb; gg += 4) {       // (group g of the data gradient goes to thread group (nf + g) mod 4)
-                const int pi = pi0 + xl, po = po0 + 4 * kq;
-                if (pi >= jb.rows2 || po >= jb.cols2) continue;
-                float uu[4][16];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float tt[9];
-                    fg_wino_subkernel(wm, taps + (4 * kq + j) * PK_ROW + xl * kk, 1, 0, gg, tt);
-                    fg_wino_u16(tt, uu[j]);
-                }
-                float* d0 = jb.dst2 + fg_wino_pack_at(0, gg, KGb, jb.rows2, jb.cols2, 0, pi, po);
-#pragma unroll
-                for (int pos = 0; pos < 16; ++pos) *(float4*)(d0 + pos * 512) = make_float4(uu[0][pos], uu[1][pos], uu[2][pos], uu[3][pos]);
-            }
-            return;
-        }
-        {   // forward pack [p][g][O_pad][I_pad]: lanes run over the in-channel
-            const int a = t >> 4, b = t & 15, po = po0 + a, pi = pi0 + b;
+        {   // forward pack [p][g][O_pad][I_pad]: lanes run over the in-channel.  Winograd pack (chunk images [pos][k half][64 out][4 in]):
+            // lanes run over the OUT-channel and a wave holds one quad of in-channels, so that each of its stores is one contiguous
+            // 256-byte run of an image (lanes over the in-channel wrote four 64-byte pieces per store: 28 us per re-pack, round 5)
+            const int a = wm.wino ? (t & 15) : (t >> 4), b = wm.wino ? (t >> 4) : (t & 15), po = po0 + a, pi = pi0 + b;
             if (po < jb.rows && pi < jb.cols) {
                 const float* w = taps + a * PK_ROW + b * kk;
                 float* d = jb.dst + (size_t)po * jb.cols + pi;
                 const size_t tile = (size_t)jb.rows * jb.cols;
+                if (wm.wino) {           // Winograd: U[parity][group][pos][out][in] in the order of wino_kernel's LDS stage
+                    int PP, KG; fg_wino_pack_shape(wm.kind, wm.wino, 0, &PP, &KG);
+                    for (int pp = 0; pp < PP; ++pp)
+                        for (int gg = 0; gg < KG; ++gg) {
+                            float tt[9], uu[16];
+                            fg_wino_subkernel(wm, w, 0, pp, gg, tt);
+                            fg_wino_u16(tt, uu);
+                            float* d0 = jb.dst + fg_wino_pack_at(pp, gg, KG, jb.rows, jb.cols, 0, po, pi);      // position stride: 512 floats
+#pragma unroll
+                            for (int pos = 0; pos < 16; ++pos) d0[pos * 512] = uu[pos];
+                        }
+                } else
                 for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
             }
         }
-        {   // data-gradient pack [p][g][I_pad][O_pad]: lanes run over the out-channel
-            const int a = t & 15, b = t >> 4, po = po0 + a, pi = pi0 + b;
+        {   // data-gradient pack [p][g][I_pad][O_pad]: lanes run over the out-channel (Winograd: over the in-channel, which is the
+            // 64-wide axis of ITS images; see above)
+            const int a = wm.wino ? (t >> 4) : (t & 15), b = wm.wino ? (t & 15) : (t >> 4), po = po0 + a, pi = pi0 + b;
             if (pi < jb.rows2 && po < jb.cols2) {
                 const float* w = taps + a * PK_ROW + b * kk;
                 float* d = jb.dst2 + (size_t)pi * jb.cols2 + po;
                 const size_t tile = (size_t)jb.rows2 * jb.cols2;
+                if (wm.wino) {           // data gradient: roles of out / in exchanged, taps flipped, parities become K groups
+                    int PP, KG; fg_wino_pack_shape(wm.kind, wm.wino, 1, &PP, &KG);
+                    for (int gg = 0; gg < KG; ++gg) {
+                        float tt[9], uu[16];
+                        fg_wino_subkernel(wm, w, 1, 0, gg, tt);
+                        fg_wino_u16(tt, uu);
+                        float* d0 = jb.dst2 + fg_wino_pack_at(0, gg, KG, jb.rows2, jb.cols2, 0, pi, po);
+#pragma unroll
+                        for (int pos = 0; pos < 16; ++pos) d0[pos * 512] = uu[pos];
+                    }
+                } else
                 for (int pg = 0; pg < ng; ++pg) d[(size_t)pg * tile] = packed_from_taps(wm, w, pg / wm.G, pg % wm.G);
             }
         }

@@ -80,7 +80,11 @@ def check_every_tensor(name, g_dev, net64, g32=None, prelu_ulps=32, prelu_rtol=0
         mean), so what both implementations hold is rounding noise of the sums it cancels from: bar = that of the module's
         weight gradient;
       * the single PReLU slope gradient is one cancelling sum over the whole tensor: + 32 ulp of its condition scale
-        ||x * gy||_2 (`gw_cond`, oracle/torch7_nn.py)."""
+        ||x * gy||_2 (`gw_cond`, oracle/torch7_nn.py).
+    FROZEN: the three-way max below (1e-4 of the tensor's own scale | 4 x the fp32 oracle's own error |
+    GLOBAL_FLOOR of the net's largest entry), the two special cases and FLIP_BOUND are the complete list of allowances.  Nothing here
+    may be widened, and no fourth term added, without a MEASURED justification written into this docstring (which tensor, which
+    number, why fp32 cannot do better) -- `test_tolerances_are_frozen` pins the constants."""
     g_dev = g_dev.astype(np.float64)
     mods = getattr(net64, "inner", net64).modules
     gmax = max(np.abs(getattr(mm, gn)).max() for m in mods for (mm, pn, gn) in m.parameters())
@@ -449,3 +453,13 @@ def test_c2f_S64_full_steps_at_batch_64_two_D_iterations(ctx):
     """BASELINE configs[4]'s per-GPU shard: B = 64, D_iterations = 2 (adversarial_c2f.lua:123-160 runs the D closure twice per
     G closure; the second D update is Adam at t = 2)."""
     c2f_full_batch_steps(ctx, 64, 2, seed=571)
+
+
+def test_tolerances_are_frozen():
+    """The allowances of this file as numbers (see check_every_tensor): a change here is a change of what "parity" means and has to be
+    argued in the docstrings above, not slipped in."""
+    import inspect
+    assert FLIP_BOUND == 1e-5 and GLOBAL_FLOOR == 2e-6
+    src = inspect.getsource(check_every_tensor)
+    assert "tol = max(1e-4 * scale, 4.0 * e32, floor * gmax) + 1e-12" in src
+    assert inspect.signature(check_every_tensor).parameters["prelu_ulps"].default == 32
