@@ -890,6 +890,24 @@ int fg_launch_prelu_backward(fg_ctx* ctx, const float* x, const float* gy, const
 }
 
 // ------------------------------------------------------------------ PReLU -> SpatialDropout -> AvgPool(2,2,2,2)
+// element index -> (channel quad, x, y, sample) of an [B][H2][W2][C4] walk.  32-bit unsigned divisions wherever the index fits (every
+// size of both workloads): a 64-bit division by a run-time divisor is ~100 instructions, and the pooling kernels did six per 16-byte
+// result (scripts/ubench/store_width.hip's first version measured exactly that: a "2 TB/s store pattern" that was its index arithmetic)
+__device__ __forceinline__ void fg_decode_quad(long long i, int C4, int W2, int H2, int& c4, int& w2, int& h2, int& b) {
+    if (i <= 0xFFFFFFFFLL) {
+        unsigned t = (unsigned)i;
+        c4 = (int)(t % (unsigned)C4); t /= (unsigned)C4;
+        w2 = (int)(t % (unsigned)W2); t /= (unsigned)W2;
+        h2 = (int)(t % (unsigned)H2);
+        b = (int)(t / (unsigned)H2);
+    } else {
+        c4 = (int)(i % C4);
+        long long t = i / C4;
+        w2 = (int)(t % W2); t /= W2;
+        h2 = (int)(t % H2);
+        b = (int)(t / H2);
+    }
+}
 __device__ __forceinline__ float4 fg_sum_parts4(const FgSplitParts& sp, size_t i4, int c) {   // i4: float4 index, c: its channel
     float4 v = ((const float4*)sp.part)[i4];
     int k = 1;
@@ -916,11 +934,8 @@ __global__ __launch_bounds__(256) void actpool_fwd_kernel(const float* __restric
     const long long total = (long long)B * H2 * W2 * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long long t = i / C4;
-        const int w2 = (int)(t % W2); t /= W2;
-        const int h2 = (int)(t % H2);
-        const int b = (int)(t / H2);
+        int c4, w2, h2, b;
+        fg_decode_quad(i, C4, W2, H2, c4, w2, h2, b);
         const float4* px = (const float4*)(x + (((size_t)b * H + 2 * h2) * W + 2 * w2) * C) + c4;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -975,11 +990,8 @@ __global__ __launch_bounds__(256) void actpool_bwd_kernel(const float* __restric
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long long t = i / C4;
-        const int w = (int)(t % W); t /= W;
-        const int h = (int)(t % H);
-        const int b = (int)(t / H);
+        int c4, w, h, b;
+        fg_decode_quad(i, C4, W, H, c4, w, h, b);
         const float4 v = ((const float4*)x)[i];
         const size_t gi4 = (((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * C4 + c4;
         float4 g = sp.splits ? fg_sum_parts4(sp, gi4, c4 * 4) : ((const float4*)gy)[gi4];      // pooled gradient (or its partials)
@@ -1219,11 +1231,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const long long total = (long long)B * H2 * W2 * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long long t = i / C4;
-        const int w2 = (int)(t % W2); t /= W2;
-        const int h2 = (int)(t % H2);
-        const int b = (int)(t / H2);
+        int c4, w2, h2, b;
+        fg_decode_quad(i, C4, W2, H2, c4, w2, h2, b);
         const float4* px = (const float4*)(x + (((size_t)b * H + 2 * h2) * W + 2 * w2) * C) + c4;
         float4 m = px[0];
         const float4 v1 = px[C4], v2 = px[(size_t)W * C4], v3 = px[(size_t)W * C4 + C4];
@@ -1322,11 +1331,8 @@ __global__ __launch_bounds__(256) void actmaxpool_fwd_kernel(const float* __rest
     const int H2 = H >> 1, W2 = W >> 1, C4 = C >> 2;
     const long long total = (long long)B * H2 * W2 * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long long t = i / C4;
-        const int w2 = (int)(t % W2); t /= W2;
-        const int h2 = (int)(t % H2);
-        const int b = (int)(t / H2);
+        int c4, w2, h2, b;
+        fg_decode_quad(i, C4, W2, H2, c4, w2, h2, b);
         const float4* px = (const float4*)(x + (((size_t)b * H + 2 * h2) * W + 2 * w2) * C) + c4;
         const float4 v0 = px[0], v1 = px[C4], v2 = px[(size_t)W * C4], v3 = px[(size_t)W * C4 + C4];
         auto act = [a](float v) { return v > 0.f ? v : a * v; };
