@@ -12,6 +12,9 @@
 #   trace-wgrad [tag]                 s_memtime rows of wino_wgrad_kernel (FG_WINO_WGRAD_TRACE=1 and 2)
 #   ubench                            scripts/ubench/issue: cost of one non-MFMA instruction next to v_mfma_f32_32x32x2_f32
 #   evidence [tag]                    scripts/collect_profiles.sh: the default bench line + kernel tables + PMC passes
+#   pmc-tail [tag]                    FETCH / WRITE / SQ wait-active / L2 hit-miss / instruction-mix passes over a few cfg2 iterations for the
+#                                     tail kernels (pack_jobs, wgrad_finish_jobs, actpool_*, adam, bn_apply) -> gpurun_out/<tag>.txt
+#   store-width                       scripts/ubench/store_width: what a store's width / shape costs (64 MB, 5 shapes x distances)
 set -u
 MODE=${1:-tests}; shift 1 || true
 OUT=gpurun_out
@@ -70,7 +73,21 @@ trace-wgrad)
 ubench)
   timeout 200 scripts/ubench/issue | tee $OUT/ubench_issue.txt ;;
 evidence)
-  bash scripts/collect_profiles.sh ${1:-r05} ;;
+  bash scripts/collect_profiles.sh ${1:-r06} ;;
+pmc-tail)
+  TAG=${1:-pmc_tail}
+  rm -f $OUT/${TAG}.txt
+  for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES"; do
+    d=$OUT/pmc_$(echo $pmc | tr ' ' '_' | cut -c1-40)
+    timeout 300 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d $d -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alt-math --no-roofline > /dev/null 2>&1
+    echo "## $pmc" >> $OUT/${TAG}.txt
+    for k in pack_jobs wgrad_finish_jobs actpool_bwd actpool_fwd adam_kernel bn_apply; do python scripts/pmc_summary.py $d $k >> $OUT/${TAG}.txt 2>&1; done
+    rm -rf $d
+  done
+  cat $OUT/${TAG}.txt ;;
+store-width)
+  [ -x scripts/ubench/store_width ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o scripts/ubench/store_width scripts/ubench/store_width.hip 2>/dev/null
+  scripts/ubench/store_width | tee $OUT/store_width.txt ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
 echo "done t=$(( $(date +%s) - T0 ))"
