@@ -76,6 +76,15 @@ def test_bench_runs_under_torchrun_single_rank():
     assert "error" not in c, c
     assert c["value"] > 0 and c["ms_per_step"] > 0 and c["config"]["workload"].startswith("configs[3]") and "roofline" in c
     assert c["config"]["step_entry"].startswith("fg_step_D")
+    # round 6: the line says which figure is which -- pipe utilisation of the dominant kernel (`frac`, live tiles x
+    # live channels), SURVEY 8(d)'s algorithmic fraction beside it, the clock granted to the dominant launch ITSELF next to the
+    # iteration average, the biggest launch on its own, and the shared object the run loaded
+    r = j["roofline"]
+    assert 0 < r["frac"] < 1 and r["bound"] == "mfma" and r["survey_8d_frac"] == j["step_roofline"]["algorithmic_frac_of_f32_mfma_peak"]
+    assert r["granted_clock_ghz"] is None or (0.5 < r["granted_clock_ghz"] < 2.6 and "ONLY the dominant launch" in r["granted_clock_source"])
+    assert "iteration_average_clock_ghz" in r and r["dominant_launch"]["label"].startswith(r["kernel"])
+    assert 0 < r["dominant_launch"]["frac"] < 1 and r["dominant_launch"]["executed_tflops"] < 157.3
+    assert j["library"].endswith("libfacegen_hip.so") and os.path.isfile(j["library"])
 
 
 def test_fg_comm_c_abi_world1():
