@@ -239,6 +239,29 @@ local function to_host_nchw(ptr, b, c, h, w)
 end
 M.to_device_nhwc, M.to_host_nchw = to_device_nhwc, to_host_nchw
 
+-- image.scale(src, width, height) (dataset_c2f.lua:54-55) on the device: src a host FloatTensor [C][H][W] or [N][C][H][W] in the
+-- reference's layout (layout 1 of fg_scale_bilinear); the `image` package's bilinear algorithm bit for bit.  -> host FloatTensor
+function M.scale(src, width, height)
+    local four = src:dim() == 4
+    local n = four and src:size(1) or 1
+    local c, hs, ws = src:size(four and 2 or 1), src:size(four and 3 or 2), src:size(four and 4 or 3)
+    local inp = M.DeviceTensor(src:nElement()):copy(src)
+    local out = M.DeviceTensor(n * c * height * width)
+    check(C.fg_scale_bilinear(ctx, inp.ptr, out.ptr, n, c, hs, ws, height, width, 1))
+    local t = out:float()
+    if four then return t:view(n, c, height, width) end
+    return t:view(c, height, width)
+end
+-- the arithmetic of dataset._toResult (dataset_c2f.lua:49-61) for a batch [N][C][S][S]: -> coarse, diff (host FloatTensors)
+function M.coarseDiff(fineImages, coarseScale)
+    local n, c, s = fineImages:size(1), fineImages:size(2), fineImages:size(3)
+    local cnt = fineImages:nElement()
+    local fine = M.DeviceTensor(cnt):copy(fineImages)
+    local coarse, diff, tmp = M.DeviceTensor(cnt), M.DeviceTensor(cnt), M.DeviceTensor(n * c * coarseScale * coarseScale)
+    check(C.fg_c2f_coarse_diff(ctx, fine.ptr, coarse.ptr, diff.ptr, tmp.ptr, n, c, s, coarseScale, 1))
+    return coarse:float():view(n, c, s, s), diff:float():view(n, c, s, s)
+end
+
 -- nn module -> fg_layer_spec (typename dispatch like weight-init.lua:52-73) ---------------------------------------------
 local function spec_of(m)
     local tn = torch.typename(m)

@@ -110,7 +110,8 @@ def test_patches_apply_to_the_reference_scripts(tmp_path):
         assert r.returncode == 0, "%s does not apply: %s" % (os.path.basename(p), r.stdout + r.stderr)
     # after patching, no CUDA rock is required on the training / sampling path
     import shutil
-    RELS = ("train.lua", "sample.lua", "utils/nn_utils.lua", "layers/cudnnSpatialConvolutionUpsample.lua", "train_c2f.lua", "models_c2f.lua")
+    RELS = ("train.lua", "sample.lua", "utils/nn_utils.lua", "layers/cudnnSpatialConvolutionUpsample.lua", "train_c2f.lua", "models_c2f.lua",
+            "dataset_c2f.lua")
     for rel in RELS:
         os.makedirs(os.path.dirname(os.path.join(str(tmp_path), rel)), exist_ok=True)
         shutil.copy(os.path.join("/root/reference", rel), os.path.join(str(tmp_path), rel))
@@ -128,7 +129,15 @@ def test_patches_apply_to_the_reference_scripts(tmp_path):
     assert mc.count("FG.attach(model_G:get(3), {dimensions[1]+1, dimensions[2], dimensions[3]}, OPT.batchSize)") == 4
     assert mc.count("FG.attach(model_D:get(3), {dimensions[1], dimensions[2], dimensions[3]}, OPT.batchSize)") == 3
     assert mc.count("nn.Copy('torch.FloatTensor', 'torch.FloatTensor')") == 14 and mc.count("nn.JoinTable(2, 2)") == 4
+    # round 6: dataset._toResult (dataset_c2f.lua:49-61) hands image.scale down / up and the subtraction to the library; the `image`
+    # package stays required for image.load only, and FG is bound (train_c2f.lua) before DATASET.loadImages runs
+    dc = strip_lua_comments(open(os.path.join(str(tmp_path), "dataset_c2f.lua")).read())
+    body = dc[dc.index("function dataset._toResult"):dc.index("local result = {}")]
+    assert "FG.coarseDiff(fineImages, dataset.coarseScale)" in body and "image.scale" not in body
+    assert dc.count("image.scale") == 2 and "image.load" in dc        # the JPEG loader (dataset_c2f.lua:111-215, out of scope) keeps its own
+    assert "result.coarse = coarseImages" in dc and "result.diff = diffImages" in dc
     tc = strip_lua_comments(open(os.path.join(str(tmp_path), "train_c2f.lua")).read())
+    assert tc.index("FG = require 'facegen_hip'") < tc.index("DATASET.loadImages(0, 500)")
     assert "ADVERSARIAL = require 'adversarial_c2f_hip'" in tc and "FG = require 'facegen_hip'" in tc
     assert tc.index("FG = require 'facegen_hip'") < tc.index("FG.setDevice(OPT.gpu + 1)") < tc.index("FG.manualSeed(OPT.seed)") \
         < tc.index("MODELS.create_D(IMG_DIMENSIONS, OPT.gpu ~= false)")
